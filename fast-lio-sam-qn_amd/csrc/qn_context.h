@@ -1,0 +1,51 @@
+// qn_context.h - the opaque qn_ctx behind include/qn_engine.h (host-side bookkeeping only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <string>
+#include <vector>
+#include "qn_gicp_kernels.cuh"
+
+struct CloudBuf {                       // one point cloud, resident in HBM
+  uint32_t n = 0, ncells = 0;
+  bool has_grid = false, has_cov = false;
+  float4* raw = nullptr;                // [max_points] original order, (x, y, z, 1)
+  float4* sorted = nullptr;             // [max_points] cell-sorted, .w = original index bits
+  uint32_t* cell_of_pt = nullptr;       // [max_points]
+  uint32_t* cell_start = nullptr;       // [max_cells + 1]
+  uint32_t* counts = nullptr;           // [max_cells + 1] histogram / scatter cursors
+  double* cov = nullptr;                // [max_points][6] xx xy xz yy yz zz (f64), original order
+  qn::GridView grid{};
+};
+
+struct ProfSpan { int family; hipEvent_t a, b; };
+
+struct qn_ctx {
+  int device = 0;
+  uint32_t max_points = 0, max_cells = 0;
+  hipStream_t stream = nullptr;
+  qn_gicp_params params{};
+  CloudBuf cloud[2];
+  char* staging = nullptr;              // [max_points * 32] H2D landing zone for strided host clouds
+  uint32_t* scan_sums = nullptr;
+  qn::BBoxOut* bbox = nullptr; qn::BBoxOut* bbox_host = nullptr;
+  qn::GicpState* state = nullptr;
+  double* partials = nullptr;
+  qn_iter_trace* trace = nullptr; uint32_t trace_len = 0;
+  int32_t* corr = nullptr; float* sqd = nullptr; float* sqd_fit = nullptr;
+  uint2* fb_list = nullptr; uint32_t* fb_count2 = nullptr;
+  float4* aligned = nullptr; bool aligned_valid = false;
+  double* pose_tmp = nullptr; float* guess_tmp = nullptr;
+  qn::ResultBlock* result_host = nullptr; double* scalar_host = nullptr;
+  int32_t* dbg_knn_idx = nullptr; float* dbg_knn_d2 = nullptr;
+  // tuning knobs
+  double cell_override = 0.0;
+  int margin_nn = 1, margin_knn = 2, ticks_per_chunk = 8;
+  // profiling
+  bool prof_on = false;
+  std::vector<ProfSpan> spans;
+  qn_kernel_stat stats[QN_K_COUNT] = {};
+  std::string last_error;
+
+  void set_error(const char* what, hipError_t e, int line);
+  void prof_begin(int family); void prof_end(); void prof_collect();
+};

@@ -1,0 +1,494 @@
+// qn_engine.hip - host side of the C-ABI declared in include/qn_engine.h: context, HBM-resident
+// buffers, kernel sequencing on ONE hipStream per context.  No CPU fallback: every entry point
+// fails with QN_ERR_NO_DEVICE / QN_ERR_HIP when there is no usable gfx950 device.
+#include <hip/hip_runtime.h>
+#include <cfloat>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+#include "qn_gicp_kernels.cuh"
+#include "qn_context.h"
+
+using namespace qn;
+
+#define HIPCHK(ctx, call)                                                                 \
+  do { hipError_t e_ = (call);                                                            \
+       if (e_ != hipSuccess) { (ctx)->set_error(#call, e_, __LINE__); return QN_ERR_HIP; } \
+  } while (0)
+
+void qn_ctx::set_error(const char* what, hipError_t e, int line) {
+  char buf[512]; snprintf(buf, sizeof(buf), "%s -> %s (qn_engine.hip:%d)", what, hipGetErrorString(e), line);
+  last_error = buf;
+}
+
+// ------------------------------------------------------------------ profiling (bench roofline leg)
+void qn_ctx::prof_begin(int family) {
+  if (!prof_on) return;
+  ProfSpan sp; sp.family = family;
+  if (hipEventCreate(&sp.a) != hipSuccess || hipEventCreate(&sp.b) != hipSuccess) return;
+  hipEventRecord(sp.a, stream);
+  spans.push_back(sp);
+}
+void qn_ctx::prof_end() {
+  if (!prof_on || spans.empty()) return;
+  hipEventRecord(spans.back().b, stream);
+}
+void qn_ctx::prof_collect() {
+  for (auto& sp : spans) {
+    float ms = 0; if (hipEventSynchronize(sp.b) == hipSuccess && hipEventElapsedTime(&ms, sp.a, sp.b) == hipSuccess) { stats[sp.family].total_ms += ms; stats[sp.family].launches += 1; }
+    hipEventDestroy(sp.a); hipEventDestroy(sp.b);
+  }
+  spans.clear();
+}
+struct ProfScope { qn_ctx* c; ProfScope(qn_ctx* c_, int fam) : c(c_) { c->prof_begin(fam); } ~ProfScope() { c->prof_end(); } };
+
+// ------------------------------------------------------------------ lifetime
+extern "C" const char* qn_status_str(int s) {
+  switch (s) {
+    case QN_OK: return "ok"; case QN_ERR_INVALID_ARG: return "invalid argument"; case QN_ERR_EMPTY_CLOUD: return "empty cloud";
+    case QN_ERR_CAPACITY: return "cloud exceeds context capacity"; case QN_ERR_NOT_READY: return "clouds/covariances not set";
+    case QN_ERR_HIP: return "HIP runtime error"; case QN_ERR_NO_DEVICE: return "no gfx950 device (no CPU fallback)";
+  }
+  return "unknown status";
+}
+extern "C" const char* qn_last_error(const qn_ctx* ctx) { return ctx ? ctx->last_error.c_str() : "null context"; }
+
+extern "C" void qn_gicp_default_params(qn_gicp_params* p) {
+  if (!p) return;
+  memset(p, 0, sizeof(*p));
+  p->k_correspondences = 20; p->max_iterations = 64; p->max_corr_dist = (double)FLT_MAX;
+  p->transformation_epsilon = 5e-4; p->rotation_epsilon = 2e-3; p->optimizer = QN_OPT_LM;
+  p->lm_max_iterations = 10; p->lm_init_lambda_factor = 1e-9; p->force_iterations = 0;
+  p->ransac_iterations = 0; p->ransac_outlier_threshold = 0.05; p->euclidean_fitness_epsilon = -DBL_MAX;
+}
+
+static int alloc_cloud(qn_ctx* c, CloudBuf& b) {
+  HIPCHK(c, hipMalloc(&b.raw, sizeof(float4) * c->max_points));
+  HIPCHK(c, hipMalloc(&b.sorted, sizeof(float4) * c->max_points));
+  HIPCHK(c, hipMalloc(&b.cell_of_pt, sizeof(uint32_t) * c->max_points));
+  HIPCHK(c, hipMalloc(&b.cell_start, sizeof(uint32_t) * ((size_t)c->max_cells + 1)));
+  HIPCHK(c, hipMalloc(&b.counts, sizeof(uint32_t) * ((size_t)c->max_cells + 1)));
+  HIPCHK(c, hipMalloc(&b.cov, sizeof(double) * 6 * c->max_points));
+  return QN_OK;
+}
+
+extern "C" int qn_ctx_create(int device, uint32_t max_points, qn_ctx** out) {
+  if (!out || max_points == 0) return QN_ERR_INVALID_ARG;
+  *out = nullptr;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) return QN_ERR_NO_DEVICE;
+  qn_ctx* c = new qn_ctx();
+  c->device = device; c->max_points = max_points;
+  // cell table capacity: ~16 cells per point, within [256 Ki, 8 Mi] cells
+  size_t mc = (size_t)max_points * 16; if (mc < (1u << 18)) mc = 1u << 18; if (mc > (1u << 23)) mc = 1u << 23;
+  c->max_cells = (uint32_t)mc;
+  qn_gicp_default_params(&c->params);
+  int rc = QN_OK;
+  auto fail = [&](int code) { qn_ctx_destroy(c); return code; };
+  if (hipSetDevice(device) != hipSuccess) return fail(QN_ERR_NO_DEVICE);
+  if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) return fail(QN_ERR_HIP);
+  if ((rc = alloc_cloud(c, c->cloud[0])) != QN_OK) return fail(rc);
+  if ((rc = alloc_cloud(c, c->cloud[1])) != QN_OK) return fail(rc);
+#define CA(call) if ((call) != hipSuccess) return fail(QN_ERR_HIP)
+  CA(hipMalloc(&c->staging, (size_t)max_points * 32));
+  CA(hipMalloc(&c->scan_sums, sizeof(uint32_t) * (c->max_cells / (QN_BLOCK * QN_SCAN_ITEMS) + 2)));
+  CA(hipMalloc(&c->bbox, sizeof(BBoxOut)));
+  CA(hipMalloc(&c->state, sizeof(GicpState)));
+  CA(hipMalloc(&c->partials, sizeof(double) * QN_ACC_BLOCKS * QN_NPART));
+  CA(hipMalloc(&c->trace, sizeof(qn_iter_trace) * QN_MAX_TRACE));
+  CA(hipMalloc(&c->corr, sizeof(int32_t) * max_points));
+  CA(hipMalloc(&c->sqd, sizeof(float) * max_points));
+  CA(hipMalloc(&c->sqd_fit, sizeof(float) * max_points));
+  CA(hipMalloc(&c->fb_list, sizeof(uint2) * max_points));
+  CA(hipMalloc(&c->fb_count2, sizeof(uint32_t)));
+  CA(hipMalloc(&c->aligned, sizeof(float4) * max_points));
+  CA(hipMalloc(&c->pose_tmp, sizeof(double) * 16));
+  CA(hipMalloc(&c->guess_tmp, sizeof(float) * 16));
+  CA(hipHostMalloc(&c->result_host, sizeof(ResultBlock), hipHostMallocDefault));
+  CA(hipHostMalloc(&c->bbox_host, sizeof(BBoxOut), hipHostMallocDefault));
+  CA(hipHostMalloc(&c->scalar_host, 64 * sizeof(double), hipHostMallocDefault));
+  CA(hipMemsetAsync(c->state, 0, sizeof(GicpState), c->stream));
+  CA(hipStreamSynchronize(c->stream));
+#undef CA
+  *out = c;
+  return QN_OK;
+}
+
+extern "C" void qn_ctx_destroy(qn_ctx* c) {
+  if (!c) return;
+  hipSetDevice(c->device);
+  if (c->stream) hipStreamSynchronize(c->stream);
+  c->prof_collect();
+  for (int w = 0; w < 2; w++) { CloudBuf& b = c->cloud[w]; hipFree(b.raw); hipFree(b.sorted); hipFree(b.cell_of_pt); hipFree(b.cell_start); hipFree(b.counts); hipFree(b.cov); }
+  hipFree(c->staging); hipFree(c->scan_sums); hipFree(c->bbox); hipFree(c->state); hipFree(c->partials); hipFree(c->trace);
+  hipFree(c->corr); hipFree(c->sqd); hipFree(c->sqd_fit); hipFree(c->fb_list); hipFree(c->fb_count2); hipFree(c->aligned);
+  hipFree(c->pose_tmp); hipFree(c->guess_tmp); hipFree(c->dbg_knn_idx); hipFree(c->dbg_knn_d2);
+  if (c->result_host) hipHostFree(c->result_host);
+  if (c->bbox_host) hipHostFree(c->bbox_host);
+  if (c->scalar_host) hipHostFree(c->scalar_host);
+  if (c->stream) hipStreamDestroy(c->stream);
+  delete c;
+}
+
+extern "C" void* qn_ctx_stream(qn_ctx* c) { return c ? (void*)c->stream : nullptr; }
+extern "C" int qn_ctx_synchronize(qn_ctx* c) {
+  if (!c) return QN_ERR_INVALID_ARG;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  c->prof_collect();
+  return QN_OK;
+}
+
+extern "C" int qn_gicp_set_params(qn_ctx* c, const qn_gicp_params* p) {
+  if (!c || !p) return QN_ERR_INVALID_ARG;
+  if (p->k_correspondences < 1 || p->k_correspondences > 32 || p->max_iterations < 0 || p->lm_max_iterations < 1 ||
+      (p->optimizer != QN_OPT_LM && p->optimizer != QN_OPT_GN) || !(p->max_corr_dist > 0)) return QN_ERR_INVALID_ARG;
+  if (p->k_correspondences != c->params.k_correspondences) { c->cloud[0].has_cov = c->cloud[1].has_cov = false; }
+  c->params = *p;
+  return QN_OK;
+}
+
+static GicpConfig make_cfg(const qn_ctx* c) {
+  GicpConfig g; const qn_gicp_params& p = c->params;
+  g.k = p.k_correspondences; g.max_iterations = p.max_iterations; g.optimizer = p.optimizer; g.lm_max_iterations = p.lm_max_iterations;
+  g.force_iterations = p.force_iterations; g.max_corr_dist_sq = p.max_corr_dist * p.max_corr_dist;
+  g.transformation_epsilon = p.transformation_epsilon; g.rotation_epsilon = p.rotation_epsilon; g.lm_init_lambda_factor = p.lm_init_lambda_factor;
+  return g;
+}
+
+// ------------------------------------------------------------------ setInputSource / setInputTarget
+// K1: pack -> bbox -> (host picks the cell size) -> count -> exclusive scan -> scatter.
+static int build_grid(qn_ctx* c, CloudBuf& b) {
+  const uint32_t n = b.n;
+  hipStream_t s = c->stream;
+  BBoxOut init; for (int d = 0; d < 3; d++) { init.mn[d] = 0x7fffffff; init.mx[d] = (int)0x80000000; } init.nonfinite = 0;
+  *c->bbox_host = init;
+  HIPCHK(c, hipMemcpyAsync(c->bbox, c->bbox_host, sizeof(BBoxOut), hipMemcpyHostToDevice, s));
+  { ProfScope ps(c, QN_K_GRID_BUILD);
+    hipLaunchKernelGGL(k_bbox, dim3(std::min<uint32_t>((n + QN_BLOCK - 1) / QN_BLOCK, 512)), dim3(QN_BLOCK), 0, s, b.raw, n, c->bbox); }
+  HIPCHK(c, hipMemcpyAsync(c->bbox_host, c->bbox, sizeof(BBoxOut), hipMemcpyDeviceToHost, s));
+  HIPCHK(c, hipStreamSynchronize(s));
+  if (c->bbox_host->nonfinite) { c->last_error = "cloud contains non-finite coordinates (is_dense == false clouds are not supported)"; return QN_ERR_INVALID_ARG; }
+  float mn[3], mx[3];
+  for (int d = 0; d < 3; d++) { mn[d] = ord2f(c->bbox_host->mn[d]); mx[d] = ord2f(c->bbox_host->mx[d]); }
+  // cell edge: ~4 points per ground-plane cell (the clouds are voxel-grid centroids sampled on surfaces,
+  // loop_closure.cpp:107), then coarsened until the dense cell table fits max_cells.
+  double L[3]; for (int d = 0; d < 3; d++) L[d] = std::max((double)mx[d] - (double)mn[d], 0.0);
+  double Lmax = std::max(L[0], std::max(L[1], L[2]));
+  double area = std::max(L[0] * L[1], std::max(L[0] * L[2], L[1] * L[2]));
+  double cell = std::sqrt(4.0 * area / (double)n);
+  cell = std::max(cell, std::max(Lmax / 2048.0, 1e-6));
+  if (c->cell_override > 0) cell = c->cell_override;
+  int dims[3];
+  for (int iter = 0; iter < 64; iter++) {
+    double tot = 1;
+    for (int d = 0; d < 3; d++) { dims[d] = (int)std::floor(L[d] / cell) + 1; tot *= dims[d]; }
+    if (tot <= (double)c->max_cells) break;
+    cell *= std::max(std::cbrt(tot / (double)c->max_cells), 1.02);
+  }
+  GridView& g = b.grid;
+  g.pts = b.sorted; g.cell_start = b.cell_start; g.ox = mn[0]; g.oy = mn[1]; g.oz = mn[2];
+  g.cell = (float)cell; g.inv_cell = 1.0f / g.cell; g.nx = dims[0]; g.ny = dims[1]; g.nz = dims[2]; g.n = n;
+  float amax = 0; for (int d = 0; d < 3; d++) amax = std::max(amax, std::max(std::fabs(mn[d]), std::fabs(mx[d])));
+  g.eps = 1e-3f * g.cell + 1e-6f * (amax + (float)Lmax);
+  const uint32_t ncells = (uint32_t)dims[0] * dims[1] * dims[2];
+  b.ncells = ncells;
+  const uint32_t nb = (n + QN_BLOCK - 1) / QN_BLOCK;
+  const uint32_t sb = (ncells + QN_BLOCK * QN_SCAN_ITEMS - 1) / (QN_BLOCK * QN_SCAN_ITEMS);
+  HIPCHK(c, hipMemsetAsync(b.counts, 0, sizeof(uint32_t) * ncells, s));
+  { ProfScope ps(c, QN_K_GRID_BUILD);
+    hipLaunchKernelGGL(k_cell_count, dim3(nb), dim3(QN_BLOCK), 0, s, b.raw, n, g, b.counts, b.cell_of_pt);
+    hipLaunchKernelGGL(k_scan_block, dim3(sb), dim3(QN_BLOCK), 0, s, b.counts, ncells, b.cell_start, c->scan_sums);
+    hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(QN_BLOCK), 0, s, c->scan_sums, sb);
+    hipLaunchKernelGGL(k_scan_add, dim3(sb), dim3(QN_BLOCK), 0, s, b.cell_start, ncells, c->scan_sums, n);
+    hipLaunchKernelGGL(k_scatter, dim3(nb), dim3(QN_BLOCK), 0, s, b.raw, n, b.cell_of_pt, b.cell_start, b.counts, b.sorted); }
+  HIPCHK(c, hipGetLastError());
+  b.has_grid = true; b.has_cov = false;
+  return QN_OK;
+}
+
+static int set_cloud(qn_ctx* c, int which, const float* xyz, uint32_t n, uint32_t stride, bool on_device) {
+  if (!c || (which != 0 && which != 1)) return QN_ERR_INVALID_ARG;
+  CloudBuf& b = c->cloud[which];
+  b.n = 0; b.has_grid = b.has_cov = false;
+  if (n == 0) return QN_ERR_EMPTY_CLOUD;
+  if (!xyz || stride < 12 || (stride & 3)) return QN_ERR_INVALID_ARG;
+  if (n > c->max_points) return QN_ERR_CAPACITY;
+  HIPCHK(c, hipSetDevice(c->device));
+  hipStream_t s = c->stream;
+  const char* dsrc = (const char*)xyz;
+  if (!on_device) {
+    if (stride <= 32) {   // one contiguous H2D of the caller's buffer; PointXYZI's intensity half is dropped by k_pack_points
+      HIPCHK(c, hipMemcpyAsync(c->staging, xyz, (size_t)(n - 1) * stride + 12, hipMemcpyHostToDevice, s));
+    } else {              // fat point types: only the leading 16 B of each point cross PCIe
+      HIPCHK(c, hipMemcpy2DAsync(c->staging, 16, xyz, stride, 16, n, hipMemcpyHostToDevice, s));
+      stride = 16;
+    }
+    dsrc = (const char*)c->staging;
+  }
+  b.n = n;
+  hipLaunchKernelGGL(k_pack_points, dim3((n + QN_BLOCK - 1) / QN_BLOCK), dim3(QN_BLOCK), 0, s, dsrc, stride, n, b.raw);
+  return build_grid(c, b);
+}
+
+extern "C" int qn_gicp_set_source(qn_ctx* c, const float* xyz, uint32_t n, uint32_t stride) { return set_cloud(c, QN_SOURCE, xyz, n, stride, false); }
+extern "C" int qn_gicp_set_target(qn_ctx* c, const float* xyz, uint32_t n, uint32_t stride) { return set_cloud(c, QN_TARGET, xyz, n, stride, false); }
+extern "C" int qn_gicp_set_source_device(qn_ctx* c, const float* xyz, uint32_t n, uint32_t stride) { return set_cloud(c, QN_SOURCE, xyz, n, stride, true); }
+extern "C" int qn_gicp_set_target_device(qn_ctx* c, const float* xyz, uint32_t n, uint32_t stride) { return set_cloud(c, QN_TARGET, xyz, n, stride, true); }
+
+// ------------------------------------------------------------------ calculateSource/TargetCovariances
+template <int KMAX>
+static void launch_knn_cov(qn_ctx* c, CloudBuf& b, int k, int32_t* kidx, float* kd2) {
+  hipStream_t s = c->stream;
+  const uint32_t nb = (b.n + QN_BLOCK - 1) / QN_BLOCK;
+  { ProfScope ps(c, QN_K_KNN_COV);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_knn_cov<KMAX>), dim3(nb), dim3(QN_BLOCK), 0, s, b.grid, b.raw, k, c->margin_knn, b.cov, kidx, kd2, c->fb_list, c->fb_count2);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_knn_cov_fallback<KMAX>), dim3(std::min<uint32_t>(nb, 1024)), dim3(QN_BLOCK), 0, s, b.grid, b.raw, k, c->margin_knn, b.cov, kidx, kd2, c->fb_list, c->fb_count2); }
+}
+static int compute_cov(qn_ctx* c, int which, int32_t* kidx, float* kd2) {
+  if (!c || (which != 0 && which != 1)) return QN_ERR_INVALID_ARG;
+  CloudBuf& b = c->cloud[which];
+  if (!b.has_grid) return b.n == 0 ? QN_ERR_EMPTY_CLOUD : QN_ERR_NOT_READY;
+  HIPCHK(c, hipSetDevice(c->device));
+  const int k = c->params.k_correspondences;
+  HIPCHK(c, hipMemsetAsync(c->fb_count2, 0, sizeof(uint32_t), c->stream));
+  if (k <= 16) launch_knn_cov<16>(c, b, k, kidx, kd2);
+  else if (k <= 24) launch_knn_cov<24>(c, b, k, kidx, kd2);
+  else launch_knn_cov<32>(c, b, k, kidx, kd2);
+  HIPCHK(c, hipGetLastError());
+  b.has_cov = true;
+  return QN_OK;
+}
+extern "C" int qn_gicp_compute_covariances(qn_ctx* c, int which) { return compute_cov(c, which, nullptr, nullptr); }
+
+// ------------------------------------------------------------------ align
+static void enqueue_nn(qn_ctx* c, int mode /*0 align, 1 fitness*/, float* sqd_out) {
+  hipStream_t s = c->stream;
+  CloudBuf &S = c->cloud[0], &T = c->cloud[1];
+  const uint32_t nb = (S.n + QN_BLOCK - 1) / QN_BLOCK;
+  const double thr2 = c->params.max_corr_dist * c->params.max_corr_dist;
+  uint32_t* fbc = &c->state->fb_count;
+  const uint32_t fbb = std::min<uint32_t>((S.n + 3) / 4, 2048);
+  if (mode == 0) {
+    { ProfScope ps(c, QN_K_NN_SEARCH);
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(k_nn_search<0>), dim3(nb), dim3(QN_BLOCK), 0, s, S.grid, T.grid, c->state, thr2, c->margin_nn, c->corr, sqd_out, c->fb_list, fbc); }
+    { ProfScope ps(c, QN_K_NN_FALLBACK);
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(k_nn_fallback<0>), dim3(fbb), dim3(QN_BLOCK), 0, s, S.grid, T.grid, c->state, thr2, c->margin_nn, c->corr, sqd_out, c->fb_list, fbc); }
+  } else {
+    { ProfScope ps(c, QN_K_FITNESS);
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(k_nn_search<1>), dim3(nb), dim3(QN_BLOCK), 0, s, S.grid, T.grid, c->state, thr2, c->margin_nn, c->corr, sqd_out, c->fb_list, fbc);
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(k_nn_fallback<1>), dim3(fbb), dim3(QN_BLOCK), 0, s, S.grid, T.grid, c->state, thr2, c->margin_nn, c->corr, sqd_out, c->fb_list, fbc); }
+  }
+}
+static void enqueue_accumulate(qn_ctx* c) {
+  ProfScope ps(c, QN_K_ACCUMULATE);
+  CloudBuf &S = c->cloud[0], &T = c->cloud[1];
+  hipLaunchKernelGGL(k_accumulate, dim3(QN_ACC_BLOCKS), dim3(QN_BLOCK), 0, c->stream, S.raw, S.n, T.raw, S.cov, T.cov, c->corr, c->state, c->partials);
+}
+static void enqueue_solve(qn_ctx* c, int mode) {
+  ProfScope ps(c, QN_K_SOLVE);
+  hipLaunchKernelGGL(k_solve, dim3(1), dim3(QN_BLOCK), 0, c->stream, c->state, c->partials, make_cfg(c), c->trace, mode);
+}
+// one "tick" of the device-side state machine: [NN pass A, NN pass B, accumulate, solve]
+static void enqueue_tick(qn_ctx* c) { enqueue_nn(c, 0, c->sqd); enqueue_accumulate(c); enqueue_solve(c, 0); }
+static void enqueue_epilogue(qn_ctx* c, double max_range) {       // fitness + output cloud; each kernel is a no-op until phase == done
+  enqueue_nn(c, 1, c->sqd_fit);
+  { ProfScope ps(c, QN_K_FITNESS);
+    hipLaunchKernelGGL(k_fitness_reduce, dim3(1), dim3(1024), 0, c->stream, c->sqd_fit, c->cloud[0].n, max_range, c->state, 1); }
+  { ProfScope ps(c, QN_K_TRANSFORM);
+    hipLaunchKernelGGL(k_transform_cloud, dim3((c->cloud[0].n + QN_BLOCK - 1) / QN_BLOCK), dim3(QN_BLOCK), 0, c->stream, c->cloud[0].raw, c->cloud[0].n, c->state, c->aligned, 1); }
+  hipLaunchKernelGGL(k_finalize, dim3(1), dim3(64), 0, c->stream, c->state, c->result_host);
+}
+
+static int ready(qn_ctx* c) {
+  if (!c) return QN_ERR_INVALID_ARG;
+  for (int w = 0; w < 2; w++) { if (c->cloud[w].n == 0) return QN_ERR_EMPTY_CLOUD; if (!c->cloud[w].has_grid || !c->cloud[w].has_cov) return QN_ERR_NOT_READY; }
+  return QN_OK;
+}
+
+extern "C" int qn_gicp_align(qn_ctx* c, const float guess[16], qn_gicp_result* out) {
+  int rc = ready(c); if (rc != QN_OK) return rc;
+  if (!out) return QN_ERR_INVALID_ARG;
+  HIPCHK(c, hipSetDevice(c->device));
+  hipStream_t s = c->stream;
+  const qn_gicp_params& p = c->params;
+  if (guess) HIPCHK(c, hipMemcpyAsync(c->guess_tmp, guess, sizeof(float) * 16, hipMemcpyHostToDevice, s));
+  hipLaunchKernelGGL(k_init_state, dim3(1), dim3(64), 0, s, c->state, c->guess_tmp, guess ? 1 : 0, 0);
+  const int maxit = p.force_iterations > 0 ? p.force_iterations : p.max_iterations;
+  if (maxit == 0) hipLaunchKernelGGL(k_set_pose, dim3(1), dim3(64), 0, s, c->state, c->pose_tmp, 2, 2);   // which=2: touch nothing, phase = done
+  // Ticks are enqueued in chunks with NO host round trip inside a chunk; kernels of ticks past
+  // convergence exit on the `phase` word.  LM needs two ticks per outer iteration (linearize, trial error).
+  const int per_outer = p.optimizer == QN_OPT_LM ? 2 : 1;
+  int chunk = p.force_iterations > 0 ? maxit * per_outer : c->ticks_per_chunk;
+  long budget = (long)maxit * (p.optimizer == QN_OPT_LM ? (p.lm_max_iterations + 1) : 1) + 2;
+  c->result_host->phase = 0;
+  for (;;) {
+    for (int t = 0; t < chunk; t++) enqueue_tick(c);
+    enqueue_epilogue(c, DBL_MAX);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(s));
+    budget -= chunk;
+    if (c->result_host->phase == 2) break;
+    if (budget <= 0) { c->last_error = "align: device state machine did not terminate"; return QN_ERR_HIP; }
+  }
+  c->prof_collect();
+  *out = c->result_host->r;
+  c->trace_len = c->result_host->trace_len;
+  c->aligned_valid = true;
+  return QN_OK;
+}
+
+extern "C" int qn_gicp_fitness(qn_ctx* c, double max_range, double* score) {
+  int rc = ready(c); if (rc != QN_OK) return rc;
+  if (!score) return QN_ERR_INVALID_ARG;
+  HIPCHK(c, hipSetDevice(c->device));
+  enqueue_nn(c, 1, c->sqd_fit);
+  hipLaunchKernelGGL(k_fitness_reduce, dim3(1), dim3(1024), 0, c->stream, c->sqd_fit, c->cloud[0].n, max_range, c->state, 1);
+  hipLaunchKernelGGL(k_finalize, dim3(1), dim3(64), 0, c->stream, c->state, c->result_host);
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  c->prof_collect();
+  if (c->result_host->phase != 2) return QN_ERR_NOT_READY;
+  *score = c->result_host->r.fitness;
+  return QN_OK;
+}
+
+extern "C" int qn_gicp_transformed_source(qn_ctx* c, float* xyz_out, uint32_t stride) {
+  if (!c || !xyz_out || stride < 12 || (stride & 3)) return QN_ERR_INVALID_ARG;
+  if (!c->aligned_valid) return QN_ERR_NOT_READY;
+  HIPCHK(c, hipSetDevice(c->device));
+  const size_t w = stride >= 16 ? 16 : 12;
+  HIPCHK(c, hipMemcpy2DAsync(xyz_out, stride, c->aligned, 16, w, c->cloud[0].n, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return QN_OK;
+}
+
+extern "C" int qn_gicp_get_trace(qn_ctx* c, qn_iter_trace* out, uint32_t cap, uint32_t* n) {
+  if (!c || !out || !n) return QN_ERR_INVALID_ARG;
+  uint32_t m = std::min(cap, c->trace_len);
+  HIPCHK(c, hipSetDevice(c->device));
+  if (m) HIPCHK(c, hipMemcpy(out, c->trace, sizeof(qn_iter_trace) * m, hipMemcpyDeviceToHost));
+  *n = m;
+  return QN_OK;
+}
+
+// LoopClosure::icpAlignment (loop_closure.cpp:110-136)
+static int icp_alignment(qn_ctx* c, const float* src, uint32_t ns, const float* dst, uint32_t nt, uint32_t stride, double thr,
+                         qn_gicp_result* out, int* valid, bool dev) {
+  if (!c || !out || !valid) return QN_ERR_INVALID_ARG;
+  *valid = 0;
+  memset(out, 0, sizeof(*out)); out->fitness = DBL_MAX;
+  for (int i = 0; i < 4; i++) { out->T[5 * i] = 1.f; out->T64[5 * i] = 1.0; }
+  int rc;
+  if ((rc = set_cloud(c, QN_SOURCE, src, ns, stride, dev)) != QN_OK) return rc;      // :120
+  if ((rc = qn_gicp_compute_covariances(c, QN_SOURCE)) != QN_OK) return rc;         // :121
+  if ((rc = set_cloud(c, QN_TARGET, dst, nt, stride, dev)) != QN_OK) return rc;     // :122
+  if ((rc = qn_gicp_compute_covariances(c, QN_TARGET)) != QN_OK) return rc;         // :123
+  if ((rc = qn_gicp_align(c, nullptr, out)) != QN_OK) return rc;                    // :124, :127
+  *valid = (out->converged && out->fitness < thr) ? 1 : 0;                          // :129
+  return QN_OK;
+}
+extern "C" int qn_icp_alignment(qn_ctx* c, const float* src, uint32_t ns, const float* dst, uint32_t nt, uint32_t stride, double thr, qn_gicp_result* out, int* valid) {
+  return icp_alignment(c, src, ns, dst, nt, stride, thr, out, valid, false);
+}
+extern "C" int qn_icp_alignment_device(qn_ctx* c, const float* src, uint32_t ns, const float* dst, uint32_t nt, uint32_t stride, double thr, qn_gicp_result* out, int* valid) {
+  return icp_alignment(c, src, ns, dst, nt, stride, thr, out, valid, true);
+}
+
+// ------------------------------------------------------------------ per-stage read-backs for parity tests
+extern "C" int qn_gicp_get_covariances(qn_ctx* c, int which, double* out9) {
+  if (!c || !out9 || (which != 0 && which != 1)) return QN_ERR_INVALID_ARG;
+  CloudBuf& b = c->cloud[which];
+  if (!b.has_cov) return QN_ERR_NOT_READY;
+  HIPCHK(c, hipSetDevice(c->device));
+  std::vector<double> h((size_t)b.n * 6);
+  HIPCHK(c, hipMemcpyAsync(h.data(), b.cov, sizeof(double) * 6 * b.n, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  for (uint32_t i = 0; i < b.n; i++) {
+    const double* s = &h[(size_t)i * 6]; double* o = out9 + (size_t)i * 9;
+    o[0] = s[0]; o[1] = s[1]; o[2] = s[2]; o[3] = s[1]; o[4] = s[3]; o[5] = s[4]; o[6] = s[2]; o[7] = s[4]; o[8] = s[5];
+  }
+  return QN_OK;
+}
+
+extern "C" int qn_gicp_knn(qn_ctx* c, int which, int k, int32_t* idx_out, float* d2_out) {
+  if (!c || !idx_out || !d2_out || (which != 0 && which != 1) || k < 1 || k > 32) return QN_ERR_INVALID_ARG;
+  CloudBuf& b = c->cloud[which];
+  if (!b.has_grid) return QN_ERR_NOT_READY;
+  HIPCHK(c, hipSetDevice(c->device));
+  hipFree(c->dbg_knn_idx); hipFree(c->dbg_knn_d2); c->dbg_knn_idx = nullptr; c->dbg_knn_d2 = nullptr;
+  HIPCHK(c, hipMalloc(&c->dbg_knn_idx, sizeof(int32_t) * (size_t)b.n * k));
+  HIPCHK(c, hipMalloc(&c->dbg_knn_d2, sizeof(float) * (size_t)b.n * k));
+  const int ksave = c->params.k_correspondences; const bool had = b.has_cov;
+  c->params.k_correspondences = k;
+  int rc = compute_cov(c, which, c->dbg_knn_idx, c->dbg_knn_d2);
+  c->params.k_correspondences = ksave;
+  b.has_cov = had && (k == ksave);
+  if (rc != QN_OK) return rc;
+  HIPCHK(c, hipMemcpyAsync(idx_out, c->dbg_knn_idx, sizeof(int32_t) * (size_t)b.n * k, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(d2_out, c->dbg_knn_d2, sizeof(float) * (size_t)b.n * k, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  c->prof_collect();
+  return QN_OK;
+}
+
+extern "C" int qn_gicp_linearize(qn_ctx* c, const double T[16], double H[36], double b6[6], double* err, int32_t* corr_out, float* sqd_out) {
+  int rc = ready(c); if (rc != QN_OK) return rc;
+  if (!T || !H || !b6 || !err) return QN_ERR_INVALID_ARG;
+  HIPCHK(c, hipSetDevice(c->device));
+  hipStream_t s = c->stream;
+  HIPCHK(c, hipMemcpyAsync(c->pose_tmp, T, sizeof(double) * 16, hipMemcpyHostToDevice, s));
+  hipLaunchKernelGGL(k_set_pose, dim3(1), dim3(64), 0, s, c->state, c->pose_tmp, 0, 0);
+  enqueue_nn(c, 0, c->sqd); enqueue_accumulate(c); enqueue_solve(c, 1);
+  GicpState* hs = (GicpState*)malloc(sizeof(GicpState));
+  hipError_t e = hipMemcpyAsync(hs, c->state, sizeof(GicpState), hipMemcpyDeviceToHost, s);
+  if (e == hipSuccess && corr_out) e = hipMemcpyAsync(corr_out, c->corr, sizeof(int32_t) * c->cloud[0].n, hipMemcpyDeviceToHost, s);
+  if (e == hipSuccess && sqd_out) e = hipMemcpyAsync(sqd_out, c->sqd, sizeof(float) * c->cloud[0].n, hipMemcpyDeviceToHost, s);
+  if (e == hipSuccess) e = hipStreamSynchronize(s);
+  if (e != hipSuccess) { free(hs); c->set_error("linearize readback", e, __LINE__); return QN_ERR_HIP; }
+  memcpy(H, hs->H, sizeof(double) * 36); memcpy(b6, hs->b, sizeof(double) * 6); *err = hs->y0;
+  free(hs);
+  c->prof_collect();
+  return QN_OK;
+}
+
+extern "C" int qn_gicp_compute_error(qn_ctx* c, const double T[16], double* err) {
+  int rc = ready(c); if (rc != QN_OK) return rc;
+  if (!T || !err) return QN_ERR_INVALID_ARG;
+  HIPCHK(c, hipSetDevice(c->device));
+  hipStream_t s = c->stream;
+  HIPCHK(c, hipMemcpyAsync(c->pose_tmp, T, sizeof(double) * 16, hipMemcpyHostToDevice, s));
+  hipLaunchKernelGGL(k_set_pose, dim3(1), dim3(64), 0, s, c->state, c->pose_tmp, 1, 1);
+  enqueue_accumulate(c); enqueue_solve(c, 2);
+  HIPCHK(c, hipMemcpyAsync(c->scalar_host, &c->state->yi, sizeof(double), hipMemcpyDeviceToHost, s));
+  HIPCHK(c, hipStreamSynchronize(s));
+  *err = c->scalar_host[0];
+  c->prof_collect();
+  return QN_OK;
+}
+
+// ------------------------------------------------------------------ profiling hooks
+extern "C" int qn_prof_enable(qn_ctx* c, int on) { if (!c) return QN_ERR_INVALID_ARG; c->prof_on = on != 0; return QN_OK; }
+extern "C" int qn_prof_reset(qn_ctx* c) { if (!c) return QN_ERR_INVALID_ARG; c->prof_collect(); for (auto& s : c->stats) { s.total_ms = 0; s.launches = 0; } return QN_OK; }
+extern "C" int qn_prof_get(qn_ctx* c, int fam, qn_kernel_stat* out) {
+  if (!c || !out || fam < 0 || fam >= QN_K_COUNT) return QN_ERR_INVALID_ARG;
+  c->prof_collect(); *out = c->stats[fam]; return QN_OK;
+}
+// test/tuning knobs (not part of the reference surface)
+extern "C" int qn_debug_set(qn_ctx* c, const char* key, double v) {
+  if (!c || !key) return QN_ERR_INVALID_ARG;
+  std::string k(key);
+  if (k == "cell") { c->cell_override = v; c->cloud[0].has_grid = c->cloud[1].has_grid = false; }
+  else if (k == "margin_nn") c->margin_nn = (int)v;
+  else if (k == "margin_knn") c->margin_knn = (int)v;
+  else if (k == "ticks_per_chunk") c->ticks_per_chunk = std::max(1, (int)v);
+  else return QN_ERR_INVALID_ARG;
+  return QN_OK;
+}
+extern "C" int qn_debug_get_grid(qn_ctx* c, int which, double out[8]) {
+  if (!c || (which != 0 && which != 1) || !c->cloud[which].has_grid) return QN_ERR_INVALID_ARG;
+  const GridView& g = c->cloud[which].grid;
+  out[0] = g.ox; out[1] = g.oy; out[2] = g.oz; out[3] = g.cell; out[4] = g.nx; out[5] = g.ny; out[6] = g.nz; out[7] = g.eps;
+  return QN_OK;
+}

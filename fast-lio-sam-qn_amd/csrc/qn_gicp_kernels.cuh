@@ -1,0 +1,593 @@
+// qn_gicp_kernels.cuh - gfx950 kernels of the Nano-GICP path.
+// Reference behaviour restated per kernel: SURVEY.md Appendix A.1; call sites
+// fast_lio_sam_qn/src/loop_closure.cpp:120-133.  No MFMA anywhere: the path has no dense
+// contraction - it is gather / scan / reduce work bound by memory latency and LDS bandwidth.
+#pragma once
+#include "qn_device.cuh"
+#include "../../include/qn_engine.h"
+
+namespace qn {
+
+#define QN_BLOCK 256
+#define QN_NPART 28            // 21 (upper H) + 6 (b) + 1 (cost)
+#define QN_ACC_BLOCKS 256      // fixed grid of the accumulate kernel -> fixed, deterministic reduction tree
+#define QN_MAX_TRACE 1024
+
+// Device-resident optimiser state: the LM / GN controller of LsqRegistration runs
+// entirely on the GPU (k_solve), so an align() needs no per-iteration host round trip.
+struct GicpState {
+  double x0[16], xi[16], delta[16];
+  double H[36], b[6], d[6];
+  double y0, yi, den;
+  double lambda, nu;
+  double final_H[36];
+  double fitness;
+  int outer, inner, phase, converged, lm_failed;   // phase: 0 = linearize at x0, 1 = error at xi, 2 = done
+  uint32_t fb_count;                                // pass-B worklist length
+  uint32_t trace_len;
+  uint32_t pad;
+};
+
+struct GicpConfig {                                 // by-value kernel argument
+  int k, max_iterations, optimizer, lm_max_iterations, force_iterations;
+  double max_corr_dist_sq, transformation_epsilon, rotation_epsilon, lm_init_lambda_factor;
+};
+
+// ------------------------------------------------------------------ K1 grid build
+struct BBoxOut { int mn[3], mx[3]; uint32_t nonfinite; };
+
+__device__ __forceinline__ int f2ord(float f) { int i = __float_as_int(f); return i >= 0 ? i : i ^ 0x7fffffff; }
+__host__ __device__ __forceinline__ float ord2f(int i) { union { int i; float f; } u; u.i = i >= 0 ? i : i ^ 0x7fffffff; return u.f; }
+
+// pack a strided xyz(+junk) host/device layout into float4 (x, y, z, 1) - PointXYZI's data[3] = 1
+__global__ void k_pack_points(const char* __restrict__ in, uint32_t stride, uint32_t n, float4* __restrict__ out) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float* p = (const float*)(in + (size_t)i * stride);
+  out[i] = make_float4(p[0], p[1], p[2], 1.0f);
+}
+
+__global__ void k_bbox(const float4* __restrict__ pts, uint32_t n, BBoxOut* out) {
+  int mn[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff}, mx[3] = {(int)0x80000000, (int)0x80000000, (int)0x80000000};
+  uint32_t bad = 0;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    float4 p = pts[i];
+    if (!(isfinite(p.x) && isfinite(p.y) && isfinite(p.z))) { bad++; continue; }
+    int ox = f2ord(p.x), oy = f2ord(p.y), oz = f2ord(p.z);
+    mn[0] = min(mn[0], ox); mn[1] = min(mn[1], oy); mn[2] = min(mn[2], oz);
+    mx[0] = max(mx[0], ox); mx[1] = max(mx[1], oy); mx[2] = max(mx[2], oz);
+  }
+#pragma unroll
+  for (int d = 0; d < 3; d++) { mn[d] = wave_min_i(mn[d]); mx[d] = wave_max_i(mx[d]); }
+  bad = (uint32_t)wave_max_i((int)bad) ? 1u : 0u;
+  if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+    for (int d = 0; d < 3; d++) { atomicMin(&out->mn[d], mn[d]); atomicMax(&out->mx[d], mx[d]); }
+    if (bad) atomicAdd(&out->nonfinite, 1u);
+  }
+}
+
+__global__ void k_cell_count(const float4* __restrict__ pts, uint32_t n, GridView g, uint32_t* __restrict__ counts, uint32_t* __restrict__ cell_of_pt) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float4 p = pts[i];
+  int cx = cell_coord(p.x, g.ox, g.inv_cell, g.nx), cy = cell_coord(p.y, g.oy, g.inv_cell, g.ny), cz = cell_coord(p.z, g.oz, g.inv_cell, g.nz);
+  uint32_t c = ((uint32_t)cz * g.ny + cy) * g.nx + cx;
+  cell_of_pt[i] = c;
+  atomicAdd(&counts[c], 1u);
+}
+
+// exclusive scan of counts[0..m) -> out[0..m], out[m] = total.  3 kernels, 4096 items per block.
+#define QN_SCAN_ITEMS 16
+__global__ void k_scan_block(const uint32_t* __restrict__ in, uint32_t m, uint32_t* __restrict__ out, uint32_t* __restrict__ block_sums) {
+  __shared__ uint32_t wsum[QN_BLOCK / 64];
+  const uint32_t base = (blockIdx.x * QN_BLOCK + threadIdx.x) * QN_SCAN_ITEMS;
+  uint32_t v[QN_SCAN_ITEMS], s = 0;
+#pragma unroll
+  for (int j = 0; j < QN_SCAN_ITEMS; j++) { v[j] = (base + j < m) ? in[base + j] : 0u; s += v[j]; }
+  // inclusive wave scan of s
+  uint32_t inc = s;
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) { uint32_t t = __shfl_up(inc, o); if (lane >= o) inc += t; }
+  if (lane == 63) wsum[wid] = inc;
+  __syncthreads();
+  uint32_t woff = 0;
+  for (int w = 0; w < wid; w++) woff += wsum[w];
+  uint32_t run = woff + inc - s;
+#pragma unroll
+  for (int j = 0; j < QN_SCAN_ITEMS; j++) { if (base + j < m) out[base + j] = run; run += v[j]; }
+  if (threadIdx.x == QN_BLOCK - 1) block_sums[blockIdx.x] = woff + inc;
+}
+__global__ void k_scan_top(uint32_t* block_sums, uint32_t nb) {          // single block, serial over chunks of 256
+  __shared__ uint32_t wsum[QN_BLOCK / 64];
+  __shared__ uint32_t carry;
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  for (uint32_t base = 0; base < nb; base += QN_BLOCK) {
+    uint32_t i = base + threadIdx.x;
+    uint32_t s = i < nb ? block_sums[i] : 0u, inc = s;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { uint32_t t = __shfl_up(inc, o); if (lane >= o) inc += t; }
+    if (lane == 63) wsum[wid] = inc;
+    __syncthreads();
+    uint32_t woff = carry;
+    for (int w = 0; w < wid; w++) woff += wsum[w];
+    if (i < nb) block_sums[i] = woff + inc - s;
+    __syncthreads();
+    if (threadIdx.x == QN_BLOCK - 1) carry = woff + inc;
+    __syncthreads();
+  }
+}
+__global__ void k_scan_add(uint32_t* __restrict__ out, uint32_t m, const uint32_t* __restrict__ block_sums, uint32_t total) {
+  const uint32_t base = (blockIdx.x * QN_BLOCK + threadIdx.x) * QN_SCAN_ITEMS;
+  const uint32_t off = block_sums[blockIdx.x];
+#pragma unroll
+  for (int j = 0; j < QN_SCAN_ITEMS; j++) if (base + j < m) out[base + j] += off;
+  if (blockIdx.x == 0 && threadIdx.x == 0) out[m] = total;
+}
+
+// counting-sort scatter: counts[] still holds the per-cell population; slots are handed out from the
+// back of each cell's run.  Order inside a cell is arbitrary - every consumer is order independent
+// (ties resolve on the original index carried in .w).
+__global__ void k_scatter(const float4* __restrict__ pts, uint32_t n, const uint32_t* __restrict__ cell_of_pt,
+                          const uint32_t* __restrict__ cell_start, uint32_t* __restrict__ counts, float4* __restrict__ sorted) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uint32_t c = cell_of_pt[i];
+  uint32_t slot = cell_start[c] + atomicSub(&counts[c], 1u) - 1u;
+  float4 p = pts[i];
+  p.w = __uint_as_float(i);
+  sorted[slot] = p;
+}
+
+// ------------------------------------------------------------------ K2+K3 k-NN + covariance
+// k nearest (self included), mean/cov in f64 (cov = X X^T / k), PLANE regularisation:
+// C = V diag(1, 1, 1e-3) V^T with V the eigenvectors of cov (eigenvalues descending).
+template <int KMAX>
+__device__ __forceinline__ void cov_from_knn(const BestK<KMAX>& sink, const float4* __restrict__ raw, double* __restrict__ cov_out,
+                                             int32_t* __restrict__ knn_idx, float* __restrict__ knn_d2) {
+  const int k = sink.k;
+  int found = 0;
+  double mean[3] = {0, 0, 0};
+#pragma unroll
+  for (int j = 0; j < KMAX; j++) if (j < k && sink.a[j] != QN_INF_KEY) {
+    float4 p = raw[key_idx(sink.a[j])];
+    mean[0] += (double)p.x; mean[1] += (double)p.y; mean[2] += (double)p.z; found++;
+  }
+  if (knn_idx) {
+#pragma unroll
+    for (int j = 0; j < KMAX; j++) if (j < k) {
+      bool ok = sink.a[j] != QN_INF_KEY;
+      knn_idx[j] = ok ? (int32_t)key_idx(sink.a[j]) : -1; knn_d2[j] = ok ? key_d2(sink.a[j]) : 0.f;
+    }
+  }
+  if (found == 0) { for (int t = 0; t < 6; t++) cov_out[t] = 0; return; }
+  mean[0] /= found; mean[1] /= found; mean[2] /= found;
+  double c[6] = {0, 0, 0, 0, 0, 0};
+#pragma unroll
+  for (int j = 0; j < KMAX; j++) if (j < k && sink.a[j] != QN_INF_KEY) {
+    float4 p = raw[key_idx(sink.a[j])];
+    double dx = (double)p.x - mean[0], dy = (double)p.y - mean[1], dz = (double)p.z - mean[2];
+    c[0] += dx * dx; c[1] += dx * dy; c[2] += dx * dz; c[3] += dy * dy; c[4] += dy * dz; c[5] += dz * dz;
+  }
+#pragma unroll
+  for (int t = 0; t < 6; t++) c[t] /= found;
+  double w[3], V[3][3];
+  sym_eig3(c, w, V);
+  const double vals[3] = {1.0, 1.0, 1e-3};
+  int t = 0;
+#pragma unroll
+  for (int a = 0; a < 3; a++)
+#pragma unroll
+    for (int b = a; b < 3; b++, t++) {
+      double s = 0;
+#pragma unroll
+      for (int e = 0; e < 3; e++) s += V[a][e] * vals[e] * V[b][e];
+      cov_out[t] = s;
+    }
+}
+
+template <int KMAX>
+__global__ void __launch_bounds__(QN_BLOCK) k_knn_cov(GridView g, const float4* __restrict__ raw, int k, int margin,
+                                                      double* __restrict__ cov, int32_t* __restrict__ knn_idx, float* __restrict__ knn_d2,
+                                                      uint2* __restrict__ fb_list, uint32_t* __restrict__ fb_count) {
+  __shared__ float4 tile[QN_BLOCK];
+  const uint32_t t = blockIdx.x * QN_BLOCK + threadIdx.x;
+  const bool active = t < g.n;
+  float4 q = active ? g.pts[t] : make_float4(0, 0, 0, 0);
+  BestK<KMAX> sink; sink.init(k);
+  const bool cert = wave_cluster_search(g, q.x, q.y, q.z, active, margin, sink, tile + (threadIdx.x & ~63));
+  if (!active) return;
+  const uint32_t i = __float_as_uint(q.w);
+  if (cert) cov_from_knn(sink, raw, cov + (size_t)i * 6, knn_idx ? knn_idx + (size_t)i * k : nullptr, knn_d2 ? knn_d2 + (size_t)i * k : nullptr);
+  else {
+    uint32_t slot = atomicAdd(fb_count, 1u);
+    fb_list[slot] = make_uint2(t, __float_as_uint(sink.full() ? sink.worst_d2() : -1.0f));
+  }
+}
+
+template <int KMAX>
+__global__ void __launch_bounds__(QN_BLOCK) k_knn_cov_fallback(GridView g, const float4* __restrict__ raw, int k, int margin,
+                                                               double* __restrict__ cov, int32_t* __restrict__ knn_idx, float* __restrict__ knn_d2,
+                                                               const uint2* __restrict__ fb_list, const uint32_t* __restrict__ fb_count) {
+  const uint32_t nfb = *fb_count;
+  for (uint32_t w = blockIdx.x * QN_BLOCK + threadIdx.x; w < nfb; w += gridDim.x * QN_BLOCK) {
+    const uint2 rec = fb_list[w];
+    const float4 q = g.pts[rec.x];
+    const float kd2 = __uint_as_float(rec.y);
+    float r = kd2 >= 0.f ? sqrtf(kd2) * 1.000001f + g.eps : (margin + 1) * g.cell;
+    BestK<KMAX> sink; sink.init(k);
+    lane_ball_knn(g, q.x, q.y, q.z, r, sink);
+    const uint32_t i = __float_as_uint(q.w);
+    cov_from_knn(sink, raw, cov + (size_t)i * 6, knn_idx ? knn_idx + (size_t)i * k : nullptr, knn_d2 ? knn_d2 + (size_t)i * k : nullptr);
+  }
+}
+
+// ------------------------------------------------------------------ K4a nearest-neighbour search
+// MODE 0: update_correspondences: q = T_f * p in f32, Eigen order ((c0 x + c1 y) + c2 z) + c3.
+// MODE 1: getFitnessScore: q = pcl::transformPointCloud, SSE order c0 x + (c1 y + (c2 z + c3)).
+template <int MODE>
+__device__ __forceinline__ void xform_query(const float Tf[12], float x, float y, float z, float& qx, float& qy, float& qz) {
+  if (MODE == 0) {
+    qx = ((Tf[0] * x + Tf[1] * y) + Tf[2] * z) + Tf[3];
+    qy = ((Tf[4] * x + Tf[5] * y) + Tf[6] * z) + Tf[7];
+    qz = ((Tf[8] * x + Tf[9] * y) + Tf[10] * z) + Tf[11];
+  } else {
+    qx = Tf[0] * x + (Tf[1] * y + (Tf[2] * z + Tf[3]));
+    qy = Tf[4] * x + (Tf[5] * y + (Tf[6] * z + Tf[7]));
+    qz = Tf[8] * x + (Tf[9] * y + (Tf[10] * z + Tf[11]));
+  }
+}
+
+template <int MODE>
+__device__ __forceinline__ void store_nn(unsigned long long key, uint32_t i, double thr2, int32_t* __restrict__ corr, float* __restrict__ sqd) {
+  const float d2 = key_d2(key);
+  if (MODE == 0) {
+    const bool found = key != QN_INF_KEY;
+    sqd[i] = found ? d2 : 0.f;
+    corr[i] = (found && (double)d2 < thr2) ? (int32_t)key_idx(key) : -1;
+  } else {
+    sqd[i] = key != QN_INF_KEY ? d2 : __int_as_float(0x7f800000);
+  }
+}
+
+template <int MODE>
+__global__ void __launch_bounds__(QN_BLOCK) k_nn_search(GridView src, GridView tgt, const GicpState* __restrict__ st, double thr2, int margin,
+                                                        int32_t* __restrict__ corr, float* __restrict__ sqd,
+                                                        uint2* __restrict__ fb_list, uint32_t* __restrict__ fb_count) {
+  __shared__ float4 tile[QN_BLOCK];
+  if (MODE == 0 && st->phase != 0) return;
+  if (MODE == 1 && st->phase != 2) return;
+  float Tf[12];
+#pragma unroll
+  for (int j = 0; j < 12; j++) Tf[j] = (float)st->x0[j];
+  const uint32_t t = blockIdx.x * QN_BLOCK + threadIdx.x;
+  const bool active = t < src.n;
+  const float4 p = active ? src.pts[t] : make_float4(0, 0, 0, 0);
+  float qx, qy, qz; xform_query<MODE>(Tf, p.x, p.y, p.z, qx, qy, qz);
+  Best1 sink; sink.init();
+  const bool cert = wave_cluster_search(tgt, qx, qy, qz, active, margin, sink, tile + (threadIdx.x & ~63));
+  if (!active) return;
+  if (cert) store_nn<MODE>(sink.key, __float_as_uint(p.w), thr2, corr, sqd);
+  else {
+    uint32_t slot = atomicAdd(fb_count, 1u);
+    fb_list[slot] = make_uint2(t, __float_as_uint(sink.full() ? sink.worst_d2() : -1.0f));
+  }
+}
+
+// pass B: one uncertified query per wavefront
+template <int MODE>
+__global__ void __launch_bounds__(QN_BLOCK) k_nn_fallback(GridView src, GridView tgt, const GicpState* __restrict__ st, double thr2, int margin,
+                                                          int32_t* __restrict__ corr, float* __restrict__ sqd,
+                                                          const uint2* __restrict__ fb_list, const uint32_t* __restrict__ fb_count) {
+  if (MODE == 0 && st->phase != 0) return;
+  if (MODE == 1 && st->phase != 2) return;
+  const uint32_t nfb = *fb_count;
+  float Tf[12];
+#pragma unroll
+  for (int j = 0; j < 12; j++) Tf[j] = (float)st->x0[j];
+  const uint32_t nwaves = gridDim.x * (QN_BLOCK / 64);
+  for (uint32_t w = blockIdx.x * (QN_BLOCK / 64) + (threadIdx.x >> 6); w < nfb; w += nwaves) {
+    const uint2 rec = fb_list[w];
+    const float4 p = src.pts[rec.x];
+    float qx, qy, qz; xform_query<MODE>(Tf, p.x, p.y, p.z, qx, qy, qz);
+    const float bd2 = __uint_as_float(rec.y);
+    const float r = bd2 >= 0.f ? sqrtf(bd2) * 1.000001f + tgt.eps : (margin + 1) * tgt.cell;
+    const unsigned long long key = wave_ball_nn1(tgt, qx, qy, qz, r);
+    if ((threadIdx.x & 63) == 0) store_nn<MODE>(key, __float_as_uint(p.w), thr2, corr, sqd);
+  }
+}
+
+// ------------------------------------------------------------------ K4b / K5 accumulate
+// phase 0: linearize: M = (C_B + R C_A R^T)^-1, e = mu_B - T mu_A, J = [skew(T mu_A) | -I],
+//          H += J^T M J (21 unique), b += J^T M e, cost += e^T M e.
+// phase 1: compute_error at the trial transform xi with the CACHED correspondences and the M of x0.
+// Fixed grid, fixed per-thread striding, fixed reduction tree => bitwise reproducible partials.
+__global__ void __launch_bounds__(QN_BLOCK) k_accumulate(const float4* __restrict__ src_raw, uint32_t ns, const float4* __restrict__ tgt_raw,
+                                                         const double* __restrict__ cov_s, const double* __restrict__ cov_t,
+                                                         const int32_t* __restrict__ corr, const GicpState* __restrict__ st,
+                                                         double* __restrict__ partials) {
+  __shared__ double red[QN_BLOCK / 64][QN_NPART];
+  const int phase = st->phase;
+  if (phase == 2) return;
+  double R[3][3], T[3][4];
+#pragma unroll
+  for (int a = 0; a < 3; a++)
+#pragma unroll
+    for (int b = 0; b < 4; b++) { T[a][b] = phase == 0 ? st->x0[4 * a + b] : st->xi[4 * a + b]; if (b < 3) R[a][b] = st->x0[4 * a + b]; }
+  double acc[QN_NPART];
+#pragma unroll
+  for (int t = 0; t < QN_NPART; t++) acc[t] = 0;
+  for (uint32_t i = blockIdx.x * QN_BLOCK + threadIdx.x; i < ns; i += gridDim.x * QN_BLOCK) {
+    const int j = corr[i];
+    if (j < 0) continue;
+    const float4 pa = src_raw[i], pb = tgt_raw[j];
+    const double* ca = cov_s + (size_t)i * 6; const double* cb = cov_t + (size_t)j * 6;
+    const double CA[3][3] = {{ca[0], ca[1], ca[2]}, {ca[1], ca[3], ca[4]}, {ca[2], ca[4], ca[5]}};
+    double RC[3][3];
+#pragma unroll
+    for (int a = 0; a < 3; a++)
+#pragma unroll
+      for (int b = 0; b < 3; b++) RC[a][b] = R[a][0] * CA[0][b] + R[a][1] * CA[1][b] + R[a][2] * CA[2][b];
+    M3 rcr;
+    const double CB[3][3] = {{cb[0], cb[1], cb[2]}, {cb[1], cb[3], cb[4]}, {cb[2], cb[4], cb[5]}};
+#pragma unroll
+    for (int a = 0; a < 3; a++)
+#pragma unroll
+      for (int b = 0; b < 3; b++) rcr.m[a][b] = CB[a][b] + (RC[a][0] * R[b][0] + RC[a][1] * R[b][1] + RC[a][2] * R[b][2]);
+    const M3 M = m3_inverse(rcr);
+    const double mA[3] = {(double)pa.x, (double)pa.y, (double)pa.z};
+    double tA[3], e[3], Me[3];
+#pragma unroll
+    for (int r = 0; r < 3; r++) tA[r] = T[r][0] * mA[0] + T[r][1] * mA[1] + T[r][2] * mA[2] + T[r][3];
+    e[0] = (double)pb.x - tA[0]; e[1] = (double)pb.y - tA[1]; e[2] = (double)pb.z - tA[2];
+#pragma unroll
+    for (int r = 0; r < 3; r++) Me[r] = M.m[r][0] * e[0] + M.m[r][1] * e[1] + M.m[r][2] * e[2];
+    acc[27] += e[0] * Me[0] + e[1] * Me[1] + e[2] * Me[2];
+    if (phase == 0) {
+      const double J[3][6] = {{0, -tA[2], tA[1], -1, 0, 0}, {tA[2], 0, -tA[0], 0, -1, 0}, {-tA[1], tA[0], 0, 0, 0, -1}};
+      double MJ[3][6];
+#pragma unroll
+      for (int r = 0; r < 3; r++)
+#pragma unroll
+        for (int c = 0; c < 6; c++) MJ[r][c] = M.m[r][0] * J[0][c] + M.m[r][1] * J[1][c] + M.m[r][2] * J[2][c];
+      int t = 0;
+#pragma unroll
+      for (int r = 0; r < 6; r++)
+#pragma unroll
+        for (int c = r; c < 6; c++, t++) acc[t] += J[0][r] * MJ[0][c] + J[1][r] * MJ[1][c] + J[2][r] * MJ[2][c];
+#pragma unroll
+      for (int r = 0; r < 6; r++) acc[21 + r] += J[0][r] * Me[0] + J[1][r] * Me[1] + J[2][r] * Me[2];
+    }
+  }
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+#pragma unroll
+  for (int t = 0; t < QN_NPART; t++) { double v = wave_sum_f64(acc[t]); if (lane == 0) red[wid][t] = v; }
+  __syncthreads();
+  if (threadIdx.x < QN_NPART) {
+    double s = 0;
+#pragma unroll
+    for (int w = 0; w < QN_BLOCK / 64; w++) s += red[w][threadIdx.x];
+    partials[(size_t)blockIdx.x * QN_NPART + threadIdx.x] = s;
+  }
+}
+
+// ------------------------------------------------------------------ K6 solver / LM-GN controller
+__device__ inline void d_so3_exp(const double om[3], double R[3][3]) {
+  double theta_sq = om[0] * om[0] + om[1] * om[1] + om[2] * om[2];
+  double imag, real;
+  if (theta_sq < 1e-10) {
+    double theta_quad = theta_sq * theta_sq;
+    imag = 0.5 - 1.0 / 48.0 * theta_sq + 1.0 / 3840.0 * theta_quad;
+    real = 1.0 - 1.0 / 8.0 * theta_sq + 1.0 / 384.0 * theta_quad;
+  } else {
+    double theta = sqrt(theta_sq), half = 0.5 * theta;
+    imag = sin(half) / theta; real = cos(half);
+  }
+  double w = real, x = imag * om[0], y = imag * om[1], z = imag * om[2];
+  double tx = 2 * x, ty = 2 * y, tz = 2 * z;
+  double twx = tx * w, twy = ty * w, twz = tz * w, txx = tx * x, txy = ty * x, txz = tz * x, tyy = ty * y, tyz = tz * y, tzz = tz * z;
+  R[0][0] = 1 - (tyy + tzz); R[0][1] = txy - twz;       R[0][2] = txz + twy;
+  R[1][0] = txy + twz;       R[1][1] = 1 - (txx + tzz); R[1][2] = tyz - twx;
+  R[2][0] = txz - twy;       R[2][1] = tyz + twx;       R[2][2] = 1 - (txx + tyy);
+}
+
+// LDL^T with diagonal pivoting (what Eigen::LDLT does), 6x6, f64
+__device__ inline void d_ldlt_solve6(const double Ain[36], double diag_add, const double rhs[6], double x[6]) {
+  double A[6][6]; int perm[6];
+  for (int i = 0; i < 6; i++) { perm[i] = i; for (int j = 0; j < 6; j++) A[i][j] = Ain[6 * i + j] + (i == j ? diag_add : 0.0); }
+  for (int k = 0; k < 6; k++) {
+    int piv = k; double best = fabs(A[k][k]);
+    for (int i = k + 1; i < 6; i++) if (fabs(A[i][i]) > best) { best = fabs(A[i][i]); piv = i; }
+    if (piv != k) {
+      for (int j = 0; j < 6; j++) { double t = A[k][j]; A[k][j] = A[piv][j]; A[piv][j] = t; }
+      for (int i = 0; i < 6; i++) { double t = A[i][k]; A[i][k] = A[i][piv]; A[i][piv] = t; }
+      int t = perm[k]; perm[k] = perm[piv]; perm[piv] = t;
+    }
+    double d = A[k][k];
+    if (d == 0.0) continue;
+    double l[6];
+    for (int i = k + 1; i < 6; i++) l[i] = A[i][k] / d;
+    for (int i = k + 1; i < 6; i++) for (int j = k + 1; j <= i; j++) { A[i][j] -= l[i] * d * l[j]; A[j][i] = A[i][j]; }
+    for (int i = k + 1; i < 6; i++) A[i][k] = l[i];
+  }
+  double y[6], z[6];
+  for (int i = 0; i < 6; i++) { double s = rhs[perm[i]]; for (int j = 0; j < i; j++) s -= A[i][j] * y[j]; y[i] = s; }
+  for (int i = 0; i < 6; i++) y[i] = (A[i][i] != 0.0) ? y[i] / A[i][i] : 0.0;
+  for (int i = 5; i >= 0; i--) { double s = y[i]; for (int j = i + 1; j < 6; j++) s -= A[j][i] * z[j]; z[i] = s; }
+  for (int i = 0; i < 6; i++) x[perm[i]] = z[i];
+}
+
+__device__ inline void d_iso_mul(const double A[16], const double B[16], double C[16]) {
+  double r[16];
+  for (int i = 0; i < 16; i++) r[i] = 0;
+  for (int i = 0; i < 3; i++) {
+    for (int j = 0; j < 3; j++) r[4 * i + j] = A[4 * i] * B[j] + A[4 * i + 1] * B[4 + j] + A[4 * i + 2] * B[8 + j];
+    r[4 * i + 3] = A[4 * i] * B[3] + A[4 * i + 1] * B[7] + A[4 * i + 2] * B[11] + A[4 * i + 3];
+  }
+  r[15] = 1.0;
+  for (int i = 0; i < 16; i++) C[i] = r[i];
+}
+
+__device__ inline bool d_is_converged(const double delta[16], const GicpConfig& cfg, double* mr_out, double* mt_out) {
+  double mr = 0, mt = 0;
+  for (int a = 0; a < 3; a++) { for (int b = 0; b < 3; b++) mr = fmax(mr, fabs(delta[4 * a + b] - (a == b ? 1.0 : 0.0))); mt = fmax(mt, fabs(delta[4 * a + 3])); }
+  if (mr_out) { *mr_out = mr; *mt_out = mt; }
+  return fmax(mr / cfg.rotation_epsilon, mt / cfg.transformation_epsilon) < 1.0;
+}
+
+__device__ inline void d_propose(GicpState* st, double lambda) {      // d = LDLT(H + lambda I).solve(-b); delta; xi = delta * x0
+  double rhs[6];
+  for (int i = 0; i < 6; i++) rhs[i] = -st->b[i];
+  d_ldlt_solve6(st->H, lambda, rhs, st->d);
+  double R[3][3]; d_so3_exp(st->d, R);
+  for (int i = 0; i < 16; i++) st->delta[i] = 0;
+  for (int a = 0; a < 3; a++) { for (int b = 0; b < 3; b++) st->delta[4 * a + b] = R[a][b]; st->delta[4 * a + 3] = st->d[3 + a]; }
+  st->delta[15] = 1.0;
+  d_iso_mul(st->delta, st->x0, st->xi);
+}
+
+// after an outer iteration finished (accepted or the rho<0 && converged early return)
+__device__ inline void d_finish_outer(GicpState* st, const GicpConfig& cfg, qn_iter_trace* trace, qn_iter_trace tr) {
+  bool conv = d_is_converged(st->delta, cfg, &tr.max_dR, &tr.max_dt);
+  if (cfg.force_iterations > 0) conv = false;
+  if (st->trace_len < QN_MAX_TRACE) trace[st->trace_len++] = tr;
+  st->outer += 1;
+  const int maxit = cfg.force_iterations > 0 ? cfg.force_iterations : cfg.max_iterations;
+  if (conv) { st->converged = 1; st->phase = 2; }
+  else if (st->outer >= maxit) { st->phase = 2; }
+  else st->phase = 0;
+}
+
+// mode 0: full controller.  mode 1: reduce a linearisation only (H, b, y0).  mode 2: reduce an error pass only (yi).
+__global__ void __launch_bounds__(QN_BLOCK) k_solve(GicpState* st, const double* __restrict__ partials, GicpConfig cfg, qn_iter_trace* trace, int mode) {
+  __shared__ double sums[QN_NPART];
+  __shared__ double part8[QN_NPART][8];
+  const int phase = st->phase;
+  if (phase == 2 && mode == 0) { if (threadIdx.x == 0) st->fb_count = 0; return; }
+  // deterministic reduction of QN_ACC_BLOCKS x 28 partials: 8 strided sub-sums per component, combined in order
+  if (threadIdx.x < QN_NPART * 8) {
+    const int c = threadIdx.x >> 3, s = threadIdx.x & 7;
+    double v = 0;
+    for (int b = s; b < QN_ACC_BLOCKS; b += 8) v += partials[(size_t)b * QN_NPART + c];
+    part8[c][s] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < QN_NPART) { double v = 0; for (int s = 0; s < 8; s++) v += part8[threadIdx.x][s]; sums[threadIdx.x] = v; }
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  st->fb_count = 0;
+  const bool lin = (mode == 1) || (mode == 0 && phase == 0);
+  if (lin) {
+    int t = 0;
+    for (int r = 0; r < 6; r++) for (int c = r; c < 6; c++, t++) { st->H[6 * r + c] = sums[t]; st->H[6 * c + r] = sums[t]; }
+    for (int r = 0; r < 6; r++) st->b[r] = sums[21 + r];
+    st->y0 = sums[27];
+  } else {
+    st->yi = sums[27];
+  }
+  if (mode != 0) return;
+
+  if (phase == 0) {
+    if (cfg.optimizer == QN_OPT_GN) {                                   // step_gn
+      d_propose(st, 0.0);
+      for (int i = 0; i < 16; i++) st->x0[i] = st->xi[i];
+      for (int i = 0; i < 36; i++) st->final_H[i] = st->H[i];
+      qn_iter_trace tr; tr.y0 = st->y0; tr.lambda = 0; tr.rho = 0; tr.inner = 1; tr.accepted = 1; tr.max_dR = tr.max_dt = 0;
+      d_finish_outer(st, cfg, trace, tr);
+      return;
+    }
+    // step_lm, first try of this outer iteration
+    if (st->lambda < 0.0) {
+      double mx = 0; for (int i = 0; i < 6; i++) mx = fmax(mx, fabs(st->H[7 * i]));
+      st->lambda = cfg.lm_init_lambda_factor * mx;
+    }
+    st->nu = 2.0; st->inner = 0;
+    d_propose(st, st->lambda);
+    st->phase = 1;
+    return;
+  }
+  // phase 1: an error pass at xi just finished
+  double den = 0; for (int i = 0; i < 6; i++) den += st->d[i] * (st->lambda * st->d[i] - st->b[i]);
+  const double rho = (st->y0 - st->yi) / den;
+  st->inner += 1;
+  qn_iter_trace tr; tr.y0 = st->y0; tr.lambda = st->lambda; tr.rho = rho; tr.inner = st->inner; tr.accepted = 0; tr.max_dR = tr.max_dt = 0;
+  if (rho < 0) {
+    if (d_is_converged(st->delta, cfg, nullptr, nullptr)) { d_finish_outer(st, cfg, trace, tr); return; }   // `return true` without accepting
+    st->lambda = st->nu * st->lambda; st->nu = 2 * st->nu;
+    if (st->inner >= cfg.lm_max_iterations) {                            // "lm not converged!!"
+      if (st->trace_len < QN_MAX_TRACE) trace[st->trace_len++] = tr;
+      st->outer += 1; st->lm_failed = 1; st->phase = 2; return;
+    }
+    d_propose(st, st->lambda);                                           // stay in phase 1
+    return;
+  }
+  for (int i = 0; i < 16; i++) st->x0[i] = st->xi[i];
+  const double c3 = (2 * rho - 1) * (2 * rho - 1) * (2 * rho - 1);
+  st->lambda = st->lambda * fmax(1.0 / 3.0, 1 - c3);
+  for (int i = 0; i < 36; i++) st->final_H[i] = st->H[i];
+  tr.accepted = 1;
+  d_finish_outer(st, cfg, trace, tr);
+}
+
+__global__ void k_init_state(GicpState* st, const float* __restrict__ guess /* 16 or null */, int has_guess, int phase) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  for (int i = 0; i < 16; i++) { double v = has_guess ? (double)guess[i] : ((i % 5 == 0) ? 1.0 : 0.0); st->x0[i] = v; st->xi[i] = v; st->delta[i] = (i % 5 == 0) ? 1.0 : 0.0; }
+  for (int i = 0; i < 36; i++) { st->H[i] = 0; st->final_H[i] = (i % 7 == 0) ? 1.0 : 0.0; }
+  for (int i = 0; i < 6; i++) { st->b[i] = 0; st->d[i] = 0; }
+  st->y0 = st->yi = st->den = 0; st->lambda = -1.0; st->nu = 2.0; st->fitness = 0;
+  st->outer = st->inner = 0; st->phase = phase; st->converged = 0; st->lm_failed = 0; st->fb_count = 0; st->trace_len = 0;
+}
+__global__ void k_set_pose(GicpState* st, const double* __restrict__ T, int which /*0 x0, 1 xi, 2 neither*/, int phase) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  for (int i = 0; i < 16; i++) { if (which == 0) st->x0[i] = T[i]; else if (which == 1) st->xi[i] = T[i]; }
+  st->phase = phase; st->fb_count = 0;
+}
+
+// ------------------------------------------------------------------ K7 fitness reduce, K8 transform
+// pcl getFitnessScore: mean of the f32 squared NN distances <= max_range, summed in f64.
+__global__ void __launch_bounds__(1024) k_fitness_reduce(const float* __restrict__ sqd, uint32_t n, double max_range, GicpState* st, int require_done) {
+  __shared__ double ssum[16]; __shared__ uint32_t scnt[16];
+  if (require_done && st->phase != 2) return;
+  double s = 0; uint32_t c = 0;
+  for (uint32_t i = threadIdx.x; i < n; i += 1024) { float d = sqd[i]; if ((double)d <= max_range) { s += (double)d; c++; } }
+  s = wave_sum_f64(s);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
+  if ((threadIdx.x & 63) == 0) { ssum[threadIdx.x >> 6] = s; scnt[threadIdx.x >> 6] = c; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = 0; uint32_t tc = 0;
+    for (int w = 0; w < 16; w++) { t += ssum[w]; tc += scnt[w]; }
+    st->fitness = tc > 0 ? t / tc : 1.7976931348623157e308;
+    st->fb_count = 0;
+  }
+}
+
+// pcl::transformPointCloud(*input_, output, final_transformation_) inside align(); also used for the
+// Quatro -> GICP hand-over transformPcd(src, T_q) (loop_closure.cpp:152, utilities.hpp:164-175) in f64 mode.
+__global__ void k_transform_cloud(const float4* __restrict__ in, uint32_t n, const GicpState* __restrict__ st, float4* __restrict__ out, int require_done) {
+  if (require_done && st->phase != 2) return;
+  float Tf[12];
+#pragma unroll
+  for (int j = 0; j < 12; j++) Tf[j] = (float)st->x0[j];
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float4 p = in[i]; float x, y, z;
+  xform_query<1>(Tf, p.x, p.y, p.z, x, y, z);
+  out[i] = make_float4(x, y, z, 1.0f);
+}
+
+struct ResultBlock { qn_gicp_result r; int32_t phase; uint32_t trace_len; };
+
+__global__ void k_finalize(const GicpState* __restrict__ st, ResultBlock* out) {   // out lives in pinned host memory
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  for (int i = 0; i < 16; i++) { out->r.T64[i] = st->x0[i]; out->r.T[i] = (float)st->x0[i]; }
+  for (int i = 0; i < 36; i++) out->r.H[i] = st->final_H[i];
+  out->r.fitness = st->fitness; out->r.iterations = st->outer; out->r.converged = st->converged; out->r.lm_failed = st->lm_failed; out->r.reserved = 0;
+  out->phase = st->phase; out->trace_len = st->trace_len;
+}
+
+}  // namespace qn

@@ -1,0 +1,291 @@
+"""ctypes binding of include/qn_engine.h.  Mirrors the reference's operator surface:
+`NanoGICP` has the member functions LoopClosure calls on nano_gicp::NanoGICP
+(fast_lio_sam_qn/src/loop_closure.cpp:9-16, 120-133), argument meaning and failure
+behaviour included (no exceptions for a failed registration: hasConverged() == False)."""
+import ctypes as C
+import os
+import numpy as np
+from . import build as _build
+
+QN_OK, QN_ERR_INVALID_ARG, QN_ERR_EMPTY_CLOUD, QN_ERR_CAPACITY, QN_ERR_NOT_READY, QN_ERR_HIP, QN_ERR_NO_DEVICE = range(7)
+QN_SOURCE, QN_TARGET = 0, 1
+FLOAT_MAX = 3.4028234663852886e38
+KERNEL_FAMILIES = ["grid_build", "knn_cov", "nn_search", "nn_fallback", "accumulate", "solve", "fitness", "transform",
+                   "fpfh_normals", "fpfh_spfh", "fpfh_fpfh", "feat_match"]
+
+
+class GicpParams(C.Structure):
+    _fields_ = [("k_correspondences", C.c_int32), ("max_iterations", C.c_int32), ("max_corr_dist", C.c_double),
+                ("transformation_epsilon", C.c_double), ("rotation_epsilon", C.c_double), ("optimizer", C.c_int32),
+                ("lm_max_iterations", C.c_int32), ("lm_init_lambda_factor", C.c_double), ("force_iterations", C.c_int32),
+                ("ransac_iterations", C.c_int32), ("ransac_outlier_threshold", C.c_double),
+                ("euclidean_fitness_epsilon", C.c_double)]
+
+
+class GicpResult(C.Structure):
+    _fields_ = [("T", C.c_float * 16), ("T64", C.c_double * 16), ("H", C.c_double * 36), ("fitness", C.c_double),
+                ("iterations", C.c_int32), ("converged", C.c_int32), ("lm_failed", C.c_int32), ("reserved", C.c_int32)]
+
+
+class IterTrace(C.Structure):
+    _fields_ = [("y0", C.c_double), ("lambda_", C.c_double), ("rho", C.c_double), ("max_dR", C.c_double),
+                ("max_dt", C.c_double), ("inner", C.c_int32), ("accepted", C.c_int32)]
+
+
+class KernelStat(C.Structure):
+    _fields_ = [("total_ms", C.c_double), ("launches", C.c_int64)]
+
+
+class EngineError(RuntimeError):
+    def __init__(self, status, msg):
+        super().__init__("qn_engine status %d (%s)" % (status, msg))
+        self.status = status
+
+
+_lib = None
+
+
+def lib():
+    """Loads the in-tree libqn_engine.so.  Fails loudly when it is missing or unloadable."""
+    global _lib
+    if _lib is None:
+        path = _build.LIB
+        if not os.path.exists(path):
+            raise ImportError("libqn_engine.so is not built (run __graft_entry__.build()); there is no CPU fallback")
+        _lib = C.CDLL(path)
+        _lib.qn_status_str.restype = C.c_char_p
+        _lib.qn_last_error.restype = C.c_char_p
+        _lib.qn_last_error.argtypes = [C.c_void_p]
+        _lib.qn_ctx_stream.restype = C.c_void_p
+        _lib.qn_ctx_stream.argtypes = [C.c_void_p]
+        _lib.qn_ctx_destroy.argtypes = [C.c_void_p]
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class Context:
+    def __init__(self, max_points, device=0):
+        self._l = lib()
+        h = C.c_void_p()
+        st = self._l.qn_ctx_create(C.c_int(device), C.c_uint32(max_points), C.byref(h))
+        if st != QN_OK:
+            raise EngineError(st, self._l.qn_status_str(st).decode())
+        self.h = h
+        self.max_points = max_points
+
+    def close(self):
+        if getattr(self, "h", None):
+            self._l.qn_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def check(self, st):
+        if st != QN_OK:
+            raise EngineError(st, self._l.qn_status_str(st).decode() + ": " + self._l.qn_last_error(self.h).decode())
+
+    @property
+    def stream(self):
+        return self._l.qn_ctx_stream(self.h)
+
+    def synchronize(self):
+        self.check(self._l.qn_ctx_synchronize(self.h))
+
+    def debug_set(self, key, value):
+        self.check(self._l.qn_debug_set(self.h, key.encode(), C.c_double(value)))
+
+    def grid_info(self, which):
+        out = np.zeros(8)
+        self.check(self._l.qn_debug_get_grid(self.h, C.c_int(which), _p(out)))
+        return dict(origin=out[:3], cell=out[3], dims=out[4:7].astype(int), eps=out[7])
+
+    # profiling hooks
+    def prof_enable(self, on=True):
+        self.check(self._l.qn_prof_enable(self.h, C.c_int(1 if on else 0)))
+
+    def prof_reset(self):
+        self.check(self._l.qn_prof_reset(self.h))
+
+    def prof_stats(self):
+        out = {}
+        for i, name in enumerate(KERNEL_FAMILIES):
+            ks = KernelStat()
+            self.check(self._l.qn_prof_get(self.h, C.c_int(i), C.byref(ks)))
+            out[name] = (ks.total_ms, ks.launches)
+        return out
+
+
+def _cloud_arg(xyz):
+    """(pointer-holder, n, stride_bytes) for an (n,3) or (n,4)/(n,8) float32 array."""
+    a = np.ascontiguousarray(xyz, dtype=np.float32)
+    if a.ndim != 2 or a.shape[1] < 3:
+        raise ValueError("cloud must be (n, >=3) float32")
+    return a, a.shape[0], a.shape[1] * 4
+
+
+class NanoGICP:
+    """nano_gicp::NanoGICP<PointType, PointType> as LoopClosure uses it."""
+
+    def __init__(self, ctx):
+        self.ctx = ctx
+        self._l = ctx._l
+        self.p = GicpParams()
+        self._l.qn_gicp_default_params(C.byref(self.p))
+        self._res = None
+        self._n = [0, 0]
+        self._push()
+
+    def _push(self):
+        self.ctx.check(self._l.qn_gicp_set_params(self.ctx.h, C.byref(self.p)))
+
+    # --- the 8 setters of loop_closure.cpp:9-16
+    def setNumThreads(self, n):                      # CPU thread count: meaningless on the GPU, accepted
+        self.num_threads = n
+
+    def setCorrespondenceRandomness(self, k):
+        self.p.k_correspondences = k; self._push()
+
+    def setMaximumIterations(self, n):
+        self.p.max_iterations = n; self._push()
+
+    def setRANSACIterations(self, n):
+        self.p.ransac_iterations = n; self._push()
+
+    def setMaxCorrespondenceDistance(self, d):
+        self.p.max_corr_dist = d; self._push()
+
+    def setTransformationEpsilon(self, e):
+        self.p.transformation_epsilon = e; self._push()
+
+    def setEuclideanFitnessEpsilon(self, e):
+        self.p.euclidean_fitness_epsilon = e; self._push()
+
+    def setRANSACOutlierRejectionThreshold(self, t):
+        self.p.ransac_outlier_threshold = t; self._push()
+
+    # extras the reference leaves at defaults
+    def setRotationEpsilon(self, e):
+        self.p.rotation_epsilon = e; self._push()
+
+    def setOptimizer(self, name):
+        self.p.optimizer = 0 if name == "lm" else 1; self._push()
+
+    def setForceIterations(self, n):
+        self.p.force_iterations = n; self._push()
+
+    # --- clouds
+    def setInputSource(self, xyz):
+        a, n, stride = _cloud_arg(xyz); self._n[0] = n
+        st = self._l.qn_gicp_set_source(self.ctx.h, _p(a), C.c_uint32(n), C.c_uint32(stride))
+        if st != QN_ERR_EMPTY_CLOUD:
+            self.ctx.check(st)
+
+    def setInputTarget(self, xyz):
+        a, n, stride = _cloud_arg(xyz); self._n[1] = n
+        st = self._l.qn_gicp_set_target(self.ctx.h, _p(a), C.c_uint32(n), C.c_uint32(stride))
+        if st != QN_ERR_EMPTY_CLOUD:
+            self.ctx.check(st)
+
+    def setInputSourceDevice(self, ptr, n, stride):
+        self._n[0] = n
+        self.ctx.check(self._l.qn_gicp_set_source_device(self.ctx.h, C.c_void_p(ptr), C.c_uint32(n), C.c_uint32(stride)))
+
+    def setInputTargetDevice(self, ptr, n, stride):
+        self._n[1] = n
+        self.ctx.check(self._l.qn_gicp_set_target_device(self.ctx.h, C.c_void_p(ptr), C.c_uint32(n), C.c_uint32(stride)))
+
+    def calculateSourceCovariances(self):
+        return self._l.qn_gicp_compute_covariances(self.ctx.h, C.c_int(QN_SOURCE)) == QN_OK
+
+    def calculateTargetCovariances(self):
+        return self._l.qn_gicp_compute_covariances(self.ctx.h, C.c_int(QN_TARGET)) == QN_OK
+
+    def align(self, guess=None):
+        """Returns the transformed source cloud like align(output) fills `output`; on an unusable
+        input (empty cloud) the engine, like the reference, reports hasConverged() == False."""
+        res = GicpResult()
+        g = None if guess is None else np.ascontiguousarray(guess, dtype=np.float32)
+        st = self._l.qn_gicp_align(self.ctx.h, None if g is None else _p(g), C.byref(res))
+        if st in (QN_ERR_EMPTY_CLOUD, QN_ERR_NOT_READY):
+            self._res = None
+            return None
+        self.ctx.check(st)
+        self._res = res
+        return res
+
+    def alignedCloud(self):
+        out = np.zeros((self._n[0], 4), dtype=np.float32)
+        self.ctx.check(self._l.qn_gicp_transformed_source(self.ctx.h, _p(out), C.c_uint32(16)))
+        return out[:, :3]
+
+    def getFitnessScore(self, max_range=1.7976931348623157e308):
+        if self._res is None:
+            return 1.7976931348623157e308
+        if max_range >= 1.7976931348623157e308:
+            return self._res.fitness
+        s = C.c_double()
+        self.ctx.check(self._l.qn_gicp_fitness(self.ctx.h, C.c_double(max_range), C.byref(s)))
+        return s.value
+
+    def hasConverged(self):
+        return bool(self._res.converged) if self._res is not None else False
+
+    def getFinalTransformation(self):
+        return np.array(self._res.T, dtype=np.float32).reshape(4, 4) if self._res is not None else np.eye(4, dtype=np.float32)
+
+    # --- parity read-backs
+    def result_dict(self):
+        r = self._res
+        return dict(T=np.array(r.T64).reshape(4, 4), Tf=np.array(r.T, dtype=np.float32).reshape(4, 4), H=np.array(r.H).reshape(6, 6),
+                    fitness=r.fitness, iterations=r.iterations, converged=bool(r.converged), lm_failed=bool(r.lm_failed),
+                    trace=self.trace())
+
+    def trace(self):
+        buf = (IterTrace * 1024)(); n = C.c_uint32()
+        self.ctx.check(self._l.qn_gicp_get_trace(self.ctx.h, buf, C.c_uint32(1024), C.byref(n)))
+        return np.array([[t.y0, t.lambda_, t.rho, t.max_dR, t.max_dt, t.inner, t.accepted] for t in buf[:n.value]]).reshape(-1, 7)
+
+    def covariances(self, which):
+        out = np.zeros((self._n[which], 3, 3))
+        self.ctx.check(self._l.qn_gicp_get_covariances(self.ctx.h, C.c_int(which), _p(out)))
+        return out
+
+    def knn(self, which, k):
+        idx = np.zeros((self._n[which], k), dtype=np.int32); d2 = np.zeros((self._n[which], k), dtype=np.float32)
+        self.ctx.check(self._l.qn_gicp_knn(self.ctx.h, C.c_int(which), C.c_int(k), _p(idx), _p(d2)))
+        return idx, d2
+
+    def linearize(self, T):
+        T = np.ascontiguousarray(T, dtype=np.float64)
+        H = np.zeros((6, 6)); b = np.zeros(6); e = C.c_double()
+        corr = np.zeros(self._n[0], dtype=np.int32); sqd = np.zeros(self._n[0], dtype=np.float32)
+        self.ctx.check(self._l.qn_gicp_linearize(self.ctx.h, _p(T), _p(H), _p(b), C.byref(e), _p(corr), _p(sqd)))
+        return H, b, e.value, corr, sqd
+
+    def compute_error(self, T):
+        T = np.ascontiguousarray(T, dtype=np.float64); e = C.c_double()
+        self.ctx.check(self._l.qn_gicp_compute_error(self.ctx.h, _p(T), C.byref(e)))
+        return e.value
+
+
+def icp_alignment(ctx, src, dst, *, k=15, max_iter=32, max_corr_dist=52.5, trans_eps=0.01, score_thr=1.5):
+    """LoopClosure::icpAlignment (loop_closure.cpp:110-136) at the reference's effective config."""
+    g = NanoGICP(ctx)
+    g.setCorrespondenceRandomness(k); g.setMaximumIterations(max_iter)
+    g.setMaxCorrespondenceDistance(max_corr_dist); g.setTransformationEpsilon(trans_eps)
+    a, ns, stride = _cloud_arg(src); b, nt, _ = _cloud_arg(dst)
+    res = GicpResult(); valid = C.c_int()
+    st = ctx._l.qn_icp_alignment(ctx.h, _p(a), C.c_uint32(ns), _p(b), C.c_uint32(nt), C.c_uint32(stride),
+                                 C.c_double(score_thr), C.byref(res), C.byref(valid))
+    if st == QN_ERR_EMPTY_CLOUD:
+        return dict(valid=False, converged=False, score=1.7976931348623157e308, T=np.eye(4), iterations=0)
+    ctx.check(st)
+    return dict(valid=bool(valid.value), converged=bool(res.converged), score=res.fitness,
+                T=np.array(res.T, dtype=np.float32).reshape(4, 4).astype(np.float64), iterations=res.iterations)

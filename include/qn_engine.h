@@ -1,0 +1,133 @@
+/* qn_engine.h - C-ABI of the MI355X-native loop-closure registration engine.
+ *
+ * This is the drop-in boundary for the ONE hot path of engcang/FAST-LIO-SAM-QN: the
+ * Nano-GICP + Quatro scan matching that FastLioSamQn::loopTimerFunc triggers
+ * (fast_lio_sam_qn/src/fast_lio_sam_qn.cpp:203-252 -> LoopClosure::icpAlignment /
+ * coarseToFineAlignment, fast_lio_sam_qn/src/loop_closure.cpp:110-159).
+ *
+ * The reference has no FFI: its boundary is two C++ class templates,
+ * nano_gicp::NanoGICP<> and quatro<> (includes at include/loop_closure.h:16-19, members at
+ * :75-76).  The header-only C++ shims in fast-lio-sam-qn_amd/shim/ reproduce those classes and
+ * call ONLY the functions declared here; each entry point below names the reference call it
+ * stands behind.  Plain C: int status returns, caller-owned buffers, no exceptions, no torch
+ * or PCL/Eigen types.  One context per host thread (the reference enters the engines from one
+ * timer thread at a time); a context is NOT re-entrant.
+ *
+ * Matrices are 4x4 ROW-major.  Point buffers are `n` points of 3 leading floats (x, y, z) with
+ * `stride_bytes` between points (32 for pcl::PointXYZI, 16 for float4, 12 for packed xyz).
+ * "_device" variants take HIP device pointers (same layout) and do no host<->device copies.
+ */
+#ifndef QN_ENGINE_H
+#define QN_ENGINE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct qn_ctx qn_ctx;
+
+enum {
+  QN_OK = 0,
+  QN_ERR_INVALID_ARG = 1,     /* null pointer, bad stride, bad enum                          */
+  QN_ERR_EMPTY_CLOUD = 2,     /* a cloud with 0 points (registration yields valid = 0)       */
+  QN_ERR_CAPACITY = 3,        /* cloud larger than the context's max_points                  */
+  QN_ERR_NOT_READY = 4,       /* align before both clouds and both covariance sets exist     */
+  QN_ERR_HIP = 5,             /* a HIP runtime call failed; see qn_last_error()              */
+  QN_ERR_NO_DEVICE = 6        /* no gfx950 device: the engine has NO CPU fallback            */
+};
+
+enum { QN_SOURCE = 0, QN_TARGET = 1 };
+enum { QN_OPT_LM = 0, QN_OPT_GN = 1 };
+
+/* Mirrors what LoopClosure's ctor pushes through the 8 NanoGICP setters
+ * (loop_closure.cpp:9-16; struct NanoGICPConfig, include/loop_closure.h:25-36) plus the
+ * LsqRegistration knobs the reference leaves at their defaults.          */
+typedef struct {
+  int32_t k_correspondences;       /* setCorrespondenceRandomness  (loop_closure.cpp:10); default 20  */
+  int32_t max_iterations;          /* setMaximumIterations         (loop_closure.cpp:11); default 64  */
+  double  max_corr_dist;           /* setMaxCorrespondenceDistance (loop_closure.cpp:13); default FLT_MAX */
+  double  transformation_epsilon;  /* setTransformationEpsilon     (loop_closure.cpp:14); default 5e-4 */
+  double  rotation_epsilon;        /* LsqRegistration default 2e-3 (no setter called by the reference) */
+  int32_t optimizer;               /* QN_OPT_LM (reference default) | QN_OPT_GN                        */
+  int32_t lm_max_iterations;       /* 10                                                               */
+  double  lm_init_lambda_factor;   /* 1e-9                                                             */
+  int32_t force_iterations;        /* bench only: > 0 runs exactly this many outer iterations          */
+  int32_t ransac_iterations;       /* setRANSACIterations (loop_closure.cpp:12): stored, unused by the LSQ path */
+  double  ransac_outlier_threshold;/* setRANSACOutlierRejectionThreshold (loop_closure.cpp:16): stored, unused  */
+  double  euclidean_fitness_epsilon;/* setEuclideanFitnessEpsilon (loop_closure.cpp:15): stored, unused         */
+} qn_gicp_params;
+
+/* What icpAlignment reads back (loop_closure.cpp:127-133): getFitnessScore(), hasConverged(),
+ * getFinalTransformation() - plus the f64 state and iteration trace used by the parity tests. */
+typedef struct {
+  float   T[16];          /* final_transformation_ (f32, as the reference returns it)            */
+  double  T64[16];        /* the f64 estimate before the cast                                     */
+  double  H[36];          /* final_hessian_                                                       */
+  double  fitness;        /* pcl getFitnessScore(): mean squared NN distance over all src points  */
+  int32_t iterations;     /* outer iterations executed                                            */
+  int32_t converged;      /* hasConverged()                                                       */
+  int32_t lm_failed;      /* "lm not converged!!" path taken                                      */
+  int32_t reserved;
+} qn_gicp_result;
+
+/* one row per outer iteration, for trajectory parity */
+typedef struct { double y0, lambda, rho, max_dR, max_dt; int32_t inner, accepted; } qn_iter_trace;
+
+typedef struct {           /* device-side accounting of one kernel family (bench roofline leg) */
+  double  total_ms;
+  int64_t launches;
+} qn_kernel_stat;
+
+enum {                     /* kernel families for qn_prof_get */
+  QN_K_GRID_BUILD = 0, QN_K_KNN_COV = 1, QN_K_NN_SEARCH = 2, QN_K_NN_FALLBACK = 3,
+  QN_K_ACCUMULATE = 4, QN_K_SOLVE = 5, QN_K_FITNESS = 6, QN_K_TRANSFORM = 7,
+  QN_K_FPFH_NORMALS = 8, QN_K_FPFH_SPFH = 9, QN_K_FPFH_FPFH = 10, QN_K_FEAT_MATCH = 11,
+  QN_K_COUNT = 16
+};
+
+/* ---- lifetime ------------------------------------------------------------------------- */
+int  qn_ctx_create(int device, uint32_t max_points, qn_ctx** out);
+void qn_ctx_destroy(qn_ctx* ctx);
+const char* qn_status_str(int status);
+const char* qn_last_error(const qn_ctx* ctx);
+void* qn_ctx_stream(qn_ctx* ctx);                   /* the hipStream_t every kernel of this ctx is launched on */
+int  qn_ctx_synchronize(qn_ctx* ctx);
+
+/* ---- Nano-GICP ------------------------------------------------------------------------ */
+void qn_gicp_default_params(qn_gicp_params* p);                       /* NanoGICP()/LsqRegistration() ctor defaults */
+int  qn_gicp_set_params(qn_ctx*, const qn_gicp_params*);              /* loop_closure.cpp:9-16  */
+int  qn_gicp_set_source(qn_ctx*, const float* xyz, uint32_t n, uint32_t stride_bytes);          /* setInputSource, loop_closure.cpp:120 */
+int  qn_gicp_set_target(qn_ctx*, const float* xyz, uint32_t n, uint32_t stride_bytes);          /* setInputTarget, loop_closure.cpp:122 */
+int  qn_gicp_set_source_device(qn_ctx*, const float* d_xyz, uint32_t n, uint32_t stride_bytes);
+int  qn_gicp_set_target_device(qn_ctx*, const float* d_xyz, uint32_t n, uint32_t stride_bytes);
+int  qn_gicp_compute_covariances(qn_ctx*, int which);                 /* calculateSource/TargetCovariances, loop_closure.cpp:121,123 */
+int  qn_gicp_align(qn_ctx*, const float guess[16], qn_gicp_result* out);  /* align(), loop_closure.cpp:124 (guess NULL = identity); also fills fitness */
+int  qn_gicp_fitness(qn_ctx*, double max_range, double* score);       /* getFitnessScore(), loop_closure.cpp:127 */
+int  qn_gicp_transformed_source(qn_ctx*, float* xyz_out, uint32_t stride_bytes);  /* the `aligned_` cloud align() fills, loop_closure.cpp:124 */
+int  qn_gicp_get_trace(qn_ctx*, qn_iter_trace* out, uint32_t cap, uint32_t* n);
+
+/* LoopClosure::icpAlignment in one call (loop_closure.cpp:110-136): set x2, cov x2, align, score,
+ * accept test `converged && score < score_thr` (loop_closure.cpp:129).  *valid receives is_valid_. */
+int  qn_icp_alignment(qn_ctx*, const float* src, uint32_t ns, const float* dst, uint32_t nt,
+                      uint32_t stride_bytes, double score_thr, qn_gicp_result* out, int* valid);
+int  qn_icp_alignment_device(qn_ctx*, const float* d_src, uint32_t ns, const float* d_dst, uint32_t nt,
+                             uint32_t stride_bytes, double score_thr, qn_gicp_result* out, int* valid);
+
+/* ---- per-stage read-backs used by the parity tests (not needed by the shims) ------------ */
+int  qn_gicp_get_covariances(qn_ctx*, int which, double* cov9_out);   /* n x 9 f64, original point order */
+int  qn_gicp_knn(qn_ctx*, int which, int k, int32_t* idx_out, float* d2_out);   /* self k-NN of a cloud, n x k */
+int  qn_gicp_linearize(qn_ctx*, const double T[16], double H[36], double b[6], double* err,
+                       int32_t* corr_out, float* sqd_out);            /* one update_correspondences + linearize */
+int  qn_gicp_compute_error(qn_ctx*, const double T[16], double* err); /* cached correspondences (LM trial)   */
+
+/* ---- profiling hooks (bench.py roofline leg) -------------------------------------------- */
+int  qn_prof_enable(qn_ctx*, int on);                /* records a hipEvent pair around every kernel family launch */
+int  qn_prof_reset(qn_ctx*);
+int  qn_prof_get(qn_ctx*, int kernel_family, qn_kernel_stat* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* QN_ENGINE_H */
