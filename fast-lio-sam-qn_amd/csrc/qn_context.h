@@ -39,7 +39,8 @@ struct qn_ctx {
   int32_t* dbg_knn_idx = nullptr; float* dbg_knn_d2 = nullptr;
   // tuning knobs
   double cell_override = 0.0;
-  int margin_nn = 1, margin_knn = 2, ticks_per_chunk = 8;
+  int margin_nn = 1, margin_nn_cap = 3, margin_knn = 2, margin_knn_cap = 5, ticks_per_chunk = 8;
+  uint32_t* dbg_counters = nullptr;
   // profiling
   bool prof_on = false;
   std::vector<ProfSpan> spans;

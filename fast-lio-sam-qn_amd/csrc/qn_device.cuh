@@ -4,32 +4,45 @@
 // PCL FLANN tree behind getFitnessScore; reference call sites loop_closure.cpp:120-127).
 //
 // Layout (all resident in HBM, owned by the context):
-//   pts[n]        float4, sorted by linear cell index (x fastest, then y, then z); .w carries the
-//                 ORIGINAL point index as raw bits - ties between equal f32 distances are broken
-//                 towards the lowest original index, exactly as the CPU oracle does.
-//   cell_start[]  uint32 [ncells + 1], exclusive prefix of per-cell counts.
-// A (y, z) row of cells [x0..x1] is therefore ONE contiguous run pts[cell_start[row + x0] ..
-// cell_start[row + x1 + 1]) - what makes coalesced float4 staging of candidate points possible.
+//   pts[n]        float4, sorted by TILE-MAJOR cell key: the grid is cut into tiles of 8 x 4 x 4
+//                 cells; tiles are ordered x-fastest, and the 128 cells inside a tile are ordered
+//                 x-fastest too.  .w carries the ORIGINAL point index as raw bits - ties between
+//                 equal f32 distances resolve to the lowest original index, as in the CPU oracle.
+//   cell_start[]  uint32 [ncells + 1], exclusive prefix of per-cell counts in key order.
+// Two properties follow:
+//   * 64 consecutive sorted points (one wavefront of queries) sit in one or two neighbouring tiles,
+//     whether they lie on the ground, on a wall or on a box (compact clusters);
+//   * the cells [xa..xb] of one (y, z) row inside one tile are ONE contiguous run of pts[] - a
+//     "segment" - so candidates are fetched with coalesced 16 B/lane loads.
 //
-// Search, pass A (one query per lane): the 64 queries of a wavefront are spatially coherent
-// (callers feed them in cell-sorted order).  Lanes are grouped into clusters around an anchor
-// lane; the cluster's cell bounding box, grown by `margin` cells, is streamed row by row through
-// a wave-private LDS tile (coalesced global float4 loads -> ds_write_b128 -> broadcast
-// ds_read_b128), and every lane of the cluster scores every staged candidate.  A lane's result
-// is CERTIFIED exact when its (k-th) best distance is smaller than its distance to the nearest
-// face of the scanned box that still has unseen cells behind it.
-// Pass B (uncertified leftovers): exact ball query, see wave_ball_nn1 / lane_ball_knn.
+// Search, pass A (one query per lane).  Lanes are grouped into clusters around an anchor lane; the
+// cluster's cell bounding box, grown by a margin, is decomposed into segments (one per lane), the
+// segment lengths are prefix-summed across the wave and the candidates are pulled as ONE dense
+// stream: slot s of the stream maps to (segment, offset) by a binary search over the prefix in
+// LDS, so every 64-wide fetch is full and all fetches of a cluster are independent.  Each chunk is
+// staged in a wave-private LDS tile (ds_write_b128) and scored by every lane of the cluster with
+// broadcast ds_read_b128.  A lane's result is CERTIFIED exact when its (k-th) best distance is
+// smaller than its distance to the nearest face of the scanned box that has unseen cells behind
+// it; uncertified lanes retry with a larger margin, and whatever is left goes to pass B
+// (exact ball queries: wave_ball_nn1 / lane_ball_knn).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
 namespace qn {
 
+#define QN_TX 8
+#define QN_TY 4
+#define QN_TZ 4
+#define QN_TILE_CELLS 128
+
 struct GridView {
   const float4* pts;
   const uint32_t* cell_start;
+  uint32_t* dbg;                       // optional counters (null in production): clusters, candidates, flushes, retries
   float ox, oy, oz, cell, inv_cell, eps;
-  int nx, ny, nz;
+  int nx, ny, nz;                      // cells per axis
+  int ntx, nty, ntz;                   // tiles per axis
   uint32_t n;
 };
 
@@ -38,6 +51,10 @@ struct GridView {
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 __device__ __forceinline__ int cell_coord(float v, float o, float inv, int n) {
   return clampi((int)floorf((v - o) * inv), 0, n - 1);
+}
+__device__ __forceinline__ uint32_t cell_key(const GridView& g, int x, int y, int z) {
+  const uint32_t tile = ((uint32_t)(z >> 2) * g.nty + (y >> 2)) * g.ntx + (x >> 3);
+  return (tile << 7) | ((z & 3) << 5) | ((y & 3) << 3) | (x & 7);
 }
 __device__ __forceinline__ unsigned long long pack_key(float d2, uint32_t idx) {
   return ((unsigned long long)__float_as_uint(d2) << 32) | idx;
@@ -51,6 +68,9 @@ __device__ __forceinline__ float sqdist(float qx, float qy, float qz, float px, 
   float dx = qx - px, dy = qy - py, dz = qz - pz;
   return dx * dx + dy * dy + dz * dz;
 }
+
+__device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ uint32_t rflu(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 
 __device__ __forceinline__ int wave_min_i(int v) {
 #pragma unroll
@@ -72,7 +92,29 @@ __device__ __forceinline__ double wave_sum_f64(double v) {
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
   return v;
 }
+__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v, int lane) {
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) { uint32_t t = __shfl_up(v, o); if (lane >= o) v += t; }
+  return v;
+}
+// DS operations of one wave execute in issue order; this only stops the compiler from reordering.
 __device__ __forceinline__ void wave_lds_fence() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); }
+
+// ------------------------------------------------------------------ wave-private LDS scratch
+#define QN_PEND_CAP 16
+struct WaveLds {                        // per-wave scratch: candidate tile + segment table + cluster boxes (~4 KiB)
+  float4 tile[64];                      // staged candidates (ds_write_b128 / broadcast ds_read_b128)
+  uint32_t tile_cid[64];                // cluster id of each staged candidate
+  uint32_t seg_excl[64];                // exclusive prefix of segment lengths (candidate-stream slots)
+  uint32_t seg_start[64];               // first pts[] index of each segment
+  uint32_t seg_cid[64];                 // cluster each segment belongs to
+  uint32_t cl_seg0[65];                 // first segment slot of each cluster (exclusive prefix of nseg)
+  int box[64][6];                       // per cluster: x0 x1 y0 y1 z0 z1 (cells, already grown by the margin and clipped)
+};
+struct WaveLdsK {
+  WaveLds s;
+  unsigned long long pend[QN_PEND_CAP][64];
+};
 
 // ------------------------------------------------------------------ result sinks
 struct Best1 {                         // 1-NN
@@ -82,26 +124,38 @@ struct Best1 {                         // 1-NN
     unsigned long long k = pack_key(d2, idx);
     if (on && k < key) key = k;
   }
+  __device__ __forceinline__ void finish(bool on) {                   // combine the 4 candidate sub-slots of a query
+    unsigned long long t = __shfl_xor(key, 16); key = (on && t < key) ? t : key;
+    t = __shfl_xor(key, 32); key = (on && t < key) ? t : key;
+  }
+  __device__ __forceinline__ void reset() { key = QN_INF_KEY; }
   __device__ __forceinline__ bool full() const { return key != QN_INF_KEY; }
   __device__ __forceinline__ float worst_d2() const { return key_d2(key); }
 };
 
+// k-NN: ascending (d2, idx) list in registers.  Inserting costs a KMAX-long compare-exchange chain
+// that the WHOLE wave executes, so candidates that pass the (stale) k-th-best filter are parked in a
+// per-lane LDS queue and merged QN_PEND_CAP at a time (lazy insertion).
 template <int KMAX>
-struct BestK {                         // k-NN, ascending (d2, idx) list kept in registers
+struct BestK {
+  // a[0 .. KMAX-k) hold the sentinel key 0 (smaller-or-equal to every real key) for ever, so the k real
+  // entries live in a[KMAX-k .. KMAX) and the k-th best is ALWAYS a[KMAX-1]: no runtime-indexed
+  // register array (which hipcc would demote to scratch memory).
   unsigned long long a[KMAX];
-  unsigned long long w;                // cached a[k-1] (the k-th best), refreshed after every insert
-  int k;
-  __device__ __forceinline__ void init(int k_) {
-    k = k_; w = QN_INF_KEY;
+  unsigned long long w;                // k-th best as of the last flush
+  unsigned long long (*pend)[64];      // this wave's pending queue in LDS
+  uint32_t* dbg;
+  int k, cnt;
+  __device__ __forceinline__ void reset() {
+    w = QN_INF_KEY; cnt = 0;
 #pragma unroll
-    for (int j = 0; j < KMAX; j++) a[j] = QN_INF_KEY;
+    for (int j = 0; j < KMAX; j++) a[j] = (j < KMAX - k) ? 0ull : QN_INF_KEY;
   }
-  __device__ __forceinline__ void refresh() {
-    unsigned long long t = a[KMAX - 1];
-#pragma unroll
-    for (int j = KMAX - 2; j >= 0; j--) if (j == k - 1) t = a[j];
-    w = t;
+  __device__ __forceinline__ void init(int k_, unsigned long long (*pend_)[64], uint32_t* dbg_ = nullptr) {
+    k = k_; pend = pend_; dbg = dbg_; reset();
   }
+  __device__ __forceinline__ bool slot_valid(int j) const { return j >= KMAX - k && a[j] != QN_INF_KEY; }   // j static
+  __device__ __forceinline__ void refresh() { w = a[KMAX - 1]; }
   __device__ __forceinline__ void insert(unsigned long long key) {   // compare-exchange chain: sorted insert, largest falls off
 #pragma unroll
     for (int j = 0; j < KMAX; j++) {
@@ -109,71 +163,198 @@ struct BestK {                         // k-NN, ascending (d2, idx) list kept in
       unsigned long long hi = key < a[j] ? a[j] : key;
       a[j] = lo; key = hi;
     }
+  }
+  __device__ __forceinline__ void flush() {                          // wave-cooperative
+    const int lane = threadIdx.x & 63;
+    const int m = wave_max_i(cnt);
+    for (int e = 0; e < m; e++) {
+      unsigned long long key = e < cnt ? pend[e][lane] : QN_INF_KEY;
+      insert(key);
+    }
+    cnt = 0;
     refresh();
+    if (dbg && lane == 0) atomicAdd(&dbg[2], 1u);
   }
   __device__ __forceinline__ void consider(bool on, float d2, uint32_t idx) {   // wave-cooperative: called by all lanes
-    unsigned long long key = pack_key(d2, idx);
-    const bool ins = on && key < w;
-    if (__any(ins)) insert(ins ? key : QN_INF_KEY);
+    const unsigned long long key = pack_key(d2, idx);
+    if (on && key < w) { pend[cnt][threadIdx.x & 63] = key; cnt++; }
+    if (__any(cnt == QN_PEND_CAP)) flush();
+  }
+  // One-directional merge: lanes whose `recv` is true insert the k real entries of lane ^ lane_xor;
+  // the sending lanes insert the +inf key (a no-op), so their lists stay intact while being read.
+  __device__ __forceinline__ void merge_from(int lane_xor, bool recv) {
+#pragma unroll
+    for (int j = 0; j < KMAX; j++) {
+      const unsigned long long other = __shfl_xor(a[j], lane_xor);
+      if (__any(j >= KMAX - k)) insert((recv && j >= KMAX - k) ? other : QN_INF_KEY);
+    }
+  }
+  // flush, then fold the 4 candidate sub-slots of a query into sub-slot 0.  `on` = this lane's query took
+  // part in the round that just ended (queries finished in an earlier round must not merge twice).
+  __device__ __forceinline__ void finish(bool on) {
+    if (__any(cnt > 0)) flush();
+    const int lane = threadIdx.x & 63;
+    merge_from(32, on && (lane & 32) == 0);        // sub 0 <- 2, sub 1 <- 3
+    merge_from(16, on && (lane & 48) == 0);        // sub 0 <- 1
+    refresh();
+    const unsigned long long w0 = __shfl(w, lane & 15);
+    if (on) w = w0;                                // every lane of the query sees the merged k-th best
   }
   __device__ __forceinline__ bool full() const { return w != QN_INF_KEY; }
   __device__ __forceinline__ float worst_d2() const { return key_d2(w); }
 };
 
-// ------------------------------------------------------------------ pass A
-// Cluster extents (cells) around the anchor lane.
-#define QN_CL_DX 8
-#define QN_CL_DY 2
-#define QN_CL_DZ 2
+// ------------------------------------------------------------------ dense candidate stream over a cell box
+// Calls body(p, valid, cnt) once per 64-candidate chunk with one candidate per lane (`valid` = lane
+// holds a real one, `cnt` = candidates in this chunk, wave-uniform).  All 64 lanes must call.
+template <class Body>
+__device__ __forceinline__ uint32_t stream_box(const GridView& g, int x0, int x1, int y0, int y1, int z0, int z1, WaveLds* lds, Body&& body) {
+  const int lane = threadIdx.x & 63;
+  const int tx0 = x0 >> 3, ntr = (x1 >> 3) - tx0 + 1, nyr = y1 - y0 + 1;
+  const int nseg = ntr * nyr * (z1 - z0 + 1);
+  uint32_t grand = 0;
+  for (int sb = 0; sb < nseg; sb += 64) {
+    const int sidx = sb + lane;
+    uint32_t s = 0, len = 0;
+    if (sidx < nseg) {
+      const int t = sidx % ntr, r = sidx / ntr;
+      const int ry = y0 + r % nyr, rz = z0 + r / nyr, tx = tx0 + t;
+      const int xa = max(x0, tx << 3), xb = min(x1, (tx << 3) + 7);
+      const uint32_t k0 = cell_key(g, xa, ry, rz);
+      s = g.cell_start[k0]; len = g.cell_start[k0 + (xb - xa) + 1] - s;
+    }
+    const uint32_t incl = wave_incl_scan_u32(len, lane);
+    const uint32_t total = rflu(__shfl(incl, 63));
+    if (total == 0) continue;
+    wave_lds_fence();
+    lds->seg_excl[lane] = incl - len; lds->seg_start[lane] = s;
+    wave_lds_fence();
+    for (uint32_t cb = 0; cb < total; cb += 64) {
+      const uint32_t slot = cb + lane;
+      const bool valid = slot < total;
+      int j = 0;
+#pragma unroll
+      for (int step = 32; step > 0; step >>= 1) { const int t = j + step; if (t < 64 && lds->seg_excl[t] <= slot) j = t; }
+      float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (valid) p = g.pts[lds->seg_start[j] + (slot - lds->seg_excl[j])];
+      body(p, valid, min(64u, total - cb));
+    }
+    grand += total;
+  }
+  return grand;
+}
 
-// All 64 lanes must call this (inactive lanes pass active = false).  `lds` points at this wave's
-// private 64-entry float4 tile.  Returns per lane whether the sink content is certified exact.
+// ------------------------------------------------------------------ pass A
+#define QN_CL_DX 8
+#define QN_CL_DY 4
+#define QN_CL_DZ 4
+
+// All 64 lanes must call this (inactive lanes pass active = false).  Returns per lane whether the
+// sink content is certified exact.  margin0 = first margin (cells); lanes that fail certification
+// retry together with margin 2 m + 1 while that stays <= margin_cap.
+//
+// A wavefront serves 16 QUERIES: lane l works for query (l & 15) as candidate sub-slot (l >> 4), i.e.
+// the four lanes of a query split the candidate stream four ways and merge in sink.finish().  100k
+// queries therefore make 6250 waves (the chip holds 8192), each with a 4x shorter candidate loop.
+//
+// One ROUND handles every cluster of the wave at once, so its memory latency is paid once, not per
+// cluster: (1) lanes are partitioned into clusters around anchor lanes (ALU only); (2) every
+// cluster's cell box is built with LDS min/max atomics; (3) all boxes are cut into segments, one
+// per lane, whose bounds come from ONE gather of cell_start; (4) the candidates of all segments form
+// one dense stream that is fetched 64 at a time (coalesced within a segment), staged in LDS together
+// with the owning cluster id, and scored by the lanes of that cluster via broadcast ds_read_b128.
 template <class Sink>
 __device__ __forceinline__ bool wave_cluster_search(const GridView& g, float qx, float qy, float qz, bool active,
-                                                    int margin, Sink& sink, float4* lds) {
+                                                    int margin0, int margin_cap, Sink& sink, WaveLds* lds) {
   const int lane = threadIdx.x & 63;
   const int cx = cell_coord(qx, g.ox, g.inv_cell, g.nx);
   const int cy = cell_coord(qy, g.oy, g.inv_cell, g.ny);
   const int cz = cell_coord(qz, g.oz, g.inv_cell, g.nz);
   bool certified = false;
-  unsigned long long remaining = __ballot(active);
-  while (remaining) {
-    const int leader = __ffsll((long long)remaining) - 1;
-    const int ax = __shfl(cx, leader), ay = __shfl(cy, leader), az = __shfl(cz, leader);
-    const bool in = active && ((remaining >> lane) & 1ull) && abs(cx - ax) <= QN_CL_DX && abs(cy - ay) <= QN_CL_DY && abs(cz - az) <= QN_CL_DZ;
-    remaining &= ~__ballot(in);
-    const int BIG = 0x3fffffff;
-    int ex0 = wave_min_i(in ? cx : BIG) - margin, ex1 = wave_max_i(in ? cx : -BIG) + margin;
-    int ey0 = wave_min_i(in ? cy : BIG) - margin, ey1 = wave_max_i(in ? cy : -BIG) + margin;
-    int ez0 = wave_min_i(in ? cz : BIG) - margin, ez1 = wave_max_i(in ? cz : -BIG) + margin;
-    ex0 = max(ex0, 0); ey0 = max(ey0, 0); ez0 = max(ez0, 0);
-    ex1 = min(ex1, g.nx - 1); ey1 = min(ey1, g.ny - 1); ez1 = min(ez1, g.nz - 1);
-    const int nyr = ey1 - ey0 + 1, nrows = nyr * (ez1 - ez0 + 1);
-    for (int rbase = 0; rbase < nrows; rbase += 64) {
-      const int r = rbase + lane;
-      uint32_t s = 0, e = 0;
-      if (r < nrows) {
-        const int ry = ey0 + r % nyr, rz = ez0 + r / nyr;
-        const uint32_t c0 = ((uint32_t)rz * g.ny + ry) * g.nx;
-        s = g.cell_start[c0 + ex0]; e = g.cell_start[c0 + ex1 + 1];
+  unsigned long long todo = __ballot(active);
+  for (int margin = margin0; todo != 0; margin = 2 * margin + 1) {
+    const bool mine = (todo >> lane) & 1ull;
+    // (1) cluster ids
+    uint32_t cid = 0xffffffffu; int ncl = 0;
+    for (unsigned long long rem = todo; rem != 0; ncl++) {
+      const int leader = __ffsll((long long)rem) - 1;
+      const int ax = rfl(__shfl(cx, leader)), ay = rfl(__shfl(cy, leader)), az = rfl(__shfl(cz, leader));
+      const bool in = ((rem >> lane) & 1ull) && abs(cx - ax) <= QN_CL_DX && abs(cy - ay) <= QN_CL_DY && abs(cz - az) <= QN_CL_DZ;
+      if (in) cid = ncl;
+      rem &= ~__ballot(in);
+    }
+    // (2) cluster boxes
+    wave_lds_fence();
+    if (lane < ncl) { lds->box[lane][0] = 0x3fffffff; lds->box[lane][1] = -1; lds->box[lane][2] = 0x3fffffff; lds->box[lane][3] = -1; lds->box[lane][4] = 0x3fffffff; lds->box[lane][5] = -1; }
+    wave_lds_fence();
+    if (mine) {
+      atomicMin(&lds->box[cid][0], max(cx - margin, 0)); atomicMax(&lds->box[cid][1], min(cx + margin, g.nx - 1));
+      atomicMin(&lds->box[cid][2], max(cy - margin, 0)); atomicMax(&lds->box[cid][3], min(cy + margin, g.ny - 1));
+      atomicMin(&lds->box[cid][4], max(cz - margin, 0)); atomicMax(&lds->box[cid][5], min(cz + margin, g.nz - 1));
+    }
+    wave_lds_fence();
+    // (3) segments per cluster, prefix over clusters
+    uint32_t my_nseg = 0;
+    if (lane < ncl) {
+      const int* b = lds->box[lane];
+      my_nseg = (uint32_t)(((b[1] >> 3) - (b[0] >> 3) + 1) * (b[3] - b[2] + 1) * (b[5] - b[4] + 1));
+    }
+    const uint32_t seg_incl = wave_incl_scan_u32(my_nseg, lane);
+    const uint32_t nseg_all = rflu(__shfl(seg_incl, 63));
+    lds->cl_seg0[lane] = seg_incl - my_nseg;
+    if (lane == 0) lds->cl_seg0[64] = nseg_all;
+    wave_lds_fence();
+    uint32_t ncand = 0;
+    for (uint32_t sb = 0; sb < nseg_all; sb += 64) {
+      const uint32_t sidx = sb + lane;
+      uint32_t s = 0, len = 0, scid = 0;
+      if (sidx < nseg_all) {
+        int c = 0;                                   // last cluster with cl_seg0[c] <= sidx  (ncl <= 64)
+#pragma unroll
+        for (int step = 32; step > 0; step >>= 1) { const int t = c + step; if (t < ncl && lds->cl_seg0[t] <= sidx) c = t; }
+        const int* b = lds->box[c];
+        const int x0 = b[0], x1 = b[1], y0 = b[2], y1 = b[3], z0 = b[4];
+        const int tx0 = x0 >> 3, ntr = (x1 >> 3) - tx0 + 1, nyr = y1 - y0 + 1;
+        const int li = (int)(sidx - lds->cl_seg0[c]);
+        const int t = li % ntr, r = li / ntr;
+        const int ry = y0 + r % nyr, rz = z0 + r / nyr, tx = tx0 + t;
+        const int xa = max(x0, tx << 3), xb = min(x1, (tx << 3) + 7);
+        const uint32_t k0 = cell_key(g, xa, ry, rz);
+        s = g.cell_start[k0]; len = g.cell_start[k0 + (xb - xa) + 1] - s; scid = (uint32_t)c;
       }
-      unsigned long long nonempty = __ballot(e > s);
-      while (nonempty) {
-        const int rl = __ffsll((long long)nonempty) - 1; nonempty &= nonempty - 1;
-        const uint32_t rs = __shfl(s, rl), re = __shfl(e, rl);
-        for (uint32_t base = rs; base < re; base += 64) {
-          const uint32_t cnt = min(64u, re - base);
-          if ((uint32_t)lane < cnt) lds[lane] = g.pts[base + lane];       // coalesced 16 B/lane -> ds_write_b128
-          wave_lds_fence();
-          for (uint32_t c = 0; c < cnt; c++) {
-            const float4 p = lds[c];                                      // broadcast ds_read_b128
-            sink.consider(in, sqdist(qx, qy, qz, p.x, p.y, p.z), __float_as_uint(p.w));
-          }
-          wave_lds_fence();
+      const uint32_t incl = wave_incl_scan_u32(len, lane);
+      const uint32_t total = rflu(__shfl(incl, 63));
+      if (total == 0) continue;
+      wave_lds_fence();
+      lds->seg_excl[lane] = incl - len; lds->seg_start[lane] = s; lds->seg_cid[lane] = scid;
+      wave_lds_fence();
+      // (4) dense candidate stream of this segment batch
+      for (uint32_t cb = 0; cb < total; cb += 64) {
+        const uint32_t slot = cb + lane;
+        int j = 0;
+#pragma unroll
+        for (int step = 32; step > 0; step >>= 1) { const int t = j + step; if (t < 64 && lds->seg_excl[t] <= slot) j = t; }
+        const uint32_t cnt = min(64u, total - cb);
+        wave_lds_fence();
+        if (slot < total) { lds->tile[lane] = g.pts[lds->seg_start[j] + (slot - lds->seg_excl[j])]; lds->tile_cid[lane] = lds->seg_cid[j]; }
+        wave_lds_fence();
+#pragma unroll 2
+        for (uint32_t c = 0; c < cnt; c += 4) {                               // 4 candidates per step: one per 16-lane sub-slot
+          const uint32_t ci = c + (uint32_t)(lane >> 4);
+          const float4 cp = lds->tile[ci & 63];                               // ds_read_b128, 4 distinct addresses per wave
+          const bool on = mine && ci < cnt && lds->tile_cid[ci & 63] == cid;
+          sink.consider(on, sqdist(qx, qy, qz, cp.x, cp.y, cp.z), __float_as_uint(cp.w));
         }
       }
+      ncand += total;
     }
-    if (in) {   // certification: nearest face of the scanned box that has unseen cells behind it
+    sink.finish(mine);
+    if (g.dbg && lane == 0) { atomicAdd(&g.dbg[0], (uint32_t)ncl); atomicAdd(&g.dbg[1], ncand); }
+    // certification: nearest face of the scanned box that has unseen cells behind it
+    bool retry = false;
+    if (mine) {
+      const int* b = lds->box[cid];
+      const int ex0 = b[0], ex1 = b[1], ey0 = b[2], ey1 = b[3], ez0 = b[4], ez1 = b[5];
       const float INF = __int_as_float(0x7f800000);
       float d = INF;
       if (ex0 > 0) d = fminf(d, qx - (g.ox + ex0 * g.cell));
@@ -184,44 +365,30 @@ __device__ __forceinline__ bool wave_cluster_search(const GridView& g, float qx,
       if (ez1 < g.nz - 1) d = fminf(d, (g.oz + (ez1 + 1) * g.cell) - qz);
       if (d == INF) certified = true;                        // the whole grid was scanned
       else { d -= g.eps; certified = d > 0.f && sink.full() && sink.worst_d2() < d * d; }
+      if (!certified && 2 * margin + 1 <= margin_cap) { retry = true; sink.reset(); }
     }
+    todo = __ballot(retry);
+    if (g.dbg && lane == 0 && todo) atomicAdd(&g.dbg[3], (uint32_t)__popcll(todo));
   }
   return certified;
 }
 
 // ------------------------------------------------------------------ pass B, 1-NN: one query per WAVE
-// Exact ball query: scans every cell that intersects the ball of radius r around q, all 64 lanes
-// striding over each row's contiguous run (coalesced), then a wave-wide min of the packed keys.
-// r starts from a known upper bound on the NN distance (pass A's uncertified best) or, when
-// nothing was found yet, from r0 and doubles until the best distance found fits inside it.
-__device__ __forceinline__ unsigned long long wave_ball_nn1(const GridView& g, float qx, float qy, float qz, float r) {
-  const int lane = threadIdx.x & 63;
+// Exact ball query: streams every cell that intersects the ball of radius r around q (one candidate
+// per lane per fetch), then a wave-wide min of the packed keys.  r starts from a known upper bound
+// on the NN distance (pass A's uncertified best) or, when nothing was found yet, doubles until the
+// best distance found fits inside it.
+__device__ __forceinline__ unsigned long long wave_ball_nn1(const GridView& g, float qx, float qy, float qz, float r, WaveLds* lds) {
   for (int round = 0;; round++) {
-    const int bx0 = cell_coord(qx - r, g.ox, g.inv_cell, g.nx), bx1 = cell_coord(qx + r, g.ox, g.inv_cell, g.nx);
-    const int by0 = cell_coord(qy - r, g.oy, g.inv_cell, g.ny), by1 = cell_coord(qy + r, g.oy, g.inv_cell, g.ny);
-    const int bz0 = cell_coord(qz - r, g.oz, g.inv_cell, g.nz), bz1 = cell_coord(qz + r, g.oz, g.inv_cell, g.nz);
+    const int bx0 = rfl(cell_coord(qx - r, g.ox, g.inv_cell, g.nx)), bx1 = rfl(cell_coord(qx + r, g.ox, g.inv_cell, g.nx));
+    const int by0 = rfl(cell_coord(qy - r, g.oy, g.inv_cell, g.ny)), by1 = rfl(cell_coord(qy + r, g.oy, g.inv_cell, g.ny));
+    const int bz0 = rfl(cell_coord(qz - r, g.oz, g.inv_cell, g.nz)), bz1 = rfl(cell_coord(qz + r, g.oz, g.inv_cell, g.nz));
     const bool all = bx0 == 0 && by0 == 0 && bz0 == 0 && bx1 == g.nx - 1 && by1 == g.ny - 1 && bz1 == g.nz - 1;
-    const int nyr = by1 - by0 + 1, nrows = nyr * (bz1 - bz0 + 1);
     unsigned long long best = QN_INF_KEY;
-    for (int rbase = 0; rbase < nrows; rbase += 64) {
-      const int rr = rbase + lane;
-      uint32_t s = 0, e = 0;
-      if (rr < nrows) {
-        const int ry = by0 + rr % nyr, rz = bz0 + rr / nyr;
-        const uint32_t c0 = ((uint32_t)rz * g.ny + ry) * g.nx;
-        s = g.cell_start[c0 + bx0]; e = g.cell_start[c0 + bx1 + 1];
-      }
-      unsigned long long nonempty = __ballot(e > s);
-      while (nonempty) {
-        const int rl = __ffsll((long long)nonempty) - 1; nonempty &= nonempty - 1;
-        const uint32_t rs = __shfl(s, rl), re = __shfl(e, rl);
-        for (uint32_t i = rs + lane; i < re; i += 64) {
-          const float4 p = g.pts[i];
-          const unsigned long long k = pack_key(sqdist(qx, qy, qz, p.x, p.y, p.z), __float_as_uint(p.w));
-          best = k < best ? k : best;
-        }
-      }
-    }
+    stream_box(g, bx0, bx1, by0, by1, bz0, bz1, lds, [&](float4 p, bool valid, uint32_t) __attribute__((always_inline)) {
+      const unsigned long long k = pack_key(sqdist(qx, qy, qz, p.x, p.y, p.z), __float_as_uint(p.w));
+      if (valid && k < best) best = k;
+    });
     best = wave_min_u64(best);
     if (all || round > 160) return best;          // round cap: non-finite queries cannot spin forever
     if (best != QN_INF_KEY) {
@@ -235,23 +402,23 @@ __device__ __forceinline__ unsigned long long wave_ball_nn1(const GridView& g, f
 }
 
 // ------------------------------------------------------------------ pass B, k-NN: one query per LANE
-// Same ball logic, per lane (divergent; only the k-NN leftovers of the covariance stage use it).
+// Same ball logic, per lane (divergent; only the rare k-NN leftovers of the covariance stage use it).
 template <int KMAX>
 __device__ __forceinline__ void lane_ball_knn(const GridView& g, float qx, float qy, float qz, float r, BestK<KMAX>& sink) {
-  const int k = sink.k;
   for (int round = 0;; round++) {
-    sink.init(k);
+    sink.reset();
     const int bx0 = cell_coord(qx - r, g.ox, g.inv_cell, g.nx), bx1 = cell_coord(qx + r, g.ox, g.inv_cell, g.nx);
     const int by0 = cell_coord(qy - r, g.oy, g.inv_cell, g.ny), by1 = cell_coord(qy + r, g.oy, g.inv_cell, g.ny);
     const int bz0 = cell_coord(qz - r, g.oz, g.inv_cell, g.nz), bz1 = cell_coord(qz + r, g.oz, g.inv_cell, g.nz);
     const bool all = bx0 == 0 && by0 == 0 && bz0 == 0 && bx1 == g.nx - 1 && by1 == g.ny - 1 && bz1 == g.nz - 1;
-    for (int rz = bz0; rz <= bz1; rz++) for (int ry = by0; ry <= by1; ry++) {
-      const uint32_t c0 = ((uint32_t)rz * g.ny + ry) * g.nx;
-      const uint32_t s = g.cell_start[c0 + bx0], e = g.cell_start[c0 + bx1 + 1];
+    for (int rz = bz0; rz <= bz1; rz++) for (int ry = by0; ry <= by1; ry++) for (int tx = bx0 >> 3; tx <= (bx1 >> 3); tx++) {
+      const int xa = max(bx0, tx << 3), xb = min(bx1, (tx << 3) + 7);
+      const uint32_t k0 = cell_key(g, xa, ry, rz);
+      const uint32_t s = g.cell_start[k0], e = g.cell_start[k0 + (xb - xa) + 1];
       for (uint32_t i = s; i < e; i++) {
         const float4 p = g.pts[i];
         const unsigned long long key = pack_key(sqdist(qx, qy, qz, p.x, p.y, p.z), __float_as_uint(p.w));
-        if (key < sink.w) sink.insert(key);                       // per-lane sorted insert
+        if (key < sink.w) { sink.insert(key); sink.refresh(); }                 // per-lane sorted insert
       }
     }
     if (all || round > 160) return;

@@ -124,7 +124,7 @@ extern "C" void qn_ctx_destroy(qn_ctx* c) {
   for (int w = 0; w < 2; w++) { CloudBuf& b = c->cloud[w]; hipFree(b.raw); hipFree(b.sorted); hipFree(b.cell_of_pt); hipFree(b.cell_start); hipFree(b.counts); hipFree(b.cov); }
   hipFree(c->staging); hipFree(c->scan_sums); hipFree(c->bbox); hipFree(c->state); hipFree(c->partials); hipFree(c->trace);
   hipFree(c->corr); hipFree(c->sqd); hipFree(c->sqd_fit); hipFree(c->fb_list); hipFree(c->fb_count2); hipFree(c->aligned);
-  hipFree(c->pose_tmp); hipFree(c->guess_tmp); hipFree(c->dbg_knn_idx); hipFree(c->dbg_knn_d2);
+  hipFree(c->pose_tmp); hipFree(c->guess_tmp); hipFree(c->dbg_knn_idx); hipFree(c->dbg_knn_d2); hipFree(c->dbg_counters);
   if (c->result_host) hipHostFree(c->result_host);
   if (c->bbox_host) hipHostFree(c->bbox_host);
   if (c->scalar_host) hipHostFree(c->scalar_host);
@@ -166,7 +166,7 @@ static int build_grid(qn_ctx* c, CloudBuf& b) {
   *c->bbox_host = init;
   HIPCHK(c, hipMemcpyAsync(c->bbox, c->bbox_host, sizeof(BBoxOut), hipMemcpyHostToDevice, s));
   { ProfScope ps(c, QN_K_GRID_BUILD);
-    hipLaunchKernelGGL(k_bbox, dim3(std::min<uint32_t>((n + QN_BLOCK - 1) / QN_BLOCK, 512)), dim3(QN_BLOCK), 0, s, b.raw, n, c->bbox); }
+    hipLaunchKernelGGL(k_bbox, dim3(std::min<uint32_t>((n + QN_BLOCK - 1) / QN_BLOCK, 128)), dim3(QN_BLOCK), 0, s, b.raw, n, c->bbox); }
   HIPCHK(c, hipMemcpyAsync(c->bbox_host, c->bbox, sizeof(BBoxOut), hipMemcpyDeviceToHost, s));
   HIPCHK(c, hipStreamSynchronize(s));
   if (c->bbox_host->nonfinite) { c->last_error = "cloud contains non-finite coordinates (is_dense == false clouds are not supported)"; return QN_ERR_INVALID_ARG; }
@@ -180,19 +180,20 @@ static int build_grid(qn_ctx* c, CloudBuf& b) {
   double cell = std::sqrt(4.0 * area / (double)n);
   cell = std::max(cell, std::max(Lmax / 2048.0, 1e-6));
   if (c->cell_override > 0) cell = c->cell_override;
-  int dims[3];
+  int dims[3], tdims[3]; const int tile[3] = {QN_TX, QN_TY, QN_TZ};
   for (int iter = 0; iter < 64; iter++) {
-    double tot = 1;
-    for (int d = 0; d < 3; d++) { dims[d] = (int)std::floor(L[d] / cell) + 1; tot *= dims[d]; }
+    double tot = 1;   // the dense cell table is padded to whole 8x4x4 tiles
+    for (int d = 0; d < 3; d++) { dims[d] = (int)std::floor(L[d] / cell) + 1; tdims[d] = (dims[d] + tile[d] - 1) / tile[d]; tot *= (double)tdims[d] * tile[d]; }
     if (tot <= (double)c->max_cells) break;
     cell *= std::max(std::cbrt(tot / (double)c->max_cells), 1.02);
   }
   GridView& g = b.grid;
-  g.pts = b.sorted; g.cell_start = b.cell_start; g.ox = mn[0]; g.oy = mn[1]; g.oz = mn[2];
+  g.pts = b.sorted; g.cell_start = b.cell_start; g.dbg = c->dbg_counters; g.ox = mn[0]; g.oy = mn[1]; g.oz = mn[2];
   g.cell = (float)cell; g.inv_cell = 1.0f / g.cell; g.nx = dims[0]; g.ny = dims[1]; g.nz = dims[2]; g.n = n;
+  g.ntx = tdims[0]; g.nty = tdims[1]; g.ntz = tdims[2];
   float amax = 0; for (int d = 0; d < 3; d++) amax = std::max(amax, std::max(std::fabs(mn[d]), std::fabs(mx[d])));
   g.eps = 1e-3f * g.cell + 1e-6f * (amax + (float)Lmax);
-  const uint32_t ncells = (uint32_t)dims[0] * dims[1] * dims[2];
+  const uint32_t ncells = (uint32_t)tdims[0] * tdims[1] * tdims[2] * QN_TILE_CELLS;
   b.ncells = ncells;
   const uint32_t nb = (n + QN_BLOCK - 1) / QN_BLOCK;
   const uint32_t sb = (ncells + QN_BLOCK * QN_SCAN_ITEMS - 1) / (QN_BLOCK * QN_SCAN_ITEMS);
@@ -241,9 +242,9 @@ extern "C" int qn_gicp_set_target_device(qn_ctx* c, const float* xyz, uint32_t n
 template <int KMAX>
 static void launch_knn_cov(qn_ctx* c, CloudBuf& b, int k, int32_t* kidx, float* kd2) {
   hipStream_t s = c->stream;
-  const uint32_t nb = (b.n + QN_BLOCK - 1) / QN_BLOCK;
+  const uint32_t nb = (b.n + QN_BLOCK / 4 - 1) / (QN_BLOCK / 4);      // 16 queries per wave, 64 per block
   { ProfScope ps(c, QN_K_KNN_COV);
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_knn_cov<KMAX>), dim3(nb), dim3(QN_BLOCK), 0, s, b.grid, b.raw, k, c->margin_knn, b.cov, kidx, kd2, c->fb_list, c->fb_count2);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_knn_cov<KMAX>), dim3(nb), dim3(QN_BLOCK), 0, s, b.grid, b.raw, k, c->margin_knn, c->margin_knn_cap, b.cov, kidx, kd2, c->fb_list, c->fb_count2);
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_knn_cov_fallback<KMAX>), dim3(std::min<uint32_t>(nb, 1024)), dim3(QN_BLOCK), 0, s, b.grid, b.raw, k, c->margin_knn, b.cov, kidx, kd2, c->fb_list, c->fb_count2); }
 }
 static int compute_cov(qn_ctx* c, int which, int32_t* kidx, float* kd2) {
@@ -254,6 +255,7 @@ static int compute_cov(qn_ctx* c, int which, int32_t* kidx, float* kd2) {
   const int k = c->params.k_correspondences;
   HIPCHK(c, hipMemsetAsync(c->fb_count2, 0, sizeof(uint32_t), c->stream));
   if (k <= 16) launch_knn_cov<16>(c, b, k, kidx, kd2);
+  else if (k <= 20) launch_knn_cov<20>(c, b, k, kidx, kd2);
   else if (k <= 24) launch_knn_cov<24>(c, b, k, kidx, kd2);
   else launch_knn_cov<32>(c, b, k, kidx, kd2);
   HIPCHK(c, hipGetLastError());
@@ -266,18 +268,18 @@ extern "C" int qn_gicp_compute_covariances(qn_ctx* c, int which) { return comput
 static void enqueue_nn(qn_ctx* c, int mode /*0 align, 1 fitness*/, float* sqd_out) {
   hipStream_t s = c->stream;
   CloudBuf &S = c->cloud[0], &T = c->cloud[1];
-  const uint32_t nb = (S.n + QN_BLOCK - 1) / QN_BLOCK;
+  const uint32_t nb = (S.n + QN_BLOCK / 4 - 1) / (QN_BLOCK / 4);      // 16 queries per wave, 64 per block
   const double thr2 = c->params.max_corr_dist * c->params.max_corr_dist;
   uint32_t* fbc = &c->state->fb_count;
   const uint32_t fbb = std::min<uint32_t>((S.n + 3) / 4, 2048);
   if (mode == 0) {
     { ProfScope ps(c, QN_K_NN_SEARCH);
-      hipLaunchKernelGGL(HIP_KERNEL_NAME(k_nn_search<0>), dim3(nb), dim3(QN_BLOCK), 0, s, S.grid, T.grid, c->state, thr2, c->margin_nn, c->corr, sqd_out, c->fb_list, fbc); }
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(k_nn_search<0>), dim3(nb), dim3(QN_BLOCK), 0, s, S.grid, T.grid, c->state, thr2, c->margin_nn, c->margin_nn_cap, c->corr, sqd_out, c->fb_list, fbc); }
     { ProfScope ps(c, QN_K_NN_FALLBACK);
       hipLaunchKernelGGL(HIP_KERNEL_NAME(k_nn_fallback<0>), dim3(fbb), dim3(QN_BLOCK), 0, s, S.grid, T.grid, c->state, thr2, c->margin_nn, c->corr, sqd_out, c->fb_list, fbc); }
   } else {
     { ProfScope ps(c, QN_K_FITNESS);
-      hipLaunchKernelGGL(HIP_KERNEL_NAME(k_nn_search<1>), dim3(nb), dim3(QN_BLOCK), 0, s, S.grid, T.grid, c->state, thr2, c->margin_nn, c->corr, sqd_out, c->fb_list, fbc);
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(k_nn_search<1>), dim3(nb), dim3(QN_BLOCK), 0, s, S.grid, T.grid, c->state, thr2, c->margin_nn, c->margin_nn_cap, c->corr, sqd_out, c->fb_list, fbc);
       hipLaunchKernelGGL(HIP_KERNEL_NAME(k_nn_fallback<1>), dim3(fbb), dim3(QN_BLOCK), 0, s, S.grid, T.grid, c->state, thr2, c->margin_nn, c->corr, sqd_out, c->fb_list, fbc); }
   }
 }
@@ -482,8 +484,22 @@ extern "C" int qn_debug_set(qn_ctx* c, const char* key, double v) {
   if (k == "cell") { c->cell_override = v; c->cloud[0].has_grid = c->cloud[1].has_grid = false; }
   else if (k == "margin_nn") c->margin_nn = (int)v;
   else if (k == "margin_knn") c->margin_knn = (int)v;
+  else if (k == "margin_nn_cap") c->margin_nn_cap = (int)v;
+  else if (k == "margin_knn_cap") c->margin_knn_cap = (int)v;
+  else if (k == "dbg_counters") {
+    if (v != 0 && !c->dbg_counters) { if (hipMalloc(&c->dbg_counters, 16 * sizeof(uint32_t)) != hipSuccess) return QN_ERR_HIP; }
+    if (c->dbg_counters) (void)hipMemset(c->dbg_counters, 0, 16 * sizeof(uint32_t));
+    if (v == 0) { (void)hipFree(c->dbg_counters); c->dbg_counters = nullptr; }
+    for (int w = 0; w < 2; w++) c->cloud[w].grid.dbg = c->dbg_counters;
+  }
   else if (k == "ticks_per_chunk") c->ticks_per_chunk = std::max(1, (int)v);
   else return QN_ERR_INVALID_ARG;
+  return QN_OK;
+}
+extern "C" int qn_debug_get_counters(qn_ctx* c, uint32_t out[16]) {
+  if (!c || !c->dbg_counters) return QN_ERR_INVALID_ARG;
+  if (hipStreamSynchronize(c->stream) != hipSuccess) return QN_ERR_HIP;
+  if (hipMemcpy(out, c->dbg_counters, 16 * sizeof(uint32_t), hipMemcpyDeviceToHost) != hipSuccess) return QN_ERR_HIP;
   return QN_OK;
 }
 extern "C" int qn_debug_get_grid(qn_ctx* c, int which, double out[8]) {

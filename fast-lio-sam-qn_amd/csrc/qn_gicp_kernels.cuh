@@ -47,21 +47,25 @@ __global__ void k_pack_points(const char* __restrict__ in, uint32_t stride, uint
   out[i] = make_float4(p[0], p[1], p[2], 1.0f);
 }
 
-__global__ void k_bbox(const float4* __restrict__ pts, uint32_t n, BBoxOut* out) {
+__global__ void __launch_bounds__(QN_BLOCK) k_bbox(const float4* __restrict__ pts, uint32_t n, BBoxOut* out) {
+  __shared__ int smn[QN_BLOCK / 64][3], smx[QN_BLOCK / 64][3], sbad[QN_BLOCK / 64];
   int mn[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff}, mx[3] = {(int)0x80000000, (int)0x80000000, (int)0x80000000};
-  uint32_t bad = 0;
+  int bad = 0;
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
     float4 p = pts[i];
-    if (!(isfinite(p.x) && isfinite(p.y) && isfinite(p.z))) { bad++; continue; }
+    if (!(isfinite(p.x) && isfinite(p.y) && isfinite(p.z))) { bad = 1; continue; }
     int ox = f2ord(p.x), oy = f2ord(p.y), oz = f2ord(p.z);
     mn[0] = min(mn[0], ox); mn[1] = min(mn[1], oy); mn[2] = min(mn[2], oz);
     mx[0] = max(mx[0], ox); mx[1] = max(mx[1], oy); mx[2] = max(mx[2], oz);
   }
 #pragma unroll
   for (int d = 0; d < 3; d++) { mn[d] = wave_min_i(mn[d]); mx[d] = wave_max_i(mx[d]); }
-  bad = (uint32_t)wave_max_i((int)bad) ? 1u : 0u;
-  if ((threadIdx.x & 63) == 0) {
-#pragma unroll
+  bad = wave_max_i(bad);
+  const int wid = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) { for (int d = 0; d < 3; d++) { smn[wid][d] = mn[d]; smx[wid][d] = mx[d]; } sbad[wid] = bad; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < QN_BLOCK / 64; w++) { for (int d = 0; d < 3; d++) { mn[d] = min(mn[d], smn[w][d]); mx[d] = max(mx[d], smx[w][d]); } bad |= sbad[w]; }
     for (int d = 0; d < 3; d++) { atomicMin(&out->mn[d], mn[d]); atomicMax(&out->mx[d], mx[d]); }
     if (bad) atomicAdd(&out->nonfinite, 1u);
   }
@@ -72,7 +76,7 @@ __global__ void k_cell_count(const float4* __restrict__ pts, uint32_t n, GridVie
   if (i >= n) return;
   float4 p = pts[i];
   int cx = cell_coord(p.x, g.ox, g.inv_cell, g.nx), cy = cell_coord(p.y, g.oy, g.inv_cell, g.ny), cz = cell_coord(p.z, g.oz, g.inv_cell, g.nz);
-  uint32_t c = ((uint32_t)cz * g.ny + cy) * g.nx + cx;
+  uint32_t c = cell_key(g, cx, cy, cz);
   cell_of_pt[i] = c;
   atomicAdd(&counts[c], 1u);
 }
@@ -152,22 +156,22 @@ __device__ __forceinline__ void cov_from_knn(const BestK<KMAX>& sink, const floa
   int found = 0;
   double mean[3] = {0, 0, 0};
 #pragma unroll
-  for (int j = 0; j < KMAX; j++) if (j < k && sink.a[j] != QN_INF_KEY) {
+  for (int j = 0; j < KMAX; j++) if (sink.slot_valid(j)) {
     float4 p = raw[key_idx(sink.a[j])];
     mean[0] += (double)p.x; mean[1] += (double)p.y; mean[2] += (double)p.z; found++;
   }
   if (knn_idx) {
 #pragma unroll
-    for (int j = 0; j < KMAX; j++) if (j < k) {
-      bool ok = sink.a[j] != QN_INF_KEY;
-      knn_idx[j] = ok ? (int32_t)key_idx(sink.a[j]) : -1; knn_d2[j] = ok ? key_d2(sink.a[j]) : 0.f;
+    for (int j = 0; j < KMAX; j++) if (j >= KMAX - k) {
+      const bool ok = sink.a[j] != QN_INF_KEY;
+      knn_idx[j - (KMAX - k)] = ok ? (int32_t)key_idx(sink.a[j]) : -1; knn_d2[j - (KMAX - k)] = ok ? key_d2(sink.a[j]) : 0.f;
     }
   }
   if (found == 0) { for (int t = 0; t < 6; t++) cov_out[t] = 0; return; }
   mean[0] /= found; mean[1] /= found; mean[2] /= found;
   double c[6] = {0, 0, 0, 0, 0, 0};
 #pragma unroll
-  for (int j = 0; j < KMAX; j++) if (j < k && sink.a[j] != QN_INF_KEY) {
+  for (int j = 0; j < KMAX; j++) if (sink.slot_valid(j)) {
     float4 p = raw[key_idx(sink.a[j])];
     double dx = (double)p.x - mean[0], dy = (double)p.y - mean[1], dz = (double)p.z - mean[2];
     c[0] += dx * dx; c[1] += dx * dy; c[2] += dx * dz; c[3] += dy * dy; c[4] += dy * dz; c[5] += dz * dz;
@@ -190,16 +194,17 @@ __device__ __forceinline__ void cov_from_knn(const BestK<KMAX>& sink, const floa
 }
 
 template <int KMAX>
-__global__ void __launch_bounds__(QN_BLOCK) k_knn_cov(GridView g, const float4* __restrict__ raw, int k, int margin,
+__global__ void __launch_bounds__(QN_BLOCK) k_knn_cov(GridView g, const float4* __restrict__ raw, int k, int margin, int margin_cap,
                                                       double* __restrict__ cov, int32_t* __restrict__ knn_idx, float* __restrict__ knn_d2,
                                                       uint2* __restrict__ fb_list, uint32_t* __restrict__ fb_count) {
-  __shared__ float4 tile[QN_BLOCK];
-  const uint32_t t = blockIdx.x * QN_BLOCK + threadIdx.x;
+  __shared__ WaveLdsK lds[QN_BLOCK / 64];
+  const uint32_t t = blockIdx.x * (QN_BLOCK / 4) + (threadIdx.x >> 6) * 16 + (threadIdx.x & 15);   // 16 queries per wave
   const bool active = t < g.n;
   float4 q = active ? g.pts[t] : make_float4(0, 0, 0, 0);
-  BestK<KMAX> sink; sink.init(k);
-  const bool cert = wave_cluster_search(g, q.x, q.y, q.z, active, margin, sink, tile + (threadIdx.x & ~63));
-  if (!active) return;
+  WaveLdsK* my = &lds[threadIdx.x >> 6];
+  BestK<KMAX> sink; sink.init(k, my->pend, g.dbg);
+  const bool cert = wave_cluster_search(g, q.x, q.y, q.z, active, margin, margin_cap, sink, &my->s);
+  if (!active || (threadIdx.x & 48) != 0) return;                  // sub-slot 0 of each query finishes the job
   const uint32_t i = __float_as_uint(q.w);
   if (cert) cov_from_knn(sink, raw, cov + (size_t)i * 6, knn_idx ? knn_idx + (size_t)i * k : nullptr, knn_d2 ? knn_d2 + (size_t)i * k : nullptr);
   else {
@@ -213,12 +218,13 @@ __global__ void __launch_bounds__(QN_BLOCK) k_knn_cov_fallback(GridView g, const
                                                                double* __restrict__ cov, int32_t* __restrict__ knn_idx, float* __restrict__ knn_d2,
                                                                const uint2* __restrict__ fb_list, const uint32_t* __restrict__ fb_count) {
   const uint32_t nfb = *fb_count;
+  if (g.dbg && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&g.dbg[4], nfb);
   for (uint32_t w = blockIdx.x * QN_BLOCK + threadIdx.x; w < nfb; w += gridDim.x * QN_BLOCK) {
     const uint2 rec = fb_list[w];
     const float4 q = g.pts[rec.x];
     const float kd2 = __uint_as_float(rec.y);
     float r = kd2 >= 0.f ? sqrtf(kd2) * 1.000001f + g.eps : (margin + 1) * g.cell;
-    BestK<KMAX> sink; sink.init(k);
+    BestK<KMAX> sink; sink.init(k, nullptr);
     lane_ball_knn(g, q.x, q.y, q.z, r, sink);
     const uint32_t i = __float_as_uint(q.w);
     cov_from_knn(sink, raw, cov + (size_t)i * 6, knn_idx ? knn_idx + (size_t)i * k : nullptr, knn_d2 ? knn_d2 + (size_t)i * k : nullptr);
@@ -254,22 +260,22 @@ __device__ __forceinline__ void store_nn(unsigned long long key, uint32_t i, dou
 }
 
 template <int MODE>
-__global__ void __launch_bounds__(QN_BLOCK) k_nn_search(GridView src, GridView tgt, const GicpState* __restrict__ st, double thr2, int margin,
+__global__ void __launch_bounds__(QN_BLOCK) k_nn_search(GridView src, GridView tgt, const GicpState* __restrict__ st, double thr2, int margin, int margin_cap,
                                                         int32_t* __restrict__ corr, float* __restrict__ sqd,
                                                         uint2* __restrict__ fb_list, uint32_t* __restrict__ fb_count) {
-  __shared__ float4 tile[QN_BLOCK];
+  __shared__ WaveLds lds[QN_BLOCK / 64];
   if (MODE == 0 && st->phase != 0) return;
   if (MODE == 1 && st->phase != 2) return;
   float Tf[12];
 #pragma unroll
   for (int j = 0; j < 12; j++) Tf[j] = (float)st->x0[j];
-  const uint32_t t = blockIdx.x * QN_BLOCK + threadIdx.x;
+  const uint32_t t = blockIdx.x * (QN_BLOCK / 4) + (threadIdx.x >> 6) * 16 + (threadIdx.x & 15);   // 16 queries per wave
   const bool active = t < src.n;
   const float4 p = active ? src.pts[t] : make_float4(0, 0, 0, 0);
   float qx, qy, qz; xform_query<MODE>(Tf, p.x, p.y, p.z, qx, qy, qz);
   Best1 sink; sink.init();
-  const bool cert = wave_cluster_search(tgt, qx, qy, qz, active, margin, sink, tile + (threadIdx.x & ~63));
-  if (!active) return;
+  const bool cert = wave_cluster_search(tgt, qx, qy, qz, active, margin, margin_cap, sink, &lds[threadIdx.x >> 6]);
+  if (!active || (threadIdx.x & 48) != 0) return;
   if (cert) store_nn<MODE>(sink.key, __float_as_uint(p.w), thr2, corr, sqd);
   else {
     uint32_t slot = atomicAdd(fb_count, 1u);
@@ -282,9 +288,11 @@ template <int MODE>
 __global__ void __launch_bounds__(QN_BLOCK) k_nn_fallback(GridView src, GridView tgt, const GicpState* __restrict__ st, double thr2, int margin,
                                                           int32_t* __restrict__ corr, float* __restrict__ sqd,
                                                           const uint2* __restrict__ fb_list, const uint32_t* __restrict__ fb_count) {
+  __shared__ WaveLds lds[QN_BLOCK / 64];
   if (MODE == 0 && st->phase != 0) return;
   if (MODE == 1 && st->phase != 2) return;
   const uint32_t nfb = *fb_count;
+  if (tgt.dbg && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&tgt.dbg[5], nfb);
   float Tf[12];
 #pragma unroll
   for (int j = 0; j < 12; j++) Tf[j] = (float)st->x0[j];
@@ -295,7 +303,7 @@ __global__ void __launch_bounds__(QN_BLOCK) k_nn_fallback(GridView src, GridView
     float qx, qy, qz; xform_query<MODE>(Tf, p.x, p.y, p.z, qx, qy, qz);
     const float bd2 = __uint_as_float(rec.y);
     const float r = bd2 >= 0.f ? sqrtf(bd2) * 1.000001f + tgt.eps : (margin + 1) * tgt.cell;
-    const unsigned long long key = wave_ball_nn1(tgt, qx, qy, qz, r);
+    const unsigned long long key = wave_ball_nn1(tgt, qx, qy, qz, r, &lds[threadIdx.x >> 6]);
     if ((threadIdx.x & 63) == 0) store_nn<MODE>(key, __float_as_uint(p.w), thr2, corr, sqd);
   }
 }
@@ -395,8 +403,8 @@ __device__ inline void d_so3_exp(const double om[3], double R[3][3]) {
 }
 
 // LDL^T with diagonal pivoting (what Eigen::LDLT does), 6x6, f64
-__device__ inline void d_ldlt_solve6(const double Ain[36], double diag_add, const double rhs[6], double x[6]) {
-  double A[6][6]; int perm[6];
+__device__ inline void d_ldlt_solve6(const double Ain[36], double diag_add, const double rhs[6], double x[6], double (*A)[6]) {
+  int perm[6];
   for (int i = 0; i < 6; i++) { perm[i] = i; for (int j = 0; j < 6; j++) A[i][j] = Ain[6 * i + j] + (i == j ? diag_add : 0.0); }
   for (int k = 0; k < 6; k++) {
     int piv = k; double best = fabs(A[k][k]);
@@ -438,10 +446,10 @@ __device__ inline bool d_is_converged(const double delta[16], const GicpConfig& 
   return fmax(mr / cfg.rotation_epsilon, mt / cfg.transformation_epsilon) < 1.0;
 }
 
-__device__ inline void d_propose(GicpState* st, double lambda) {      // d = LDLT(H + lambda I).solve(-b); delta; xi = delta * x0
+__device__ inline void d_propose(GicpState* st, double lambda, double (*A)[6]) {      // d = LDLT(H + lambda I).solve(-b); delta; xi = delta * x0
   double rhs[6];
   for (int i = 0; i < 6; i++) rhs[i] = -st->b[i];
-  d_ldlt_solve6(st->H, lambda, rhs, st->d);
+  d_ldlt_solve6(st->H, lambda, rhs, st->d, A);
   double R[3][3]; d_so3_exp(st->d, R);
   for (int i = 0; i < 16; i++) st->delta[i] = 0;
   for (int a = 0; a < 3; a++) { for (int b = 0; b < 3; b++) st->delta[4 * a + b] = R[a][b]; st->delta[4 * a + 3] = st->d[3 + a]; }
@@ -462,22 +470,7 @@ __device__ inline void d_finish_outer(GicpState* st, const GicpConfig& cfg, qn_i
 }
 
 // mode 0: full controller.  mode 1: reduce a linearisation only (H, b, y0).  mode 2: reduce an error pass only (yi).
-__global__ void __launch_bounds__(QN_BLOCK) k_solve(GicpState* st, const double* __restrict__ partials, GicpConfig cfg, qn_iter_trace* trace, int mode) {
-  __shared__ double sums[QN_NPART];
-  __shared__ double part8[QN_NPART][8];
-  const int phase = st->phase;
-  if (phase == 2 && mode == 0) { if (threadIdx.x == 0) st->fb_count = 0; return; }
-  // deterministic reduction of QN_ACC_BLOCKS x 28 partials: 8 strided sub-sums per component, combined in order
-  if (threadIdx.x < QN_NPART * 8) {
-    const int c = threadIdx.x >> 3, s = threadIdx.x & 7;
-    double v = 0;
-    for (int b = s; b < QN_ACC_BLOCKS; b += 8) v += partials[(size_t)b * QN_NPART + c];
-    part8[c][s] = v;
-  }
-  __syncthreads();
-  if (threadIdx.x < QN_NPART) { double v = 0; for (int s = 0; s < 8; s++) v += part8[threadIdx.x][s]; sums[threadIdx.x] = v; }
-  __syncthreads();
-  if (threadIdx.x != 0) return;
+__device__ inline void solve_controller(GicpState* st, const double* sums, const GicpConfig& cfg, qn_iter_trace* trace, int mode, int phase, double (*Awork)[6]) {
   st->fb_count = 0;
   const bool lin = (mode == 1) || (mode == 0 && phase == 0);
   if (lin) {
@@ -492,7 +485,7 @@ __global__ void __launch_bounds__(QN_BLOCK) k_solve(GicpState* st, const double*
 
   if (phase == 0) {
     if (cfg.optimizer == QN_OPT_GN) {                                   // step_gn
-      d_propose(st, 0.0);
+      d_propose(st, 0.0, Awork);
       for (int i = 0; i < 16; i++) st->x0[i] = st->xi[i];
       for (int i = 0; i < 36; i++) st->final_H[i] = st->H[i];
       qn_iter_trace tr; tr.y0 = st->y0; tr.lambda = 0; tr.rho = 0; tr.inner = 1; tr.accepted = 1; tr.max_dR = tr.max_dt = 0;
@@ -505,7 +498,7 @@ __global__ void __launch_bounds__(QN_BLOCK) k_solve(GicpState* st, const double*
       st->lambda = cfg.lm_init_lambda_factor * mx;
     }
     st->nu = 2.0; st->inner = 0;
-    d_propose(st, st->lambda);
+    d_propose(st, st->lambda, Awork);
     st->phase = 1;
     return;
   }
@@ -521,7 +514,7 @@ __global__ void __launch_bounds__(QN_BLOCK) k_solve(GicpState* st, const double*
       if (st->trace_len < QN_MAX_TRACE) trace[st->trace_len++] = tr;
       st->outer += 1; st->lm_failed = 1; st->phase = 2; return;
     }
-    d_propose(st, st->lambda);                                           // stay in phase 1
+    d_propose(st, st->lambda, Awork);                                    // stay in phase 1
     return;
   }
   for (int i = 0; i < 16; i++) st->x0[i] = st->xi[i];
@@ -530,6 +523,31 @@ __global__ void __launch_bounds__(QN_BLOCK) k_solve(GicpState* st, const double*
   for (int i = 0; i < 36; i++) st->final_H[i] = st->H[i];
   tr.accepted = 1;
   d_finish_outer(st, cfg, trace, tr);
+}
+
+
+__global__ void __launch_bounds__(QN_BLOCK) k_solve(GicpState* gst, const double* __restrict__ partials, GicpConfig cfg, qn_iter_trace* trace, int mode) {
+  __shared__ double sums[QN_NPART];
+  __shared__ double part8[QN_NPART][8];
+  __shared__ GicpState sh;                       // the controller works on an LDS copy: one coalesced read, one coalesced write-back
+  __shared__ double Awork[6][6];
+  static_assert(sizeof(GicpState) % 8 == 0, "GicpState is copied as 8-byte words");
+  const int phase = gst->phase;
+  if (phase == 2 && mode == 0) { if (threadIdx.x == 0) gst->fb_count = 0; return; }
+  for (int i = threadIdx.x; i < (int)(sizeof(GicpState) / 8); i += QN_BLOCK) ((unsigned long long*)&sh)[i] = ((const unsigned long long*)gst)[i];
+  // deterministic reduction of QN_ACC_BLOCKS x 28 partials: 8 strided sub-sums per component, combined in order
+  if (threadIdx.x < QN_NPART * 8) {
+    const int c = threadIdx.x >> 3, s = threadIdx.x & 7;
+    double v = 0;
+    for (int b = s; b < QN_ACC_BLOCKS; b += 8) v += partials[(size_t)b * QN_NPART + c];
+    part8[c][s] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < QN_NPART) { double v = 0; for (int s = 0; s < 8; s++) v += part8[threadIdx.x][s]; sums[threadIdx.x] = v; }
+  __syncthreads();
+  if (threadIdx.x == 0) solve_controller(&sh, sums, cfg, trace, mode, phase, Awork);
+  __syncthreads();
+  for (int i = threadIdx.x; i < (int)(sizeof(GicpState) / 8); i += QN_BLOCK) ((unsigned long long*)gst)[i] = ((const unsigned long long*)&sh)[i];
 }
 
 __global__ void k_init_state(GicpState* st, const float* __restrict__ guess /* 16 or null */, int has_guess, int phase) {
