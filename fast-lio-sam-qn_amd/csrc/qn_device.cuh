@@ -92,6 +92,23 @@ __device__ __forceinline__ double wave_sum_f64(double v) {
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
   return v;
 }
+// Wave64 sum with DPP for the 4 intra-row steps (VALU rate) and two cross-row bpermutes; the total
+// lands in every lane (callers read lane 63 or any lane).  Fixed tree -> deterministic.
+__device__ __forceinline__ double dpp_add_f64(double v, const int ctrl_sel) {
+  union { double d; int i[2]; } a, b; a.d = v;
+  switch (ctrl_sel) {
+    case 0: b.i[0] = __builtin_amdgcn_mov_dpp(a.i[0], 0xB1, 0xF, 0xF, true); b.i[1] = __builtin_amdgcn_mov_dpp(a.i[1], 0xB1, 0xF, 0xF, true); break;   // quad_perm [1,0,3,2]
+    case 1: b.i[0] = __builtin_amdgcn_mov_dpp(a.i[0], 0x4E, 0xF, 0xF, true); b.i[1] = __builtin_amdgcn_mov_dpp(a.i[1], 0x4E, 0xF, 0xF, true); break;   // quad_perm [2,3,0,1]
+    case 2: b.i[0] = __builtin_amdgcn_mov_dpp(a.i[0], 0x141, 0xF, 0xF, true); b.i[1] = __builtin_amdgcn_mov_dpp(a.i[1], 0x141, 0xF, 0xF, true); break; // row_half_mirror
+    default: b.i[0] = __builtin_amdgcn_mov_dpp(a.i[0], 0x140, 0xF, 0xF, true); b.i[1] = __builtin_amdgcn_mov_dpp(a.i[1], 0x140, 0xF, 0xF, true); break; // row_mirror
+  }
+  return v + b.d;
+}
+__device__ __forceinline__ double wave_sum_f64_dpp(double v) {
+  v = dpp_add_f64(v, 0); v = dpp_add_f64(v, 1); v = dpp_add_f64(v, 2); v = dpp_add_f64(v, 3);   // 16-lane row sums in every lane
+  v += __shfl_xor(v, 16); v += __shfl_xor(v, 32);
+  return v;
+}
 __device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v, int lane) {
 #pragma unroll
   for (int o = 1; o < 64; o <<= 1) { uint32_t t = __shfl_up(v, o); if (lane >= o) v += t; }
@@ -109,6 +126,7 @@ struct WaveLds {                        // per-wave scratch: candidate tile + se
   uint32_t seg_start[64];               // first pts[] index of each segment
   uint32_t seg_cid[64];                 // cluster each segment belongs to
   uint32_t cl_seg0[65];                 // first segment slot of each cluster (exclusive prefix of nseg)
+  uint32_t cl_tile_mode[64];            // 1: the cluster's box is enumerated tile by tile (large boxes)
   int box[64][6];                       // per cluster: x0 x1 y0 y1 z0 z1 (cells, already grown by the margin and clipped)
 };
 struct WaveLdsK {
@@ -117,18 +135,27 @@ struct WaveLdsK {
 };
 
 // ------------------------------------------------------------------ result sinks
-struct Best1 {                         // 1-NN
+struct Best1 {                         // 1-NN, plus the squared distance of the runner-up (for bound pruning)
   unsigned long long key;
-  __device__ __forceinline__ void init() { key = QN_INF_KEY; }
+  float second;                        // smallest d2 among scanned points other than `key`'s point
+  __device__ __forceinline__ void init() { key = QN_INF_KEY; second = __int_as_float(0x7f800000); }
   __device__ __forceinline__ void consider(bool on, float d2, uint32_t idx) {
-    unsigned long long k = pack_key(d2, idx);
-    if (on && k < key) key = k;
+    const unsigned long long k = pack_key(d2, idx);
+    if (on) {
+      if (k < key) { if (key != QN_INF_KEY) second = key_d2(key); key = k; }
+      else if (k != key && d2 < second) second = d2;
+    }
   }
   __device__ __forceinline__ void finish(bool on) {                   // combine the 4 candidate sub-slots of a query
-    unsigned long long t = __shfl_xor(key, 16); key = (on && t < key) ? t : key;
-    t = __shfl_xor(key, 32); key = (on && t < key) ? t : key;
+    unsigned long long b = key, t;
+    t = __shfl_xor(b, 16); b = t < b ? t : b;
+    t = __shfl_xor(b, 32); b = t < b ? t : b;
+    float c = (key == b) ? second : key_d2(key);                      // this sub-slot's best runner-up candidate
+    if (key == QN_INF_KEY) c = __int_as_float(0x7f800000);
+    c = fminf(c, __shfl_xor(c, 16)); c = fminf(c, __shfl_xor(c, 32));
+    if (on) { key = b; second = c; }
   }
-  __device__ __forceinline__ void reset() { key = QN_INF_KEY; }
+  __device__ __forceinline__ void reset() { key = QN_INF_KEY; second = __int_as_float(0x7f800000); }
   __device__ __forceinline__ bool full() const { return key != QN_INF_KEY; }
   __device__ __forceinline__ float worst_d2() const { return key_d2(key); }
 };
@@ -244,35 +271,40 @@ __device__ __forceinline__ uint32_t stream_box(const GridView& g, int x0, int x1
   return grand;
 }
 
-// ------------------------------------------------------------------ pass A
+// ------------------------------------------------------------------ cooperative exact search
 #define QN_CL_DX 8
 #define QN_CL_DY 4
 #define QN_CL_DZ 4
 
-// All 64 lanes must call this (inactive lanes pass active = false).  Returns per lane whether the
-// sink content is certified exact.  margin0 = first margin (cells); lanes that fail certification
-// retry together with margin 2 m + 1 while that stays <= margin_cap.
+// wave_search: the ONE cooperative search routine (1-NN and k-NN, first search and seeded re-search).
 //
-// A wavefront serves 16 QUERIES: lane l works for query (l & 15) as candidate sub-slot (l >> 4), i.e.
-// the four lanes of a query split the candidate stream four ways and merge in sink.finish().  100k
-// queries therefore make 6250 waves (the chip holds 8192), each with a 4x shorter candidate loop.
+// A wavefront serves 16 QUERIES: lane l works for query (l & 15) as candidate sub-slot (l >> 4), i.e. the
+// four lanes of a query split the candidate stream four ways and merge in sink.finish().  100k queries
+// make 6250 waves (the chip holds 8192), each with a 4x shorter candidate loop.  All 64 lanes must call
+// (idle lanes pass active = false; the 4 lanes of a query pass identical q, r).
 //
-// One ROUND handles every cluster of the wave at once, so its memory latency is paid once, not per
-// cluster: (1) lanes are partitioned into clusters around anchor lanes (ALU only); (2) every
-// cluster's cell box is built with LDS min/max atomics; (3) all boxes are cut into segments, one
-// per lane, whose bounds come from ONE gather of cell_start; (4) the candidates of all segments form
-// one dense stream that is fetched 64 at a time (coalesced within a segment), staged in LDS together
-// with the owning cluster id, and scored by the lanes of that cluster via broadcast ds_read_b128.
+// Every query carries a search radius r (world units): a seed bound when the caller knows one (distance
+// to last iteration's neighbour), else margin * cell.  One ROUND handles every cluster of the wave at once
+// so its memory latency is paid once: (1) lanes are partitioned into clusters around anchor lanes (ALU
+// only); (2) each cluster's cell box = union of its queries' ball boxes, built with LDS min/max atomics;
+// (3) all boxes are cut into segments, one per lane, whose bounds come from ONE gather of cell_start;
+// (4) the candidates of all segments form one dense stream fetched 64 at a time (coalesced within a
+// segment), staged in LDS with the owning cluster id, and scored by that cluster's lanes via
+// ds_read_b128.  A query is CERTIFIED exact when its (k-th) best distance is smaller than its distance to
+// the nearest box face that still has unseen cells behind it; otherwise its radius grows (to the k-th
+// best distance if known - then the next round certifies - else 2 r + cell, never beyond the proven
+// bound r_cap) and it retries, up to max_rounds.  Returns certified; r is updated to the radius the next
+// round would use; d_unseen = lower bound on the distance of every point NOT scanned in the last round.
 template <class Sink>
-__device__ __forceinline__ bool wave_cluster_search(const GridView& g, float qx, float qy, float qz, bool active,
-                                                    int margin0, int margin_cap, Sink& sink, WaveLds* lds) {
+__device__ __forceinline__ bool wave_search(const GridView& g, float qx, float qy, float qz, bool active, float& r, const float r_cap,
+                                            int max_rounds, Sink& sink, WaveLds* lds, float& d_unseen) {
   const int lane = threadIdx.x & 63;
   const int cx = cell_coord(qx, g.ox, g.inv_cell, g.nx);
   const int cy = cell_coord(qy, g.oy, g.inv_cell, g.ny);
   const int cz = cell_coord(qz, g.oz, g.inv_cell, g.nz);
   bool certified = false;
   unsigned long long todo = __ballot(active);
-  for (int margin = margin0; todo != 0; margin = 2 * margin + 1) {
+  for (int round = 0; todo != 0 && round < max_rounds; round++) {
     const bool mine = (todo >> lane) & 1ull;
     // (1) cluster ids
     uint32_t cid = 0xffffffffu; int ncl = 0;
@@ -283,21 +315,33 @@ __device__ __forceinline__ bool wave_cluster_search(const GridView& g, float qx,
       if (in) cid = ncl;
       rem &= ~__ballot(in);
     }
-    // (2) cluster boxes
+    // (2) cluster boxes = union of the member queries' ball boxes
     wave_lds_fence();
     if (lane < ncl) { lds->box[lane][0] = 0x3fffffff; lds->box[lane][1] = -1; lds->box[lane][2] = 0x3fffffff; lds->box[lane][3] = -1; lds->box[lane][4] = 0x3fffffff; lds->box[lane][5] = -1; }
     wave_lds_fence();
-    if (mine) {
-      atomicMin(&lds->box[cid][0], max(cx - margin, 0)); atomicMax(&lds->box[cid][1], min(cx + margin, g.nx - 1));
-      atomicMin(&lds->box[cid][2], max(cy - margin, 0)); atomicMax(&lds->box[cid][3], min(cy + margin, g.ny - 1));
-      atomicMin(&lds->box[cid][4], max(cz - margin, 0)); atomicMax(&lds->box[cid][5], min(cz + margin, g.nz - 1));
+    if (mine && (lane >> 4) == 0) {
+      atomicMin(&lds->box[cid][0], cell_coord(qx - r, g.ox, g.inv_cell, g.nx)); atomicMax(&lds->box[cid][1], cell_coord(qx + r, g.ox, g.inv_cell, g.nx));
+      atomicMin(&lds->box[cid][2], cell_coord(qy - r, g.oy, g.inv_cell, g.ny)); atomicMax(&lds->box[cid][3], cell_coord(qy + r, g.oy, g.inv_cell, g.ny));
+      atomicMin(&lds->box[cid][4], cell_coord(qz - r, g.oz, g.inv_cell, g.nz)); atomicMax(&lds->box[cid][5], cell_coord(qz + r, g.oz, g.inv_cell, g.nz));
     }
     wave_lds_fence();
     // (3) segments per cluster, prefix over clusters
+    // A box with many (y, z) rows is mostly empty space around a surface: enumerate it TILE by tile
+    // instead (a tile's 128 cells are one contiguous run of pts[]), which needs far fewer cell_start
+    // look-ups; the box is widened to whole tiles, so certification sees the larger scanned volume.
     uint32_t my_nseg = 0;
     if (lane < ncl) {
-      const int* b = lds->box[lane];
+      int* b = lds->box[lane];
       my_nseg = (uint32_t)(((b[1] >> 3) - (b[0] >> 3) + 1) * (b[3] - b[2] + 1) * (b[5] - b[4] + 1));
+      uint32_t tm = 0;
+      if (my_nseg > 384) {
+        tm = 1;
+        b[0] = (b[0] >> 3) << 3; b[1] = min(((b[1] >> 3) << 3) + 7, g.nx - 1);
+        b[2] = (b[2] >> 2) << 2; b[3] = min(((b[3] >> 2) << 2) + 3, g.ny - 1);
+        b[4] = (b[4] >> 2) << 2; b[5] = min(((b[5] >> 2) << 2) + 3, g.nz - 1);
+        my_nseg = (uint32_t)(((b[1] >> 3) - (b[0] >> 3) + 1) * ((b[3] >> 2) - (b[2] >> 2) + 1) * ((b[5] >> 2) - (b[4] >> 2) + 1));
+      }
+      lds->cl_tile_mode[lane] = tm;
     }
     const uint32_t seg_incl = wave_incl_scan_u32(my_nseg, lane);
     const uint32_t nseg_all = rflu(__shfl(seg_incl, 63));
@@ -314,13 +358,21 @@ __device__ __forceinline__ bool wave_cluster_search(const GridView& g, float qx,
         for (int step = 32; step > 0; step >>= 1) { const int t = c + step; if (t < ncl && lds->cl_seg0[t] <= sidx) c = t; }
         const int* b = lds->box[c];
         const int x0 = b[0], x1 = b[1], y0 = b[2], y1 = b[3], z0 = b[4];
-        const int tx0 = x0 >> 3, ntr = (x1 >> 3) - tx0 + 1, nyr = y1 - y0 + 1;
+        const int tx0 = x0 >> 3, ntr = (x1 >> 3) - tx0 + 1;
         const int li = (int)(sidx - lds->cl_seg0[c]);
-        const int t = li % ntr, r = li / ntr;
-        const int ry = y0 + r % nyr, rz = z0 + r / nyr, tx = tx0 + t;
-        const int xa = max(x0, tx << 3), xb = min(x1, (tx << 3) + 7);
-        const uint32_t k0 = cell_key(g, xa, ry, rz);
-        s = g.cell_start[k0]; len = g.cell_start[k0 + (xb - xa) + 1] - s; scid = (uint32_t)c;
+        const int t = li % ntr, rr = li / ntr;
+        if (lds->cl_tile_mode[c]) {                  // segment = one whole tile
+          const int ty0 = y0 >> 2, ntyr = (y1 >> 2) - ty0 + 1;
+          const uint32_t tile = ((uint32_t)((z0 >> 2) + rr / ntyr) * g.nty + (ty0 + rr % ntyr)) * g.ntx + (tx0 + t);
+          s = g.cell_start[tile << 7]; len = g.cell_start[(tile + 1) << 7] - s;
+        } else {                                     // segment = cells [xa..xb] of row (ry, rz) inside tile tx
+          const int nyr = y1 - y0 + 1;
+          const int ry = y0 + rr % nyr, rz = z0 + rr / nyr, tx = tx0 + t;
+          const int xa = max(x0, tx << 3), xb = min(x1, (tx << 3) + 7);
+          const uint32_t k0 = cell_key(g, xa, ry, rz);
+          s = g.cell_start[k0]; len = g.cell_start[k0 + (xb - xa) + 1] - s;
+        }
+        scid = (uint32_t)c;
       }
       const uint32_t incl = wave_incl_scan_u32(len, lane);
       const uint32_t total = rflu(__shfl(incl, 63));
@@ -363,9 +415,13 @@ __device__ __forceinline__ bool wave_cluster_search(const GridView& g, float qx,
       if (ey1 < g.ny - 1) d = fminf(d, (g.oy + (ey1 + 1) * g.cell) - qy);
       if (ez0 > 0) d = fminf(d, qz - (g.oz + ez0 * g.cell));
       if (ez1 < g.nz - 1) d = fminf(d, (g.oz + (ez1 + 1) * g.cell) - qz);
-      if (d == INF) certified = true;                        // the whole grid was scanned
-      else { d -= g.eps; certified = d > 0.f && sink.full() && sink.worst_d2() < d * d; }
-      if (!certified && 2 * margin + 1 <= margin_cap) { retry = true; sink.reset(); }
+      if (d == INF || !(r == r)) { certified = true; d_unseen = INF; }   // the whole grid was scanned (or a non-finite query: nothing to find)
+      else { d -= g.eps; d_unseen = d; certified = d > 0.f && sink.full() && sink.worst_d2() < d * d; }
+      if (!certified) {
+        r = sink.full() ? fmaxf(sqrtf(sink.worst_d2()) * 1.000001f + g.eps, r) : 2.f * r + g.cell;
+        r = fminf(r, r_cap);                                 // r_cap: a proven upper bound on the (k-th) NN distance, +inf if none
+        if (round + 1 < max_rounds) { retry = true; sink.reset(); }
+      }
     }
     todo = __ballot(retry);
     if (g.dbg && lane == 0 && todo) atomicAdd(&g.dbg[3], (uint32_t)__popcll(todo));
@@ -373,31 +429,86 @@ __device__ __forceinline__ bool wave_cluster_search(const GridView& g, float qx,
   return certified;
 }
 
-// ------------------------------------------------------------------ pass B, 1-NN: one query per WAVE
-// Exact ball query: streams every cell that intersects the ball of radius r around q (one candidate
-// per lane per fetch), then a wave-wide min of the packed keys.  r starts from a known upper bound
-// on the NN distance (pass A's uncertified best) or, when nothing was found yet, doubles until the
-// best distance found fits inside it.
-__device__ __forceinline__ unsigned long long wave_ball_nn1(const GridView& g, float qx, float qy, float qz, float r, WaveLds* lds) {
+// ------------------------------------------------------------------ single-query search: one query per WAVE
+// For the few queries whose neighbour is far away (several cells): all 64 lanes share ONE query and each
+// scores its own candidate of the dense stream (no LDS tile needed), so a big ball is scanned 16x faster
+// than in the 16-query layout.  The ball's cell box is enumerated row by row, or tile by tile when it is
+// large (the inside of the ball is empty space - the neighbour sits on its surface - so most tiles cost
+// one look-up and contribute no candidates).  Same certification and growth rule as wave_search.
+__device__ __forceinline__ void wave_search_single(const GridView& g, float qx, float qy, float qz, float r, const float r_cap,
+                                                   unsigned long long& best_out, float& second_out, float& d_unseen, WaveLds* lds) {
+  const int lane = threadIdx.x & 63;
+  const float INF = __int_as_float(0x7f800000);
   for (int round = 0;; round++) {
-    const int bx0 = rfl(cell_coord(qx - r, g.ox, g.inv_cell, g.nx)), bx1 = rfl(cell_coord(qx + r, g.ox, g.inv_cell, g.nx));
-    const int by0 = rfl(cell_coord(qy - r, g.oy, g.inv_cell, g.ny)), by1 = rfl(cell_coord(qy + r, g.oy, g.inv_cell, g.ny));
-    const int bz0 = rfl(cell_coord(qz - r, g.oz, g.inv_cell, g.nz)), bz1 = rfl(cell_coord(qz + r, g.oz, g.inv_cell, g.nz));
-    const bool all = bx0 == 0 && by0 == 0 && bz0 == 0 && bx1 == g.nx - 1 && by1 == g.ny - 1 && bz1 == g.nz - 1;
-    unsigned long long best = QN_INF_KEY;
-    stream_box(g, bx0, bx1, by0, by1, bz0, bz1, lds, [&](float4 p, bool valid, uint32_t) __attribute__((always_inline)) {
-      const unsigned long long k = pack_key(sqdist(qx, qy, qz, p.x, p.y, p.z), __float_as_uint(p.w));
-      if (valid && k < best) best = k;
-    });
-    best = wave_min_u64(best);
-    if (all || round > 160) return best;          // round cap: non-finite queries cannot spin forever
-    if (best != QN_INF_KEY) {
-      const float bd = sqrtf(key_d2(best)) * 1.000001f + g.eps;   // every point that could beat or tie `best` lies within bd
-      if (bd <= r) return best;
-      r = bd;                                                      // one more scan at exactly the needed radius
-    } else {
-      r = 2.f * r + g.cell;
+    int x0 = rfl(cell_coord(qx - r, g.ox, g.inv_cell, g.nx)), x1 = rfl(cell_coord(qx + r, g.ox, g.inv_cell, g.nx));
+    int y0 = rfl(cell_coord(qy - r, g.oy, g.inv_cell, g.ny)), y1 = rfl(cell_coord(qy + r, g.oy, g.inv_cell, g.ny));
+    int z0 = rfl(cell_coord(qz - r, g.oz, g.inv_cell, g.nz)), z1 = rfl(cell_coord(qz + r, g.oz, g.inv_cell, g.nz));
+    const int tx0 = x0 >> 3, ntr = (x1 >> 3) - tx0 + 1;
+    int nseg = ntr * (y1 - y0 + 1) * (z1 - z0 + 1);
+    const bool tile_mode = nseg > 128;
+    int ty0 = 0, ntyr = 1;
+    if (tile_mode) {
+      x0 = (x0 >> 3) << 3; x1 = min(((x1 >> 3) << 3) + 7, g.nx - 1);
+      y0 = (y0 >> 2) << 2; y1 = min(((y1 >> 2) << 2) + 3, g.ny - 1);
+      z0 = (z0 >> 2) << 2; z1 = min(((z1 >> 2) << 2) + 3, g.nz - 1);
+      ty0 = y0 >> 2; ntyr = (y1 >> 2) - ty0 + 1;
+      nseg = ntr * ntyr * ((z1 >> 2) - (z0 >> 2) + 1);
     }
+    const int nyr = y1 - y0 + 1;
+    unsigned long long best = QN_INF_KEY; float second = INF;
+    for (int sb = 0; sb < nseg; sb += 64) {
+      const int sidx = sb + lane;
+      uint32_t s = 0, len = 0;
+      if (sidx < nseg) {
+        const int t = sidx % ntr, rr = sidx / ntr;
+        if (tile_mode) {
+          const uint32_t tile = ((uint32_t)((z0 >> 2) + rr / ntyr) * g.nty + (ty0 + rr % ntyr)) * g.ntx + (tx0 + t);
+          s = g.cell_start[tile << 7]; len = g.cell_start[(tile + 1) << 7] - s;
+        } else {
+          const int ry = y0 + rr % nyr, rz = z0 + rr / nyr, tx = tx0 + t;
+          const int xa = max(x0, tx << 3), xb = min(x1, (tx << 3) + 7);
+          const uint32_t k0 = cell_key(g, xa, ry, rz);
+          s = g.cell_start[k0]; len = g.cell_start[k0 + (xb - xa) + 1] - s;
+        }
+      }
+      const uint32_t incl = wave_incl_scan_u32(len, lane);
+      const uint32_t total = rflu(__shfl(incl, 63));
+      if (total == 0) continue;
+      wave_lds_fence();
+      lds->seg_excl[lane] = incl - len; lds->seg_start[lane] = s;
+      wave_lds_fence();
+      for (uint32_t cb = 0; cb < total; cb += 64) {
+        const uint32_t slot = cb + lane;
+        int j = 0;
+#pragma unroll
+        for (int step = 32; step > 0; step >>= 1) { const int t = j + step; if (t < 64 && lds->seg_excl[t] <= slot) j = t; }
+        if (slot < total) {
+          const float4 p = g.pts[lds->seg_start[j] + (slot - lds->seg_excl[j])];
+          const float d2 = sqdist(qx, qy, qz, p.x, p.y, p.z);
+          const unsigned long long k = pack_key(d2, __float_as_uint(p.w));
+          if (k < best) { if (best != QN_INF_KEY) second = key_d2(best); best = k; }
+          else if (d2 < second) second = d2;
+        }
+      }
+    }
+    const unsigned long long b = wave_min_u64(best);
+    float c = (best == b) ? second : key_d2(best);
+    if (best == QN_INF_KEY) c = INF;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) c = fminf(c, __shfl_xor(c, o));
+    float d = INF;
+    if (x0 > 0) d = fminf(d, qx - (g.ox + x0 * g.cell));
+    if (x1 < g.nx - 1) d = fminf(d, (g.ox + (x1 + 1) * g.cell) - qx);
+    if (y0 > 0) d = fminf(d, qy - (g.oy + y0 * g.cell));
+    if (y1 < g.ny - 1) d = fminf(d, (g.oy + (y1 + 1) * g.cell) - qy);
+    if (z0 > 0) d = fminf(d, qz - (g.oz + z0 * g.cell));
+    if (z1 < g.nz - 1) d = fminf(d, (g.oz + (z1 + 1) * g.cell) - qz);
+    bool cert;
+    if (d == INF || !(r == r) || round > 160) { cert = true; d_unseen = INF; }
+    else { d -= g.eps; d_unseen = d; cert = d > 0.f && b != QN_INF_KEY && key_d2(b) < d * d; }
+    if (cert) { best_out = b; second_out = c; return; }
+    r = (b != QN_INF_KEY) ? fmaxf(sqrtf(key_d2(b)) * 1.000001f + g.eps, r) : 2.f * r + g.cell;
+    r = fminf(r, r_cap);
   }
 }
 

@@ -96,12 +96,17 @@ extern "C" int qn_ctx_create(int device, uint32_t max_points, qn_ctx** out) {
   CA(hipMalloc(&c->scan_sums, sizeof(uint32_t) * (c->max_cells / (QN_BLOCK * QN_SCAN_ITEMS) + 2)));
   CA(hipMalloc(&c->bbox, sizeof(BBoxOut)));
   CA(hipMalloc(&c->state, sizeof(GicpState)));
-  CA(hipMalloc(&c->partials, sizeof(double) * QN_ACC_BLOCKS * QN_NPART));
+  CA(hipMalloc(&c->partials, sizeof(double) * QN_ACC_MAX_BLOCKS * QN_NPART));
+  CA(hipMalloc(&c->nn_idx, sizeof(int32_t) * max_points));
+  CA(hipMalloc(&c->nn_ref, sizeof(float4) * max_points));
+  CA(hipMalloc(&c->fit_psum, sizeof(double) * QN_FIT_BLOCKS));
+  CA(hipMalloc(&c->fit_pcnt, sizeof(uint32_t) * QN_FIT_BLOCKS));
   CA(hipMalloc(&c->trace, sizeof(qn_iter_trace) * QN_MAX_TRACE));
   CA(hipMalloc(&c->corr, sizeof(int32_t) * max_points));
   CA(hipMalloc(&c->sqd, sizeof(float) * max_points));
   CA(hipMalloc(&c->sqd_fit, sizeof(float) * max_points));
   CA(hipMalloc(&c->fb_list, sizeof(uint2) * max_points));
+  CA(hipMalloc(&c->big_list, sizeof(uint2) * max_points));
   CA(hipMalloc(&c->fb_count2, sizeof(uint32_t)));
   CA(hipMalloc(&c->aligned, sizeof(float4) * max_points));
   CA(hipMalloc(&c->pose_tmp, sizeof(double) * 16));
@@ -123,7 +128,7 @@ extern "C" void qn_ctx_destroy(qn_ctx* c) {
   c->prof_collect();
   for (int w = 0; w < 2; w++) { CloudBuf& b = c->cloud[w]; hipFree(b.raw); hipFree(b.sorted); hipFree(b.cell_of_pt); hipFree(b.cell_start); hipFree(b.counts); hipFree(b.cov); }
   hipFree(c->staging); hipFree(c->scan_sums); hipFree(c->bbox); hipFree(c->state); hipFree(c->partials); hipFree(c->trace);
-  hipFree(c->corr); hipFree(c->sqd); hipFree(c->sqd_fit); hipFree(c->fb_list); hipFree(c->fb_count2); hipFree(c->aligned);
+  hipFree(c->nn_idx); hipFree(c->nn_ref); hipFree(c->fit_psum); hipFree(c->fit_pcnt); hipFree(c->corr); hipFree(c->sqd); hipFree(c->sqd_fit); hipFree(c->fb_list); hipFree(c->big_list); hipFree(c->fb_count2); hipFree(c->aligned);
   hipFree(c->pose_tmp); hipFree(c->guess_tmp); hipFree(c->dbg_knn_idx); hipFree(c->dbg_knn_d2); hipFree(c->dbg_counters);
   if (c->result_host) hipHostFree(c->result_host);
   if (c->bbox_host) hipHostFree(c->bbox_host);
@@ -243,9 +248,10 @@ template <int KMAX>
 static void launch_knn_cov(qn_ctx* c, CloudBuf& b, int k, int32_t* kidx, float* kd2) {
   hipStream_t s = c->stream;
   const uint32_t nb = (b.n + QN_BLOCK / 4 - 1) / (QN_BLOCK / 4);      // 16 queries per wave, 64 per block
-  { ProfScope ps(c, QN_K_KNN_COV);
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_knn_cov<KMAX>), dim3(nb), dim3(QN_BLOCK), 0, s, b.grid, b.raw, k, c->margin_knn, c->margin_knn_cap, b.cov, kidx, kd2, c->fb_list, c->fb_count2);
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_knn_cov_fallback<KMAX>), dim3(std::min<uint32_t>(nb, 1024)), dim3(QN_BLOCK), 0, s, b.grid, b.raw, k, c->margin_knn, b.cov, kidx, kd2, c->fb_list, c->fb_count2); }
+  const float r0 = c->margin_knn * b.grid.cell;
+  ProfScope ps(c, QN_K_KNN_COV);
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_knn_cov<KMAX, false>), dim3(nb), dim3(QN_BLOCK), 0, s, b.grid, b.raw, k, r0, 2, b.cov, kidx, kd2, c->fb_list, c->fb_count2);
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_knn_cov<KMAX, true>), dim3(std::min<uint32_t>(nb, 512)), dim3(QN_BLOCK), 0, s, b.grid, b.raw, k, r0, 64, b.cov, kidx, kd2, c->fb_list, c->fb_count2);
 }
 static int compute_cov(qn_ctx* c, int which, int32_t* kidx, float* kd2) {
   if (!c || (which != 0 && which != 1)) return QN_ERR_INVALID_ARG;
@@ -265,39 +271,47 @@ static int compute_cov(qn_ctx* c, int which, int32_t* kidx, float* kd2) {
 extern "C" int qn_gicp_compute_covariances(qn_ctx* c, int which) { return compute_cov(c, which, nullptr, nullptr); }
 
 // ------------------------------------------------------------------ align
-static void enqueue_nn(qn_ctx* c, int mode /*0 align, 1 fitness*/, float* sqd_out) {
+// seeded = true: the previous iteration's NN indices are valid -> temporal tracking kernel; false -> full grid search
+static void enqueue_nn(qn_ctx* c, int mode /*0 align, 1 fitness*/, float* sqd_out, bool seeded) {
   hipStream_t s = c->stream;
   CloudBuf &S = c->cloud[0], &T = c->cloud[1];
   const uint32_t nb = (S.n + QN_BLOCK / 4 - 1) / (QN_BLOCK / 4);      // 16 queries per wave, 64 per block
+  const uint32_t nbt = (S.n + QN_BLOCK - 1) / QN_BLOCK;               // tracking: one query per lane
   const double thr2 = c->params.max_corr_dist * c->params.max_corr_dist;
-  uint32_t* fbc = &c->state->fb_count;
-  const uint32_t fbb = std::min<uint32_t>((S.n + 3) / 4, 2048);
+  uint32_t* fbc = &c->state->fb_count; uint32_t* bgc = &c->state->big_count;
+  const int big_blocks = 1024;                                       // up to 4096 waves, one far query each (idle blocks exit at once)
+  const uint32_t fbb = std::min<uint32_t>(nb, 512);               // list pass: wave-stride over the leftovers
+  const float r0 = c->margin_nn * T.grid.cell;
   if (mode == 0) {
     { ProfScope ps(c, QN_K_NN_SEARCH);
-      hipLaunchKernelGGL(HIP_KERNEL_NAME(k_nn_search<0>), dim3(nb), dim3(QN_BLOCK), 0, s, S.grid, T.grid, c->state, thr2, c->margin_nn, c->margin_nn_cap, c->corr, sqd_out, c->fb_list, fbc); }
+      if (seeded) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_nn_track<0>), dim3(nbt), dim3(QN_BLOCK), 0, s, S.grid, T.grid, T.raw, c->state, thr2, c->corr, sqd_out, c->nn_idx, c->nn_ref, c->fb_list, fbc, c->big_list, bgc);
+      else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_nn_search<0, false>), dim3(nb), dim3(QN_BLOCK), 0, s, S.grid, T.grid, c->state, thr2, r0, 1, c->corr, sqd_out, c->nn_idx, c->nn_ref, c->fb_list, fbc, c->big_list, bgc, 0); }
     { ProfScope ps(c, QN_K_NN_FALLBACK);
-      hipLaunchKernelGGL(HIP_KERNEL_NAME(k_nn_fallback<0>), dim3(fbb), dim3(QN_BLOCK), 0, s, S.grid, T.grid, c->state, thr2, c->margin_nn, c->corr, sqd_out, c->fb_list, fbc); }
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(k_nn_search<0, true>), dim3(fbb + big_blocks), dim3(QN_BLOCK), 0, s, S.grid, T.grid, c->state, thr2, r0, 64, c->corr, sqd_out, c->nn_idx, c->nn_ref, c->fb_list, fbc, c->big_list, bgc, big_blocks); }
   } else {
-    { ProfScope ps(c, QN_K_FITNESS);
-      hipLaunchKernelGGL(HIP_KERNEL_NAME(k_nn_search<1>), dim3(nb), dim3(QN_BLOCK), 0, s, S.grid, T.grid, c->state, thr2, c->margin_nn, c->margin_nn_cap, c->corr, sqd_out, c->fb_list, fbc);
-      hipLaunchKernelGGL(HIP_KERNEL_NAME(k_nn_fallback<1>), dim3(fbb), dim3(QN_BLOCK), 0, s, S.grid, T.grid, c->state, thr2, c->margin_nn, c->corr, sqd_out, c->fb_list, fbc); }
+    ProfScope ps(c, QN_K_FITNESS);
+    if (seeded) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_nn_track<1>), dim3(nbt), dim3(QN_BLOCK), 0, s, S.grid, T.grid, T.raw, c->state, thr2, c->corr, sqd_out, c->nn_idx, c->nn_ref, c->fb_list, fbc, c->big_list, bgc);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_nn_search<1, false>), dim3(nb), dim3(QN_BLOCK), 0, s, S.grid, T.grid, c->state, thr2, r0, 1, c->corr, sqd_out, c->nn_idx, c->nn_ref, c->fb_list, fbc, c->big_list, bgc, 0);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_nn_search<1, true>), dim3(fbb + big_blocks), dim3(QN_BLOCK), 0, s, S.grid, T.grid, c->state, thr2, r0, 64, c->corr, sqd_out, c->nn_idx, c->nn_ref, c->fb_list, fbc, c->big_list, bgc, big_blocks);
   }
 }
+static uint32_t acc_blocks(const qn_ctx* c) { return std::min<uint32_t>((c->cloud[0].n + QN_BLOCK - 1) / QN_BLOCK, QN_ACC_MAX_BLOCKS); }
 static void enqueue_accumulate(qn_ctx* c) {
   ProfScope ps(c, QN_K_ACCUMULATE);
   CloudBuf &S = c->cloud[0], &T = c->cloud[1];
-  hipLaunchKernelGGL(k_accumulate, dim3(QN_ACC_BLOCKS), dim3(QN_BLOCK), 0, c->stream, S.raw, S.n, T.raw, S.cov, T.cov, c->corr, c->state, c->partials);
+  hipLaunchKernelGGL(k_accumulate, dim3(acc_blocks(c)), dim3(QN_BLOCK), 0, c->stream, S.raw, S.n, T.raw, S.cov, T.cov, c->corr, c->state, c->partials);
 }
 static void enqueue_solve(qn_ctx* c, int mode) {
   ProfScope ps(c, QN_K_SOLVE);
-  hipLaunchKernelGGL(k_solve, dim3(1), dim3(QN_BLOCK), 0, c->stream, c->state, c->partials, make_cfg(c), c->trace, mode);
+  hipLaunchKernelGGL(k_solve, dim3(1), dim3(QN_SOLVE_THREADS), 0, c->stream, c->state, c->partials, (int)acc_blocks(c), make_cfg(c), c->trace, mode);
 }
 // one "tick" of the device-side state machine: [NN pass A, NN pass B, accumulate, solve]
-static void enqueue_tick(qn_ctx* c) { enqueue_nn(c, 0, c->sqd); enqueue_accumulate(c); enqueue_solve(c, 0); }
-static void enqueue_epilogue(qn_ctx* c, double max_range) {       // fitness + output cloud; each kernel is a no-op until phase == done
-  enqueue_nn(c, 1, c->sqd_fit);
+static void enqueue_tick(qn_ctx* c, bool seeded) { enqueue_nn(c, 0, c->sqd, seeded); enqueue_accumulate(c); enqueue_solve(c, 0); }
+static void enqueue_epilogue(qn_ctx* c, double max_range, bool seeded) {       // fitness + output cloud; each kernel is a no-op until phase == done
+  enqueue_nn(c, 1, c->sqd_fit, seeded);
   { ProfScope ps(c, QN_K_FITNESS);
-    hipLaunchKernelGGL(k_fitness_reduce, dim3(1), dim3(1024), 0, c->stream, c->sqd_fit, c->cloud[0].n, max_range, c->state, 1); }
+    hipLaunchKernelGGL(k_fitness_partial, dim3(QN_FIT_BLOCKS), dim3(QN_BLOCK), 0, c->stream, c->sqd_fit, c->cloud[0].n, max_range, c->state, c->fit_psum, c->fit_pcnt, 1);
+    hipLaunchKernelGGL(k_fitness_final, dim3(1), dim3(QN_FIT_BLOCKS), 0, c->stream, c->fit_psum, c->fit_pcnt, c->state, 1); }
   { ProfScope ps(c, QN_K_TRANSFORM);
     hipLaunchKernelGGL(k_transform_cloud, dim3((c->cloud[0].n + QN_BLOCK - 1) / QN_BLOCK), dim3(QN_BLOCK), 0, c->stream, c->cloud[0].raw, c->cloud[0].n, c->state, c->aligned, 1); }
   hipLaunchKernelGGL(k_finalize, dim3(1), dim3(64), 0, c->stream, c->state, c->result_host);
@@ -325,9 +339,10 @@ extern "C" int qn_gicp_align(qn_ctx* c, const float guess[16], qn_gicp_result* o
   int chunk = p.force_iterations > 0 ? maxit * per_outer : c->ticks_per_chunk;
   long budget = (long)maxit * (p.optimizer == QN_OPT_LM ? (p.lm_max_iterations + 1) : 1) + 2;
   c->result_host->phase = 0;
+  bool seeded = false;          // the first linearisation runs the full grid search; every later NN pass tracks from it
   for (;;) {
-    for (int t = 0; t < chunk; t++) enqueue_tick(c);
-    enqueue_epilogue(c, DBL_MAX);
+    for (int t = 0; t < chunk; t++) { enqueue_tick(c, seeded); seeded = true; }
+    enqueue_epilogue(c, DBL_MAX, maxit > 0);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipStreamSynchronize(s));
     budget -= chunk;
@@ -345,8 +360,9 @@ extern "C" int qn_gicp_fitness(qn_ctx* c, double max_range, double* score) {
   int rc = ready(c); if (rc != QN_OK) return rc;
   if (!score) return QN_ERR_INVALID_ARG;
   HIPCHK(c, hipSetDevice(c->device));
-  enqueue_nn(c, 1, c->sqd_fit);
-  hipLaunchKernelGGL(k_fitness_reduce, dim3(1), dim3(1024), 0, c->stream, c->sqd_fit, c->cloud[0].n, max_range, c->state, 1);
+  enqueue_nn(c, 1, c->sqd_fit, false);
+  hipLaunchKernelGGL(k_fitness_partial, dim3(QN_FIT_BLOCKS), dim3(QN_BLOCK), 0, c->stream, c->sqd_fit, c->cloud[0].n, max_range, c->state, c->fit_psum, c->fit_pcnt, 1);
+  hipLaunchKernelGGL(k_fitness_final, dim3(1), dim3(QN_FIT_BLOCKS), 0, c->stream, c->fit_psum, c->fit_pcnt, c->state, 1);
   hipLaunchKernelGGL(k_finalize, dim3(1), dim3(64), 0, c->stream, c->state, c->result_host);
   HIPCHK(c, hipGetLastError());
   HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -442,7 +458,7 @@ extern "C" int qn_gicp_linearize(qn_ctx* c, const double T[16], double H[36], do
   hipStream_t s = c->stream;
   HIPCHK(c, hipMemcpyAsync(c->pose_tmp, T, sizeof(double) * 16, hipMemcpyHostToDevice, s));
   hipLaunchKernelGGL(k_set_pose, dim3(1), dim3(64), 0, s, c->state, c->pose_tmp, 0, 0);
-  enqueue_nn(c, 0, c->sqd); enqueue_accumulate(c); enqueue_solve(c, 1);
+  enqueue_nn(c, 0, c->sqd, false); enqueue_accumulate(c); enqueue_solve(c, 1);
   GicpState* hs = (GicpState*)malloc(sizeof(GicpState));
   hipError_t e = hipMemcpyAsync(hs, c->state, sizeof(GicpState), hipMemcpyDeviceToHost, s);
   if (e == hipSuccess && corr_out) e = hipMemcpyAsync(corr_out, c->corr, sizeof(int32_t) * c->cloud[0].n, hipMemcpyDeviceToHost, s);

@@ -10,7 +10,7 @@ namespace qn {
 
 #define QN_BLOCK 256
 #define QN_NPART 28            // 21 (upper H) + 6 (b) + 1 (cost)
-#define QN_ACC_BLOCKS 256      // fixed grid of the accumulate kernel -> fixed, deterministic reduction tree
+#define QN_ACC_MAX_BLOCKS 512  // accumulate grid = min(ceil(n / 256), this): fixed for a given n -> deterministic reduction tree
 #define QN_MAX_TRACE 1024
 
 // Device-resident optimiser state: the LM / GN controller of LsqRegistration runs
@@ -23,9 +23,9 @@ struct GicpState {
   double final_H[36];
   double fitness;
   int outer, inner, phase, converged, lm_failed;   // phase: 0 = linearize at x0, 1 = error at xi, 2 = done
-  uint32_t fb_count;                                // pass-B worklist length
+  uint32_t fb_count;                                // 16-query list length
   uint32_t trace_len;
-  uint32_t pad;
+  uint32_t big_count;                               // one-query-per-wave list length
 };
 
 struct GicpConfig {                                 // by-value kernel argument
@@ -193,41 +193,34 @@ __device__ __forceinline__ void cov_from_knn(const BestK<KMAX>& sink, const floa
     }
 }
 
-template <int KMAX>
-__global__ void __launch_bounds__(QN_BLOCK) k_knn_cov(GridView g, const float4* __restrict__ raw, int k, int margin, int margin_cap,
+// One kernel body for both passes.  LIST = false: query t = global query slot, radius margin * cell, two
+// rounds, leftovers appended to fb_list with the radius to continue from.  LIST = true: the queries are
+// the fb_list entries of the first pass (16 per wave, wave-stride), rounds until exact.
+template <int KMAX, bool LIST>
+__global__ void __launch_bounds__(QN_BLOCK) k_knn_cov(GridView g, const float4* __restrict__ raw, int k, float r0, int max_rounds,
                                                       double* __restrict__ cov, int32_t* __restrict__ knn_idx, float* __restrict__ knn_d2,
                                                       uint2* __restrict__ fb_list, uint32_t* __restrict__ fb_count) {
   __shared__ WaveLdsK lds[QN_BLOCK / 64];
-  const uint32_t t = blockIdx.x * (QN_BLOCK / 4) + (threadIdx.x >> 6) * 16 + (threadIdx.x & 15);   // 16 queries per wave
-  const bool active = t < g.n;
-  float4 q = active ? g.pts[t] : make_float4(0, 0, 0, 0);
   WaveLdsK* my = &lds[threadIdx.x >> 6];
-  BestK<KMAX> sink; sink.init(k, my->pend, g.dbg);
-  const bool cert = wave_cluster_search(g, q.x, q.y, q.z, active, margin, margin_cap, sink, &my->s);
-  if (!active || (threadIdx.x & 48) != 0) return;                  // sub-slot 0 of each query finishes the job
-  const uint32_t i = __float_as_uint(q.w);
-  if (cert) cov_from_knn(sink, raw, cov + (size_t)i * 6, knn_idx ? knn_idx + (size_t)i * k : nullptr, knn_d2 ? knn_d2 + (size_t)i * k : nullptr);
-  else {
-    uint32_t slot = atomicAdd(fb_count, 1u);
-    fb_list[slot] = make_uint2(t, __float_as_uint(sink.full() ? sink.worst_d2() : -1.0f));
-  }
-}
-
-template <int KMAX>
-__global__ void __launch_bounds__(QN_BLOCK) k_knn_cov_fallback(GridView g, const float4* __restrict__ raw, int k, int margin,
-                                                               double* __restrict__ cov, int32_t* __restrict__ knn_idx, float* __restrict__ knn_d2,
-                                                               const uint2* __restrict__ fb_list, const uint32_t* __restrict__ fb_count) {
-  const uint32_t nfb = *fb_count;
-  if (g.dbg && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&g.dbg[4], nfb);
-  for (uint32_t w = blockIdx.x * QN_BLOCK + threadIdx.x; w < nfb; w += gridDim.x * QN_BLOCK) {
-    const uint2 rec = fb_list[w];
-    const float4 q = g.pts[rec.x];
-    const float kd2 = __uint_as_float(rec.y);
-    float r = kd2 >= 0.f ? sqrtf(kd2) * 1.000001f + g.eps : (margin + 1) * g.cell;
-    BestK<KMAX> sink; sink.init(k, nullptr);
-    lane_ball_knn(g, q.x, q.y, q.z, r, sink);
+  const uint32_t nq = LIST ? *fb_count : g.n;
+  if (LIST && g.dbg && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&g.dbg[4], nq);
+  const uint32_t wave0 = blockIdx.x * (QN_BLOCK / 64) + (threadIdx.x >> 6), nwaves = gridDim.x * (QN_BLOCK / 64);
+  for (uint32_t base = wave0 * 16; base < nq; base += nwaves * 16) {       // (non-LIST grids cover nq in one trip)
+    const uint32_t slot = base + (threadIdx.x & 15);
+    const bool active = slot < nq;
+    uint32_t t = slot; float r = r0;
+    if (LIST && active) { const uint2 rec = fb_list[slot]; t = rec.x; r = __uint_as_float(rec.y); }   // continue from r
+    const float4 q = active ? g.pts[t] : make_float4(0, 0, 0, 0);
+    BestK<KMAX> sink; sink.init(k, my->pend, g.dbg);
+    float d_unseen;
+    const bool cert = wave_search(g, q.x, q.y, q.z, active, r, __int_as_float(0x7f800000), max_rounds, sink, &my->s, d_unseen);
+    if (!active || (threadIdx.x & 48) != 0) continue;               // sub-slot 0 of each query finishes the job
     const uint32_t i = __float_as_uint(q.w);
-    cov_from_knn(sink, raw, cov + (size_t)i * 6, knn_idx ? knn_idx + (size_t)i * k : nullptr, knn_d2 ? knn_d2 + (size_t)i * k : nullptr);
+    if (cert || LIST) cov_from_knn(sink, raw, cov + (size_t)i * 6, knn_idx ? knn_idx + (size_t)i * k : nullptr, knn_d2 ? knn_d2 + (size_t)i * k : nullptr);
+    else {
+      const uint32_t fs = atomicAdd(fb_count, 1u);
+      fb_list[fs] = make_uint2(t, __float_as_uint(r));
+    }
   }
 }
 
@@ -248,8 +241,9 @@ __device__ __forceinline__ void xform_query(const float Tf[12], float x, float y
 }
 
 template <int MODE>
-__device__ __forceinline__ void store_nn(unsigned long long key, uint32_t i, double thr2, int32_t* __restrict__ corr, float* __restrict__ sqd) {
+__device__ __forceinline__ void store_nn(unsigned long long key, uint32_t i, double thr2, int32_t* __restrict__ corr, float* __restrict__ sqd, int32_t* __restrict__ nn_idx) {
   const float d2 = key_d2(key);
+  if (MODE == 0 && key != QN_INF_KEY) nn_idx[i] = (int32_t)key_idx(key);        // ungated NN: next iteration's search seed (k_nn_track)
   if (MODE == 0) {
     const bool found = key != QN_INF_KEY;
     sqd[i] = found ? d2 : 0.f;
@@ -259,52 +253,155 @@ __device__ __forceinline__ void store_nn(unsigned long long key, uint32_t i, dou
   }
 }
 
-template <int MODE>
-__global__ void __launch_bounds__(QN_BLOCK) k_nn_search(GridView src, GridView tgt, const GicpState* __restrict__ st, double thr2, int margin, int margin_cap,
-                                                        int32_t* __restrict__ corr, float* __restrict__ sqd,
-                                                        uint2* __restrict__ fb_list, uint32_t* __restrict__ fb_count) {
+// LIST = false: first search of an align (no seed): every source point, radius margin * cell, two rounds,
+// leftovers to fb_list.  LIST = true: the fb_list entries (leftovers of the first search, or the big-ball
+// queries of k_nn_track with their seed radius), 16 per wave, rounds until exact.
+// In the LIST launch the last `big_blocks` blocks serve big_list instead, one query per wave (wave_search_single).
+template <int MODE, bool LIST>
+__global__ void __launch_bounds__(QN_BLOCK) k_nn_search(GridView src, GridView tgt, const GicpState* __restrict__ st, double thr2, float r0, int max_rounds,
+                                                        int32_t* __restrict__ corr, float* __restrict__ sqd, int32_t* __restrict__ nn_idx, float4* __restrict__ nn_ref,
+                                                        uint2* __restrict__ fb_list, uint32_t* __restrict__ fb_count,
+                                                        uint2* __restrict__ big_list, uint32_t* __restrict__ big_count, int big_blocks) {
   __shared__ WaveLds lds[QN_BLOCK / 64];
   if (MODE == 0 && st->phase != 0) return;
   if (MODE == 1 && st->phase != 2) return;
   float Tf[12];
 #pragma unroll
   for (int j = 0; j < 12; j++) Tf[j] = (float)st->x0[j];
-  const uint32_t t = blockIdx.x * (QN_BLOCK / 4) + (threadIdx.x >> 6) * 16 + (threadIdx.x & 15);   // 16 queries per wave
-  const bool active = t < src.n;
-  const float4 p = active ? src.pts[t] : make_float4(0, 0, 0, 0);
-  float qx, qy, qz; xform_query<MODE>(Tf, p.x, p.y, p.z, qx, qy, qz);
-  Best1 sink; sink.init();
-  const bool cert = wave_cluster_search(tgt, qx, qy, qz, active, margin, margin_cap, sink, &lds[threadIdx.x >> 6]);
-  if (!active || (threadIdx.x & 48) != 0) return;
-  if (cert) store_nn<MODE>(sink.key, __float_as_uint(p.w), thr2, corr, sqd);
-  else {
-    uint32_t slot = atomicAdd(fb_count, 1u);
-    fb_list[slot] = make_uint2(t, __float_as_uint(sink.full() ? sink.worst_d2() : -1.0f));
+  if (LIST && (int)blockIdx.x >= (int)gridDim.x - big_blocks) {            // ---- big entries: one query per wave
+    const uint32_t nbig = *big_count;
+    if (tgt.dbg && blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) atomicAdd(&tgt.dbg[7], nbig);
+    const uint32_t bw0 = (blockIdx.x - (gridDim.x - big_blocks)) * (QN_BLOCK / 64) + (threadIdx.x >> 6), nbw = big_blocks * (QN_BLOCK / 64);
+    for (uint32_t w = bw0; w < nbig; w += nbw) {
+      const uint2 rec = big_list[w];
+      const float4 p = src.pts[rec.x];
+      float qx, qy, qz; xform_query<MODE>(Tf, p.x, p.y, p.z, qx, qy, qz);
+      const float v = __uint_as_float(rec.y);
+      // v > 0: tight seed (the query barely moved since its last scan): scan a little wider than the bound so that the
+      // following iterations can prove the neighbour unchanged; v < 0: unseeded, continue from |v|
+      const float r = v > 0.f ? v * 1.1f + 0.5f * tgt.cell : -v;
+      unsigned long long key; float second, d_unseen;
+      wave_search_single(tgt, qx, qy, qz, r, __int_as_float(0x7f800000), key, second, d_unseen, &lds[threadIdx.x >> 6]);
+      if ((threadIdx.x & 63) == 0) {
+        store_nn<MODE>(key, __float_as_uint(p.w), thr2, corr, sqd, nn_idx);
+        if (MODE == 0) nn_ref[__float_as_uint(p.w)] = make_float4(qx, qy, qz, fminf(sqrtf(second), d_unseen));
+      }
+    }
+    return;
+  }
+  const uint32_t nq = LIST ? *fb_count : src.n;
+  if (LIST && tgt.dbg && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&tgt.dbg[5], nq);
+  const uint32_t wave0 = blockIdx.x * (QN_BLOCK / 64) + (threadIdx.x >> 6), nwaves = (gridDim.x - (LIST ? big_blocks : 0)) * (QN_BLOCK / 64);
+  for (uint32_t base = wave0 * 16; base < nq; base += nwaves * 16) {
+    const uint32_t slot = base + (threadIdx.x & 15);
+    const bool active = slot < nq;
+    uint32_t t = slot; float r = r0, r_cap = __int_as_float(0x7f800000);
+    if (LIST && active) {        // rec.y > 0: seeded entry (proven bound on the NN distance); < 0: continue from |rec.y|
+      const uint2 rec = fb_list[slot]; t = rec.x;
+      const float v = __uint_as_float(rec.y);
+      if (v < 0.f) r = -v; else { r_cap = v; r = fminf(v, r0); }   // seeded (possibly loose after a big pose step): start small, never beyond the bound
+    }
+    const float4 p = active ? src.pts[t] : make_float4(0, 0, 0, 0);
+    float qx, qy, qz; xform_query<MODE>(Tf, p.x, p.y, p.z, qx, qy, qz);
+    Best1 sink; sink.init();
+    float d_unseen;
+    const bool cert = wave_search(tgt, qx, qy, qz, active, r, r_cap, max_rounds, sink, &lds[threadIdx.x >> 6], d_unseen);
+    if (!active || (threadIdx.x & 48) != 0) continue;
+    if (cert || LIST) {
+      store_nn<MODE>(sink.key, __float_as_uint(p.w), thr2, corr, sqd, nn_idx);
+      // bound-pruning reference: where this query was scanned and how far away every other point is at least
+      if (MODE == 0) nn_ref[__float_as_uint(p.w)] = make_float4(qx, qy, qz, fminf(sqrtf(sink.second), d_unseen));
+    }
+    else if (r > 2.5f * r0) { const uint32_t fs = atomicAdd(big_count, 1u); big_list[fs] = make_uint2(t, __float_as_uint(-r)); }   // far: one query per wave
+    else { const uint32_t fs = atomicAdd(fb_count, 1u); fb_list[fs] = make_uint2(t, __float_as_uint(-r)); }                         // continue from r
   }
 }
 
-// pass B: one uncertified query per wavefront
+// ------------------------------------------------------------------ K4a', temporal tracking
+// Iterations after the first (and the fitness pass) start from the previous iteration's nearest
+// neighbour j0: d(q, p_j0) is an upper bound on the NN distance, so the exact NN lies in the ball of that
+// radius - after the first Gauss-Newton step that is one to eight grid cells.  One query per lane,
+// at most QN_TRACK_SEG segments (bounds gathered first, then the points); larger balls go to the
+// wave-per-query pass B with the same bound.  Exact by construction: every point that could beat or
+// tie j0 (lower index wins) is scanned.
+#define QN_TRACK_SEG 8
+// Bound pruning: nn_ref[i] = (position q_ref at which query i was last SCANNED, lower bound d_other on the
+// distance from q_ref to every target point other than its neighbour j0).  If the query has moved by delta
+// since, every other point is still >= d_other - delta away, so  d(q, p_j0) + delta < d_other  PROVES that
+// j0 is still the unique nearest neighbour and the scan is skipped - bit-identical result, no search.
+// As the optimiser converges delta -> 0 and almost every query takes this path.
 template <int MODE>
-__global__ void __launch_bounds__(QN_BLOCK) k_nn_fallback(GridView src, GridView tgt, const GicpState* __restrict__ st, double thr2, int margin,
-                                                          int32_t* __restrict__ corr, float* __restrict__ sqd,
-                                                          const uint2* __restrict__ fb_list, const uint32_t* __restrict__ fb_count) {
-  __shared__ WaveLds lds[QN_BLOCK / 64];
+__global__ void __launch_bounds__(QN_BLOCK) k_nn_track(GridView src, GridView tgt, const float4* __restrict__ tgt_raw, const GicpState* __restrict__ st,
+                                                       double thr2, int32_t* __restrict__ corr, float* __restrict__ sqd, int32_t* __restrict__ nn_idx,
+                                                       float4* __restrict__ nn_ref, uint2* __restrict__ fb_list, uint32_t* __restrict__ fb_count,
+                                                       uint2* __restrict__ big_list, uint32_t* __restrict__ big_count) {
   if (MODE == 0 && st->phase != 0) return;
   if (MODE == 1 && st->phase != 2) return;
-  const uint32_t nfb = *fb_count;
-  if (tgt.dbg && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&tgt.dbg[5], nfb);
   float Tf[12];
 #pragma unroll
   for (int j = 0; j < 12; j++) Tf[j] = (float)st->x0[j];
-  const uint32_t nwaves = gridDim.x * (QN_BLOCK / 64);
-  for (uint32_t w = blockIdx.x * (QN_BLOCK / 64) + (threadIdx.x >> 6); w < nfb; w += nwaves) {
-    const uint2 rec = fb_list[w];
-    const float4 p = src.pts[rec.x];
-    float qx, qy, qz; xform_query<MODE>(Tf, p.x, p.y, p.z, qx, qy, qz);
-    const float bd2 = __uint_as_float(rec.y);
-    const float r = bd2 >= 0.f ? sqrtf(bd2) * 1.000001f + tgt.eps : (margin + 1) * tgt.cell;
-    const unsigned long long key = wave_ball_nn1(tgt, qx, qy, qz, r, &lds[threadIdx.x >> 6]);
-    if ((threadIdx.x & 63) == 0) store_nn<MODE>(key, __float_as_uint(p.w), thr2, corr, sqd);
+  const uint32_t t = blockIdx.x * QN_BLOCK + threadIdx.x;
+  if (t >= src.n) return;
+  const float4 p = src.pts[t];
+  const uint32_t i = __float_as_uint(p.w);
+  float qx, qy, qz; xform_query<MODE>(Tf, p.x, p.y, p.z, qx, qy, qz);
+  const int32_t j0 = nn_idx[i];
+  const float4 ref = nn_ref[i];
+  const float4 p0 = tgt_raw[j0];
+  const float d0 = sqdist(qx, qy, qz, p0.x, p0.y, p0.z);
+  unsigned long long best = pack_key(d0, (uint32_t)j0);
+  const float delta = sqrtf(sqdist(qx, qy, qz, ref.x, ref.y, ref.z));
+  if ((sqrtf(d0) + delta) * 1.000004f < ref.w) {                   // proven: j0 is still the unique NN (the factor covers f32 rounding)
+    if (tgt.dbg && (threadIdx.x & 63) == 0) atomicAdd(&tgt.dbg[6], (uint32_t)__popcll(__ballot(1)));
+    store_nn<MODE>(best, i, thr2, corr, sqd, nn_idx);
+    return;
+  }
+  const float r = sqrtf(d0) * 1.000001f + tgt.eps;
+  const int bx0 = cell_coord(qx - r, tgt.ox, tgt.inv_cell, tgt.nx), bx1 = cell_coord(qx + r, tgt.ox, tgt.inv_cell, tgt.nx);
+  const int by0 = cell_coord(qy - r, tgt.oy, tgt.inv_cell, tgt.ny), by1 = cell_coord(qy + r, tgt.oy, tgt.inv_cell, tgt.ny);
+  const int bz0 = cell_coord(qz - r, tgt.oz, tgt.inv_cell, tgt.nz), bz1 = cell_coord(qz + r, tgt.oz, tgt.inv_cell, tgt.nz);
+  const int tx0 = bx0 >> 3, ntr = (bx1 >> 3) - tx0 + 1, nyr = by1 - by0 + 1;
+  const int nseg = ntr * nyr * (bz1 - bz0 + 1);
+  if (!(d0 == d0) || nseg > QN_TRACK_SEG) {                       // big ball (or non-finite query): list passes, seeded with the bound
+    // tight seed (the query barely moved since it was scanned) AND far neighbour: one query per wave; else the 16-query pass
+    if (r > 2.5f * tgt.cell && delta < 0.25f * r) { const uint32_t slot = atomicAdd(big_count, 1u); big_list[slot] = make_uint2(t, __float_as_uint(r)); }
+    else { const uint32_t slot = atomicAdd(fb_count, 1u); fb_list[slot] = make_uint2(t, __float_as_uint(r)); }   // r is NaN for a non-finite query: resolved at once
+    return;
+  }
+  uint32_t s[QN_TRACK_SEG], e[QN_TRACK_SEG];
+#pragma unroll
+  for (int sg = 0; sg < QN_TRACK_SEG; sg++) {
+    s[sg] = 0; e[sg] = 0;
+    if (sg < nseg) {
+      const int tt = sg % ntr, rr = sg / ntr;
+      const int ry = by0 + rr % nyr, rz = bz0 + rr / nyr, tx = tx0 + tt;
+      const int xa = max(bx0, tx << 3), xb = min(bx1, (tx << 3) + 7);
+      const uint32_t k0 = cell_key(tgt, xa, ry, rz);
+      s[sg] = tgt.cell_start[k0]; e[sg] = tgt.cell_start[k0 + (xb - xa) + 1];
+    }
+  }
+  float second = __int_as_float(0x7f800000);
+#pragma unroll
+  for (int sg = 0; sg < QN_TRACK_SEG; sg++) {
+    for (uint32_t u = s[sg]; u < e[sg]; u++) {
+      const float4 a = tgt.pts[u];
+      const float da = sqdist(qx, qy, qz, a.x, a.y, a.z);
+      const unsigned long long ka = pack_key(da, __float_as_uint(a.w));
+      if (ka < best) { second = key_d2(best); best = ka; }
+      else if (ka != best && da < second) second = da;
+    }
+  }
+  store_nn<MODE>(best, i, thr2, corr, sqd, nn_idx);
+  if (MODE == 0) {   // distance to the faces of the scanned cell box that have unseen cells behind them
+    const float INF = __int_as_float(0x7f800000);
+    float d = INF;
+    if (bx0 > 0) d = fminf(d, qx - (tgt.ox + bx0 * tgt.cell));
+    if (bx1 < tgt.nx - 1) d = fminf(d, (tgt.ox + (bx1 + 1) * tgt.cell) - qx);
+    if (by0 > 0) d = fminf(d, qy - (tgt.oy + by0 * tgt.cell));
+    if (by1 < tgt.ny - 1) d = fminf(d, (tgt.oy + (by1 + 1) * tgt.cell) - qy);
+    if (bz0 > 0) d = fminf(d, qz - (tgt.oz + bz0 * tgt.cell));
+    if (bz1 < tgt.nz - 1) d = fminf(d, (tgt.oz + (bz1 + 1) * tgt.cell) - qz);
+    nn_ref[i] = make_float4(qx, qy, qz, fminf(sqrtf(second), d - tgt.eps));
   }
 }
 
@@ -371,8 +468,13 @@ __global__ void __launch_bounds__(QN_BLOCK) k_accumulate(const float4* __restric
     }
   }
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  if (phase == 0) {
 #pragma unroll
-  for (int t = 0; t < QN_NPART; t++) { double v = wave_sum_f64(acc[t]); if (lane == 0) red[wid][t] = v; }
+    for (int t = 0; t < QN_NPART; t++) { double v = wave_sum_f64_dpp(acc[t]); if (lane == 63) red[wid][t] = v; }
+  } else {
+    double v = wave_sum_f64_dpp(acc[27]);
+    if (lane == 63) { for (int t = 0; t < 27; t++) red[wid][t] = 0; red[wid][27] = v; }
+  }
   __syncthreads();
   if (threadIdx.x < QN_NPART) {
     double s = 0;
@@ -402,6 +504,46 @@ __device__ inline void d_so3_exp(const double om[3], double R[3][3]) {
   R[2][0] = txz - twy;       R[2][1] = tyz + twx;       R[2][2] = 1 - (txx + tyy);
 }
 
+// Unpivoted LDL^T, fully unrolled (static register indexing).  H + lambda I is SPD in every healthy
+// registration; returns false when a pivot is not strictly positive so the caller can take the
+// pivoted path (semi-definite systems: too few correspondences).  Same solution as the pivoted
+// factorisation up to rounding.
+__device__ __forceinline__ bool d_ldlt_solve6_fast(const double Ain[36], double diag_add, const double rhs[6], double x[6]) {
+  double A[6][6];
+#pragma unroll
+  for (int i = 0; i < 6; i++)
+#pragma unroll
+    for (int j = 0; j < 6; j++) A[i][j] = Ain[6 * i + j] + (i == j ? diag_add : 0.0);
+  bool ok = true;
+#pragma unroll
+  for (int k = 0; k < 6; k++) {
+    const double d = A[k][k];
+    ok = ok && (d > 0.0) && (d < 1.7976931348623157e308);
+    const double inv = 1.0 / d;
+    double l[6];
+#pragma unroll
+    for (int i = k + 1; i < 6; i++) l[i] = A[i][k] * inv;
+#pragma unroll
+    for (int i = k + 1; i < 6; i++)
+#pragma unroll
+      for (int j = k + 1; j <= i; j++) A[i][j] -= l[i] * d * l[j];
+#pragma unroll
+    for (int i = k + 1; i < 6; i++) A[i][k] = l[i];
+  }
+  double y[6];
+#pragma unroll
+  for (int i = 0; i < 6; i++) { double s = rhs[i];
+#pragma unroll
+    for (int j = 0; j < i; j++) s -= A[i][j] * y[j]; y[i] = s; }
+#pragma unroll
+  for (int i = 0; i < 6; i++) y[i] = y[i] / A[i][i];
+#pragma unroll
+  for (int i = 5; i >= 0; i--) { double s = y[i];
+#pragma unroll
+    for (int j = i + 1; j < 6; j++) s -= A[j][i] * x[j]; x[i] = s; }
+  return ok;
+}
+
 // LDL^T with diagonal pivoting (what Eigen::LDLT does), 6x6, f64
 __device__ inline void d_ldlt_solve6(const double Ain[36], double diag_add, const double rhs[6], double x[6], double (*A)[6]) {
   int perm[6];
@@ -428,14 +570,18 @@ __device__ inline void d_ldlt_solve6(const double Ain[36], double diag_add, cons
   for (int i = 0; i < 6; i++) x[perm[i]] = z[i];
 }
 
-__device__ inline void d_iso_mul(const double A[16], const double B[16], double C[16]) {
+__device__ __forceinline__ void d_iso_mul(const double A[16], const double B[16], double C[16]) {
   double r[16];
+#pragma unroll
   for (int i = 0; i < 16; i++) r[i] = 0;
+#pragma unroll
   for (int i = 0; i < 3; i++) {
+#pragma unroll
     for (int j = 0; j < 3; j++) r[4 * i + j] = A[4 * i] * B[j] + A[4 * i + 1] * B[4 + j] + A[4 * i + 2] * B[8 + j];
     r[4 * i + 3] = A[4 * i] * B[3] + A[4 * i + 1] * B[7] + A[4 * i + 2] * B[11] + A[4 * i + 3];
   }
   r[15] = 1.0;
+#pragma unroll
   for (int i = 0; i < 16; i++) C[i] = r[i];
 }
 
@@ -447,14 +593,34 @@ __device__ inline bool d_is_converged(const double delta[16], const GicpConfig& 
 }
 
 __device__ inline void d_propose(GicpState* st, double lambda, double (*A)[6]) {      // d = LDLT(H + lambda I).solve(-b); delta; xi = delta * x0
-  double rhs[6];
+  double Hl[36], rhs[6], dl[6], x0l[16];
+#pragma unroll
+  for (int i = 0; i < 36; i++) Hl[i] = st->H[i];
+#pragma unroll
   for (int i = 0; i < 6; i++) rhs[i] = -st->b[i];
-  d_ldlt_solve6(st->H, lambda, rhs, st->d, A);
-  double R[3][3]; d_so3_exp(st->d, R);
-  for (int i = 0; i < 16; i++) st->delta[i] = 0;
-  for (int a = 0; a < 3; a++) { for (int b = 0; b < 3; b++) st->delta[4 * a + b] = R[a][b]; st->delta[4 * a + 3] = st->d[3 + a]; }
-  st->delta[15] = 1.0;
-  d_iso_mul(st->delta, st->x0, st->xi);
+#pragma unroll
+  for (int i = 0; i < 16; i++) x0l[i] = st->x0[i];
+  if (!d_ldlt_solve6_fast(Hl, lambda, rhs, dl)) {
+    d_ldlt_solve6(st->H, lambda, rhs, st->d, A);
+#pragma unroll
+    for (int i = 0; i < 6; i++) dl[i] = st->d[i];
+  }
+  double R[3][3]; d_so3_exp(dl, R);
+  double delta[16], xi[16];
+#pragma unroll
+  for (int i = 0; i < 16; i++) delta[i] = 0;
+#pragma unroll
+  for (int a = 0; a < 3; a++) {
+#pragma unroll
+    for (int b = 0; b < 3; b++) delta[4 * a + b] = R[a][b];
+    delta[4 * a + 3] = dl[3 + a];
+  }
+  delta[15] = 1.0;
+  d_iso_mul(delta, x0l, xi);
+#pragma unroll
+  for (int i = 0; i < 6; i++) st->d[i] = dl[i];
+#pragma unroll
+  for (int i = 0; i < 16; i++) { st->delta[i] = delta[i]; st->xi[i] = xi[i]; }
 }
 
 // after an outer iteration finished (accepted or the rho<0 && converged early return)
@@ -471,7 +637,7 @@ __device__ inline void d_finish_outer(GicpState* st, const GicpConfig& cfg, qn_i
 
 // mode 0: full controller.  mode 1: reduce a linearisation only (H, b, y0).  mode 2: reduce an error pass only (yi).
 __device__ inline void solve_controller(GicpState* st, const double* sums, const GicpConfig& cfg, qn_iter_trace* trace, int mode, int phase, double (*Awork)[6]) {
-  st->fb_count = 0;
+  st->fb_count = 0; st->big_count = 0;
   const bool lin = (mode == 1) || (mode == 0 && phase == 0);
   if (lin) {
     int t = 0;
@@ -526,28 +692,34 @@ __device__ inline void solve_controller(GicpState* st, const double* sums, const
 }
 
 
-__global__ void __launch_bounds__(QN_BLOCK) k_solve(GicpState* gst, const double* __restrict__ partials, GicpConfig cfg, qn_iter_trace* trace, int mode) {
+#define QN_SOLVE_THREADS 1024
+__global__ void __launch_bounds__(QN_SOLVE_THREADS) k_solve(GicpState* gst, const double* __restrict__ partials, int nblk, GicpConfig cfg, qn_iter_trace* trace, int mode) {
   __shared__ double sums[QN_NPART];
-  __shared__ double part8[QN_NPART][8];
+  __shared__ double part32[QN_NPART][33];
   __shared__ GicpState sh;                       // the controller works on an LDS copy: one coalesced read, one coalesced write-back
   __shared__ double Awork[6][6];
   static_assert(sizeof(GicpState) % 8 == 0, "GicpState is copied as 8-byte words");
   const int phase = gst->phase;
-  if (phase == 2 && mode == 0) { if (threadIdx.x == 0) gst->fb_count = 0; return; }
-  for (int i = threadIdx.x; i < (int)(sizeof(GicpState) / 8); i += QN_BLOCK) ((unsigned long long*)&sh)[i] = ((const unsigned long long*)gst)[i];
-  // deterministic reduction of QN_ACC_BLOCKS x 28 partials: 8 strided sub-sums per component, combined in order
-  if (threadIdx.x < QN_NPART * 8) {
-    const int c = threadIdx.x >> 3, s = threadIdx.x & 7;
-    double v = 0;
-    for (int b = s; b < QN_ACC_BLOCKS; b += 8) v += partials[(size_t)b * QN_NPART + c];
-    part8[c][s] = v;
+  if (phase == 2 && mode == 0) { if (threadIdx.x == 0) { gst->fb_count = 0; gst->big_count = 0; } return; }
+  for (int i = threadIdx.x; i < (int)(sizeof(GicpState) / 8); i += QN_SOLVE_THREADS) ((unsigned long long*)&sh)[i] = ((const unsigned long long*)gst)[i];
+  // deterministic reduction of nblk x 28 partials: 32 strided sub-sums per component (all loads of a thread
+  // are independent and issued together), combined in a fixed order
+  if (threadIdx.x < QN_NPART * 32) {
+    const int c = threadIdx.x >> 5, s = threadIdx.x & 31;
+    double v[QN_ACC_MAX_BLOCKS / 32];
+#pragma unroll
+    for (int u = 0; u < QN_ACC_MAX_BLOCKS / 32; u++) { const int b = s + 32 * u; v[u] = b < nblk ? partials[(size_t)b * QN_NPART + c] : 0.0; }
+    double a = 0;
+#pragma unroll
+    for (int u = 0; u < QN_ACC_MAX_BLOCKS / 32; u++) a += v[u];
+    part32[c][s] = a;
   }
   __syncthreads();
-  if (threadIdx.x < QN_NPART) { double v = 0; for (int s = 0; s < 8; s++) v += part8[threadIdx.x][s]; sums[threadIdx.x] = v; }
+  if (threadIdx.x < QN_NPART) { double v = 0; for (int s = 0; s < 32; s++) v += part32[threadIdx.x][s]; sums[threadIdx.x] = v; }
   __syncthreads();
   if (threadIdx.x == 0) solve_controller(&sh, sums, cfg, trace, mode, phase, Awork);
   __syncthreads();
-  for (int i = threadIdx.x; i < (int)(sizeof(GicpState) / 8); i += QN_BLOCK) ((unsigned long long*)gst)[i] = ((const unsigned long long*)&sh)[i];
+  for (int i = threadIdx.x; i < (int)(sizeof(GicpState) / 8); i += QN_SOLVE_THREADS) ((unsigned long long*)gst)[i] = ((const unsigned long long*)&sh)[i];
 }
 
 __global__ void k_init_state(GicpState* st, const float* __restrict__ guess /* 16 or null */, int has_guess, int phase) {
@@ -556,31 +728,44 @@ __global__ void k_init_state(GicpState* st, const float* __restrict__ guess /* 1
   for (int i = 0; i < 36; i++) { st->H[i] = 0; st->final_H[i] = (i % 7 == 0) ? 1.0 : 0.0; }
   for (int i = 0; i < 6; i++) { st->b[i] = 0; st->d[i] = 0; }
   st->y0 = st->yi = st->den = 0; st->lambda = -1.0; st->nu = 2.0; st->fitness = 0;
-  st->outer = st->inner = 0; st->phase = phase; st->converged = 0; st->lm_failed = 0; st->fb_count = 0; st->trace_len = 0;
+  st->outer = st->inner = 0; st->phase = phase; st->converged = 0; st->lm_failed = 0; st->fb_count = 0; st->big_count = 0; st->trace_len = 0;
 }
 __global__ void k_set_pose(GicpState* st, const double* __restrict__ T, int which /*0 x0, 1 xi, 2 neither*/, int phase) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   for (int i = 0; i < 16; i++) { if (which == 0) st->x0[i] = T[i]; else if (which == 1) st->xi[i] = T[i]; }
-  st->phase = phase; st->fb_count = 0;
+  st->phase = phase; st->fb_count = 0; st->big_count = 0;
 }
 
 // ------------------------------------------------------------------ K7 fitness reduce, K8 transform
 // pcl getFitnessScore: mean of the f32 squared NN distances <= max_range, summed in f64.
-__global__ void __launch_bounds__(1024) k_fitness_reduce(const float* __restrict__ sqd, uint32_t n, double max_range, GicpState* st, int require_done) {
-  __shared__ double ssum[16]; __shared__ uint32_t scnt[16];
+#define QN_FIT_BLOCKS 128
+__global__ void __launch_bounds__(QN_BLOCK) k_fitness_partial(const float* __restrict__ sqd, uint32_t n, double max_range, const GicpState* __restrict__ st,
+                                                              double* __restrict__ psum, uint32_t* __restrict__ pcnt, int require_done) {
+  __shared__ double ssum[QN_BLOCK / 64]; __shared__ uint32_t scnt[QN_BLOCK / 64];
   if (require_done && st->phase != 2) return;
   double s = 0; uint32_t c = 0;
-  for (uint32_t i = threadIdx.x; i < n; i += 1024) { float d = sqd[i]; if ((double)d <= max_range) { s += (double)d; c++; } }
-  s = wave_sum_f64(s);
+  for (uint32_t i = blockIdx.x * QN_BLOCK + threadIdx.x; i < n; i += QN_FIT_BLOCKS * QN_BLOCK) { float d = sqd[i]; if ((double)d <= max_range) { s += (double)d; c++; } }
+  s = wave_sum_f64_dpp(s);
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
   if ((threadIdx.x & 63) == 0) { ssum[threadIdx.x >> 6] = s; scnt[threadIdx.x >> 6] = c; }
   __syncthreads();
   if (threadIdx.x == 0) {
     double t = 0; uint32_t tc = 0;
-    for (int w = 0; w < 16; w++) { t += ssum[w]; tc += scnt[w]; }
+    for (int w = 0; w < QN_BLOCK / 64; w++) { t += ssum[w]; tc += scnt[w]; }
+    psum[blockIdx.x] = t; pcnt[blockIdx.x] = tc;
+  }
+}
+__global__ void __launch_bounds__(QN_FIT_BLOCKS) k_fitness_final(const double* __restrict__ psum, const uint32_t* __restrict__ pcnt, GicpState* st, int require_done) {
+  __shared__ double ssum[QN_FIT_BLOCKS]; __shared__ uint32_t scnt[QN_FIT_BLOCKS];
+  if (require_done && st->phase != 2) return;
+  ssum[threadIdx.x] = psum[threadIdx.x]; scnt[threadIdx.x] = pcnt[threadIdx.x];
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = 0; uint32_t tc = 0;
+    for (int w = 0; w < QN_FIT_BLOCKS; w++) { t += ssum[w]; tc += scnt[w]; }       // fixed order
     st->fitness = tc > 0 ? t / tc : 1.7976931348623157e308;
-    st->fb_count = 0;
+    st->fb_count = 0; st->big_count = 0;
   }
 }
 
