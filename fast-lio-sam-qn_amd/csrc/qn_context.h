@@ -31,7 +31,7 @@ struct qn_ctx {
   qn::GicpState* state = nullptr;
   double* partials = nullptr; double* fit_psum = nullptr; uint32_t* fit_pcnt = nullptr;
   qn_iter_trace* trace = nullptr; uint32_t trace_len = 0;
-  int32_t* corr = nullptr; int32_t* nn_idx = nullptr; float4* nn_ref = nullptr; float* sqd = nullptr; float* sqd_fit = nullptr;
+  int32_t* corr = nullptr; int32_t* nn_idx = nullptr; int32_t* knn_idx = nullptr; float4* nn_ref = nullptr; float* sqd = nullptr; float* sqd_fit = nullptr;
   uint2* fb_list = nullptr; uint2* big_list = nullptr; uint32_t* fb_count2 = nullptr;
   float4* aligned = nullptr; bool aligned_valid = false;
   double* pose_tmp = nullptr; float* guess_tmp = nullptr;

@@ -98,6 +98,7 @@ extern "C" int qn_ctx_create(int device, uint32_t max_points, qn_ctx** out) {
   CA(hipMalloc(&c->state, sizeof(GicpState)));
   CA(hipMalloc(&c->partials, sizeof(double) * QN_ACC_MAX_BLOCKS * QN_NPART));
   CA(hipMalloc(&c->nn_idx, sizeof(int32_t) * max_points));
+  CA(hipMalloc(&c->knn_idx, sizeof(int32_t) * (size_t)max_points * 32));
   CA(hipMalloc(&c->nn_ref, sizeof(float4) * max_points));
   CA(hipMalloc(&c->fit_psum, sizeof(double) * QN_FIT_BLOCKS));
   CA(hipMalloc(&c->fit_pcnt, sizeof(uint32_t) * QN_FIT_BLOCKS));
@@ -128,7 +129,7 @@ extern "C" void qn_ctx_destroy(qn_ctx* c) {
   c->prof_collect();
   for (int w = 0; w < 2; w++) { CloudBuf& b = c->cloud[w]; hipFree(b.raw); hipFree(b.sorted); hipFree(b.cell_of_pt); hipFree(b.cell_start); hipFree(b.counts); hipFree(b.cov); }
   hipFree(c->staging); hipFree(c->scan_sums); hipFree(c->bbox); hipFree(c->state); hipFree(c->partials); hipFree(c->trace);
-  hipFree(c->nn_idx); hipFree(c->nn_ref); hipFree(c->fit_psum); hipFree(c->fit_pcnt); hipFree(c->corr); hipFree(c->sqd); hipFree(c->sqd_fit); hipFree(c->fb_list); hipFree(c->big_list); hipFree(c->fb_count2); hipFree(c->aligned);
+  hipFree(c->nn_idx); hipFree(c->knn_idx); hipFree(c->nn_ref); hipFree(c->fit_psum); hipFree(c->fit_pcnt); hipFree(c->corr); hipFree(c->sqd); hipFree(c->sqd_fit); hipFree(c->fb_list); hipFree(c->big_list); hipFree(c->fb_count2); hipFree(c->aligned);
   hipFree(c->pose_tmp); hipFree(c->guess_tmp); hipFree(c->dbg_knn_idx); hipFree(c->dbg_knn_d2); hipFree(c->dbg_counters);
   if (c->result_host) hipHostFree(c->result_host);
   if (c->bbox_host) hipHostFree(c->bbox_host);
@@ -252,6 +253,7 @@ static void launch_knn_cov(qn_ctx* c, CloudBuf& b, int k, int32_t* kidx, float* 
   ProfScope ps(c, QN_K_KNN_COV);
   hipLaunchKernelGGL(HIP_KERNEL_NAME(k_knn_cov<KMAX, false>), dim3(nb), dim3(QN_BLOCK), 0, s, b.grid, b.raw, k, r0, 2, b.cov, kidx, kd2, c->fb_list, c->fb_count2);
   hipLaunchKernelGGL(HIP_KERNEL_NAME(k_knn_cov<KMAX, true>), dim3(std::min<uint32_t>(nb, 512)), dim3(QN_BLOCK), 0, s, b.grid, b.raw, k, r0, 64, b.cov, kidx, kd2, c->fb_list, c->fb_count2);
+  hipLaunchKernelGGL(k_cov_from_idx, dim3((b.n + QN_BLOCK - 1) / QN_BLOCK), dim3(QN_BLOCK), 0, s, b.raw, b.n, k, kidx, b.cov);
 }
 static int compute_cov(qn_ctx* c, int which, int32_t* kidx, float* kd2) {
   if (!c || (which != 0 && which != 1)) return QN_ERR_INVALID_ARG;
@@ -268,7 +270,7 @@ static int compute_cov(qn_ctx* c, int which, int32_t* kidx, float* kd2) {
   b.has_cov = true;
   return QN_OK;
 }
-extern "C" int qn_gicp_compute_covariances(qn_ctx* c, int which) { return compute_cov(c, which, nullptr, nullptr); }
+extern "C" int qn_gicp_compute_covariances(qn_ctx* c, int which) { return compute_cov(c, which, c->knn_idx, nullptr); }
 
 // ------------------------------------------------------------------ align
 // seeded = true: the previous iteration's NN indices are valid -> temporal tracking kernel; false -> full grid search

@@ -193,11 +193,59 @@ __device__ __forceinline__ void cov_from_knn(const BestK<KMAX>& sink, const floa
     }
 }
 
+// k-NN selection and covariance are separate kernels: the selection keeps a 2k-register list alive, the
+// covariance needs ~40 f64 registers for the Jacobi sweep - fused, the kernel sat at 2 waves/SIMD.
+template <int KMAX>
+__device__ __forceinline__ void store_knn(const BestK<KMAX>& sink, int32_t* __restrict__ knn_idx, float* __restrict__ knn_d2) {
+  const int k = sink.k;
+#pragma unroll
+  for (int j = 0; j < KMAX; j++) if (j >= KMAX - k) {
+    const bool ok = sink.a[j] != QN_INF_KEY;
+    knn_idx[j - (KMAX - k)] = ok ? (int32_t)key_idx(sink.a[j]) : -1;
+    if (knn_d2) knn_d2[j - (KMAX - k)] = ok ? key_d2(sink.a[j]) : 0.f;
+  }
+}
+
+// SURVEY A.1.3 from stored neighbour indices (ascending (d2, idx) order, -1 = missing): one point per lane.
+__global__ void __launch_bounds__(QN_BLOCK) k_cov_from_idx(const float4* __restrict__ raw, uint32_t n, int k, const int32_t* __restrict__ knn_idx, double* __restrict__ cov) {
+  const uint32_t i = blockIdx.x * QN_BLOCK + threadIdx.x;
+  if (i >= n) return;
+  const int32_t* nb = knn_idx + (size_t)i * k;
+  int found = 0;
+  double mean[3] = {0, 0, 0};
+  for (int j = 0; j < k; j++) { const int32_t u = nb[j]; if (u < 0) continue; const float4 p = raw[u]; mean[0] += (double)p.x; mean[1] += (double)p.y; mean[2] += (double)p.z; found++; }
+  double* cov_out = cov + (size_t)i * 6;
+  if (found == 0) { for (int t = 0; t < 6; t++) cov_out[t] = 0; return; }
+  mean[0] /= found; mean[1] /= found; mean[2] /= found;
+  double c[6] = {0, 0, 0, 0, 0, 0};
+  for (int j = 0; j < k; j++) {
+    const int32_t u = nb[j]; if (u < 0) continue;
+    const float4 p = raw[u];
+    const double dx = (double)p.x - mean[0], dy = (double)p.y - mean[1], dz = (double)p.z - mean[2];
+    c[0] += dx * dx; c[1] += dx * dy; c[2] += dx * dz; c[3] += dy * dy; c[4] += dy * dz; c[5] += dz * dz;
+  }
+#pragma unroll
+  for (int t = 0; t < 6; t++) c[t] /= found;
+  double w[3], V[3][3];
+  sym_eig3(c, w, V);
+  const double vals[3] = {1.0, 1.0, 1e-3};
+  int t = 0;
+#pragma unroll
+  for (int a = 0; a < 3; a++)
+#pragma unroll
+    for (int b = a; b < 3; b++, t++) {
+      double s = 0;
+#pragma unroll
+      for (int e = 0; e < 3; e++) s += V[a][e] * vals[e] * V[b][e];
+      cov_out[t] = s;
+    }
+}
+
 // One kernel body for both passes.  LIST = false: query t = global query slot, radius margin * cell, two
 // rounds, leftovers appended to fb_list with the radius to continue from.  LIST = true: the queries are
 // the fb_list entries of the first pass (16 per wave, wave-stride), rounds until exact.
 template <int KMAX, bool LIST>
-__global__ void __launch_bounds__(QN_BLOCK) k_knn_cov(GridView g, const float4* __restrict__ raw, int k, float r0, int max_rounds,
+__global__ void __launch_bounds__(QN_BLOCK, 3) k_knn_cov(GridView g, const float4* __restrict__ raw, int k, float r0, int max_rounds,
                                                       double* __restrict__ cov, int32_t* __restrict__ knn_idx, float* __restrict__ knn_d2,
                                                       uint2* __restrict__ fb_list, uint32_t* __restrict__ fb_count) {
   __shared__ WaveLdsK lds[QN_BLOCK / 64];
@@ -216,7 +264,7 @@ __global__ void __launch_bounds__(QN_BLOCK) k_knn_cov(GridView g, const float4* 
     const bool cert = wave_search(g, q.x, q.y, q.z, active, r, __int_as_float(0x7f800000), max_rounds, sink, &my->s, d_unseen);
     if (!active || (threadIdx.x & 48) != 0) continue;               // sub-slot 0 of each query finishes the job
     const uint32_t i = __float_as_uint(q.w);
-    if (cert || LIST) cov_from_knn(sink, raw, cov + (size_t)i * 6, knn_idx ? knn_idx + (size_t)i * k : nullptr, knn_d2 ? knn_d2 + (size_t)i * k : nullptr);
+    if (cert || LIST) store_knn(sink, knn_idx + (size_t)i * k, knn_d2 ? knn_d2 + (size_t)i * k : nullptr);
     else {
       const uint32_t fs = atomicAdd(fb_count, 1u);
       fb_list[fs] = make_uint2(t, __float_as_uint(r));
