@@ -1,0 +1,61 @@
+// LoopClosure::icpAlignment (fast_lio_sam_qn/src/loop_closure.cpp:110-136) written against the drop-in
+// shim exactly as the reference writes it against nano_gicp - proves the shim's surface is sufficient.
+// usage: shim_icp_alignment src.bin dst.bin   (raw float32 xyz triplets) -> prints valid converged score T(16)
+#include <cstdio>
+#include <vector>
+#include <limits>
+#include <nano_gicp/point_type_nano_gicp.hpp>
+#include <nano_gicp/nano_gicp.hpp>
+
+using PointType = pcl::PointXYZI;
+
+struct RegistrationOutput {
+  bool is_valid_ = false, is_converged_ = false;
+  double score_ = std::numeric_limits<double>::max();
+  Eigen::Matrix4d pose_between_eig_ = Eigen::Matrix4d::Identity();
+};
+
+static pcl::PointCloud<PointType> load(const char* path) {
+  pcl::PointCloud<PointType> c; FILE* f = std::fopen(path, "rb"); float v[3];
+  while (f && std::fread(v, sizeof(float), 3, f) == 3) { PointType p; p.x = v[0]; p.y = v[1]; p.z = v[2]; p.intensity = 42.f; c.push_back(p); }
+  if (f) std::fclose(f);
+  return c;
+}
+
+int main(int argc, char** argv) {
+  if (argc < 3) return 2;
+  nano_gicp::NanoGICP<PointType, PointType> nano_gicp_;
+  // LoopClosure ctor, loop_closure.cpp:9-16 with the reference's effective config
+  nano_gicp_.setNumThreads(0);
+  nano_gicp_.setCorrespondenceRandomness(15);
+  nano_gicp_.setMaximumIterations(32);
+  nano_gicp_.setRANSACIterations(5);
+  nano_gicp_.setMaxCorrespondenceDistance(52.5);
+  nano_gicp_.setTransformationEpsilon(0.01);
+  nano_gicp_.setEuclideanFitnessEpsilon(0.01);
+  nano_gicp_.setRANSACOutlierRejectionThreshold(1.0);
+  const pcl::PointCloud<PointType> src = load(argv[1]), dst = load(argv[2]);
+  // icpAlignment, loop_closure.cpp:113-135
+  RegistrationOutput reg_output;
+  pcl::PointCloud<PointType> aligned_;
+  pcl::PointCloud<PointType>::Ptr src_cloud(new pcl::PointCloud<PointType>());
+  pcl::PointCloud<PointType>::Ptr dst_cloud(new pcl::PointCloud<PointType>());
+  *src_cloud = src;
+  *dst_cloud = dst;
+  nano_gicp_.setInputSource(src_cloud);
+  nano_gicp_.calculateSourceCovariances();
+  nano_gicp_.setInputTarget(dst_cloud);
+  nano_gicp_.calculateTargetCovariances();
+  nano_gicp_.align(aligned_);
+  reg_output.score_ = nano_gicp_.getFitnessScore();
+  if (nano_gicp_.hasConverged() && reg_output.score_ < 1.5) {
+    reg_output.is_valid_ = true;
+    reg_output.is_converged_ = true;
+    reg_output.pose_between_eig_ = nano_gicp_.getFinalTransformation().cast<double>();
+  }
+  std::printf("%d %d %.17g", (int)reg_output.is_valid_, (int)nano_gicp_.hasConverged(), reg_output.score_);
+  const Eigen::Matrix4f T = nano_gicp_.getFinalTransformation();
+  for (int r = 0; r < 4; r++) for (int c = 0; c < 4; c++) std::printf(" %.9g", T(r, c));
+  std::printf(" %zu %.9g %.9g\n", aligned_.size(), aligned_.size() ? aligned_[0].x : 0.f, aligned_.size() ? aligned_[0].intensity : 0.f);
+  return 0;
+}
