@@ -37,6 +37,11 @@ struct qn_ctx {
   double* pose_tmp = nullptr; float* guess_tmp = nullptr;
   qn::ResultBlock* result_host = nullptr; double* scalar_host = nullptr;
   int32_t* dbg_knn_idx = nullptr; float* dbg_knn_d2 = nullptr;
+  // Quatro (allocated on first use)
+  qn_quatro_params qparams{}; bool qparams_set = false, q_ready = false;
+  float4* q_normals[2] = {nullptr, nullptr}; float* q_spfh[2] = {nullptr, nullptr}; float* q_fpfh_s[2] = {nullptr, nullptr}; float* q_fpfh[2] = {nullptr, nullptr};
+  unsigned long long* q_key[2] = {nullptr, nullptr};
+  uint32_t* q_hit = nullptr; uint32_t* q_list = nullptr; uint2* q_pairs = nullptr; uint32_t* q_counts = nullptr; double* q_T = nullptr;
   // tuning knobs
   double cell_override = 0.0;
   int margin_nn = 1, margin_nn_cap = 3, margin_knn = 2, margin_knn_cap = 5, ticks_per_chunk = 8;

@@ -130,6 +130,8 @@ extern "C" void qn_ctx_destroy(qn_ctx* c) {
   for (int w = 0; w < 2; w++) { CloudBuf& b = c->cloud[w]; hipFree(b.raw); hipFree(b.sorted); hipFree(b.cell_of_pt); hipFree(b.cell_start); hipFree(b.counts); hipFree(b.cov); }
   hipFree(c->staging); hipFree(c->scan_sums); hipFree(c->bbox); hipFree(c->state); hipFree(c->partials); hipFree(c->trace);
   hipFree(c->nn_idx); hipFree(c->knn_idx); hipFree(c->nn_ref); hipFree(c->fit_psum); hipFree(c->fit_pcnt); hipFree(c->corr); hipFree(c->sqd); hipFree(c->sqd_fit); hipFree(c->fb_list); hipFree(c->big_list); hipFree(c->fb_count2); hipFree(c->aligned);
+  for (int w = 0; w < 2; w++) { hipFree(c->q_normals[w]); hipFree(c->q_spfh[w]); hipFree(c->q_fpfh_s[w]); hipFree(c->q_fpfh[w]); hipFree(c->q_key[w]); }
+  hipFree(c->q_hit); hipFree(c->q_list); hipFree(c->q_pairs); hipFree(c->q_counts); hipFree(c->q_T);
   hipFree(c->pose_tmp); hipFree(c->guess_tmp); hipFree(c->dbg_knn_idx); hipFree(c->dbg_knn_d2); hipFree(c->dbg_counters);
   if (c->result_host) hipHostFree(c->result_host);
   if (c->bbox_host) hipHostFree(c->bbox_host);
@@ -393,27 +395,28 @@ extern "C" int qn_gicp_get_trace(qn_ctx* c, qn_iter_trace* out, uint32_t cap, ui
   return QN_OK;
 }
 
-// LoopClosure::icpAlignment (loop_closure.cpp:110-136)
+// LoopClosure::icpAlignment (loop_closure.cpp:110-136).  where: 0 = both clouds on the host, 1 = both on the device,
+// 2 = source on the device as packed float4 (the coarse-aligned cloud of coarseToFineAlignment), target on the host.
 static int icp_alignment(qn_ctx* c, const float* src, uint32_t ns, const float* dst, uint32_t nt, uint32_t stride, double thr,
-                         qn_gicp_result* out, int* valid, bool dev) {
+                         qn_gicp_result* out, int* valid, int where) {
   if (!c || !out || !valid) return QN_ERR_INVALID_ARG;
   *valid = 0;
   memset(out, 0, sizeof(*out)); out->fitness = DBL_MAX;
   for (int i = 0; i < 4; i++) { out->T[5 * i] = 1.f; out->T64[5 * i] = 1.0; }
   int rc;
-  if ((rc = set_cloud(c, QN_SOURCE, src, ns, stride, dev)) != QN_OK) return rc;      // :120
+  if ((rc = set_cloud(c, QN_SOURCE, src, ns, where == 2 ? 16 : stride, where != 0)) != QN_OK) return rc;   // :120
   if ((rc = qn_gicp_compute_covariances(c, QN_SOURCE)) != QN_OK) return rc;         // :121
-  if ((rc = set_cloud(c, QN_TARGET, dst, nt, stride, dev)) != QN_OK) return rc;     // :122
+  if ((rc = set_cloud(c, QN_TARGET, dst, nt, stride, where == 1)) != QN_OK) return rc;     // :122
   if ((rc = qn_gicp_compute_covariances(c, QN_TARGET)) != QN_OK) return rc;         // :123
   if ((rc = qn_gicp_align(c, nullptr, out)) != QN_OK) return rc;                    // :124, :127
   *valid = (out->converged && out->fitness < thr) ? 1 : 0;                          // :129
   return QN_OK;
 }
 extern "C" int qn_icp_alignment(qn_ctx* c, const float* src, uint32_t ns, const float* dst, uint32_t nt, uint32_t stride, double thr, qn_gicp_result* out, int* valid) {
-  return icp_alignment(c, src, ns, dst, nt, stride, thr, out, valid, false);
+  return icp_alignment(c, src, ns, dst, nt, stride, thr, out, valid, 0);
 }
 extern "C" int qn_icp_alignment_device(qn_ctx* c, const float* src, uint32_t ns, const float* dst, uint32_t nt, uint32_t stride, double thr, qn_gicp_result* out, int* valid) {
-  return icp_alignment(c, src, ns, dst, nt, stride, thr, out, valid, true);
+  return icp_alignment(c, src, ns, dst, nt, stride, thr, out, valid, 1);
 }
 
 // ------------------------------------------------------------------ per-stage read-backs for parity tests
@@ -526,3 +529,5 @@ extern "C" int qn_debug_get_grid(qn_ctx* c, int which, double out[8]) {
   out[0] = g.ox; out[1] = g.oy; out[2] = g.oz; out[3] = g.cell; out[4] = g.nx; out[5] = g.ny; out[6] = g.nz; out[7] = g.eps;
   return QN_OK;
 }
+
+#include "qn_quatro_host.inc"

@@ -1,0 +1,246 @@
+// qn_quatro_kernels.cuh - gfx950 kernels of the Quatro coarse stage:
+// FPFH descriptors (normals -> SPFH -> FPFH) and the 33-D feature nearest-neighbour search behind
+// Matcher::optimizedMatching.  Reference call site: quatro_handler_->align(src, dst, ok),
+// fast_lio_sam_qn/src/loop_closure.cpp:144; behaviour restated in SURVEY.md Appendix A.2 (the
+// Quatro submodule is empty in the reference tree).
+//
+// Per-point arrays live in CELL-SORTED order (position t of GridView::pts), so a radius query walks
+// contiguous segments of the point array and every neighbour attribute (normal, SPFH row) is fetched
+// from the same neighbourhood of memory; k_rows_to_original permutes the final descriptors back.
+// No MFMA: the only contraction-like stage (33-D distances) must reproduce a sequential f32 sum
+// bit for bit, which the f32 MFMA (different summation tree) would not.
+#pragma once
+#include "qn_device.cuh"
+
+namespace qn {
+
+#define QN_FROW 36                      // 33 histogram bins padded to 9 x float4
+
+// deterministic f32 atan2 (Cephes atanf reduction + polynomial), identical to oracle qn_atan2f
+__device__ __forceinline__ float qn_atanf_pos(float x) {
+  float y;
+  if (x > 2.414213562373095f) { y = 1.5707963267948966f; x = -(1.0f / x); }
+  else if (x > 0.4142135623730950f) { y = 0.7853981633974483f; x = (x - 1.0f) / (x + 1.0f); }
+  else y = 0.0f;
+  const float z = x * x;
+  y += (((8.05374449538e-2f * z - 1.38776856032e-1f) * z + 1.99777106478e-1f) * z - 3.33329491539e-1f) * z * x + x;
+  return y;
+}
+__device__ __forceinline__ float qn_atan2f(float y, float x) {
+  const float PI_F = 3.14159265358979323846f;
+  if (x == 0.0f) { if (y == 0.0f) return 0.0f; return y > 0.0f ? 1.5707963267948966f : -1.5707963267948966f; }
+  const float a = qn_atanf_pos(fabsf(y) / fabsf(x));
+  const float r = x > 0.0f ? a : PI_F - a;
+  return y < 0.0f ? -r : r;
+}
+
+// Walk every point u of the grid whose cell intersects the ball (q, r); body(u, point).  One query per lane.
+template <class Body>
+__device__ __forceinline__ void for_each_in_ball_cells(const GridView& g, float qx, float qy, float qz, float r, Body&& body) {
+  const int bx0 = cell_coord(qx - r, g.ox, g.inv_cell, g.nx), bx1 = cell_coord(qx + r, g.ox, g.inv_cell, g.nx);
+  const int by0 = cell_coord(qy - r, g.oy, g.inv_cell, g.ny), by1 = cell_coord(qy + r, g.oy, g.inv_cell, g.ny);
+  const int bz0 = cell_coord(qz - r, g.oz, g.inv_cell, g.nz), bz1 = cell_coord(qz + r, g.oz, g.inv_cell, g.nz);
+  for (int rz = bz0; rz <= bz1; rz++) for (int ry = by0; ry <= by1; ry++) for (int tx = bx0 >> 3; tx <= (bx1 >> 3); tx++) {
+    const int xa = max(bx0, tx << 3), xb = min(bx1, (tx << 3) + 7);
+    const uint32_t k0 = cell_key(g, xa, ry, rz);
+    const uint32_t s = g.cell_start[k0], e = g.cell_start[k0 + (xb - xa) + 1];
+    for (uint32_t u = s; u < e; u++) body(u, g.pts[u]);
+  }
+}
+
+// K9: PCL NormalEstimation, radius search.  normals[t] = (nx, ny, nz, 1) or NaNs.
+__global__ void __launch_bounds__(QN_BLOCK) k_normals(GridView g, float r, float r2, float4* __restrict__ normals) {
+  const uint32_t t = blockIdx.x * QN_BLOCK + threadIdx.x;
+  if (t >= g.n) return;
+  const float4 p = g.pts[t];
+  int cnt = 0; double s[3] = {0, 0, 0}, c[6] = {0, 0, 0, 0, 0, 0};
+  for_each_in_ball_cells(g, p.x, p.y, p.z, r, [&](uint32_t, float4 q) __attribute__((always_inline)) {
+    if (sqdist(p.x, p.y, p.z, q.x, q.y, q.z) < r2) {
+      const double dx = (double)q.x - (double)p.x, dy = (double)q.y - (double)p.y, dz = (double)q.z - (double)p.z;   // relative to p: no cancellation
+      cnt++; s[0] += dx; s[1] += dy; s[2] += dz;
+      c[0] += dx * dx; c[1] += dx * dy; c[2] += dx * dz; c[3] += dy * dy; c[4] += dy * dz; c[5] += dz * dz;
+    }
+  });
+  const float qnan = __int_as_float(0x7fc00000);
+  if (cnt < 3) { normals[t] = make_float4(qnan, qnan, qnan, 0.f); return; }
+  const double inv = 1.0 / cnt, mx = s[0] * inv, my = s[1] * inv, mz = s[2] * inv;
+  const double cov[6] = {c[0] * inv - mx * mx, c[1] * inv - mx * my, c[2] * inv - mx * mz, c[3] * inv - my * my, c[4] * inv - my * mz, c[5] * inv - mz * mz};
+  double w[3], V[3][3]; sym_eig3(cov, w, V);
+  double nx = V[0][2], ny = V[1][2], nz = V[2][2];
+  if (-(nx * (double)p.x + ny * (double)p.y + nz * (double)p.z) < 0) { nx = -nx; ny = -ny; nz = -nz; }   // flip towards the viewpoint (0,0,0)
+  normals[t] = make_float4((float)nx, (float)ny, (float)nz, 1.f);
+}
+
+// pcl::computePairFeatures in f32 with the oracle's operation order
+__device__ __forceinline__ bool pair_features(const float4 p1, const float4 n1, const float4 p2, const float4 n2, float& f1, float& f2, float& f3) {
+  float dx = p2.x - p1.x, dy = p2.y - p1.y, dz = p2.z - p1.z;
+  const float f4 = sqrtf((dx * dx + dy * dy) + dz * dz);
+  if (f4 == 0.0f) return false;
+  const float angle1 = ((n1.x * dx + n1.y * dy) + n1.z * dz) / f4;
+  const float angle2 = ((n2.x * dx + n2.y * dy) + n2.z * dz) / f4;
+  float ax = n1.x, ay = n1.y, az = n1.z, bx = n2.x, by = n2.y, bz = n2.z;
+  if (fabsf(angle1) < fabsf(angle2)) { ax = n2.x; ay = n2.y; az = n2.z; bx = n1.x; by = n1.y; bz = n1.z; dx = -dx; dy = -dy; dz = -dz; f3 = -angle2; }
+  else f3 = angle1;
+  float vx = dy * az - dz * ay, vy = dz * ax - dx * az, vz = dx * ay - dy * ax;
+  const float vn = sqrtf((vx * vx + vy * vy) + vz * vz);
+  if (vn == 0.0f) return false;
+  vx /= vn; vy /= vn; vz /= vn;
+  const float wx = ay * vz - az * vy, wy = az * vx - ax * vz, wz = ax * vy - ay * vx;
+  f2 = (vx * bx + vy * by) + vz * bz;
+  f1 = qn_atan2f((wx * bx + wy * by) + wz * bz, (ax * bx + ay * by) + az * bz);
+  return true;
+}
+
+// K10: SPFH - 3 x 11-bin histograms of (theta, alpha, phi) over the r_f neighbourhood; bin = count * 100 / (n_nbrs - 1)
+__global__ void __launch_bounds__(QN_BLOCK) k_spfh(GridView g, float r, float r2, const float4* __restrict__ normals, float* __restrict__ spfh) {
+  const uint32_t t = blockIdx.x * QN_BLOCK + threadIdx.x;
+  if (t >= g.n) return;
+  const float4 p = g.pts[t], np = normals[t];
+  float* out = spfh + (size_t)t * QN_FROW;
+  if (!(np.x == np.x)) { for (int b = 0; b < QN_FROW; b++) out[b] = 0.f; return; }
+  int cnt[33];
+#pragma unroll
+  for (int b = 0; b < 33; b++) cnt[b] = 0;
+  int nn = 0;
+  const float d_pi = 1.0f / (2.0f * 3.14159265358979323846f);
+  for_each_in_ball_cells(g, p.x, p.y, p.z, r, [&](uint32_t u, float4 q) __attribute__((always_inline)) {
+    if (!(sqdist(p.x, p.y, p.z, q.x, q.y, q.z) < r2)) return;
+    nn++;
+    if (u == t) return;
+    const float4 nq = normals[u];
+    if (!(nq.x == nq.x)) return;
+    float f1, f2, f3;
+    if (!pair_features(p, np, q, nq, f1, f2, f3)) return;
+    const int h1 = min(max((int)floor(11.0 * (((double)f1 + 3.14159265358979323846) * (double)d_pi)), 0), 10);
+    const int h2 = min(max((int)floor(11.0 * (((double)f2 + 1.0) * 0.5)), 0), 10);
+    const int h3 = min(max((int)floor(11.0 * (((double)f3 + 1.0) * 0.5)), 0), 10);
+#pragma unroll
+    for (int b = 0; b < 11; b++) { cnt[b] += (h1 == b); cnt[11 + b] += (h2 == b); cnt[22 + b] += (h3 == b); }
+  });
+  const float incr = 100.0f / (float)(nn - 1);
+#pragma unroll
+  for (int b = 0; b < 33; b++) out[b] = cnt[b] > 0 ? (float)cnt[b] * incr : 0.f;
+  out[33] = out[34] = out[35] = 0.f;
+}
+
+// K11: FPFH(p) = sum_q SPFH(q) / d2(p, q) over the r_f neighbourhood (d2 > 0), each 11-bin group normalised to 100
+__global__ void __launch_bounds__(QN_BLOCK) k_fpfh(GridView g, float r, float r2, const float4* __restrict__ normals, const float* __restrict__ spfh, float* __restrict__ fpfh) {
+  const uint32_t t = blockIdx.x * QN_BLOCK + threadIdx.x;
+  if (t >= g.n) return;
+  const float4 p = g.pts[t], np = normals[t];
+  float* out = fpfh + (size_t)t * QN_FROW;
+  const float qnan = __int_as_float(0x7fc00000);
+  double acc[33];
+#pragma unroll
+  for (int b = 0; b < 33; b++) acc[b] = 0.0;
+  if (np.x == np.x) {
+    for_each_in_ball_cells(g, p.x, p.y, p.z, r, [&](uint32_t u, float4 q) __attribute__((always_inline)) {
+      const float d2 = sqdist(p.x, p.y, p.z, q.x, q.y, q.z);
+      if (!(d2 < r2) || d2 == 0.0f) return;
+      const float w = 1.0f / d2;
+      const float4* s = (const float4*)(spfh + (size_t)u * QN_FROW);
+#pragma unroll
+      for (int v = 0; v < 9; v++) {
+        const float4 x = s[v];
+        if (4 * v + 0 < 33) acc[4 * v + 0] += (double)(x.x * w);
+        if (4 * v + 1 < 33) acc[4 * v + 1] += (double)(x.y * w);
+        if (4 * v + 2 < 33) acc[4 * v + 2] += (double)(x.z * w);
+        if (4 * v + 3 < 33) acc[4 * v + 3] += (double)(x.w * w);
+      }
+    });
+  }
+  double sum[3] = {0, 0, 0};
+#pragma unroll
+  for (int b = 0; b < 33; b++) sum[b / 11] += acc[b];
+  if (!(np.x == np.x) || sum[0] == 0.0) { for (int b = 0; b < QN_FROW; b++) out[b] = b < 33 ? qnan : 0.f; return; }
+#pragma unroll
+  for (int b = 0; b < 33; b++) out[b] = (float)(acc[b] * (sum[b / 11] != 0.0 ? 100.0 / sum[b / 11] : 0.0));
+  out[33] = out[34] = out[35] = 0.f;
+}
+
+// sorted-position rows -> original-index rows (rows of `w` floats)
+__global__ void k_rows_to_original(const float4* __restrict__ pts, uint32_t n, const float* __restrict__ in, float* __restrict__ out, int w_in, int w_out) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  const uint32_t i = __float_as_uint(pts[t].w);
+  for (int b = 0; b < w_out; b++) out[(size_t)i * w_out + b] = b < w_in ? in[(size_t)t * w_in + b] : 0.f;
+}
+
+// K12: exact nearest neighbour in 33-D (f32 sequential sum over the dimensions, ties -> lowest candidate index).
+// grid.x tiles the queries (256 per block), grid.y splits the candidates; partial winners meet in a 64-bit
+// atomicMin on (distance bits << 32 | index).  Queries optionally come through an index list.
+#define QN_FM_TILE 64
+__global__ void __launch_bounds__(QN_BLOCK) k_feat_nn(const float* __restrict__ Q, uint32_t nq, const uint32_t* __restrict__ qlist, const uint32_t* __restrict__ qlist_n,
+                                                      const float* __restrict__ Cn, uint32_t nc, uint32_t chunk, unsigned long long* __restrict__ best_key) {
+  __shared__ float4 tile[QN_FM_TILE * 9];
+  const uint32_t nqueries = qlist ? *qlist_n : nq;
+  const uint32_t slot = blockIdx.x * QN_BLOCK + threadIdx.x;
+  if (blockIdx.x * QN_BLOCK >= nqueries) return;
+  const bool active = slot < nqueries;
+  const uint32_t qi = active ? (qlist ? qlist[slot] : slot) : 0;
+  float q[33];
+  const float4* qrow = (const float4*)(Q + (size_t)qi * QN_FROW);
+#pragma unroll
+  for (int v = 0; v < 9; v++) { const float4 x = qrow[v]; q[4 * v] = x.x; if (4 * v + 1 < 33) q[4 * v + 1] = x.y; if (4 * v + 2 < 33) q[4 * v + 2] = x.z; if (4 * v + 3 < 33) q[4 * v + 3] = x.w; }
+  const bool qok = active && (q[0] == q[0]);
+  const uint32_t c0 = blockIdx.y * chunk, c1 = min(nc, c0 + chunk);
+  float best = __int_as_float(0x7f7fffff); uint32_t bi = 0xffffffffu;
+  for (uint32_t base = c0; base < c1; base += QN_FM_TILE) {
+    const uint32_t cnt = min((uint32_t)QN_FM_TILE, c1 - base);
+    __syncthreads();
+    for (uint32_t e = threadIdx.x; e < cnt * 9; e += QN_BLOCK) tile[e] = ((const float4*)(Cn + (size_t)base * QN_FROW))[e];
+    __syncthreads();
+    for (uint32_t c = 0; c < cnt; c++) {
+      float s = 0.f;
+#pragma unroll
+      for (int v = 0; v < 9; v++) {
+        const float4 x = tile[c * 9 + v];                       // broadcast ds_read_b128
+        float d;
+        d = q[4 * v] - x.x; s = s + d * d;
+        if (4 * v + 1 < 33) { d = q[4 * v + 1] - x.y; s = s + d * d; }
+        if (4 * v + 2 < 33) { d = q[4 * v + 2] - x.z; s = s + d * d; }
+        if (4 * v + 3 < 33) { d = q[4 * v + 3] - x.w; s = s + d * d; }
+      }
+      if (s < best) { best = s; bi = base + c; }                // NaN never wins; ascending scan keeps the lowest index
+    }
+  }
+  if (qok && bi != 0xffffffffu) atomicMin(&best_key[qi], ((unsigned long long)__float_as_uint(best) << 32) | bi);
+}
+
+__global__ void k_fill_u64(unsigned long long* p, uint32_t n, unsigned long long v) { uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; if (i < n) p[i] = v; }
+
+// mark the candidates that were somebody's nearest neighbour and compact them into a query list
+__global__ void k_mark_hits(const unsigned long long* __restrict__ j_key, uint32_t nj, uint32_t* __restrict__ hit) {
+  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= nj) return;
+  const unsigned long long k = j_key[j];
+  if (k != QN_INF_KEY) hit[(uint32_t)k] = 1u;
+}
+__global__ void k_compact_hits(const uint32_t* __restrict__ hit, uint32_t ni, uint32_t* __restrict__ list, uint32_t* __restrict__ count) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < ni && hit[i]) list[atomicAdd(count, 1u)] = i;
+}
+// cross-check: keep (i, j) when i's own nearest neighbour is j
+__global__ void k_mutual(const unsigned long long* __restrict__ j_key, uint32_t nj, const unsigned long long* __restrict__ i_key,
+                         uint2* __restrict__ pairs, uint32_t* __restrict__ count) {
+  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= nj) return;
+  const unsigned long long kj = j_key[j];
+  if (kj == QN_INF_KEY) return;
+  const uint32_t i = (uint32_t)kj;
+  const unsigned long long ki = i_key[i];
+  if (ki != QN_INF_KEY && (uint32_t)ki == j) pairs[atomicAdd(count, 1u)] = make_uint2(i, j);
+}
+
+// transformPcd(src, T_q): pcl::transformPointCloud with a Matrix4d on f32 points (utilities.hpp:164-175,
+// loop_closure.cpp:152): double arithmetic ((t0 x + t1 y) + t2 z) + t3, rounded to f32
+__global__ void k_transform_cloud_f64(const float4* __restrict__ in, uint32_t n, const double* __restrict__ T, float4* __restrict__ out) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float4 p = in[i];
+  const double x = p.x, y = p.y, z = p.z;
+  out[i] = make_float4((float)(((T[0] * x + T[1] * y) + T[2] * z) + T[3]), (float)(((T[4] * x + T[5] * y) + T[6] * z) + T[7]),
+                       (float)(((T[8] * x + T[9] * y) + T[10] * z) + T[11]), 1.0f);
+}
+
+}  // namespace qn

@@ -289,3 +289,83 @@ def icp_alignment(ctx, src, dst, *, k=15, max_iter=32, max_corr_dist=52.5, trans
     ctx.check(st)
     return dict(valid=bool(valid.value), converged=bool(res.converged), score=res.fitness,
                 T=np.array(res.T, dtype=np.float32).reshape(4, 4).astype(np.float64), iterations=res.iterations)
+
+
+# ---------------------------------------------------------------------------------------- Quatro
+class QuatroParams(C.Structure):
+    _fields_ = [("fpfh_normal_radius", C.c_double), ("fpfh_radius", C.c_double), ("noise_bound", C.c_double),
+                ("rot_gnc_factor", C.c_double), ("rot_cost_diff_thr", C.c_double), ("rot_max_iter", C.c_int32),
+                ("estimate_scale", C.c_int32), ("use_optimized_matching", C.c_int32), ("distance_threshold", C.c_double),
+                ("max_num_corres", C.c_int32), ("rng_seed", C.c_uint32), ("tuple_scale", C.c_double)]
+
+
+def quatro_default_params():
+    p = QuatroParams(); lib().qn_quatro_default_params(C.byref(p)); return p
+
+
+class Quatro:
+    """quatro<PointType> as LoopClosure uses it: the 10-argument constructor in the reference's order
+    (fast_lio_sam_qn/src/loop_closure.cpp:18-27) and align(src, dst) -> (4x4 f64, is_converged) (:144)."""
+
+    def __init__(self, ctx, fpfh_normal_radius=0.9, fpfh_radius=1.5, noise_bound=0.3, rot_gnc_factor=1.4, rot_cost_diff_thr=1e-4,
+                 rot_max_iter=50, estimate_scale=False, use_optimized_matching=True, distance_threshold=35.0, max_num_corres=200,
+                 rng_seed=1):
+        self.ctx = ctx; self._l = ctx._l
+        p = quatro_default_params()
+        p.fpfh_normal_radius, p.fpfh_radius, p.noise_bound = fpfh_normal_radius, fpfh_radius, noise_bound
+        p.rot_gnc_factor, p.rot_cost_diff_thr, p.rot_max_iter = rot_gnc_factor, rot_cost_diff_thr, rot_max_iter
+        p.estimate_scale, p.use_optimized_matching = int(estimate_scale), int(use_optimized_matching)
+        p.distance_threshold, p.max_num_corres, p.rng_seed = distance_threshold, max_num_corres, rng_seed
+        self.p = p
+        ctx.check(self._l.qn_quatro_set_params(ctx.h, C.byref(p)))
+        self._n = [0, 0]
+
+    def align(self, src, dst, debug=False):
+        a, ns, stride = _cloud_arg(src); b, nt, _ = _cloud_arg(dst); self._n = [ns, nt]
+        T = np.zeros((4, 4)); valid = C.c_int()
+        if not debug:
+            st = self._l.qn_quatro_align(self.ctx.h, _p(a), C.c_uint32(ns), _p(b), C.c_uint32(nt), C.c_uint32(stride), _p(T), C.byref(valid))
+            if st != QN_ERR_EMPTY_CLOUD:
+                self.ctx.check(st)
+            return T, bool(valid.value)
+        cap = min(ns, nt) + 8
+        mutual = np.zeros((cap, 2), np.int32); corres = np.zeros((cap, 2), np.int32); clique = np.zeros(cap, np.int32)
+        nm, nc, nq, it = C.c_uint32(), C.c_uint32(), C.c_uint32(), C.c_int32()
+        self.ctx.check(self._l.qn_quatro_align_debug(self.ctx.h, _p(a), C.c_uint32(ns), _p(b), C.c_uint32(nt), C.c_uint32(stride), _p(T), C.byref(valid),
+                                                     _p(mutual), C.byref(nm), _p(corres), C.byref(nc), C.c_uint32(cap), _p(clique), C.byref(nq), C.byref(it)))
+        return dict(T=T, valid=bool(valid.value), mutual=mutual[:nm.value].copy(), corres=corres[:nc.value].copy(),
+                    clique=clique[:nq.value].copy(), rot_iterations=it.value)
+
+    def features(self, which):
+        n = self._n[which]
+        nrm = np.zeros((n, 3), np.float32); sp = np.zeros((n, 33), np.float32); fp = np.zeros((n, 33), np.float32)
+        self.ctx.check(self._l.qn_quatro_get_features(self.ctx.h, C.c_int(which), _p(nrm), _p(sp), _p(fp)))
+        return nrm, sp, fp
+
+
+def quatro_solve(src, dst, corres, params=None):
+    """Host-side Matcher tail + TEASER++/Quatro solve on given correspondences (no GPU involved)."""
+    p = params or quatro_default_params()
+    a, _, stride = _cloud_arg(src); b, _, _ = _cloud_arg(dst)
+    corres = np.ascontiguousarray(corres, dtype=np.int32)
+    T = np.zeros((4, 4)); valid = C.c_int(); clique = np.zeros(max(len(corres), 1), np.int32); nq = C.c_uint32()
+    st = lib().qn_quatro_solve(_p(a), _p(b), C.c_uint32(stride), _p(corres), C.c_uint32(len(corres)), C.byref(p), _p(T), C.byref(valid), _p(clique), C.byref(nq))
+    if st != QN_OK:
+        raise EngineError(st, lib().qn_status_str(st).decode())
+    return dict(T=T, valid=bool(valid.value), clique=clique[:nq.value].copy())
+
+
+def coarse_to_fine_alignment(ctx, src, dst, *, quatro=None, k=15, max_iter=32, max_corr_dist=52.5, trans_eps=0.01, score_thr=1.5):
+    """LoopClosure::coarseToFineAlignment (loop_closure.cpp:138-159) at the reference's effective config."""
+    quatro = quatro or Quatro(ctx)
+    g = NanoGICP(ctx)
+    g.setCorrespondenceRandomness(k); g.setMaximumIterations(max_iter)
+    g.setMaxCorrespondenceDistance(max_corr_dist); g.setTransformationEpsilon(trans_eps)
+    a, ns, stride = _cloud_arg(src); b, nt, _ = _cloud_arg(dst)
+    res = GicpResult(); valid = C.c_int(); T = np.zeros((4, 4)); Tq = np.zeros((4, 4))
+    st = ctx._l.qn_coarse_to_fine_alignment(ctx.h, _p(a), C.c_uint32(ns), _p(b), C.c_uint32(nt), C.c_uint32(stride), C.c_double(score_thr),
+                                            C.byref(res), _p(T), _p(Tq), C.byref(valid))
+    if st == QN_ERR_EMPTY_CLOUD:
+        return dict(valid=False, converged=False, score=1.7976931348623157e308, T=np.eye(4), T_quatro=np.eye(4))
+    ctx.check(st)
+    return dict(valid=bool(valid.value), converged=bool(res.converged), score=res.fitness, T=T, T_quatro=Tq, iterations=res.iterations)

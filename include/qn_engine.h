@@ -115,6 +115,41 @@ int  qn_icp_alignment(qn_ctx*, const float* src, uint32_t ns, const float* dst, 
 int  qn_icp_alignment_device(qn_ctx*, const float* d_src, uint32_t ns, const float* d_dst, uint32_t nt,
                              uint32_t stride_bytes, double score_thr, qn_gicp_result* out, int* valid);
 
+/* ---- Quatro coarse registration ---------------------------------------------------------- */
+/* The 10 constructor arguments of quatro<PointType>, in the order LoopClosure passes them
+ * (loop_closure.cpp:18-27; struct QuatroConfig, include/loop_closure.h:38-50), plus the seed of the
+ * tuple test (the reference seeds rand() from wall-clock and does not reproduce itself).       */
+typedef struct {
+  double  fpfh_normal_radius;      /* loop_closure.cpp:18 */
+  double  fpfh_radius;             /* :19 */
+  double  noise_bound;             /* :20 */
+  double  rot_gnc_factor;          /* :21 */
+  double  rot_cost_diff_thr;       /* :22 */
+  int32_t rot_max_iter;            /* :23 */
+  int32_t estimate_scale;          /* :24 (must be 0: the reference never enables it) */
+  int32_t use_optimized_matching;  /* :25 */
+  double  distance_threshold;      /* :26 */
+  int32_t max_num_corres;          /* :27 */
+  uint32_t rng_seed;
+  double  tuple_scale;             /* Matcher::calculateCorrespondences argument, 0.95 upstream */
+} qn_quatro_params;
+
+void qn_quatro_default_params(qn_quatro_params* p);                  /* the reference's effective values */
+int  qn_quatro_set_params(qn_ctx*, const qn_quatro_params*);         /* quatro<PointType> ctor, loop_closure.cpp:18-27 */
+/* quatro<PointType>::align(src, dst, is_converged), loop_closure.cpp:144: T = 4x4 f64 row-major, *valid = is_converged */
+int  qn_quatro_align(qn_ctx*, const float* src, uint32_t ns, const float* dst, uint32_t nt, uint32_t stride_bytes, double T[16], int* valid);
+/* LoopClosure::coarseToFineAlignment, loop_closure.cpp:138-159: Quatro, transformPcd, icpAlignment, T_gicp * T_quatro */
+int  qn_coarse_to_fine_alignment(qn_ctx*, const float* src, uint32_t ns, const float* dst, uint32_t nt, uint32_t stride_bytes, double score_thr,
+                                 qn_gicp_result* gicp_out, double T_total[16], double T_quatro[16], int* valid);
+/* stages, for the parity tests: descriptors of the last qn_quatro_align (original point order; n x 3, n x 33, n x 33),
+ * the align with its intermediate products, and the host solver alone (Matcher + TEASER++/Quatro solve)            */
+int  qn_quatro_get_features(qn_ctx*, int which, float* normals3, float* spfh33, float* fpfh33);
+int  qn_quatro_align_debug(qn_ctx*, const float* src, uint32_t ns, const float* dst, uint32_t nt, uint32_t stride_bytes, double T[16], int* valid,
+                           int32_t* mutual_pairs, uint32_t* n_mutual, int32_t* corres_pairs, uint32_t* n_corres, uint32_t cap,
+                           int32_t* clique, uint32_t* n_clique, int32_t* rot_iterations);
+int  qn_quatro_solve(const float* src, const float* dst, uint32_t stride_bytes, const int32_t* corres_pairs, uint32_t n_corres,
+                     const qn_quatro_params* p, double T[16], int* valid, int32_t* clique, uint32_t* n_clique);
+
 /* ---- per-stage read-backs used by the parity tests (not needed by the shims) ------------ */
 int  qn_gicp_get_covariances(qn_ctx*, int which, double* cov9_out);   /* n x 9 f64, original point order */
 int  qn_gicp_knn(qn_ctx*, int which, int k, int32_t* idx_out, float* d2_out);   /* self k-NN of a cloud, n x k */
@@ -126,6 +161,10 @@ int  qn_gicp_compute_error(qn_ctx*, const double T[16], double* err); /* cached 
 int  qn_prof_enable(qn_ctx*, int on);                /* records a hipEvent pair around every kernel family launch */
 int  qn_prof_reset(qn_ctx*);
 int  qn_prof_get(qn_ctx*, int kernel_family, qn_kernel_stat* out);
+/* developer knobs (cell size, margins, debug counters); not part of the reference surface */
+int  qn_debug_set(qn_ctx*, const char* key, double value);
+int  qn_debug_get_counters(qn_ctx*, uint32_t out[16]);
+int  qn_debug_get_grid(qn_ctx*, int which, double out[8]);
 
 #ifdef __cplusplus
 }

@@ -146,3 +146,73 @@ def ldlt_solve6(A, rhs):
 
 def num_threads():
     return int(lib().orc_num_threads())
+
+
+# ---------------------------------------------------------------- Quatro
+class QuatroParams:
+    """The 10 ctor arguments of quatro<PointType> (loop_closure.cpp:18-27) at the reference's effective values
+    (SURVEY Appendix C), plus the tuple-test seed."""
+
+    def __init__(self, fpfh_normal_radius=0.9, fpfh_radius=1.5, noise_bound=0.3, rot_gnc_factor=1.4, rot_cost_diff_thr=1e-4,
+                 rot_max_iter=50, estimate_scale=False, use_optimized_matching=True, distance_threshold=35.0,
+                 max_num_corres=200, rng_seed=1, tuple_scale=0.95):
+        self.dp = np.array([fpfh_normal_radius, fpfh_radius, noise_bound, rot_gnc_factor, rot_cost_diff_thr,
+                            distance_threshold, tuple_scale], dtype=np.float64)
+        self.ip = np.array([rot_max_iter, int(estimate_scale), int(use_optimized_matching), max_num_corres, rng_seed], dtype=np.int32)
+        self.fpfh_normal_radius, self.fpfh_radius = fpfh_normal_radius, fpfh_radius
+
+
+def quatro_fpfh(xyz, rn=0.9, rf=1.5):
+    xyz = _f32(xyz); n = len(xyz)
+    nrm = np.zeros((n, 3), np.float32); sp = np.zeros((n, 33), np.float32); fp = np.zeros((n, 33), np.float32)
+    lib().orc_quatro_fpfh(_p(xyz), C.c_int(n), C.c_double(rn), C.c_double(rf), _p(nrm), _p(sp), _p(fp))
+    return nrm, sp, fp
+
+
+def quatro_feature_nn(q, c):
+    q = _f32(q); c = _f32(c); nn = np.zeros(len(q), np.int32)
+    lib().orc_quatro_feature_nn(_p(q), C.c_int(len(q)), _p(c), C.c_int(len(c)), _p(nn))
+    return nn
+
+
+def quatro_match(src, dst, fs, ft, p=None):
+    p = p or QuatroParams(); src = _f32(src); dst = _f32(dst); fs = _f32(fs); ft = _f32(ft)
+    cap = min(len(src), len(dst)) + 8
+    mutual = np.zeros((cap, 2), np.int32); corres = np.zeros((cap, 2), np.int32); n_out = np.zeros(2, np.int32)
+    lib().orc_quatro_match(_p(src), C.c_int(len(src)), _p(dst), C.c_int(len(dst)), _p(fs), _p(ft), _p(p.dp), _p(p.ip), _p(mutual), _p(corres), _p(n_out))
+    return mutual[:n_out[0]].copy(), corres[:n_out[1]].copy()
+
+
+def quatro_solve(src, dst, corres, p=None):
+    p = p or QuatroParams(); src = _f32(src); dst = _f32(dst); corres = np.ascontiguousarray(corres, dtype=np.int32)
+    T = np.zeros((4, 4)); oi = np.zeros(3, np.int32); clique = np.zeros(max(len(corres), 1), np.int32)
+    lib().orc_quatro_solve(_p(src), _p(dst), _p(corres), C.c_int(len(corres)), _p(p.dp), _p(p.ip), _p(T), _p(oi), _p(clique))
+    return dict(T=T, valid=bool(oi[0]), clique=clique[:oi[1]].copy(), rot_iterations=int(oi[2]))
+
+
+def quatro_align(src, dst, p=None):
+    p = p or QuatroParams(); src = _f32(src); dst = _f32(dst)
+    T = np.zeros((4, 4)); oi = np.zeros(4, np.int32); corres = np.zeros((4096, 2), np.int32)
+    lib().orc_quatro_align(_p(src), C.c_int(len(src)), _p(dst), C.c_int(len(dst)), _p(p.dp), _p(p.ip), _p(T), _p(oi), _p(corres), C.c_int(4096))
+    return dict(T=T, valid=bool(oi[0]), clique_size=int(oi[1]), rot_iterations=int(oi[2]), corres=corres[:oi[3]].copy())
+
+
+def max_clique(adj):
+    adj = np.ascontiguousarray(adj, dtype=np.uint8); n = len(adj); out = np.zeros(n, np.int32)
+    m = lib().orc_max_clique(_p(adj), C.c_int(n), _p(out))
+    return out[:m].copy()
+
+
+def coarse_to_fine_alignment(src, dst, qp=None, **gicp_kw):
+    """LoopClosure::coarseToFineAlignment (loop_closure.cpp:138-159): Quatro, transformPcd (f64 matrix on f32
+    points, utilities.hpp:164-175), icpAlignment, compose T_gicp * T_quatro."""
+    q = quatro_align(src, dst, qp)
+    if not q["valid"]:
+        return dict(valid=False, converged=False, score=1.7976931348623157e308, T=np.eye(4), quatro=q)
+    Tq = q["T"]
+    s = np.ascontiguousarray(src, dtype=np.float32).astype(np.float64)
+    coarse = (((Tq[:3, 0] * s[:, :1] + Tq[:3, 1] * s[:, 1:2]) + Tq[:3, 2] * s[:, 2:3]) + Tq[:3, 3]).astype(np.float32)
+    r = icp_alignment(coarse, dst, **gicp_kw)
+    r["T"] = r["T"] @ Tq
+    r["quatro"] = q; r["coarse"] = coarse
+    return r

@@ -2,6 +2,7 @@
 // Plain-C entry points so tests/ and bench.py's cpu_baseline leg can drive the restatement
 // through ctypes.  Not the product boundary: that is include/qn_engine.h.
 #include "gicp_oracle.hpp"
+#include "quatro_oracle.hpp"
 #include <cstring>
 #include <chrono>
 #include <omp.h>
@@ -63,5 +64,39 @@ void orc_so3_exp(const double* om, double* R9) { Mat3 R = so3_exp(om); std::memc
 void orc_sym_eig3(const double* A9, double* w3, double* V9) { Mat3 A, V; std::memcpy(A.m, A9, sizeof(A.m)); sym_eig3(A, w3, V); std::memcpy(V9, V.m, sizeof(V.m)); }
 void orc_ldlt_solve6(const double* A36, const double* rhs, double* x) { double A[6][6]; std::memcpy(A, A36, sizeof(A)); ldlt_solve6(A, rhs, x); }
 int orc_num_threads() { return omp_get_max_threads(); }
+
+// ---------------------------------------------------------------- Quatro
+static QuatroParams qp_from(const double* dp, const int* ip) {
+  QuatroParams p; p.fpfh_normal_radius = dp[0]; p.fpfh_radius = dp[1]; p.noise_bound = dp[2]; p.rot_gnc_factor = dp[3]; p.rot_cost_diff_thr = dp[4];
+  p.distance_threshold = dp[5]; p.tuple_scale = dp[6]; p.rot_max_iter = ip[0]; p.estimate_scale = ip[1] != 0; p.use_optimized_matching = ip[2] != 0;
+  p.max_num_corres = ip[3]; p.rng_seed = (uint32_t)ip[4]; return p;
+}
+void orc_quatro_fpfh(const float* xyz, int n, double rn, double rf, float* normals, float* spfh, float* fpfh) {
+  std::vector<float> a, b, c; compute_fpfh(xyz, n, rn, rf, a, b, c);
+  std::memcpy(normals, a.data(), a.size() * 4); std::memcpy(spfh, b.data(), b.size() * 4); std::memcpy(fpfh, c.data(), c.size() * 4);
+}
+void orc_quatro_feature_nn(const float* q, int nq, const float* c, int nc, int* nn) { std::vector<int> v; feature_nn(q, nq, c, nc, v); std::memcpy(nn, v.data(), v.size() * 4); }
+// returns counts through n_out[0] (mutual), n_out[1] (corres); pair arrays sized min(ns, nt) x 2
+void orc_quatro_match(const float* src, int ns, const float* dst, int nt, const float* fs, const float* ft, const double* dp, const int* ip,
+                      int* mutual, int* corres, int* n_out) {
+  std::vector<std::pair<int, int>> m, c; optimized_matching(src, ns, dst, nt, fs, ft, qp_from(dp, ip), m, c);
+  for (size_t i = 0; i < m.size(); i++) { mutual[2 * i] = m[i].first; mutual[2 * i + 1] = m[i].second; }
+  for (size_t i = 0; i < c.size(); i++) { corres[2 * i] = c[i].first; corres[2 * i + 1] = c[i].second; }
+  n_out[0] = (int)m.size(); n_out[1] = (int)c.size();
+}
+// out_i: valid, clique_size, rot_iterations ; clique buffer sized ncorr
+void orc_quatro_solve(const float* src, const float* dst, const int* corres, int ncorr, const double* dp, const int* ip, double* T, int* out_i, int* clique) {
+  std::vector<std::pair<int, int>> c(ncorr); for (int i = 0; i < ncorr; i++) c[i] = {corres[2 * i], corres[2 * i + 1]};
+  QuatroResult r; solve(src, dst, c, qp_from(dp, ip), &r);
+  std::memcpy(T, r.T, sizeof(r.T)); out_i[0] = r.valid; out_i[1] = (int)r.clique.size(); out_i[2] = r.rot_iterations;
+  for (size_t i = 0; i < r.clique.size(); i++) clique[i] = r.clique[i];
+}
+void orc_quatro_align(const float* src, int ns, const float* dst, int nt, const double* dp, const int* ip, double* T, int* out_i, int* corres, int corres_cap) {
+  QuatroResult r; quatro_align(src, ns, dst, nt, qp_from(dp, ip), &r);
+  std::memcpy(T, r.T, sizeof(r.T)); out_i[0] = r.valid; out_i[1] = (int)r.clique.size(); out_i[2] = r.rot_iterations; out_i[3] = (int)r.corres.size();
+  for (size_t i = 0; i < r.corres.size() && (int)i < corres_cap; i++) { corres[2 * i] = r.corres[i].first; corres[2 * i + 1] = r.corres[i].second; }
+}
+int orc_max_clique(const unsigned char* adj, int n, int* out) { std::vector<uint8_t> a(adj, adj + (size_t)n * n); auto c = max_clique_lex(a, n); for (size_t i = 0; i < c.size(); i++) out[i] = c[i]; return (int)c.size(); }
+float orc_atan2f(float y, float x) { return qn_atan2f(y, x); }
 
 }  // extern "C"

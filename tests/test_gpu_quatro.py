@@ -1,0 +1,97 @@
+"""GPU-vs-oracle parity for the Quatro coarse stage, through the C-ABI.
+Histogram counts (SPFH), feature-NN indices and correspondence lists are integer work and are compared
+exactly; descriptors are f32 sums accumulated in f64 (tolerance written below); the coarse transform
+and the final coarse-to-fine transform are held to BASELINE.json's 1e-4 m / 1e-4 rad."""
+import numpy as np
+import pytest
+from qn_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from qn_amd import engine
+    ctx = engine.Context(60000)
+    yield engine, ctx
+    ctx.close()
+
+
+@pytest.fixture(scope="module")
+def pair():
+    return synth.make_pair(310, 7000, extent=45.0, mode="quatro")
+
+
+def test_fpfh_parity(eng, oracle, pair):
+    engine, ctx = eng
+    src, tgt, _ = pair
+    q = engine.Quatro(ctx)
+    q.align(src, tgt)
+    for which, cloud in ((0, src), (1, tgt)):
+        nrm, sp, fp = q.features(which)
+        on, osp, ofp = oracle.quatro_fpfh(cloud, 0.9, 1.5)
+        assert np.array_equal(np.isnan(nrm), np.isnan(on))
+        ok = ~np.isnan(on[:, 0])
+        # normals: f64 eigenvectors rounded to f32 - identical up to a last-bit rounding on a handful of points
+        assert (np.abs(nrm[ok] - on[ok]).max(1) > 0).mean() < 1e-3 and np.abs(nrm[ok] - on[ok]).max() < 1e-6
+        # SPFH bins are counts * 100/(n-1): exact unless one of those last-bit normals moved a pair across a bin edge
+        assert (np.abs(sp - osp).max(1) > 0).mean() < 2e-3
+        assert np.array_equal(np.isnan(fp), np.isnan(ofp))
+        good = ~np.isnan(ofp[:, 0])
+        assert (np.abs(fp[good] - ofp[good]).max(1) > 1e-3).mean() < 5e-3       # f32 descriptors in [0, 100]
+        assert np.allclose(fp[good].reshape(-1, 3, 11).sum(2), 100.0, atol=1e-2)
+
+
+def test_feature_matching_and_solution_parity(eng, oracle, pair):
+    engine, ctx = eng
+    src, tgt, T = pair
+    q = engine.Quatro(ctx)
+    r = q.align(src, tgt, debug=True)
+    # oracle matching run on the GPU's descriptors: isolates the matcher (feature NN, cross-check, gate, tuple test)
+    _, _, fs = q.features(0); _, _, ft = q.features(1)
+    mutual, corres = oracle.quatro_match(src, tgt, fs, ft)
+    assert np.array_equal(r["mutual"], mutual)
+    assert np.array_equal(r["corres"], corres)
+    o = oracle.quatro_solve(src, tgt, corres)
+    assert r["valid"] == o["valid"] and r["clique"].tolist() == o["clique"].tolist()
+    assert np.abs(r["T"] - o["T"]).max() < 1e-9
+
+
+@pytest.mark.parametrize("pair_id", [311, 312, 313])
+def test_quatro_align_parity_end_to_end(eng, oracle, pair_id):
+    """Whole coarse stage, GPU descriptors vs oracle descriptors: same correspondences, same transform."""
+    engine, ctx = eng
+    src, tgt, T = synth.make_pair(pair_id, 6000, extent=42.0, mode="quatro")
+    q = engine.Quatro(ctx)
+    r = q.align(src, tgt, debug=True)
+    o = oracle.quatro_align(src, tgt)
+    assert r["valid"] == o["valid"]
+    assert np.array_equal(r["corres"], o["corres"])
+    dt, dr = synth.pose_error(r["T"], o["T"])
+    assert dt <= 1e-4 and dr <= 1e-4
+
+
+@pytest.mark.parametrize("pair_id", [320, 321])
+def test_coarse_to_fine_parity(eng, oracle, pair_id):
+    """LoopClosure::coarseToFineAlignment: Quatro -> transformPcd -> Nano-GICP -> T_gicp * T_quatro."""
+    engine, ctx = eng
+    src, tgt, T = synth.make_pair(pair_id, 6000, extent=42.0, mode="quatro")
+    r = engine.coarse_to_fine_alignment(ctx, src, tgt)
+    o = oracle.coarse_to_fine_alignment(src, tgt)
+    assert r["valid"] == o["valid"] and r["converged"] == o["converged"]
+    dt, dr = synth.pose_error(r["T"], o["T"])
+    assert dt <= 1e-4 and dr <= 1e-4
+    assert abs(r["score"] - o["score"]) <= 1e-6 * o["score"]
+    dt, dr = synth.pose_error(r["T"], T)
+    assert dt < 0.05 and dr < 0.005                       # and it is the right answer
+
+
+def test_quatro_no_correspondences_is_invalid_not_a_crash(eng):
+    engine, ctx = eng
+    rng = np.random.default_rng(0)
+    a = rng.uniform(-20, 20, size=(300, 3)).astype(np.float32)       # too sparse for any normal: all descriptors NaN
+    b = rng.uniform(-20, 20, size=(280, 3)).astype(np.float32)
+    T, valid = engine.Quatro(ctx).align(a, b)
+    assert not valid and np.array_equal(T, np.eye(4))
+    T, valid = engine.Quatro(ctx).align(np.zeros((0, 3), np.float32), b)
+    assert not valid

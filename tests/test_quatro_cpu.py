@@ -1,0 +1,85 @@
+"""CPU-side tests of the Quatro path: oracle known-answer tests, and the PRODUCT's host solver
+(qn_quatro_solve: max clique, yaw-only GNC-TLS rotation, TLS translation - pure host C++ inside
+libqn_engine.so, no GPU call) against the oracle's independent implementation."""
+import itertools
+import numpy as np
+import pytest
+from qn_amd import synth
+
+
+def yaw_T(yaw, t):
+    c, s = np.cos(yaw), np.sin(yaw)
+    T = np.eye(4); T[:3, :3] = [[c, -s, 0], [s, c, 0], [0, 0, 1]]; T[:3, 3] = t
+    return T
+
+
+def test_atan2_polynomial_accuracy(oracle):
+    import ctypes as C
+    f = oracle.lib().orc_atan2f; f.restype = C.c_float
+    rng = np.random.default_rng(0)
+    for y, x in rng.normal(size=(3000, 2)).astype(np.float32):
+        assert abs(f(C.c_float(y), C.c_float(x)) - np.arctan2(float(y), float(x))) < 5e-7
+    assert f(C.c_float(0), C.c_float(0)) == 0.0
+
+
+def test_max_clique_lexicographic_vs_bruteforce(oracle):
+    rng = np.random.default_rng(1)
+    for n, p in [(9, 0.5), (12, 0.6), (14, 0.7)]:
+        A = (rng.random((n, n)) < p).astype(np.uint8); A = np.triu(A, 1); A = A + A.T
+        best = []
+        for r in range(n, 0, -1):
+            cl = [c for c in itertools.combinations(range(n), r) if all(A[i, j] for i, j in itertools.combinations(c, 2))]
+            if cl:
+                best = list(min(cl)); break
+        assert oracle.max_clique(A).tolist() == best
+
+
+def test_fpfh_plane_has_peaked_histograms(oracle):
+    """All normals parallel on a plane => alpha = 0 (bin 5), phi = 0 (bin 5) for every pair."""
+    g = np.stack(np.meshgrid(np.arange(0, 12, 0.3), np.arange(0, 12, 0.3)), -1).reshape(-1, 2)
+    pts = np.c_[g + 5.0, np.full(len(g), 1.0)].astype(np.float32)
+    nrm, sp, fp = oracle.quatro_fpfh(pts, 0.9, 1.5)
+    inner = (g[:, 0] > 2) & (g[:, 0] < 9) & (g[:, 1] > 2) & (g[:, 1] < 9)
+    assert np.allclose(np.abs(nrm[inner, 2]), 1.0, atol=1e-6)
+    assert np.allclose(fp[inner, 11 + 5], 100.0, atol=1e-3) and np.allclose(fp[inner, 22 + 5], 100.0, atol=1e-3)
+    assert np.allclose(fp[inner].reshape(-1, 3, 11).sum(2), 100.0, atol=1e-3)
+
+
+def test_solver_recovers_planar_motion_with_outliers(oracle):
+    rng = np.random.default_rng(2)
+    src = rng.uniform(-20, 20, size=(60, 3)).astype(np.float32); src[:, 2] = rng.uniform(0, 3, 60)
+    T = yaw_T(0.7, [3.0, -2.0, 0.1])
+    dst = (src.astype(np.float64) @ T[:3, :3].T + T[:3, 3] + rng.normal(0, 0.02, (60, 3))).astype(np.float32)
+    dst[40:] = rng.uniform(-20, 20, size=(20, 3))                   # 1/3 outliers
+    corres = np.c_[np.arange(60), np.arange(60)]
+    r = oracle.quatro_solve(src, dst, corres)
+    assert r["valid"] and set(range(40)) <= set(r["clique"].tolist())
+    dt, dr = synth.pose_error(r["T"], T)
+    assert dt < 0.1 and dr < 0.01
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_product_host_solver_matches_oracle(oracle, seed):
+    from qn_amd import engine
+    rng = np.random.default_rng(100 + seed)
+    n = 80
+    src = rng.uniform(-25, 25, size=(n, 3)).astype(np.float32); src[:, 2] = rng.uniform(0, 4, n)
+    T = yaw_T(rng.uniform(-3, 3), [rng.uniform(-8, 8), rng.uniform(-8, 8), 0.05])
+    dst = (src.astype(np.float64) @ T[:3, :3].T + T[:3, 3] + rng.normal(0, 0.05, (n, 3))).astype(np.float32)
+    bad = rng.choice(n, n // 2, replace=False); dst[bad] = rng.uniform(-25, 25, size=(len(bad), 3))
+    idx = np.sort(rng.permutation(n)[:70])
+    corres = np.c_[idx, idx]
+    a = engine.quatro_solve(src, dst, corres)
+    b = oracle.quatro_solve(src, dst, corres)
+    assert a["valid"] == b["valid"] and a["clique"].tolist() == b["clique"].tolist()
+    assert np.abs(a["T"] - b["T"]).max() < 1e-9
+
+
+def test_oracle_coarse_to_fine_recovers_large_yaw(oracle):
+    src, tgt, T = synth.make_pair(300, 6000, extent=40.0, mode="quatro")
+    r = oracle.coarse_to_fine_alignment(src, tgt)
+    assert r["quatro"]["valid"]
+    dt, dr = synth.pose_error(r["quatro"]["T"], T)
+    assert dt < 3.0 and dr < 0.2                                   # coarse stage: loose
+    dt, dr = synth.pose_error(r["T"], T)
+    assert r["converged"] and dt < 0.05 and dr < 0.005             # after Nano-GICP refinement
