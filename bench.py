@@ -48,6 +48,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-quatro", action="store_true")
     ap.add_argument("--pairs", type=int, default=2, help="distinct synthetic pairs per rank, cycled over the steps")
     args = ap.parse_args()
 
@@ -149,8 +150,9 @@ def main():
                 pmc = json.load(open(pmc_path)).get(dom)
             except Exception:
                 pmc = None
+        traffic = pmc.get("hbm_bytes_per_launch") if isinstance(pmc, dict) else None
         roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": pmc,
+                    "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_detail": pmc,
                     "avg_launch_ms": round(dom_ms, 5), "algorithmic_bytes_per_launch": per_launch_bytes,
                     "whole_registration": {"algorithmic_bytes": ab["full"], "achieved": round(ab["full"] / (ms_step * 1e-3) / 1e9, 2),
                                            "frac": round(ab["full"] / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)},
@@ -158,6 +160,17 @@ def main():
                                    "frac": round(ab["align"] / (align_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)},
                     "family_ms_per_registration": {k: round(v, 4) for k, v in fam_ms.items()},
                     "note": "working set (<=20 MB) is L2/MALL resident: nominal HBM yardstick (SURVEY 8d)"}
+
+        # ---- Quatro coarse stage (BASELINE configs[2]): FPFH + optimizedMatching (cap 200) + GNC solve, 30k-point pair from the host
+        quatro = None
+        if world == 1 and not args.no_quatro:
+            qs, qt, _ = synth.make_pair(400, 30000, mode="quatro")
+            q = engine.Quatro(ctx)
+            q.align(qs, qt)
+            tq = time.perf_counter()
+            for _ in range(3):
+                Tq, qvalid = q.align(qs, qt)
+            quatro = {"ms_per_align_30k": round(1e3 * (time.perf_counter() - tq) / 3, 3), "valid": bool(qvalid)}
 
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
@@ -190,7 +203,7 @@ def main():
                "config": {"workload": "Nano-GICP icpAlignment, synthetic 100k x 100k street-scene pair, k=20 covariances, 20 forced GN iterations (BASELINE configs[1])",
                           "points": N_PTS, "k": K_COV, "gn_iterations": GN_ITERS, "sharding": "pair i -> rank i mod N, all_gather of best record",
                           "ms_per_align": round(align_ms, 4), "winner_pair": int(winner[0]), "winner_score": winner[2],
-                          "max_abs_T_diff_vs_oracle": dtp},
+                          "max_abs_T_diff_vs_oracle": dtp, "quatro": quatro},
                "roofline": roofline, "cpu_baseline": cpu}
         print(json.dumps(out))
     if dist is not None:

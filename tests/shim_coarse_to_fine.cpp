@@ -1,0 +1,85 @@
+// LoopClosure's constructor and coarseToFineAlignment (fast_lio_sam_qn/src/loop_closure.cpp:3-30, 138-159)
+// written against the two drop-in shims, in the reference's own shape.
+// usage: shim_coarse_to_fine src.bin dst.bin -> prints valid converged score T(16)
+#include <cstdio>
+#include <limits>
+#include <memory>
+#include <nano_gicp/point_type_nano_gicp.hpp>
+#include <nano_gicp/nano_gicp.hpp>
+#include <quatro/quatro_module.h>
+
+using PointType = pcl::PointXYZI;
+
+struct RegistrationOutput {
+  bool is_valid_ = false, is_converged_ = false;
+  double score_ = std::numeric_limits<double>::max();
+  Eigen::Matrix4d pose_between_eig_ = Eigen::Matrix4d::Identity();
+};
+
+static pcl::PointCloud<PointType> load(const char* path) {
+  pcl::PointCloud<PointType> c; FILE* f = std::fopen(path, "rb"); float v[3];
+  while (f && std::fread(v, sizeof(float), 3, f) == 3) { PointType p; p.x = v[0]; p.y = v[1]; p.z = v[2]; c.push_back(p); }
+  if (f) std::fclose(f);
+  return c;
+}
+
+// utilities.hpp:164-175 (pcl::transformPointCloud with a Matrix4d)
+static pcl::PointCloud<PointType> transformPcd(const pcl::PointCloud<PointType>& in, const Eigen::Matrix4d& T) {
+  pcl::PointCloud<PointType> out = in;
+  for (size_t i = 0; i < in.size(); i++) {
+    const double x = in[i].x, y = in[i].y, z = in[i].z;
+    out[i].x = (float)(((T(0, 0) * x + T(0, 1) * y) + T(0, 2) * z) + T(0, 3));
+    out[i].y = (float)(((T(1, 0) * x + T(1, 1) * y) + T(1, 2) * z) + T(1, 3));
+    out[i].z = (float)(((T(2, 0) * x + T(2, 1) * y) + T(2, 2) * z) + T(2, 3));
+  }
+  return out;
+}
+
+struct LoopClosureLike {
+  nano_gicp::NanoGICP<PointType, PointType> nano_gicp_;
+  std::shared_ptr<quatro<PointType>> quatro_handler_ = nullptr;
+  pcl::PointCloud<PointType> coarse_aligned_, aligned_;
+  LoopClosureLike() {
+    nano_gicp_.setNumThreads(0); nano_gicp_.setCorrespondenceRandomness(15); nano_gicp_.setMaximumIterations(32);
+    nano_gicp_.setRANSACIterations(5); nano_gicp_.setMaxCorrespondenceDistance(52.5); nano_gicp_.setTransformationEpsilon(0.01);
+    nano_gicp_.setEuclideanFitnessEpsilon(0.01); nano_gicp_.setRANSACOutlierRejectionThreshold(1.0);
+    quatro_handler_ = std::make_shared<quatro<PointType>>(0.9, 1.5, 0.3, 1.4, 0.0001, 50, false, true, 35.0, 200);   // loop_closure.cpp:18-27, SURVEY App. C values
+  }
+  RegistrationOutput icpAlignment(const pcl::PointCloud<PointType>& src, const pcl::PointCloud<PointType>& dst) {
+    RegistrationOutput reg_output;
+    aligned_.clear();
+    pcl::PointCloud<PointType>::Ptr src_cloud(new pcl::PointCloud<PointType>()), dst_cloud(new pcl::PointCloud<PointType>());
+    *src_cloud = src; *dst_cloud = dst;
+    nano_gicp_.setInputSource(src_cloud); nano_gicp_.calculateSourceCovariances();
+    nano_gicp_.setInputTarget(dst_cloud); nano_gicp_.calculateTargetCovariances();
+    nano_gicp_.align(aligned_);
+    reg_output.score_ = nano_gicp_.getFitnessScore();
+    if (nano_gicp_.hasConverged() && reg_output.score_ < 1.5) {
+      reg_output.is_valid_ = true; reg_output.is_converged_ = true;
+      reg_output.pose_between_eig_ = nano_gicp_.getFinalTransformation().cast<double>();
+    }
+    return reg_output;
+  }
+  RegistrationOutput coarseToFineAlignment(const pcl::PointCloud<PointType>& src, const pcl::PointCloud<PointType>& dst) {
+    RegistrationOutput reg_output;
+    coarse_aligned_.clear();
+    reg_output.pose_between_eig_ = (quatro_handler_->align(src, dst, reg_output.is_converged_));
+    if (!reg_output.is_converged_) return reg_output;
+    coarse_aligned_ = transformPcd(src, reg_output.pose_between_eig_);
+    const auto& fine_output = icpAlignment(coarse_aligned_, dst);
+    const auto quatro_tf_ = reg_output.pose_between_eig_;
+    reg_output = fine_output;
+    reg_output.pose_between_eig_ = fine_output.pose_between_eig_ * quatro_tf_;
+    return reg_output;
+  }
+};
+
+int main(int argc, char** argv) {
+  if (argc < 3) return 2;
+  LoopClosureLike lc;
+  const RegistrationOutput r = lc.coarseToFineAlignment(load(argv[1]), load(argv[2]));
+  std::printf("%d %d %.17g", (int)r.is_valid_, (int)r.is_converged_, r.score_);
+  for (int a = 0; a < 4; a++) for (int b = 0; b < 4; b++) std::printf(" %.17g", r.pose_between_eig_(a, b));
+  std::printf("\n");
+  return 0;
+}

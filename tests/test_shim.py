@@ -8,21 +8,42 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 BIN = os.path.join(ROOT, "tests", "shim_icp_alignment")
+BIN2 = os.path.join(ROOT, "tests", "shim_coarse_to_fine")
 
 
 def build_shim_program():
     from qn_amd import build
     build.build()
-    cmd = ["g++", "-std=c++17", "-O2", "-I" + os.path.join(ROOT, "tests", "standins"),
-           "-I" + os.path.join(ROOT, "fast-lio-sam-qn_amd", "shim"), "-I" + os.path.join(ROOT, "include"),
-           os.path.join(ROOT, "tests", "shim_icp_alignment.cpp"), "-L" + os.path.join(ROOT, "fast-lio-sam-qn_amd"),
-           "-lqn_engine", "-Wl,-rpath," + os.path.join(ROOT, "fast-lio-sam-qn_amd"), "-o", BIN]
-    subprocess.check_call(cmd)
+    for name, out in (("shim_icp_alignment.cpp", BIN), ("shim_coarse_to_fine.cpp", BIN2)):
+        cmd = ["g++", "-std=c++17", "-O2", "-I" + os.path.join(ROOT, "tests", "standins"),
+               "-I" + os.path.join(ROOT, "fast-lio-sam-qn_amd", "shim"), "-I" + os.path.join(ROOT, "include"),
+               os.path.join(ROOT, "tests", name), "-L" + os.path.join(ROOT, "fast-lio-sam-qn_amd"),
+               "-lqn_engine", "-Wl,-rpath," + os.path.join(ROOT, "fast-lio-sam-qn_amd"), "-o", out]
+        subprocess.check_call(cmd)
     return BIN
 
 
 def test_shim_compiles_and_links():
-    assert os.path.exists(build_shim_program())
+    assert os.path.exists(build_shim_program()) and os.path.exists(BIN2)
+
+
+@pytest.mark.gpu
+def test_shims_reproduce_coarse_to_fine(tmp_path, oracle):
+    """nano_gicp + quatro shims driven exactly like LoopClosure::coarseToFineAlignment (loop_closure.cpp:138-159)."""
+    from qn_amd import synth
+    if not os.path.exists(BIN2):
+        build_shim_program()
+    src, tgt, T = synth.make_pair(320, 6000, extent=42.0, mode="quatro")
+    a, b = tmp_path / "src.bin", tmp_path / "dst.bin"
+    src.tofile(a); tgt.tofile(b)
+    out = subprocess.check_output([BIN2, str(a), str(b)]).decode().split()
+    valid, conv, score = int(out[0]), int(out[1]), float(out[2])
+    Tm = np.array([float(x) for x in out[3:19]]).reshape(4, 4)
+    o = oracle.coarse_to_fine_alignment(src, tgt)
+    assert bool(valid) == o["valid"] and bool(conv) == o["converged"]
+    assert abs(score - o["score"]) <= 1e-6 * o["score"]
+    dt, dr = synth.pose_error(Tm, o["T"])
+    assert dt <= 1e-4 and dr <= 1e-4
 
 
 @pytest.mark.gpu
