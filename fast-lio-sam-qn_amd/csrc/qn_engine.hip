@@ -276,15 +276,18 @@ extern "C" int qn_gicp_compute_covariances(qn_ctx* c, int which) { return comput
 
 // ------------------------------------------------------------------ align
 // seeded = true: the previous iteration's NN indices are valid -> temporal tracking kernel; false -> full grid search
-static void enqueue_nn(qn_ctx* c, int mode /*0 align, 1 fitness*/, float* sqd_out, bool seeded) {
+// tick = index of this NN pass within the align (list-pass grids shrink as the optimiser converges: the first search
+// leaves ~10-20 % of the queries to the list passes, the first tracked pass most of them after the big initial pose
+// step, later passes a handful - any grid is correct, the lists are walked wave-stride)
+static void enqueue_nn(qn_ctx* c, int mode /*0 align, 1 fitness*/, float* sqd_out, bool seeded, int tick = 0) {
   hipStream_t s = c->stream;
   CloudBuf &S = c->cloud[0], &T = c->cloud[1];
   const uint32_t nb = (S.n + QN_BLOCK / 4 - 1) / (QN_BLOCK / 4);      // 16 queries per wave, 64 per block
   const uint32_t nbt = (S.n + QN_BLOCK - 1) / QN_BLOCK;               // tracking: one query per lane
   const double thr2 = c->params.max_corr_dist * c->params.max_corr_dist;
   uint32_t* fbc = &c->state->fb_count; uint32_t* bgc = &c->state->big_count;
-  const int big_blocks = 1024;                                       // up to 4096 waves, one far query each (idle blocks exit at once)
-  const uint32_t fbb = std::min<uint32_t>(nb, 512);               // list pass: wave-stride over the leftovers
+  const int big_blocks = tick == 0 ? 1024 : (tick == 1 ? 256 : (tick == 2 ? 512 : 64));   // waves with one far query each (idle blocks exit at once)
+  const uint32_t fbb = std::min<uint32_t>(nb, tick <= 1 ? 512 : (tick == 2 ? 128 : 64));  // list pass: wave-stride over the leftovers
   const float r0 = c->margin_nn * T.grid.cell;
   if (mode == 0) {
     { ProfScope ps(c, QN_K_NN_SEARCH);
@@ -310,9 +313,9 @@ static void enqueue_solve(qn_ctx* c, int mode) {
   hipLaunchKernelGGL(k_solve, dim3(1), dim3(QN_SOLVE_THREADS), 0, c->stream, c->state, c->partials, (int)acc_blocks(c), make_cfg(c), c->trace, mode);
 }
 // one "tick" of the device-side state machine: [NN pass A, NN pass B, accumulate, solve]
-static void enqueue_tick(qn_ctx* c, bool seeded) { enqueue_nn(c, 0, c->sqd, seeded); enqueue_accumulate(c); enqueue_solve(c, 0); }
+static void enqueue_tick(qn_ctx* c, bool seeded, int tick) { enqueue_nn(c, 0, c->sqd, seeded, tick); enqueue_accumulate(c); enqueue_solve(c, 0); }
 static void enqueue_epilogue(qn_ctx* c, double max_range, bool seeded) {       // fitness + output cloud; each kernel is a no-op until phase == done
-  enqueue_nn(c, 1, c->sqd_fit, seeded);
+  enqueue_nn(c, 1, c->sqd_fit, seeded, 1);
   { ProfScope ps(c, QN_K_FITNESS);
     hipLaunchKernelGGL(k_fitness_partial, dim3(QN_FIT_BLOCKS), dim3(QN_BLOCK), 0, c->stream, c->sqd_fit, c->cloud[0].n, max_range, c->state, c->fit_psum, c->fit_pcnt, 1);
     hipLaunchKernelGGL(k_fitness_final, dim3(1), dim3(QN_FIT_BLOCKS), 0, c->stream, c->fit_psum, c->fit_pcnt, c->state, 1); }
@@ -343,9 +346,9 @@ extern "C" int qn_gicp_align(qn_ctx* c, const float guess[16], qn_gicp_result* o
   int chunk = p.force_iterations > 0 ? maxit * per_outer : c->ticks_per_chunk;
   long budget = (long)maxit * (p.optimizer == QN_OPT_LM ? (p.lm_max_iterations + 1) : 1) + 2;
   c->result_host->phase = 0;
-  bool seeded = false;          // the first linearisation runs the full grid search; every later NN pass tracks from it
+  bool seeded = false; int tick_no = 0;   // the first linearisation runs the full grid search; every later NN pass tracks from it
   for (;;) {
-    for (int t = 0; t < chunk; t++) { enqueue_tick(c, seeded); seeded = true; }
+    for (int t = 0; t < chunk; t++) { enqueue_tick(c, seeded, tick_no / per_outer); tick_no++; seeded = true; }
     enqueue_epilogue(c, DBL_MAX, maxit > 0);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipStreamSynchronize(s));
