@@ -50,6 +50,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-quatro", action="store_true")
     ap.add_argument("--pairs", type=int, default=2, help="distinct synthetic pairs per rank, cycled over the steps")
+    ap.add_argument("--in-flight", type=int, default=4, help="candidate pairs registered concurrently per GPU (one context = one hipStream each)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -64,10 +65,16 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
 
     from qn_amd import engine, synth
-    ctx = engine.Context(N_PTS + 1024, device=local)
-    g = engine.NanoGICP(ctx)
-    g.setCorrespondenceRandomness(K_COV); g.setMaximumIterations(GN_ITERS); g.setMaxCorrespondenceDistance(52.5)
-    g.setOptimizer("gn"); g.setForceIterations(GN_ITERS)
+    # `in_flight` contexts (= hipStreams) per GPU: the candidate pairs of a loop-closure query are independent
+    # registrations (BASELINE "batch of candidate keyframe pairs"), several are kept in flight to fill the chip
+    ctxs = [engine.Context(N_PTS + 1024, device=local) for _ in range(max(1, args.in_flight))]
+    gs = []
+    for cx in ctxs:
+        gg = engine.NanoGICP(cx)
+        gg.setCorrespondenceRandomness(K_COV); gg.setMaximumIterations(GN_ITERS); gg.setMaxCorrespondenceDistance(52.5)
+        gg.setOptimizer("gn"); gg.setForceIterations(GN_ITERS)
+        gs.append(gg)
+    ctx, g = ctxs[0], gs[0]
 
     # candidate pairs of this rank: pair_id = rank + world * j   (pair i -> rank i mod N)
     pairs = []
@@ -82,19 +89,24 @@ def main():
         g.setInputTargetDevice(t.data_ptr(), N_PTS, 12); g.calculateTargetCovariances()
         return g.align()
 
+    def batch(n):
+        descs = [(pairs[j % len(pairs)][0].data_ptr(), N_PTS, pairs[j % len(pairs)][1].data_ptr(), N_PTS, 12, 1) for j in range(n)]
+        return engine.icp_alignment_batch(ctxs, descs, score_thr=1.5)
+
     def barrier():
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for j in range(args.warmup):
-        register(j)
+    if args.warmup > 0:
+        batch(args.warmup)
     barrier()
     t0 = time.perf_counter()
+    results, valid, status = batch(args.steps)                      # EXACTLY `steps` registrations
+    assert all(st == 0 for st in status), status
     best = None
-    for j in range(args.steps):
-        r = register(j)
+    for j, r in enumerate(results):
         rec = [float(rank + world * (j % len(pairs))), float(r.converged), r.fitness] + list(r.T)
         if best is None or rec[2] < best[2]:
             best = rec
@@ -115,6 +127,13 @@ def main():
     out = None
     if rank == 0:
         ms_step = 1e3 * elapsed / args.steps
+        # ---- one registration at a time on one stream (latency view)
+        for j in range(2):
+            register(j)
+        tl = time.perf_counter()
+        for j in range(10):
+            register(j)
+        single_ms = 1e3 * (time.perf_counter() - tl) / 10
         # ---- align-only timing (clouds + covariances resident): BASELINE's "ms/align"
         reps = max(5, args.steps // 2)
         register(0); ctx.synchronize(); torch.cuda.synchronize()
@@ -155,7 +174,8 @@ def main():
                     "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_detail": pmc,
                     "avg_launch_ms": round(dom_ms, 5), "algorithmic_bytes_per_launch": per_launch_bytes,
                     "whole_registration": {"algorithmic_bytes": ab["full"], "achieved": round(ab["full"] / (ms_step * 1e-3) / 1e9, 2),
-                                           "frac": round(ab["full"] / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)},
+                                           "frac": round(ab["full"] / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                                           "note": "amortised over the registrations in flight"},
                     "align_only": {"algorithmic_bytes": ab["align"], "ms": round(align_ms, 4),
                                    "frac": round(ab["align"] / (align_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)},
                     "family_ms_per_registration": {k: round(v, 4) for k, v in fam_ms.items()},
@@ -202,6 +222,7 @@ def main():
                "dtype": "f32 search / f64 accumulate", "data": "synthetic",
                "config": {"workload": "Nano-GICP icpAlignment, synthetic 100k x 100k street-scene pair, k=20 covariances, 20 forced GN iterations (BASELINE configs[1])",
                           "points": N_PTS, "k": K_COV, "gn_iterations": GN_ITERS, "sharding": "pair i -> rank i mod N, all_gather of best record",
+                          "in_flight": len(ctxs), "ms_per_registration_single_stream": round(single_ms, 4),
                           "ms_per_align": round(align_ms, 4), "winner_pair": int(winner[0]), "winner_score": winner[2],
                           "max_abs_T_diff_vs_oracle": dtp, "quatro": quatro},
                "roofline": roofline, "cpu_baseline": cpu}
@@ -209,7 +230,8 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
-    ctx.close()
+    for cx in ctxs:
+        cx.close()
 
 
 if __name__ == "__main__":

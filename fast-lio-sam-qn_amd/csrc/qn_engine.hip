@@ -8,6 +8,8 @@
 #include <cstring>
 #include <string>
 #include <vector>
+#include <atomic>
+#include <thread>
 #include "qn_gicp_kernels.cuh"
 #include "qn_context.h"
 
@@ -420,6 +422,27 @@ extern "C" int qn_icp_alignment(qn_ctx* c, const float* src, uint32_t ns, const 
 }
 extern "C" int qn_icp_alignment_device(qn_ctx* c, const float* src, uint32_t ns, const float* dst, uint32_t nt, uint32_t stride, double thr, qn_gicp_result* out, int* valid) {
   return icp_alignment(c, src, ns, dst, nt, stride, thr, out, valid, 1);
+}
+
+// batch over several contexts (streams): one host worker thread per context, dynamic pair assignment
+extern "C" int qn_icp_alignment_batch(qn_ctx* const* ctxs, uint32_t n_ctx, const qn_pair_desc* pairs, uint32_t n_pairs, double thr,
+                                      qn_gicp_result* results, int* valid, int* status) {
+  if (!ctxs || n_ctx == 0 || (n_pairs && (!pairs || !results || !valid || !status))) return QN_ERR_INVALID_ARG;
+  for (uint32_t i = 0; i < n_ctx; i++) if (!ctxs[i]) return QN_ERR_INVALID_ARG;
+  std::atomic<uint32_t> next{0};
+  auto worker = [&](qn_ctx* c) {
+    for (;;) {
+      const uint32_t i = next.fetch_add(1);
+      if (i >= n_pairs) break;
+      const qn_pair_desc& p = pairs[i];
+      status[i] = icp_alignment(c, p.src, p.ns, p.dst, p.nt, p.stride_bytes, thr, &results[i], &valid[i], p.on_device ? 1 : 0);
+    }
+  };
+  std::vector<std::thread> th;
+  for (uint32_t i = 1; i < n_ctx; i++) th.emplace_back(worker, ctxs[i]);
+  worker(ctxs[0]);
+  for (auto& t : th) t.join();
+  return QN_OK;
 }
 
 // ------------------------------------------------------------------ per-stage read-backs for parity tests

@@ -10,8 +10,8 @@ LIB = os.path.join(PKG, "libqn_engine.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # -ffp-contract=off: the f32 distance / transform arithmetic must be plain mul+add in source order
 # (bit-for-bit the reference's non-FMA x86 build; see DESIGN.md "numerics").
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
-         "-Wno-unused-result", "-Wno-unused-value", "-I" + os.path.join(ROOT, "include")]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-pthread",
+         "-Wno-unused-result", "-Wno-unused-value", "-Wno-pass-failed", "-I" + os.path.join(ROOT, "include")]
 
 
 def sources():

@@ -369,3 +369,28 @@ def coarse_to_fine_alignment(ctx, src, dst, *, quatro=None, k=15, max_iter=32, m
         return dict(valid=False, converged=False, score=1.7976931348623157e308, T=np.eye(4), T_quatro=np.eye(4))
     ctx.check(st)
     return dict(valid=bool(valid.value), converged=bool(res.converged), score=res.fitness, T=T, T_quatro=Tq, iterations=res.iterations)
+
+
+# ---------------------------------------------------------------------------------------- batch
+class PairDesc(C.Structure):
+    _fields_ = [("src", C.c_void_p), ("ns", C.c_uint32), ("dst", C.c_void_p), ("nt", C.c_uint32), ("stride_bytes", C.c_uint32), ("on_device", C.c_int32)]
+
+
+def icp_alignment_batch(contexts, pairs, score_thr=1.5):
+    """pairs: list of (src_ptr_or_array, ns, dst_ptr_or_array, nt, stride_bytes, on_device).  Arrays are host float32
+    clouds; ints are device pointers.  Every context must already carry its NanoGICP parameters.
+    Returns (results[GicpResult], valid[int], status[int])."""
+    n = len(pairs)
+    descs = (PairDesc * n)(); keep = []
+    for i, (s, ns, d, nt, stride, dev) in enumerate(pairs):
+        if not dev:
+            s = np.ascontiguousarray(s, dtype=np.float32); d = np.ascontiguousarray(d, dtype=np.float32); keep += [s, d]
+            descs[i] = PairDesc(s.ctypes.data, ns, d.ctypes.data, nt, stride, 0)
+        else:
+            descs[i] = PairDesc(s, ns, d, nt, stride, 1)
+    results = (GicpResult * n)(); valid = (C.c_int * n)(); status = (C.c_int * n)()
+    hs = (C.c_void_p * len(contexts))(*[c.h for c in contexts])
+    st = lib().qn_icp_alignment_batch(hs, C.c_uint32(len(contexts)), descs, C.c_uint32(n), C.c_double(score_thr), results, valid, status)
+    if st != QN_OK:
+        raise EngineError(st, lib().qn_status_str(st).decode())
+    return results, list(valid), list(status)

@@ -115,6 +115,20 @@ int  qn_icp_alignment(qn_ctx*, const float* src, uint32_t ns, const float* dst, 
 int  qn_icp_alignment_device(qn_ctx*, const float* d_src, uint32_t ns, const float* d_dst, uint32_t nt,
                              uint32_t stride_bytes, double score_thr, qn_gicp_result* out, int* valid);
 
+/* ---- batch of independent candidate pairs (BASELINE config "batch of 64 candidate keyframe pairs") ----
+ * Every candidate pair of a loop-closure query is an independent icpAlignment (loop_closure.cpp:116-123 rebuilds
+ * everything per call), so a batch is spread over several contexts = several hipStreams of one GPU: worker i drives
+ * ctxs[i] and pulls the next unprocessed pair.  Parameters are those already set on each context.  status[i] receives
+ * the per-pair status code.  Returns QN_OK when every pair ran (individual pairs may still be invalid).          */
+typedef struct {
+  const float* src; uint32_t ns;
+  const float* dst; uint32_t nt;
+  uint32_t stride_bytes;
+  int32_t  on_device;              /* 1: src/dst are HIP device pointers */
+} qn_pair_desc;
+int  qn_icp_alignment_batch(qn_ctx* const* ctxs, uint32_t n_ctx, const qn_pair_desc* pairs, uint32_t n_pairs, double score_thr,
+                            qn_gicp_result* results, int* valid, int* status);
+
 /* ---- Quatro coarse registration ---------------------------------------------------------- */
 /* The 10 constructor arguments of quatro<PointType>, in the order LoopClosure passes them
  * (loop_closure.cpp:18-27; struct QuatroConfig, include/loop_closure.h:38-50), plus the seed of the
