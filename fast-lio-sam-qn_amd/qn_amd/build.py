@@ -18,18 +18,34 @@ def sources():
     return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip"))
 
 
+def _deps():
+    return [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".cuh", ".h", ".inc"))] + [os.path.join(ROOT, "include", "qn_engine.h")]
+
+
 def needs_build():
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(ROOT, "include", "qn_engine.h")]
-    return any(os.path.getmtime(d) > t for d in deps)
+    return any(os.path.getmtime(d) > t for d in sources() + _deps())
 
 
 def build(force=False, verbose=False):
+    """One object per .hip translation unit (cached by mtime: qn_cloud.hip pulls in hipCUB's radix sort, minutes to
+    compile), then one link into the in-tree libqn_engine.so."""
     if not force and not needs_build():
         return LIB
-    cmd = [HIPCC] + FLAGS + sources() + ["-o", LIB]
+    objs = []
+    cflags = [f for f in FLAGS if f != "-shared"]
+    for src in sources():
+        obj = src[:-4] + ".o"
+        stale = force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(p) for p in [src] + _deps())
+        if stale:
+            cmd = [HIPCC] + cflags + ["-c", src, "-o", obj]
+            if verbose:
+                print(" ".join(cmd))
+            subprocess.check_call(cmd)
+        objs.append(obj)
+    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-pthread"] + objs + ["-o", LIB]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

@@ -394,3 +394,57 @@ def icp_alignment_batch(contexts, pairs, score_thr=1.5):
     if st != QN_OK:
         raise EngineError(st, lib().qn_status_str(st).decode())
     return results, list(valid), list(status)
+
+
+# ---------------------------------------------------------------------------------------- keyframe store / cloud assembly
+class KeyframeStore:
+    """Device-resident keyframe clouds + LoopClosure::setSrcAndDstCloud on the GPU (loop_closure.cpp:58-108)."""
+
+    def __init__(self, device=0):
+        self._l = lib(); h = C.c_void_p()
+        st = self._l.qn_kf_store_create(C.c_int(device), C.byref(h))
+        if st != QN_OK:
+            raise EngineError(st, self._l.qn_status_str(st).decode())
+        self.h = h
+        self._l.qn_kf_last_error.restype = C.c_char_p; self._l.qn_kf_last_error.argtypes = [C.c_void_p]
+        self._l.qn_kf_store_destroy.argtypes = [C.c_void_p]
+
+    def close(self):
+        if getattr(self, "h", None):
+            self._l.qn_kf_store_destroy(self.h); self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, st):
+        if st != QN_OK:
+            raise EngineError(st, self._l.qn_status_str(st).decode() + ": " + self._l.qn_kf_last_error(self.h).decode())
+
+    def add(self, xyz):
+        a, n, stride = _cloud_arg(xyz); kid = C.c_int32()
+        self._check(self._l.qn_kf_add(self.h, _p(a), C.c_uint32(n), C.c_uint32(stride), C.byref(kid)))
+        return kid.value
+
+    def assemble(self, ids, poses, leaf, slot):
+        """-> (device pointer of float4 points, count)"""
+        ids = np.ascontiguousarray(ids, dtype=np.int32); poses = np.ascontiguousarray(poses, dtype=np.float64).reshape(len(ids), 16)
+        ptr = C.c_void_p(); n = C.c_uint32()
+        self._check(self._l.qn_kf_assemble(self.h, _p(ids), _p(poses), C.c_uint32(len(ids)), C.c_double(leaf), C.c_int(slot), C.byref(ptr), C.byref(n)))
+        return ptr.value, n.value
+
+    def download(self, slot, n):
+        out = np.zeros((n, 3), np.float32)
+        self._check(self._l.qn_kf_download(self.h, C.c_int(slot), _p(out)))
+        return out
+
+
+def loop_candidates(pos, stamps, query, radius, tdiff, max_k=64):
+    pos = np.ascontiguousarray(pos, dtype=np.float64); stamps = np.ascontiguousarray(stamps, dtype=np.float64)
+    out = np.zeros(max_k, np.int32); n = C.c_uint32()
+    st = lib().qn_loop_candidates(_p(pos), _p(stamps), C.c_uint32(len(pos)), C.c_uint32(query), C.c_double(radius), C.c_double(tdiff), C.c_uint32(max_k), _p(out), C.byref(n))
+    if st != QN_OK:
+        raise EngineError(st, lib().qn_status_str(st).decode())
+    return out[:n.value].copy()

@@ -164,6 +164,24 @@ int  qn_quatro_align_debug(qn_ctx*, const float* src, uint32_t ns, const float* 
 int  qn_quatro_solve(const float* src, const float* dst, uint32_t stride_bytes, const int32_t* corres_pairs, uint32_t n_corres,
                      const qn_quatro_params* p, double T[16], int* valid, int32_t* clique, uint32_t* n_clique);
 
+/* ---- feeder of the path, kept on the device -------------------------------
+ * Keyframe clouds (PosePcd::pcd_, sensor frame, include/pose_pcd.hpp:7-19) are uploaded once and stay resident;
+ * qn_kf_assemble = the inner loops of LoopClosure::setSrcAndDstCloud (loop_closure.cpp:70-107): transformPcd of each
+ * listed keyframe with its pose, concatenation, voxelizePcd (pcl::VoxelGrid, include/utilities.hpp:38-51), entirely
+ * on the GPU; the returned device pointer (float4, stride 16) feeds qn_icp_alignment_device / the batch API.     */
+typedef struct qn_kf_store qn_kf_store;
+int  qn_kf_store_create(int device, qn_kf_store** out);
+void qn_kf_store_destroy(qn_kf_store*);
+const char* qn_kf_last_error(const qn_kf_store*);
+int  qn_kf_add(qn_kf_store*, const float* xyz, uint32_t n, uint32_t stride_bytes, int32_t* id_out);
+int  qn_kf_assemble(qn_kf_store*, const int32_t* ids, const double* poses16, uint32_t count, double leaf, int slot,
+                    const float** d_xyz_out, uint32_t* n_out);
+int  qn_kf_download(qn_kf_store*, int slot, float* xyz_out /* n x 3 packed */);
+/* LoopClosure::fetchClosestKeyframeIdx (loop_closure.cpp:34-56) generalised to the max_k nearest admissible keyframes,
+ * ascending distance; out[0] is the reference's single choice.  Host code (O(#keyframes)).                        */
+int  qn_loop_candidates(const double* pos_xyz, const double* stamps, uint32_t n, uint32_t query, double radius, double tdiff,
+                        uint32_t max_k, int32_t* out, uint32_t* n_out);
+
 /* ---- per-stage read-backs used by the parity tests (not needed by the shims) ------------ */
 int  qn_gicp_get_covariances(qn_ctx*, int which, double* cov9_out);   /* n x 9 f64, original point order */
 int  qn_gicp_knn(qn_ctx*, int which, int k, int32_t* idx_out, float* d2_out);   /* self k-NN of a cloud, n x k */

@@ -216,3 +216,29 @@ def coarse_to_fine_alignment(src, dst, qp=None, **gicp_kw):
     r["T"] = r["T"] @ Tq
     r["quatro"] = q; r["coarse"] = coarse
     return r
+
+
+# ---------------------------------------------------------------- cloud assembly feeder
+def transform_pcd(xyz, T):
+    xyz = _f32(xyz); out = np.zeros_like(xyz)
+    lib().orc_transform_pcd(_p(xyz), C.c_int(len(xyz)), _p(_f64(T)), _p(out)); return out
+
+
+def voxel_grid(xyz, leaf):
+    xyz = _f32(xyz); out = np.zeros_like(xyz)
+    m = lib().orc_voxel_grid(_p(xyz), C.c_int(len(xyz)), C.c_float(leaf), _p(out))
+    if m < 0:
+        raise OverflowError("leaf grid exceeds 2^31 cells")
+    return out[:m].copy()
+
+
+def assemble_submap(keyframes, poses, idxs, leaf):
+    """setSrcAndDstCloud's inner loop (loop_closure.cpp:70-107): transformPcd of each keyframe, concatenate, voxelize."""
+    parts = [transform_pcd(keyframes[i], poses[i]) for i in idxs]
+    return voxel_grid(np.concatenate(parts, 0), leaf)
+
+
+def loop_candidates(pos, stamp, query, radius, tdiff, max_k=64):
+    pos = _f64(pos); stamp = _f64(stamp); out = np.zeros(max_k, np.int32)
+    m = lib().orc_loop_candidates(_p(pos), _p(stamp), C.c_int(len(pos)), C.c_int(query), C.c_double(radius), C.c_double(tdiff), C.c_int(max_k), _p(out))
+    return out[:m].copy()
