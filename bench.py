@@ -57,12 +57,20 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the engine has no CPU fallback")
+    # one process per GPU (RCCL over xGMI).  QN_BENCH_BACKEND=gloo lets the N > 1 code path be exercised on a 1-GPU box
+    # (all ranks share cuda:0, collectives on host tensors) - a plumbing test, not a measurement.
+    backend = os.environ.get("QN_BENCH_BACKEND", "nccl")
+    local = local % torch.cuda.device_count() if backend != "nccl" else local
     torch.cuda.set_device(local)
+    cdev = "cuda" if backend == "nccl" else "cpu"
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from qn_amd import engine, synth
     # `in_flight` contexts (= hipStreams) per GPU: the candidate pairs of a loop-closure query are independent
@@ -111,7 +119,7 @@ def main():
         if best is None or rec[2] < best[2]:
             best = rec
     if dist is not None:          # the one exchange step: gather every rank's best record to pick the winning loop
-        mine = torch.tensor(best, dtype=torch.float64, device="cuda")
+        mine = torch.tensor(best, dtype=torch.float64, device=cdev)
         allrec = [torch.empty_like(mine) for _ in range(world)]
         dist.all_gather(allrec, mine)
         winner = min((a.tolist() for a in allrec), key=lambda a: a[2])
@@ -120,7 +128,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 

@@ -146,7 +146,9 @@ struct Best1 {                         // 1-NN, plus the squared distance of the
       else if (k != key && d2 < second) second = d2;
     }
   }
-  __device__ __forceinline__ void finish(bool on) {                   // combine the 4 candidate sub-slots of a query
+  template <int S>
+  __device__ __forceinline__ void finish(bool on) {                   // combine the S candidate sub-slots of a query
+    if (S == 1) return;
     unsigned long long b = key, t;
     t = __shfl_xor(b, 16); b = t < b ? t : b;
     t = __shfl_xor(b, 32); b = t < b ? t : b;
@@ -218,8 +220,10 @@ struct BestK {
   }
   // flush, then fold the 4 candidate sub-slots of a query into sub-slot 0.  `on` = this lane's query took
   // part in the round that just ended (queries finished in an earlier round must not merge twice).
+  template <int S>
   __device__ __forceinline__ void finish(bool on) {
     if (__any(cnt > 0)) flush();
+    if (S == 1) return;
     const int lane = threadIdx.x & 63;
     merge_from(32, on && (lane & 32) == 0);        // sub 0 <- 2, sub 1 <- 3
     merge_from(16, on && (lane & 48) == 0);        // sub 0 <- 1
@@ -278,10 +282,11 @@ __device__ __forceinline__ uint32_t stream_box(const GridView& g, int x0, int x1
 
 // wave_search: the ONE cooperative search routine (1-NN and k-NN, first search and seeded re-search).
 //
-// A wavefront serves 16 QUERIES: lane l works for query (l & 15) as candidate sub-slot (l >> 4), i.e. the
-// four lanes of a query split the candidate stream four ways and merge in sink.finish().  100k queries
-// make 6250 waves (the chip holds 8192), each with a 4x shorter candidate loop.  All 64 lanes must call
-// (idle lanes pass active = false; the 4 lanes of a query pass identical q, r).
+// A wavefront serves 64 / S QUERIES (S = 4: lane l works for query (l & 15) as candidate sub-slot (l >> 4), i.e. the
+// four lanes of a query split the candidate stream four ways and merge in sink.finish(); 100k queries then make
+// 6250 waves of the chip's 8192, each with a 4x shorter candidate loop - best latency.  S = 1: one query per lane,
+// 4x fewer wave-instructions per query - best throughput when several registrations are in flight).  All 64 lanes
+// must call (idle lanes pass active = false; the S lanes of a query pass identical q, r).
 //
 // Every query carries a search radius r (world units): a seed bound when the caller knows one (distance
 // to last iteration's neighbour), else margin * cell.  One ROUND handles every cluster of the wave at once
@@ -295,7 +300,7 @@ __device__ __forceinline__ uint32_t stream_box(const GridView& g, int x0, int x1
 // best distance if known - then the next round certifies - else 2 r + cell, never beyond the proven
 // bound r_cap) and it retries, up to max_rounds.  Returns certified; r is updated to the radius the next
 // round would use; d_unseen = lower bound on the distance of every point NOT scanned in the last round.
-template <class Sink>
+template <int S, class Sink>
 __device__ __forceinline__ bool wave_search(const GridView& g, float qx, float qy, float qz, bool active, float& r, const float r_cap,
                                             int max_rounds, Sink& sink, WaveLds* lds, float& d_unseen) {
   const int lane = threadIdx.x & 63;
@@ -319,7 +324,7 @@ __device__ __forceinline__ bool wave_search(const GridView& g, float qx, float q
     wave_lds_fence();
     if (lane < ncl) { lds->box[lane][0] = 0x3fffffff; lds->box[lane][1] = -1; lds->box[lane][2] = 0x3fffffff; lds->box[lane][3] = -1; lds->box[lane][4] = 0x3fffffff; lds->box[lane][5] = -1; }
     wave_lds_fence();
-    if (mine && (lane >> 4) == 0) {
+    if (mine && lane < 64 / S) {
       atomicMin(&lds->box[cid][0], cell_coord(qx - r, g.ox, g.inv_cell, g.nx)); atomicMax(&lds->box[cid][1], cell_coord(qx + r, g.ox, g.inv_cell, g.nx));
       atomicMin(&lds->box[cid][2], cell_coord(qy - r, g.oy, g.inv_cell, g.ny)); atomicMax(&lds->box[cid][3], cell_coord(qy + r, g.oy, g.inv_cell, g.ny));
       atomicMin(&lds->box[cid][4], cell_coord(qz - r, g.oz, g.inv_cell, g.nz)); atomicMax(&lds->box[cid][5], cell_coord(qz + r, g.oz, g.inv_cell, g.nz));
@@ -391,16 +396,16 @@ __device__ __forceinline__ bool wave_search(const GridView& g, float qx, float q
         if (slot < total) { lds->tile[lane] = g.pts[lds->seg_start[j] + (slot - lds->seg_excl[j])]; lds->tile_cid[lane] = lds->seg_cid[j]; }
         wave_lds_fence();
 #pragma unroll 2
-        for (uint32_t c = 0; c < cnt; c += 4) {                               // 4 candidates per step: one per 16-lane sub-slot
-          const uint32_t ci = c + (uint32_t)(lane >> 4);
-          const float4 cp = lds->tile[ci & 63];                               // ds_read_b128, 4 distinct addresses per wave
+        for (uint32_t c = 0; c < cnt; c += S) {                               // S candidates per step: one per sub-slot
+          const uint32_t ci = c + (uint32_t)(S == 1 ? 0 : lane / (64 / S));
+          const float4 cp = lds->tile[ci & 63];                               // ds_read_b128, S distinct addresses per wave
           const bool on = mine && ci < cnt && lds->tile_cid[ci & 63] == cid;
           sink.consider(on, sqdist(qx, qy, qz, cp.x, cp.y, cp.z), __float_as_uint(cp.w));
         }
       }
       ncand += total;
     }
-    sink.finish(mine);
+    sink.template finish<S>(mine);
     if (g.dbg && lane == 0) { atomicAdd(&g.dbg[0], (uint32_t)ncl); atomicAdd(&g.dbg[1], ncand); }
     // certification: nearest face of the scanned box that has unseen cells behind it
     bool retry = false;

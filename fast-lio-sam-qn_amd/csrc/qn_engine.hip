@@ -252,11 +252,16 @@ extern "C" int qn_gicp_set_target_device(qn_ctx* c, const float* xyz, uint32_t n
 template <int KMAX>
 static void launch_knn_cov(qn_ctx* c, CloudBuf& b, int k, int32_t* kidx, float* kd2) {
   hipStream_t s = c->stream;
-  const uint32_t nb = (b.n + QN_BLOCK / 4 - 1) / (QN_BLOCK / 4);      // 16 queries per wave, 64 per block
   const float r0 = c->margin_knn * b.grid.cell;
   ProfScope ps(c, QN_K_KNN_COV);
-  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_knn_cov<KMAX, false>), dim3(nb), dim3(QN_BLOCK), 0, s, b.grid, b.raw, k, r0, 2, b.cov, kidx, kd2, c->fb_list, c->fb_count2);
-  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_knn_cov<KMAX, true>), dim3(std::min<uint32_t>(nb, 512)), dim3(QN_BLOCK), 0, s, b.grid, b.raw, k, r0, 64, b.cov, kidx, kd2, c->fb_list, c->fb_count2);
+  if (c->knn_lanes_per_query == 1) {        // one query per lane: fewest wave-instructions per query (throughput)
+    const uint32_t nb = (b.n + QN_BLOCK - 1) / QN_BLOCK;
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_knn_cov<KMAX, false, 1>), dim3(nb), dim3(QN_BLOCK), 0, s, b.grid, b.raw, k, r0, 2, b.cov, kidx, kd2, c->fb_list, c->fb_count2);
+  } else {                                  // 16 queries per wave x 4 candidate sub-slots: shortest critical path (latency)
+    const uint32_t nb = (b.n + QN_BLOCK / 4 - 1) / (QN_BLOCK / 4);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_knn_cov<KMAX, false, 4>), dim3(nb), dim3(QN_BLOCK), 0, s, b.grid, b.raw, k, r0, 2, b.cov, kidx, kd2, c->fb_list, c->fb_count2);
+  }
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_knn_cov<KMAX, true, 4>), dim3(std::min<uint32_t>((b.n + 63) / 64, 512)), dim3(QN_BLOCK), 0, s, b.grid, b.raw, k, r0, 64, b.cov, kidx, kd2, c->fb_list, c->fb_count2);
   hipLaunchKernelGGL(k_cov_from_idx, dim3((b.n + QN_BLOCK - 1) / QN_BLOCK), dim3(QN_BLOCK), 0, s, b.raw, b.n, k, kidx, b.cov);
 }
 static int compute_cov(qn_ctx* c, int which, int32_t* kidx, float* kd2) {
@@ -531,6 +536,7 @@ extern "C" int qn_debug_set(qn_ctx* c, const char* key, double v) {
   if (k == "cell") { c->cell_override = v; c->cloud[0].has_grid = c->cloud[1].has_grid = false; }
   else if (k == "margin_nn") c->margin_nn = (int)v;
   else if (k == "margin_knn") c->margin_knn = (int)v;
+  else if (k == "knn_lanes_per_query") c->knn_lanes_per_query = v == 1 ? 1 : 4;
   else if (k == "margin_nn_cap") c->margin_nn_cap = (int)v;
   else if (k == "margin_knn_cap") c->margin_knn_cap = (int)v;
   else if (k == "dbg_counters") {

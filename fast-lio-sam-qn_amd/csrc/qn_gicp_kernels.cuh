@@ -156,7 +156,7 @@ __global__ void __launch_bounds__(QN_BLOCK) k_cov_from_idx(const float4* __restr
 // One kernel body for both passes.  LIST = false: query t = global query slot, radius margin * cell, two
 // rounds, leftovers appended to fb_list with the radius to continue from.  LIST = true: the queries are
 // the fb_list entries of the first pass (16 per wave, wave-stride), rounds until exact.
-template <int KMAX, bool LIST>
+template <int KMAX, bool LIST, int S>
 __global__ void __launch_bounds__(QN_BLOCK, 3) k_knn_cov(GridView g, const float4* __restrict__ raw, int k, float r0, int max_rounds,
                                                       double* __restrict__ cov, int32_t* __restrict__ knn_idx, float* __restrict__ knn_d2,
                                                       uint2* __restrict__ fb_list, uint32_t* __restrict__ fb_count) {
@@ -165,16 +165,17 @@ __global__ void __launch_bounds__(QN_BLOCK, 3) k_knn_cov(GridView g, const float
   const uint32_t nq = LIST ? *fb_count : g.n;
   if (LIST && g.dbg && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&g.dbg[4], nq);
   const uint32_t wave0 = blockIdx.x * (QN_BLOCK / 64) + (threadIdx.x >> 6), nwaves = gridDim.x * (QN_BLOCK / 64);
-  for (uint32_t base = wave0 * 16; base < nq; base += nwaves * 16) {       // (non-LIST grids cover nq in one trip)
-    const uint32_t slot = base + (threadIdx.x & 15);
+  constexpr uint32_t QPW = 64 / S;                                          // queries per wave
+  for (uint32_t base = wave0 * QPW; base < nq; base += nwaves * QPW) {      // (non-LIST grids cover nq in one trip)
+    const uint32_t slot = base + (threadIdx.x & (QPW - 1));
     const bool active = slot < nq;
     uint32_t t = slot; float r = r0;
     if (LIST && active) { const uint2 rec = fb_list[slot]; t = rec.x; r = __uint_as_float(rec.y); }   // continue from r
     const float4 q = active ? g.pts[t] : make_float4(0, 0, 0, 0);
     BestK<KMAX> sink; sink.init(k, my->pend, g.dbg);
     float d_unseen;
-    const bool cert = wave_search(g, q.x, q.y, q.z, active, r, __int_as_float(0x7f800000), max_rounds, sink, &my->s, d_unseen);
-    if (!active || (threadIdx.x & 48) != 0) continue;               // sub-slot 0 of each query finishes the job
+    const bool cert = wave_search<S>(g, q.x, q.y, q.z, active, r, __int_as_float(0x7f800000), max_rounds, sink, &my->s, d_unseen);
+    if (!active || (threadIdx.x & 63) >= QPW) continue;             // sub-slot 0 of each query finishes the job
     const uint32_t i = __float_as_uint(q.w);
     if (cert || LIST) store_knn(sink, knn_idx + (size_t)i * k, knn_d2 ? knn_d2 + (size_t)i * k : nullptr);
     else {
@@ -265,7 +266,7 @@ __global__ void __launch_bounds__(QN_BLOCK) k_nn_search(GridView src, GridView t
     float qx, qy, qz; xform_query<MODE>(Tf, p.x, p.y, p.z, qx, qy, qz);
     Best1 sink; sink.init();
     float d_unseen;
-    const bool cert = wave_search(tgt, qx, qy, qz, active, r, r_cap, max_rounds, sink, &lds[threadIdx.x >> 6], d_unseen);
+    const bool cert = wave_search<4>(tgt, qx, qy, qz, active, r, r_cap, max_rounds, sink, &lds[threadIdx.x >> 6], d_unseen);
     if (!active || (threadIdx.x & 48) != 0) continue;
     if (cert || LIST) {
       store_nn<MODE>(sink.key, __float_as_uint(p.w), thr2, corr, sqd, nn_idx);
