@@ -298,13 +298,13 @@ static void enqueue_nn(qn_ctx* c, int mode /*0 align, 1 fitness*/, float* sqd_ou
   const float r0 = c->margin_nn * T.grid.cell;
   if (mode == 0) {
     { ProfScope ps(c, QN_K_NN_SEARCH);
-      if (seeded) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_nn_track<0>), dim3(nbt), dim3(QN_BLOCK), 0, s, S.grid, T.grid, T.raw, c->state, thr2, c->corr, sqd_out, c->nn_idx, c->nn_ref, c->fb_list, fbc, c->big_list, bgc);
+      if (seeded) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_nn_track<0, false>), dim3(nbt), dim3(QN_BLOCK), 0, s, S.grid, T.grid, T.raw, c->state, thr2, c->corr, sqd_out, c->nn_idx, c->nn_ref, c->fb_list, fbc, c->big_list, bgc, nullptr, nullptr, nullptr);
       else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_nn_search<0, false>), dim3(nb), dim3(QN_BLOCK), 0, s, S.grid, T.grid, c->state, thr2, r0, 1, c->corr, sqd_out, c->nn_idx, c->nn_ref, c->fb_list, fbc, c->big_list, bgc, 0); }
     { ProfScope ps(c, QN_K_NN_FALLBACK);
       hipLaunchKernelGGL(HIP_KERNEL_NAME(k_nn_search<0, true>), dim3(fbb + big_blocks), dim3(QN_BLOCK), 0, s, S.grid, T.grid, c->state, thr2, r0, 64, c->corr, sqd_out, c->nn_idx, c->nn_ref, c->fb_list, fbc, c->big_list, bgc, big_blocks); }
   } else {
     ProfScope ps(c, QN_K_FITNESS);
-    if (seeded) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_nn_track<1>), dim3(nbt), dim3(QN_BLOCK), 0, s, S.grid, T.grid, T.raw, c->state, thr2, c->corr, sqd_out, c->nn_idx, c->nn_ref, c->fb_list, fbc, c->big_list, bgc);
+    if (seeded) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_nn_track<1, false>), dim3(nbt), dim3(QN_BLOCK), 0, s, S.grid, T.grid, T.raw, c->state, thr2, c->corr, sqd_out, c->nn_idx, c->nn_ref, c->fb_list, fbc, c->big_list, bgc, nullptr, nullptr, nullptr);
     else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_nn_search<1, false>), dim3(nb), dim3(QN_BLOCK), 0, s, S.grid, T.grid, c->state, thr2, r0, 1, c->corr, sqd_out, c->nn_idx, c->nn_ref, c->fb_list, fbc, c->big_list, bgc, 0);
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_nn_search<1, true>), dim3(fbb + big_blocks), dim3(QN_BLOCK), 0, s, S.grid, T.grid, c->state, thr2, r0, 64, c->corr, sqd_out, c->nn_idx, c->nn_ref, c->fb_list, fbc, c->big_list, bgc, big_blocks);
   }
@@ -320,7 +320,21 @@ static void enqueue_solve(qn_ctx* c, int mode) {
   hipLaunchKernelGGL(k_solve, dim3(1), dim3(QN_SOLVE_THREADS), 0, c->stream, c->state, c->partials, (int)acc_blocks(c), make_cfg(c), c->trace, mode);
 }
 // one "tick" of the device-side state machine: [NN pass A, NN pass B, accumulate, solve]
-static void enqueue_tick(qn_ctx* c, bool seeded, int tick) { enqueue_nn(c, 0, c->sqd, seeded, tick); enqueue_accumulate(c); enqueue_solve(c, 0); }
+// Gauss-Newton ticks in the converged regime (tick >= 3): tracking, leftovers and accumulation in ONE kernel, then the solver.
+static void enqueue_tick_fused(qn_ctx* c) {
+  hipStream_t s = c->stream;
+  CloudBuf &S = c->cloud[0], &T = c->cloud[1];
+  const uint32_t nbt = (S.n + QN_BLOCK - 1) / QN_BLOCK;
+  const double thr2 = c->params.max_corr_dist * c->params.max_corr_dist;
+  { ProfScope ps(c, QN_K_NN_SEARCH);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_nn_track<0, true>), dim3(nbt), dim3(QN_BLOCK), 0, s, S.grid, T.grid, T.raw, c->state, thr2, c->corr, c->sqd, c->nn_idx, c->nn_ref,
+                       c->fb_list, &c->state->fb_count, c->big_list, &c->state->big_count, S.cov, T.cov, c->partials); }
+  enqueue_solve(c, 0);
+}
+static void enqueue_tick(qn_ctx* c, bool seeded, int tick) {
+  if (seeded && tick >= 3 && c->fused_ticks && c->params.optimizer == QN_OPT_GN && acc_blocks(c) == (c->cloud[0].n + QN_BLOCK - 1) / QN_BLOCK) { enqueue_tick_fused(c); return; }
+  enqueue_nn(c, 0, c->sqd, seeded, tick); enqueue_accumulate(c); enqueue_solve(c, 0);
+}
 static void enqueue_epilogue(qn_ctx* c, double max_range, bool seeded) {       // fitness + output cloud; each kernel is a no-op until phase == done
   enqueue_nn(c, 1, c->sqd_fit, seeded, 1);
   { ProfScope ps(c, QN_K_FITNESS);
@@ -537,6 +551,7 @@ extern "C" int qn_debug_set(qn_ctx* c, const char* key, double v) {
   else if (k == "margin_nn") c->margin_nn = (int)v;
   else if (k == "margin_knn") c->margin_knn = (int)v;
   else if (k == "knn_lanes_per_query") c->knn_lanes_per_query = v == 1 ? 1 : 4;
+  else if (k == "fused_ticks") c->fused_ticks = v != 0;
   else if (k == "margin_nn_cap") c->margin_nn_cap = (int)v;
   else if (k == "margin_knn_cap") c->margin_knn_cap = (int)v;
   else if (k == "dbg_counters") {

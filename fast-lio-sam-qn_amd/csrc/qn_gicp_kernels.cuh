@@ -278,99 +278,72 @@ __global__ void __launch_bounds__(QN_BLOCK) k_nn_search(GridView src, GridView t
   }
 }
 
-// ------------------------------------------------------------------ K4a', temporal tracking
-// Iterations after the first (and the fitness pass) start from the previous iteration's nearest
-// neighbour j0: d(q, p_j0) is an upper bound on the NN distance, so the exact NN lies in the ball of that
-// radius - after the first Gauss-Newton step that is one to eight grid cells.  One query per lane,
-// at most QN_TRACK_SEG segments (bounds gathered first, then the points); larger balls go to the
-// wave-per-query pass B with the same bound.  Exact by construction: every point that could beat or
-// tie j0 (lower index wins) is scanned.
-#define QN_TRACK_SEG 8
-// Bound pruning: nn_ref[i] = (position q_ref at which query i was last SCANNED, lower bound d_other on the
-// distance from q_ref to every target point other than its neighbour j0).  If the query has moved by delta
-// since, every other point is still >= d_other - delta away, so  d(q, p_j0) + delta < d_other  PROVES that
-// j0 is still the unique nearest neighbour and the scan is skipped - bit-identical result, no search.
-// As the optimiser converges delta -> 0 and almost every query takes this path.
-template <int MODE>
-__global__ void __launch_bounds__(QN_BLOCK) k_nn_track(GridView src, GridView tgt, const float4* __restrict__ tgt_raw, const GicpState* __restrict__ st,
-                                                       double thr2, int32_t* __restrict__ corr, float* __restrict__ sqd, int32_t* __restrict__ nn_idx,
-                                                       float4* __restrict__ nn_ref, uint2* __restrict__ fb_list, uint32_t* __restrict__ fb_count,
-                                                       uint2* __restrict__ big_list, uint32_t* __restrict__ big_count) {
-  if (MODE == 0 && st->phase != 0) return;
-  if (MODE == 1 && st->phase != 2) return;
-  float Tf[12];
-#pragma unroll
-  for (int j = 0; j < 12; j++) Tf[j] = (float)st->x0[j];
-  const uint32_t t = blockIdx.x * QN_BLOCK + threadIdx.x;
-  if (t >= src.n) return;
-  const float4 p = src.pts[t];
-  const uint32_t i = __float_as_uint(p.w);
-  float qx, qy, qz; xform_query<MODE>(Tf, p.x, p.y, p.z, qx, qy, qz);
-  const int32_t j0 = nn_idx[i];
-  const float4 ref = nn_ref[i];
-  const float4 p0 = tgt_raw[j0];
-  const float d0 = sqdist(qx, qy, qz, p0.x, p0.y, p0.z);
-  unsigned long long best = pack_key(d0, (uint32_t)j0);
-  const float delta = sqrtf(sqdist(qx, qy, qz, ref.x, ref.y, ref.z));
-  if ((sqrtf(d0) + delta) * 1.000004f < ref.w) {                   // proven: j0 is still the unique NN (the factor covers f32 rounding)
-    if (tgt.dbg && (threadIdx.x & 63) == 0) atomicAdd(&tgt.dbg[6], (uint32_t)__popcll(__ballot(1)));
-    store_nn<MODE>(best, i, thr2, corr, sqd, nn_idx);
-    return;
-  }
-  const float r = sqrtf(d0) * 1.000001f + tgt.eps;
-  const int bx0 = cell_coord(qx - r, tgt.ox, tgt.inv_cell, tgt.nx), bx1 = cell_coord(qx + r, tgt.ox, tgt.inv_cell, tgt.nx);
-  const int by0 = cell_coord(qy - r, tgt.oy, tgt.inv_cell, tgt.ny), by1 = cell_coord(qy + r, tgt.oy, tgt.inv_cell, tgt.ny);
-  const int bz0 = cell_coord(qz - r, tgt.oz, tgt.inv_cell, tgt.nz), bz1 = cell_coord(qz + r, tgt.oz, tgt.inv_cell, tgt.nz);
-  const int tx0 = bx0 >> 3, ntr = (bx1 >> 3) - tx0 + 1, nyr = by1 - by0 + 1;
-  const int nseg = ntr * nyr * (bz1 - bz0 + 1);
-  if (!(d0 == d0) || nseg > QN_TRACK_SEG) {                       // big ball (or non-finite query): list passes, seeded with the bound
-    // tight seed (the query barely moved since it was scanned) AND far neighbour: one query per wave; else the 16-query pass
-    if (r > 2.5f * tgt.cell && delta < 0.25f * r) { const uint32_t slot = atomicAdd(big_count, 1u); big_list[slot] = make_uint2(t, __float_as_uint(r)); }
-    else { const uint32_t slot = atomicAdd(fb_count, 1u); fb_list[slot] = make_uint2(t, __float_as_uint(r)); }   // r is NaN for a non-finite query: resolved at once
-    return;
-  }
-  uint32_t s[QN_TRACK_SEG], e[QN_TRACK_SEG];
-#pragma unroll
-  for (int sg = 0; sg < QN_TRACK_SEG; sg++) {
-    s[sg] = 0; e[sg] = 0;
-    if (sg < nseg) {
-      const int tt = sg % ntr, rr = sg / ntr;
-      const int ry = by0 + rr % nyr, rz = bz0 + rr / nyr, tx = tx0 + tt;
-      const int xa = max(bx0, tx << 3), xb = min(bx1, (tx << 3) + 7);
-      const uint32_t k0 = cell_key(tgt, xa, ry, rz);
-      s[sg] = tgt.cell_start[k0]; e[sg] = tgt.cell_start[k0 + (xb - xa) + 1];
-    }
-  }
-  float second = __int_as_float(0x7f800000);
-#pragma unroll
-  for (int sg = 0; sg < QN_TRACK_SEG; sg++) {
-    for (uint32_t u = s[sg]; u < e[sg]; u++) {
-      const float4 a = tgt.pts[u];
-      const float da = sqdist(qx, qy, qz, a.x, a.y, a.z);
-      const unsigned long long ka = pack_key(da, __float_as_uint(a.w));
-      if (ka < best) { second = key_d2(best); best = ka; }
-      else if (ka != best && da < second) second = da;
-    }
-  }
-  store_nn<MODE>(best, i, thr2, corr, sqd, nn_idx);
-  if (MODE == 0) {   // distance to the faces of the scanned cell box that have unseen cells behind them
-    const float INF = __int_as_float(0x7f800000);
-    float d = INF;
-    if (bx0 > 0) d = fminf(d, qx - (tgt.ox + bx0 * tgt.cell));
-    if (bx1 < tgt.nx - 1) d = fminf(d, (tgt.ox + (bx1 + 1) * tgt.cell) - qx);
-    if (by0 > 0) d = fminf(d, qy - (tgt.oy + by0 * tgt.cell));
-    if (by1 < tgt.ny - 1) d = fminf(d, (tgt.oy + (by1 + 1) * tgt.cell) - qy);
-    if (bz0 > 0) d = fminf(d, qz - (tgt.oz + bz0 * tgt.cell));
-    if (bz1 < tgt.nz - 1) d = fminf(d, (tgt.oz + (bz1 + 1) * tgt.cell) - qz);
-    nn_ref[i] = make_float4(qx, qy, qz, fminf(sqrtf(second), d - tgt.eps));
-  }
-}
-
 // ------------------------------------------------------------------ K4b / K5 accumulate
 // phase 0: linearize: M = (C_B + R C_A R^T)^-1, e = mu_B - T mu_A, J = [skew(T mu_A) | -I],
 //          H += J^T M J (21 unique), b += J^T M e, cost += e^T M e.
 // phase 1: compute_error at the trial transform xi with the CACHED correspondences and the M of x0.
 // Fixed grid, fixed per-thread striding, fixed reduction tree => bitwise reproducible partials.
+// one correspondence's contribution: M = (C_B + R C_A R^T)^-1, e = mu_B - T mu_A, J = [skew(T mu_A) | -I];
+// acc[0..20] += upper J^T M J, acc[21..26] += J^T M e (both only when `lin`), acc[27] += e^T M e
+__device__ __forceinline__ void accumulate_point(const double R[3][3], const double T[3][4], const float4 pa, const float4 pb,
+                                                 const double* __restrict__ ca, const double* __restrict__ cb, const bool lin, double acc[QN_NPART]) {
+  const double CA[3][3] = {{ca[0], ca[1], ca[2]}, {ca[1], ca[3], ca[4]}, {ca[2], ca[4], ca[5]}};
+  double RC[3][3];
+#pragma unroll
+  for (int a = 0; a < 3; a++)
+#pragma unroll
+    for (int b = 0; b < 3; b++) RC[a][b] = R[a][0] * CA[0][b] + R[a][1] * CA[1][b] + R[a][2] * CA[2][b];
+  M3 rcr;
+  const double CB[3][3] = {{cb[0], cb[1], cb[2]}, {cb[1], cb[3], cb[4]}, {cb[2], cb[4], cb[5]}};
+#pragma unroll
+  for (int a = 0; a < 3; a++)
+#pragma unroll
+    for (int b = 0; b < 3; b++) rcr.m[a][b] = CB[a][b] + (RC[a][0] * R[b][0] + RC[a][1] * R[b][1] + RC[a][2] * R[b][2]);
+  const M3 M = m3_inverse(rcr);
+  const double mA[3] = {(double)pa.x, (double)pa.y, (double)pa.z};
+  double tA[3], e[3], Me[3];
+#pragma unroll
+  for (int r = 0; r < 3; r++) tA[r] = T[r][0] * mA[0] + T[r][1] * mA[1] + T[r][2] * mA[2] + T[r][3];
+  e[0] = (double)pb.x - tA[0]; e[1] = (double)pb.y - tA[1]; e[2] = (double)pb.z - tA[2];
+#pragma unroll
+  for (int r = 0; r < 3; r++) Me[r] = M.m[r][0] * e[0] + M.m[r][1] * e[1] + M.m[r][2] * e[2];
+  acc[27] += e[0] * Me[0] + e[1] * Me[1] + e[2] * Me[2];
+  if (lin) {
+    const double J[3][6] = {{0, -tA[2], tA[1], -1, 0, 0}, {tA[2], 0, -tA[0], 0, -1, 0}, {-tA[1], tA[0], 0, 0, 0, -1}};
+    double MJ[3][6];
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+#pragma unroll
+      for (int c = 0; c < 6; c++) MJ[r][c] = M.m[r][0] * J[0][c] + M.m[r][1] * J[1][c] + M.m[r][2] * J[2][c];
+    int t = 0;
+#pragma unroll
+    for (int r = 0; r < 6; r++)
+#pragma unroll
+      for (int c = r; c < 6; c++, t++) acc[t] += J[0][r] * MJ[0][c] + J[1][r] * MJ[1][c] + J[2][r] * MJ[2][c];
+#pragma unroll
+    for (int r = 0; r < 6; r++) acc[21 + r] += J[0][r] * Me[0] + J[1][r] * Me[1] + J[2][r] * Me[2];
+  }
+}
+
+// block-level reduction of the 28 per-thread sums (DPP row sums + 2 cross-row shuffles per wave, then the 4 waves in order)
+__device__ __forceinline__ void reduce_block_partials(const double acc[QN_NPART], const bool lin, double* __restrict__ partials, double (*red)[QN_NPART]) {
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  if (lin) {
+#pragma unroll
+    for (int t = 0; t < QN_NPART; t++) { double v = wave_sum_f64_dpp(acc[t]); if (lane == 63) red[wid][t] = v; }
+  } else {
+    double v = wave_sum_f64_dpp(acc[27]);
+    if (lane == 63) { for (int t = 0; t < 27; t++) red[wid][t] = 0; red[wid][27] = v; }
+  }
+  __syncthreads();
+  if (threadIdx.x < QN_NPART) {
+    double s = 0;
+#pragma unroll
+    for (int w = 0; w < QN_BLOCK / 64; w++) s += red[w][threadIdx.x];
+    partials[(size_t)blockIdx.x * QN_NPART + threadIdx.x] = s;
+  }
+}
+
 __global__ void __launch_bounds__(QN_BLOCK) k_accumulate(const float4* __restrict__ src_raw, uint32_t ns, const float4* __restrict__ tgt_raw,
                                                          const double* __restrict__ cov_s, const double* __restrict__ cov_t,
                                                          const int32_t* __restrict__ corr, const GicpState* __restrict__ st,
@@ -389,59 +362,139 @@ __global__ void __launch_bounds__(QN_BLOCK) k_accumulate(const float4* __restric
   for (uint32_t i = blockIdx.x * QN_BLOCK + threadIdx.x; i < ns; i += gridDim.x * QN_BLOCK) {
     const int j = corr[i];
     if (j < 0) continue;
-    const float4 pa = src_raw[i], pb = tgt_raw[j];
-    const double* ca = cov_s + (size_t)i * 6; const double* cb = cov_t + (size_t)j * 6;
-    const double CA[3][3] = {{ca[0], ca[1], ca[2]}, {ca[1], ca[3], ca[4]}, {ca[2], ca[4], ca[5]}};
-    double RC[3][3];
+    accumulate_point(R, T, src_raw[i], tgt_raw[j], cov_s + (size_t)i * 6, cov_t + (size_t)j * 6, phase == 0, acc);
+  }
+  reduce_block_partials(acc, phase == 0, partials, red);
+}
+
+// ------------------------------------------------------------------ K4a', temporal tracking
+// Iterations after the first (and the fitness pass) start from the previous iteration's nearest
+// neighbour j0: d(q, p_j0) is an upper bound on the NN distance, so the exact NN lies in the ball of that
+// radius - after the first Gauss-Newton step that is one to eight grid cells.  One query per lane,
+// at most QN_TRACK_SEG segments (bounds gathered first, then the points); larger balls go to the
+// list passes with the same bound.  Exact by construction: every point that could beat or
+// tie j0 (lower index wins) is scanned.
+//
+// Bound pruning: nn_ref[i] = (position q_ref at which query i was last SCANNED, lower bound d_other on the
+// distance from q_ref to every target point other than its neighbour j0).  If the query has moved by delta
+// since, every other point is still >= d_other - delta away, so  d(q, p_j0) + delta < d_other  PROVES that
+// j0 is still the unique nearest neighbour and the scan is skipped - bit-identical result, no search.
+// As the optimiser converges delta -> 0 and almost every query takes this path.
+//
+// FUSED (MODE 0, Gauss-Newton, converged regime): leftovers with a big ball are resolved inside the kernel, one at a
+// time by the whole wave (wave_search_single), and every lane adds its correspondence's contribution to the block's 28
+// partial sums - no list pass and no separate accumulate kernel in that tick.
+#define QN_TRACK_SEG 8
+template <int MODE, bool FUSED>
+__global__ void __launch_bounds__(QN_BLOCK) k_nn_track(GridView src, GridView tgt, const float4* __restrict__ tgt_raw, const GicpState* __restrict__ st,
+                                                       double thr2, int32_t* __restrict__ corr, float* __restrict__ sqd, int32_t* __restrict__ nn_idx,
+                                                       float4* __restrict__ nn_ref, uint2* __restrict__ fb_list, uint32_t* __restrict__ fb_count,
+                                                       uint2* __restrict__ big_list, uint32_t* __restrict__ big_count,
+                                                       const double* __restrict__ cov_s, const double* __restrict__ cov_t, double* __restrict__ partials) {
+  __shared__ WaveLds lds[FUSED ? QN_BLOCK / 64 : 1];
+  __shared__ double red[FUSED ? QN_BLOCK / 64 : 1][QN_NPART];
+  if (MODE == 0 && st->phase != 0) return;
+  if (MODE == 1 && st->phase != 2) return;
+  float Tf[12];
 #pragma unroll
-    for (int a = 0; a < 3; a++)
+  for (int j = 0; j < 12; j++) Tf[j] = (float)st->x0[j];
+  const uint32_t t = blockIdx.x * QN_BLOCK + threadIdx.x;
+  const bool valid = t < src.n;
+  if (!FUSED && !valid) return;
+  const float INF = __int_as_float(0x7f800000);
+  const float4 p = valid ? src.pts[t] : make_float4(0, 0, 0, 0);
+  const uint32_t i = __float_as_uint(p.w);
+  float qx, qy, qz; xform_query<MODE>(Tf, p.x, p.y, p.z, qx, qy, qz);
+  unsigned long long best = QN_INF_KEY; float second = INF, d_unseen = INF;
+  bool rescanned = false, big = false;
+  float r = 0.f, delta = 0.f;
+  if (valid) {
+    const int32_t j0 = nn_idx[i];
+    const float4 ref = nn_ref[i];
+    const float4 p0 = tgt_raw[j0];
+    const float d0 = sqdist(qx, qy, qz, p0.x, p0.y, p0.z);
+    best = pack_key(d0, (uint32_t)j0);
+    delta = sqrtf(sqdist(qx, qy, qz, ref.x, ref.y, ref.z));
+    if ((sqrtf(d0) + delta) * 1.000004f < ref.w) {                  // proven: j0 is still the unique NN (the factor covers f32 rounding)
+      if (tgt.dbg && (threadIdx.x & 63) == 0) atomicAdd(&tgt.dbg[6], (uint32_t)__popcll(__ballot(1)));
+    } else {
+      r = sqrtf(d0) * 1.000001f + tgt.eps;
+      const int bx0 = cell_coord(qx - r, tgt.ox, tgt.inv_cell, tgt.nx), bx1 = cell_coord(qx + r, tgt.ox, tgt.inv_cell, tgt.nx);
+      const int by0 = cell_coord(qy - r, tgt.oy, tgt.inv_cell, tgt.ny), by1 = cell_coord(qy + r, tgt.oy, tgt.inv_cell, tgt.ny);
+      const int bz0 = cell_coord(qz - r, tgt.oz, tgt.inv_cell, tgt.nz), bz1 = cell_coord(qz + r, tgt.oz, tgt.inv_cell, tgt.nz);
+      const int tx0 = bx0 >> 3, ntr = (bx1 >> 3) - tx0 + 1, nyr = by1 - by0 + 1;
+      const int nseg = ntr * nyr * (bz1 - bz0 + 1);
+      if (!(d0 == d0) || nseg > QN_TRACK_SEG) big = true;           // big ball (or non-finite query)
+      else {
+        uint32_t s[QN_TRACK_SEG], e[QN_TRACK_SEG];
 #pragma unroll
-      for (int b = 0; b < 3; b++) RC[a][b] = R[a][0] * CA[0][b] + R[a][1] * CA[1][b] + R[a][2] * CA[2][b];
-    M3 rcr;
-    const double CB[3][3] = {{cb[0], cb[1], cb[2]}, {cb[1], cb[3], cb[4]}, {cb[2], cb[4], cb[5]}};
+        for (int sg = 0; sg < QN_TRACK_SEG; sg++) {
+          s[sg] = 0; e[sg] = 0;
+          if (sg < nseg) {
+            const int tt = sg % ntr, rr = sg / ntr;
+            const int ry = by0 + rr % nyr, rz = bz0 + rr / nyr, tx = tx0 + tt;
+            const int xa = max(bx0, tx << 3), xb = min(bx1, (tx << 3) + 7);
+            const uint32_t k0 = cell_key(tgt, xa, ry, rz);
+            s[sg] = tgt.cell_start[k0]; e[sg] = tgt.cell_start[k0 + (xb - xa) + 1];
+          }
+        }
 #pragma unroll
-    for (int a = 0; a < 3; a++)
-#pragma unroll
-      for (int b = 0; b < 3; b++) rcr.m[a][b] = CB[a][b] + (RC[a][0] * R[b][0] + RC[a][1] * R[b][1] + RC[a][2] * R[b][2]);
-    const M3 M = m3_inverse(rcr);
-    const double mA[3] = {(double)pa.x, (double)pa.y, (double)pa.z};
-    double tA[3], e[3], Me[3];
-#pragma unroll
-    for (int r = 0; r < 3; r++) tA[r] = T[r][0] * mA[0] + T[r][1] * mA[1] + T[r][2] * mA[2] + T[r][3];
-    e[0] = (double)pb.x - tA[0]; e[1] = (double)pb.y - tA[1]; e[2] = (double)pb.z - tA[2];
-#pragma unroll
-    for (int r = 0; r < 3; r++) Me[r] = M.m[r][0] * e[0] + M.m[r][1] * e[1] + M.m[r][2] * e[2];
-    acc[27] += e[0] * Me[0] + e[1] * Me[1] + e[2] * Me[2];
-    if (phase == 0) {
-      const double J[3][6] = {{0, -tA[2], tA[1], -1, 0, 0}, {tA[2], 0, -tA[0], 0, -1, 0}, {-tA[1], tA[0], 0, 0, 0, -1}};
-      double MJ[3][6];
-#pragma unroll
-      for (int r = 0; r < 3; r++)
-#pragma unroll
-        for (int c = 0; c < 6; c++) MJ[r][c] = M.m[r][0] * J[0][c] + M.m[r][1] * J[1][c] + M.m[r][2] * J[2][c];
-      int t = 0;
-#pragma unroll
-      for (int r = 0; r < 6; r++)
-#pragma unroll
-        for (int c = r; c < 6; c++, t++) acc[t] += J[0][r] * MJ[0][c] + J[1][r] * MJ[1][c] + J[2][r] * MJ[2][c];
-#pragma unroll
-      for (int r = 0; r < 6; r++) acc[21 + r] += J[0][r] * Me[0] + J[1][r] * Me[1] + J[2][r] * Me[2];
+        for (int sg = 0; sg < QN_TRACK_SEG; sg++) {
+          for (uint32_t u = s[sg]; u < e[sg]; u++) {
+            const float4 a = tgt.pts[u];
+            const float da = sqdist(qx, qy, qz, a.x, a.y, a.z);
+            const unsigned long long ka = pack_key(da, __float_as_uint(a.w));
+            if (ka < best) { second = key_d2(best); best = ka; }
+            else if (ka != best && da < second) second = da;
+          }
+        }
+        // distance to the faces of the scanned cell box that have unseen cells behind them
+        float d = INF;
+        if (bx0 > 0) d = fminf(d, qx - (tgt.ox + bx0 * tgt.cell));
+        if (bx1 < tgt.nx - 1) d = fminf(d, (tgt.ox + (bx1 + 1) * tgt.cell) - qx);
+        if (by0 > 0) d = fminf(d, qy - (tgt.oy + by0 * tgt.cell));
+        if (by1 < tgt.ny - 1) d = fminf(d, (tgt.oy + (by1 + 1) * tgt.cell) - qy);
+        if (bz0 > 0) d = fminf(d, qz - (tgt.oz + bz0 * tgt.cell));
+        if (bz1 < tgt.nz - 1) d = fminf(d, (tgt.oz + (bz1 + 1) * tgt.cell) - qz);
+        d_unseen = d - tgt.eps; rescanned = true;
+      }
     }
   }
-  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  if (phase == 0) {
-#pragma unroll
-    for (int t = 0; t < QN_NPART; t++) { double v = wave_sum_f64_dpp(acc[t]); if (lane == 63) red[wid][t] = v; }
-  } else {
-    double v = wave_sum_f64_dpp(acc[27]);
-    if (lane == 63) { for (int t = 0; t < 27; t++) red[wid][t] = 0; red[wid][27] = v; }
+  if (!FUSED) {
+    if (big) {   // list passes, seeded with the bound.  tight seed (the query barely moved since it was scanned) AND far neighbour: one query per wave
+      if (r > 2.5f * tgt.cell && delta < 0.25f * r) { const uint32_t slot = atomicAdd(big_count, 1u); big_list[slot] = make_uint2(t, __float_as_uint(r)); }
+      else { const uint32_t slot = atomicAdd(fb_count, 1u); fb_list[slot] = make_uint2(t, __float_as_uint(r)); }   // r is NaN for a non-finite query: resolved at once
+      return;
+    }
+  } else {       // resolve the wave's big-ball queries here, one after the other, all 64 lanes on each
+    const int lane = threadIdx.x & 63;
+    for (unsigned long long pending = __ballot(big); pending != 0; pending &= pending - 1) {
+      const int L = __ffsll((long long)pending) - 1;
+      const float ax = __shfl(qx, L), ay = __shfl(qy, L), az = __shfl(qz, L), ar = __shfl(r, L), ad = __shfl(delta, L);
+      const float rs = (ad < 0.25f * ar) ? ar * 1.1f + 0.5f * tgt.cell : ar;     // tight seed: scan a little wider (bound pruning next time)
+      unsigned long long key; float sec, du;
+      wave_search_single(tgt, ax, ay, az, rs, INF, key, sec, du, &lds[threadIdx.x >> 6]);
+      if (lane == L) { best = key; second = sec; d_unseen = du; rescanned = true; }
+    }
   }
-  __syncthreads();
-  if (threadIdx.x < QN_NPART) {
-    double s = 0;
+  if (valid) {
+    store_nn<MODE>(best, i, thr2, corr, sqd, nn_idx);
+    if (MODE == 0 && rescanned) nn_ref[i] = make_float4(qx, qy, qz, fminf(sqrtf(second), d_unseen));
+  }
+  if (FUSED) {
+    double R[3][3], T[3][4];
 #pragma unroll
-    for (int w = 0; w < QN_BLOCK / 64; w++) s += red[w][threadIdx.x];
-    partials[(size_t)blockIdx.x * QN_NPART + threadIdx.x] = s;
+    for (int a = 0; a < 3; a++)
+#pragma unroll
+      for (int b = 0; b < 4; b++) { T[a][b] = st->x0[4 * a + b]; if (b < 3) R[a][b] = st->x0[4 * a + b]; }
+    double acc[QN_NPART];
+#pragma unroll
+    for (int u = 0; u < QN_NPART; u++) acc[u] = 0;
+    if (valid && best != QN_INF_KEY && (double)key_d2(best) < thr2) {
+      const uint32_t j = key_idx(best);
+      accumulate_point(R, T, make_float4(p.x, p.y, p.z, 1.f), tgt_raw[j], cov_s + (size_t)i * 6, cov_t + (size_t)j * 6, true, acc);
+    }
+    reduce_block_partials(acc, true, partials, red);
   }
 }
 
