@@ -44,6 +44,7 @@ struct qn_ctx {
   uint32_t* q_hit = nullptr; uint32_t* q_list = nullptr; uint2* q_pairs = nullptr; uint32_t* q_counts = nullptr; double* q_T = nullptr;
   // tuning knobs
   double cell_override = 0.0;
+  float big_ratio = 2.5f;               // first-search leftovers whose next radius exceeds big_ratio * r0 go one-per-wave
   bool fused_ticks = true;              // GN ticks >= 3: tracking + leftovers + accumulation in one kernel
   int knn_lanes_per_query = 4;          // 4: latency-optimal k-NN layout, 1: throughput-optimal (see wave_search)
   int margin_nn = 1, margin_nn_cap = 3, margin_knn = 2, margin_knn_cap = 5, ticks_per_chunk = 8;

@@ -299,14 +299,14 @@ static void enqueue_nn(qn_ctx* c, int mode /*0 align, 1 fitness*/, float* sqd_ou
   if (mode == 0) {
     { ProfScope ps(c, QN_K_NN_SEARCH);
       if (seeded) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_nn_track<0, false>), dim3(nbt), dim3(QN_BLOCK), 0, s, S.grid, T.grid, T.raw, c->state, thr2, c->corr, sqd_out, c->nn_idx, c->nn_ref, c->fb_list, fbc, c->big_list, bgc, nullptr, nullptr, nullptr);
-      else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_nn_search<0, false>), dim3(nb), dim3(QN_BLOCK), 0, s, S.grid, T.grid, c->state, thr2, r0, 1, c->corr, sqd_out, c->nn_idx, c->nn_ref, c->fb_list, fbc, c->big_list, bgc, 0); }
+      else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_nn_search<0, false>), dim3(nb), dim3(QN_BLOCK), 0, s, S.grid, T.grid, c->state, thr2, r0, 1, c->corr, sqd_out, c->nn_idx, c->nn_ref, c->fb_list, fbc, c->big_list, bgc, 0, c->big_ratio); }
     { ProfScope ps(c, QN_K_NN_FALLBACK);
-      hipLaunchKernelGGL(HIP_KERNEL_NAME(k_nn_search<0, true>), dim3(fbb + big_blocks), dim3(QN_BLOCK), 0, s, S.grid, T.grid, c->state, thr2, r0, 64, c->corr, sqd_out, c->nn_idx, c->nn_ref, c->fb_list, fbc, c->big_list, bgc, big_blocks); }
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(k_nn_search<0, true>), dim3(fbb + big_blocks), dim3(QN_BLOCK), 0, s, S.grid, T.grid, c->state, thr2, r0, 64, c->corr, sqd_out, c->nn_idx, c->nn_ref, c->fb_list, fbc, c->big_list, bgc, big_blocks, c->big_ratio); }
   } else {
     ProfScope ps(c, QN_K_FITNESS);
     if (seeded) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_nn_track<1, false>), dim3(nbt), dim3(QN_BLOCK), 0, s, S.grid, T.grid, T.raw, c->state, thr2, c->corr, sqd_out, c->nn_idx, c->nn_ref, c->fb_list, fbc, c->big_list, bgc, nullptr, nullptr, nullptr);
-    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_nn_search<1, false>), dim3(nb), dim3(QN_BLOCK), 0, s, S.grid, T.grid, c->state, thr2, r0, 1, c->corr, sqd_out, c->nn_idx, c->nn_ref, c->fb_list, fbc, c->big_list, bgc, 0);
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_nn_search<1, true>), dim3(fbb + big_blocks), dim3(QN_BLOCK), 0, s, S.grid, T.grid, c->state, thr2, r0, 64, c->corr, sqd_out, c->nn_idx, c->nn_ref, c->fb_list, fbc, c->big_list, bgc, big_blocks);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_nn_search<1, false>), dim3(nb), dim3(QN_BLOCK), 0, s, S.grid, T.grid, c->state, thr2, r0, 1, c->corr, sqd_out, c->nn_idx, c->nn_ref, c->fb_list, fbc, c->big_list, bgc, 0, c->big_ratio);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_nn_search<1, true>), dim3(fbb + big_blocks), dim3(QN_BLOCK), 0, s, S.grid, T.grid, c->state, thr2, r0, 64, c->corr, sqd_out, c->nn_idx, c->nn_ref, c->fb_list, fbc, c->big_list, bgc, big_blocks, c->big_ratio);
   }
 }
 static uint32_t acc_blocks(const qn_ctx* c) { return std::min<uint32_t>((c->cloud[0].n + QN_BLOCK - 1) / QN_BLOCK, QN_ACC_MAX_BLOCKS); }
@@ -552,6 +552,7 @@ extern "C" int qn_debug_set(qn_ctx* c, const char* key, double v) {
   else if (k == "margin_knn") c->margin_knn = (int)v;
   else if (k == "knn_lanes_per_query") c->knn_lanes_per_query = v == 1 ? 1 : 4;
   else if (k == "fused_ticks") c->fused_ticks = v != 0;
+  else if (k == "big_ratio") c->big_ratio = (float)v;
   else if (k == "margin_nn_cap") c->margin_nn_cap = (int)v;
   else if (k == "margin_knn_cap") c->margin_knn_cap = (int)v;
   else if (k == "dbg_counters") {

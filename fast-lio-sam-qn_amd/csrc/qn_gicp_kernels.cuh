@@ -222,7 +222,7 @@ template <int MODE, bool LIST>
 __global__ void __launch_bounds__(QN_BLOCK) k_nn_search(GridView src, GridView tgt, const GicpState* __restrict__ st, double thr2, float r0, int max_rounds,
                                                         int32_t* __restrict__ corr, float* __restrict__ sqd, int32_t* __restrict__ nn_idx, float4* __restrict__ nn_ref,
                                                         uint2* __restrict__ fb_list, uint32_t* __restrict__ fb_count,
-                                                        uint2* __restrict__ big_list, uint32_t* __restrict__ big_count, int big_blocks) {
+                                                        uint2* __restrict__ big_list, uint32_t* __restrict__ big_count, int big_blocks, float big_ratio) {
   __shared__ WaveLds lds[QN_BLOCK / 64];
   if (MODE == 0 && st->phase != 0) return;
   if (MODE == 1 && st->phase != 2) return;
@@ -273,7 +273,7 @@ __global__ void __launch_bounds__(QN_BLOCK) k_nn_search(GridView src, GridView t
       // bound-pruning reference: where this query was scanned and how far away every other point is at least
       if (MODE == 0) nn_ref[__float_as_uint(p.w)] = make_float4(qx, qy, qz, fminf(sqrtf(sink.second), d_unseen));
     }
-    else if (r > 2.5f * r0) { const uint32_t fs = atomicAdd(big_count, 1u); big_list[fs] = make_uint2(t, __float_as_uint(-r)); }   // far: one query per wave
+    else if (r > big_ratio * r0) { const uint32_t fs = atomicAdd(big_count, 1u); big_list[fs] = make_uint2(t, __float_as_uint(-r)); }   // far: one query per wave
     else { const uint32_t fs = atomicAdd(fb_count, 1u); fb_list[fs] = make_uint2(t, __float_as_uint(-r)); }                         // continue from r
   }
 }

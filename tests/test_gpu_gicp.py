@@ -226,3 +226,44 @@ def test_deterministic_rerun(eng):
     src, tgt, _ = synth.make_pair(67, 6000, extent=45.0)
     a = engine.icp_alignment(ctx, src, tgt); b = engine.icp_alignment(ctx, src, tgt)
     assert np.array_equal(a["T"], b["T"]) and a["score"] == b["score"]
+
+
+def test_ragged_sizes_and_far_from_origin(eng, oracle):
+    """ns != nt, and map-frame coordinates kilometres from the origin (f32 cell arithmetic under stress)."""
+    engine, ctx = eng
+    src, _, _ = synth.make_pair(80, 3000, extent=40.0)
+    _, tgt, _ = synth.make_pair(80, 9000, extent=40.0)
+    for off in (np.zeros(3), np.array([5231.5, -8120.25, 312.0])):
+        s = (src.astype(np.float64) + off).astype(np.float32); t = (tgt.astype(np.float64) + off).astype(np.float32)
+        g, r, o, ro = _align_both(engine, ctx, oracle, s, t)
+        _check_parity(r, ro)
+        H, b, e, corr, sqd = g.linearize(np.eye(4)); Ho, bo, eo, co, so = o.linearize(np.eye(4))
+        assert np.array_equal(corr, co) and np.array_equal(sqd, so)
+
+
+def test_tiny_clouds_and_k_larger_than_cloud(eng, oracle):
+    engine, ctx = eng
+    rng = np.random.default_rng(9)
+    src = rng.uniform(-2, 2, size=(11, 3)).astype(np.float32)
+    tgt = (src + rng.normal(0, 0.01, src.shape) + [0.05, 0.02, 0.0]).astype(np.float32)
+    g = engine.NanoGICP(ctx); g.setCorrespondenceRandomness(15)
+    g.setInputSource(src); g.calculateSourceCovariances(); g.setInputTarget(tgt); g.calculateTargetCovariances()
+    o = oracle.GicpOracle(k=15); o.set_source(src); o.compute_covariances(0); o.set_target(tgt); o.compute_covariances(1)
+    assert np.abs(g.covariances(0) - o.covariances(0)).max() < 1e-9        # k > n: all n points are the neighbourhood
+    H, b, e, corr, sqd = g.linearize(np.eye(4)); Ho, bo, eo, co, so = o.linearize(np.eye(4))
+    assert np.array_equal(corr, co) and np.array_equal(sqd, so) and np.allclose(H, Ho, rtol=1e-9)
+    assert g.align() is not None                                           # never a crash, whatever it converges to
+
+
+def test_lm_path_with_rejections(eng, oracle):
+    """A bad initial guess makes LM reject steps (inner tries > 1): the device controller must follow the same branches."""
+    engine, ctx = eng
+    src, tgt, T = synth.make_pair(81, 5000, extent=45.0)
+    guess = np.eye(4, dtype=np.float32); guess[:3, 3] = [3.0, -2.5, 0.4]
+    g = engine.NanoGICP(ctx); g.setCorrespondenceRandomness(15); g.setMaximumIterations(32); g.setMaxCorrespondenceDistance(52.5); g.setTransformationEpsilon(0.01)
+    g.setInputSource(src); g.calculateSourceCovariances(); g.setInputTarget(tgt); g.calculateTargetCovariances()
+    g.align(guess); r = g.result_dict()
+    o = oracle.GicpOracle(k=15, max_iter=32, max_corr_dist=52.5, trans_eps=0.01)
+    o.set_source(src); o.compute_covariances(0); o.set_target(tgt); o.compute_covariances(1)
+    ro = o.align(guess.astype(np.float64))
+    _check_parity(r, ro)
