@@ -47,7 +47,8 @@ struct qn_ctx {
   float big_ratio = 2.5f;               // first-search leftovers whose next radius exceeds big_ratio * r0 go one-per-wave
   bool fused_ticks = true;              // GN ticks >= 3: tracking + leftovers + accumulation in one kernel
   int knn_lanes_per_query = 4;          // 4: latency-optimal k-NN layout, 1: throughput-optimal (see wave_search)
-  int margin_nn = 1, margin_nn_cap = 3, margin_knn = 2, margin_knn_cap = 5, ticks_per_chunk = 8;
+  float margin_nn = 1.f, margin_knn = 2.f;   // first search radius in cells (1-NN of the first tick / k-NN of the covariances)
+  int margin_nn_cap = 3, margin_knn_cap = 5, ticks_per_chunk = 8;
   uint32_t* dbg_counters = nullptr;
   // profiling
   bool prof_on = false;

@@ -150,11 +150,12 @@ struct Best1 {                         // 1-NN, plus the squared distance of the
   __device__ __forceinline__ void finish(bool on) {                   // combine the S candidate sub-slots of a query
     if (S == 1) return;
     unsigned long long b = key, t;
-    t = __shfl_xor(b, 16); b = t < b ? t : b;
+    if (S == 4) { t = __shfl_xor(b, 16); b = t < b ? t : b; }
     t = __shfl_xor(b, 32); b = t < b ? t : b;
     float c = (key == b) ? second : key_d2(key);                      // this sub-slot's best runner-up candidate
     if (key == QN_INF_KEY) c = __int_as_float(0x7f800000);
-    c = fminf(c, __shfl_xor(c, 16)); c = fminf(c, __shfl_xor(c, 32));
+    if (S == 4) c = fminf(c, __shfl_xor(c, 16));
+    c = fminf(c, __shfl_xor(c, 32));
     if (on) { key = b; second = c; }
   }
   __device__ __forceinline__ void reset() { key = QN_INF_KEY; second = __int_as_float(0x7f800000); }
@@ -225,10 +226,10 @@ struct BestK {
     if (__any(cnt > 0)) flush();
     if (S == 1) return;
     const int lane = threadIdx.x & 63;
-    merge_from(32, on && (lane & 32) == 0);        // sub 0 <- 2, sub 1 <- 3
-    merge_from(16, on && (lane & 48) == 0);        // sub 0 <- 1
+    merge_from(32, on && (lane & 32) == 0);        // sub 0 <- 2, sub 1 <- 3   (S = 2: sub 0 <- 1)
+    if (S == 4) merge_from(16, on && (lane & 48) == 0);        // sub 0 <- 1
     refresh();
-    const unsigned long long w0 = __shfl(w, lane & 15);
+    const unsigned long long w0 = __shfl(w, lane & (64 / S - 1));
     if (on) w = w0;                                // every lane of the query sees the merged k-th best
   }
   __device__ __forceinline__ bool full() const { return w != QN_INF_KEY; }

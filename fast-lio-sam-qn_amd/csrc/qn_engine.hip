@@ -254,10 +254,13 @@ static void launch_knn_cov(qn_ctx* c, CloudBuf& b, int k, int32_t* kidx, float* 
   hipStream_t s = c->stream;
   const float r0 = c->margin_knn * b.grid.cell;
   ProfScope ps(c, QN_K_KNN_COV);
-  if (c->knn_lanes_per_query == 1) {        // one query per lane: fewest wave-instructions per query (throughput)
+  if (c->knn_lanes_per_query == 1) {        // one query per lane: fewest wave-instructions per query
     const uint32_t nb = (b.n + QN_BLOCK - 1) / QN_BLOCK;
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_knn_cov<KMAX, false, 1>), dim3(nb), dim3(QN_BLOCK), 0, s, b.grid, b.raw, k, r0, 2, b.cov, kidx, kd2, c->fb_list, c->fb_count2);
-  } else {                                  // 16 queries per wave x 4 candidate sub-slots: shortest critical path (latency)
+  } else if (c->knn_lanes_per_query == 2) { // 32 queries per wave x 2 candidate sub-slots
+    const uint32_t nb = (b.n + QN_BLOCK / 2 - 1) / (QN_BLOCK / 2);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_knn_cov<KMAX, false, 2>), dim3(nb), dim3(QN_BLOCK), 0, s, b.grid, b.raw, k, r0, 2, b.cov, kidx, kd2, c->fb_list, c->fb_count2);
+  } else {                                  // 16 queries per wave x 4 candidate sub-slots: shortest critical path
     const uint32_t nb = (b.n + QN_BLOCK / 4 - 1) / (QN_BLOCK / 4);
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_knn_cov<KMAX, false, 4>), dim3(nb), dim3(QN_BLOCK), 0, s, b.grid, b.raw, k, r0, 2, b.cov, kidx, kd2, c->fb_list, c->fb_count2);
   }
@@ -548,9 +551,9 @@ extern "C" int qn_debug_set(qn_ctx* c, const char* key, double v) {
   if (!c || !key) return QN_ERR_INVALID_ARG;
   std::string k(key);
   if (k == "cell") { c->cell_override = v; c->cloud[0].has_grid = c->cloud[1].has_grid = false; }
-  else if (k == "margin_nn") c->margin_nn = (int)v;
-  else if (k == "margin_knn") c->margin_knn = (int)v;
-  else if (k == "knn_lanes_per_query") c->knn_lanes_per_query = v == 1 ? 1 : 4;
+  else if (k == "margin_nn") c->margin_nn = (float)v;
+  else if (k == "margin_knn") c->margin_knn = (float)v;
+  else if (k == "knn_lanes_per_query") c->knn_lanes_per_query = v == 1 ? 1 : (v == 2 ? 2 : 4);
   else if (k == "fused_ticks") c->fused_ticks = v != 0;
   else if (k == "big_ratio") c->big_ratio = (float)v;
   else if (k == "margin_nn_cap") c->margin_nn_cap = (int)v;
