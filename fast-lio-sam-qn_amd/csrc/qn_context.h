@@ -31,7 +31,7 @@ struct qn_ctx {
   qn::GicpState* state = nullptr;
   double* partials = nullptr; double* fit_psum = nullptr; uint32_t* fit_pcnt = nullptr;
   qn_iter_trace* trace = nullptr; uint32_t trace_len = 0;
-  int32_t* corr = nullptr; int32_t* nn_idx = nullptr; int32_t* knn_idx = nullptr; float4* nn_ref = nullptr; float* sqd = nullptr; float* sqd_fit = nullptr;
+  int32_t* corr = nullptr; int32_t* nn_idx = nullptr; int32_t* knn_idx = nullptr; float4* nn_ref = nullptr; double* cov_s_sorted = nullptr; qn::TargetRec* tgt_rec = nullptr; float* sqd = nullptr; float* sqd_fit = nullptr;
   uint2* fb_list = nullptr; uint2* big_list = nullptr; uint32_t* fb_count2 = nullptr;
   float4* aligned = nullptr; bool aligned_valid = false;
   double* pose_tmp = nullptr; float* guess_tmp = nullptr;
@@ -46,6 +46,8 @@ struct qn_ctx {
   double cell_override = 0.0;
   float big_ratio = 2.5f;               // first-search leftovers whose next radius exceeds big_ratio * r0 go one-per-wave
   bool fused_ticks = true;              // GN ticks >= 3: tracking + leftovers + accumulation in one kernel
+  int knn_rounds = 2;                   // rounds of the first k-NN pass before a query goes to the list pass
+  int knn_hist = 1;                     // 1: k-NN by histogram selection (wave_knn_hist), 0: sorted-list sink (wave_search + BestK)
   int knn_lanes_per_query = 4;          // 4: latency-optimal k-NN layout, 1: throughput-optimal (see wave_search)
   float margin_nn = 1.f, margin_knn = 2.f;   // first search radius in cells (1-NN of the first tick / k-NN of the covariances)
   int margin_nn_cap = 3, margin_knn_cap = 5, ticks_per_chunk = 8;

@@ -281,6 +281,117 @@ __device__ __forceinline__ uint32_t stream_box(const GridView& g, int x0, int x1
 #define QN_CL_DY 4
 #define QN_CL_DZ 4
 
+// Steps (1)-(3) of a search round.  The queries of the `todo` lanes are grouped into clusters by anchor proximity, each
+// cluster's cell box (union of its members' ball boxes) is left in lds->box[cluster], and the boxes are cut into
+// segments (runs of pts[]): lds->cl_seg0 / cl_tile_mode.  cid = this lane's cluster, ncl = clusters, nseg_all = segments.
+template <int S>
+__device__ __forceinline__ void build_clusters(const GridView& g, WaveLds* lds, unsigned long long todo, int cx, int cy, int cz,
+                                               float qx, float qy, float qz, float r, uint32_t& cid, int& ncl, uint32_t& nseg_all) {
+  const int lane = threadIdx.x & 63;
+  const bool mine = (todo >> lane) & 1ull;
+  // (1) cluster ids
+  cid = 0xffffffffu; ncl = 0;
+  for (unsigned long long rem = todo; rem != 0; ncl++) {
+    const int leader = __ffsll((long long)rem) - 1;
+    const int ax = rfl(__shfl(cx, leader)), ay = rfl(__shfl(cy, leader)), az = rfl(__shfl(cz, leader));
+    const bool in = ((rem >> lane) & 1ull) && abs(cx - ax) <= QN_CL_DX && abs(cy - ay) <= QN_CL_DY && abs(cz - az) <= QN_CL_DZ;
+    if (in) cid = ncl;
+    rem &= ~__ballot(in);
+  }
+  // (2) cluster boxes = union of the member queries' ball boxes
+  wave_lds_fence();
+  if (lane < ncl) { lds->box[lane][0] = 0x3fffffff; lds->box[lane][1] = -1; lds->box[lane][2] = 0x3fffffff; lds->box[lane][3] = -1; lds->box[lane][4] = 0x3fffffff; lds->box[lane][5] = -1; }
+  wave_lds_fence();
+  if (mine && lane < 64 / S) {
+    atomicMin(&lds->box[cid][0], cell_coord(qx - r, g.ox, g.inv_cell, g.nx)); atomicMax(&lds->box[cid][1], cell_coord(qx + r, g.ox, g.inv_cell, g.nx));
+    atomicMin(&lds->box[cid][2], cell_coord(qy - r, g.oy, g.inv_cell, g.ny)); atomicMax(&lds->box[cid][3], cell_coord(qy + r, g.oy, g.inv_cell, g.ny));
+    atomicMin(&lds->box[cid][4], cell_coord(qz - r, g.oz, g.inv_cell, g.nz)); atomicMax(&lds->box[cid][5], cell_coord(qz + r, g.oz, g.inv_cell, g.nz));
+  }
+  wave_lds_fence();
+  // (3) segments per cluster, prefix over clusters
+  // A box with many (y, z) rows is mostly empty space around a surface: enumerate it TILE by tile
+  // instead (a tile's 128 cells are one contiguous run of pts[]), which needs far fewer cell_start
+  // look-ups; the box is widened to whole tiles, so certification sees the larger scanned volume.
+  uint32_t my_nseg = 0;
+  if (lane < ncl) {
+    int* b = lds->box[lane];
+    my_nseg = (uint32_t)(((b[1] >> 3) - (b[0] >> 3) + 1) * (b[3] - b[2] + 1) * (b[5] - b[4] + 1));
+    uint32_t tm = 0;
+    if (my_nseg > 384) {
+      tm = 1;
+      b[0] = (b[0] >> 3) << 3; b[1] = min(((b[1] >> 3) << 3) + 7, g.nx - 1);
+      b[2] = (b[2] >> 2) << 2; b[3] = min(((b[3] >> 2) << 2) + 3, g.ny - 1);
+      b[4] = (b[4] >> 2) << 2; b[5] = min(((b[5] >> 2) << 2) + 3, g.nz - 1);
+      my_nseg = (uint32_t)(((b[1] >> 3) - (b[0] >> 3) + 1) * ((b[3] >> 2) - (b[2] >> 2) + 1) * ((b[5] >> 2) - (b[4] >> 2) + 1));
+    }
+    lds->cl_tile_mode[lane] = tm;
+  }
+  const uint32_t seg_incl = wave_incl_scan_u32(my_nseg, lane);
+  nseg_all = rflu(__shfl(seg_incl, 63));
+  lds->cl_seg0[lane] = seg_incl - my_nseg;
+  if (lane == 0) lds->cl_seg0[64] = nseg_all;
+  wave_lds_fence();
+}
+
+// Step (4): the points of all cluster boxes as one dense candidate stream.  fn(cp, in_tile, ccid) is called once per
+// step by all 64 lanes; the S sub-slots see S consecutive candidates (cp = point, .w = original index bits; in_tile =
+// the slot holds a real candidate; ccid = the cluster whose box the candidate came from).  Returns the stream length.
+template <int S, class Fn>
+__device__ __forceinline__ uint32_t stream_clusters(const GridView& g, WaveLds* lds, int ncl, uint32_t nseg_all, Fn&& fn) {
+  const int lane = threadIdx.x & 63;
+  uint32_t ncand = 0;
+  for (uint32_t sb = 0; sb < nseg_all; sb += 64) {
+    const uint32_t sidx = sb + lane;
+    uint32_t s = 0, len = 0, scid = 0;
+    if (sidx < nseg_all) {
+      int c = 0;                                   // last cluster with cl_seg0[c] <= sidx  (ncl <= 64)
+#pragma unroll
+      for (int step = 32; step > 0; step >>= 1) { const int t = c + step; if (t < ncl && lds->cl_seg0[t] <= sidx) c = t; }
+      const int* b = lds->box[c];
+      const int x0 = b[0], x1 = b[1], y0 = b[2], y1 = b[3], z0 = b[4];
+      const int tx0 = x0 >> 3, ntr = (x1 >> 3) - tx0 + 1;
+      const int li = (int)(sidx - lds->cl_seg0[c]);
+      const int t = li % ntr, rr = li / ntr;
+      if (lds->cl_tile_mode[c]) {                  // segment = one whole tile
+        const int ty0 = y0 >> 2, ntyr = (y1 >> 2) - ty0 + 1;
+        const uint32_t tile = ((uint32_t)((z0 >> 2) + rr / ntyr) * g.nty + (ty0 + rr % ntyr)) * g.ntx + (tx0 + t);
+        s = g.cell_start[tile << 7]; len = g.cell_start[(tile + 1) << 7] - s;
+      } else {                                     // segment = cells [xa..xb] of row (ry, rz) inside tile tx
+        const int nyr = y1 - y0 + 1;
+        const int ry = y0 + rr % nyr, rz = z0 + rr / nyr, tx = tx0 + t;
+        const int xa = max(x0, tx << 3), xb = min(x1, (tx << 3) + 7);
+        const uint32_t k0 = cell_key(g, xa, ry, rz);
+        s = g.cell_start[k0]; len = g.cell_start[k0 + (xb - xa) + 1] - s;
+      }
+      scid = (uint32_t)c;
+    }
+    const uint32_t incl = wave_incl_scan_u32(len, lane);
+    const uint32_t total = rflu(__shfl(incl, 63));
+    if (total == 0) continue;
+    wave_lds_fence();
+    lds->seg_excl[lane] = incl - len; lds->seg_start[lane] = s; lds->seg_cid[lane] = scid;
+    wave_lds_fence();
+    for (uint32_t cb = 0; cb < total; cb += 64) {
+      const uint32_t slot = cb + lane;
+      int j = 0;
+#pragma unroll
+      for (int step = 32; step > 0; step >>= 1) { const int t = j + step; if (t < 64 && lds->seg_excl[t] <= slot) j = t; }
+      const uint32_t cnt = min(64u, total - cb);
+      wave_lds_fence();
+      if (slot < total) { lds->tile[lane] = g.pts[lds->seg_start[j] + (slot - lds->seg_excl[j])]; lds->tile_cid[lane] = lds->seg_cid[j]; }
+      wave_lds_fence();
+#pragma unroll 2
+      for (uint32_t c = 0; c < cnt; c += S) {                               // S candidates per step: one per sub-slot
+        const uint32_t ci = c + (uint32_t)(S == 1 ? 0 : lane / (64 / S));
+        const float4 cp = lds->tile[ci & 63];                               // ds_read_b128, S distinct addresses per wave
+        fn(cp, ci < cnt, lds->tile_cid[ci & 63]);
+      }
+    }
+    ncand += total;
+  }
+  return ncand;
+}
+
 // wave_search: the ONE cooperative search routine (1-NN and k-NN, first search and seeded re-search).
 //
 // A wavefront serves 64 / S QUERIES (S = 4: lane l works for query (l & 15) as candidate sub-slot (l >> 4), i.e. the
@@ -312,100 +423,11 @@ __device__ __forceinline__ bool wave_search(const GridView& g, float qx, float q
   unsigned long long todo = __ballot(active);
   for (int round = 0; todo != 0 && round < max_rounds; round++) {
     const bool mine = (todo >> lane) & 1ull;
-    // (1) cluster ids
-    uint32_t cid = 0xffffffffu; int ncl = 0;
-    for (unsigned long long rem = todo; rem != 0; ncl++) {
-      const int leader = __ffsll((long long)rem) - 1;
-      const int ax = rfl(__shfl(cx, leader)), ay = rfl(__shfl(cy, leader)), az = rfl(__shfl(cz, leader));
-      const bool in = ((rem >> lane) & 1ull) && abs(cx - ax) <= QN_CL_DX && abs(cy - ay) <= QN_CL_DY && abs(cz - az) <= QN_CL_DZ;
-      if (in) cid = ncl;
-      rem &= ~__ballot(in);
-    }
-    // (2) cluster boxes = union of the member queries' ball boxes
-    wave_lds_fence();
-    if (lane < ncl) { lds->box[lane][0] = 0x3fffffff; lds->box[lane][1] = -1; lds->box[lane][2] = 0x3fffffff; lds->box[lane][3] = -1; lds->box[lane][4] = 0x3fffffff; lds->box[lane][5] = -1; }
-    wave_lds_fence();
-    if (mine && lane < 64 / S) {
-      atomicMin(&lds->box[cid][0], cell_coord(qx - r, g.ox, g.inv_cell, g.nx)); atomicMax(&lds->box[cid][1], cell_coord(qx + r, g.ox, g.inv_cell, g.nx));
-      atomicMin(&lds->box[cid][2], cell_coord(qy - r, g.oy, g.inv_cell, g.ny)); atomicMax(&lds->box[cid][3], cell_coord(qy + r, g.oy, g.inv_cell, g.ny));
-      atomicMin(&lds->box[cid][4], cell_coord(qz - r, g.oz, g.inv_cell, g.nz)); atomicMax(&lds->box[cid][5], cell_coord(qz + r, g.oz, g.inv_cell, g.nz));
-    }
-    wave_lds_fence();
-    // (3) segments per cluster, prefix over clusters
-    // A box with many (y, z) rows is mostly empty space around a surface: enumerate it TILE by tile
-    // instead (a tile's 128 cells are one contiguous run of pts[]), which needs far fewer cell_start
-    // look-ups; the box is widened to whole tiles, so certification sees the larger scanned volume.
-    uint32_t my_nseg = 0;
-    if (lane < ncl) {
-      int* b = lds->box[lane];
-      my_nseg = (uint32_t)(((b[1] >> 3) - (b[0] >> 3) + 1) * (b[3] - b[2] + 1) * (b[5] - b[4] + 1));
-      uint32_t tm = 0;
-      if (my_nseg > 384) {
-        tm = 1;
-        b[0] = (b[0] >> 3) << 3; b[1] = min(((b[1] >> 3) << 3) + 7, g.nx - 1);
-        b[2] = (b[2] >> 2) << 2; b[3] = min(((b[3] >> 2) << 2) + 3, g.ny - 1);
-        b[4] = (b[4] >> 2) << 2; b[5] = min(((b[5] >> 2) << 2) + 3, g.nz - 1);
-        my_nseg = (uint32_t)(((b[1] >> 3) - (b[0] >> 3) + 1) * ((b[3] >> 2) - (b[2] >> 2) + 1) * ((b[5] >> 2) - (b[4] >> 2) + 1));
-      }
-      lds->cl_tile_mode[lane] = tm;
-    }
-    const uint32_t seg_incl = wave_incl_scan_u32(my_nseg, lane);
-    const uint32_t nseg_all = rflu(__shfl(seg_incl, 63));
-    lds->cl_seg0[lane] = seg_incl - my_nseg;
-    if (lane == 0) lds->cl_seg0[64] = nseg_all;
-    wave_lds_fence();
-    uint32_t ncand = 0;
-    for (uint32_t sb = 0; sb < nseg_all; sb += 64) {
-      const uint32_t sidx = sb + lane;
-      uint32_t s = 0, len = 0, scid = 0;
-      if (sidx < nseg_all) {
-        int c = 0;                                   // last cluster with cl_seg0[c] <= sidx  (ncl <= 64)
-#pragma unroll
-        for (int step = 32; step > 0; step >>= 1) { const int t = c + step; if (t < ncl && lds->cl_seg0[t] <= sidx) c = t; }
-        const int* b = lds->box[c];
-        const int x0 = b[0], x1 = b[1], y0 = b[2], y1 = b[3], z0 = b[4];
-        const int tx0 = x0 >> 3, ntr = (x1 >> 3) - tx0 + 1;
-        const int li = (int)(sidx - lds->cl_seg0[c]);
-        const int t = li % ntr, rr = li / ntr;
-        if (lds->cl_tile_mode[c]) {                  // segment = one whole tile
-          const int ty0 = y0 >> 2, ntyr = (y1 >> 2) - ty0 + 1;
-          const uint32_t tile = ((uint32_t)((z0 >> 2) + rr / ntyr) * g.nty + (ty0 + rr % ntyr)) * g.ntx + (tx0 + t);
-          s = g.cell_start[tile << 7]; len = g.cell_start[(tile + 1) << 7] - s;
-        } else {                                     // segment = cells [xa..xb] of row (ry, rz) inside tile tx
-          const int nyr = y1 - y0 + 1;
-          const int ry = y0 + rr % nyr, rz = z0 + rr / nyr, tx = tx0 + t;
-          const int xa = max(x0, tx << 3), xb = min(x1, (tx << 3) + 7);
-          const uint32_t k0 = cell_key(g, xa, ry, rz);
-          s = g.cell_start[k0]; len = g.cell_start[k0 + (xb - xa) + 1] - s;
-        }
-        scid = (uint32_t)c;
-      }
-      const uint32_t incl = wave_incl_scan_u32(len, lane);
-      const uint32_t total = rflu(__shfl(incl, 63));
-      if (total == 0) continue;
-      wave_lds_fence();
-      lds->seg_excl[lane] = incl - len; lds->seg_start[lane] = s; lds->seg_cid[lane] = scid;
-      wave_lds_fence();
-      // (4) dense candidate stream of this segment batch
-      for (uint32_t cb = 0; cb < total; cb += 64) {
-        const uint32_t slot = cb + lane;
-        int j = 0;
-#pragma unroll
-        for (int step = 32; step > 0; step >>= 1) { const int t = j + step; if (t < 64 && lds->seg_excl[t] <= slot) j = t; }
-        const uint32_t cnt = min(64u, total - cb);
-        wave_lds_fence();
-        if (slot < total) { lds->tile[lane] = g.pts[lds->seg_start[j] + (slot - lds->seg_excl[j])]; lds->tile_cid[lane] = lds->seg_cid[j]; }
-        wave_lds_fence();
-#pragma unroll 2
-        for (uint32_t c = 0; c < cnt; c += S) {                               // S candidates per step: one per sub-slot
-          const uint32_t ci = c + (uint32_t)(S == 1 ? 0 : lane / (64 / S));
-          const float4 cp = lds->tile[ci & 63];                               // ds_read_b128, S distinct addresses per wave
-          const bool on = mine && ci < cnt && lds->tile_cid[ci & 63] == cid;
-          sink.consider(on, sqdist(qx, qy, qz, cp.x, cp.y, cp.z), __float_as_uint(cp.w));
-        }
-      }
-      ncand += total;
-    }
+    uint32_t cid; int ncl; uint32_t nseg_all;
+    build_clusters<S>(g, lds, todo, cx, cy, cz, qx, qy, qz, r, cid, ncl, nseg_all);
+    const uint32_t ncand = stream_clusters<S>(g, lds, ncl, nseg_all, [&](const float4& cp, bool in_tile, uint32_t ccid) __attribute__((always_inline)) {
+      sink.consider(mine && in_tile && ccid == cid, sqdist(qx, qy, qz, cp.x, cp.y, cp.z), __float_as_uint(cp.w));
+    });
     sink.template finish<S>(mine);
     if (g.dbg && lane == 0) { atomicAdd(&g.dbg[0], (uint32_t)ncl); atomicAdd(&g.dbg[1], ncand); }
     // certification: nearest face of the scanned box that has unseen cells behind it
@@ -433,6 +455,145 @@ __device__ __forceinline__ bool wave_search(const GridView& g, float qx, float q
     if (g.dbg && lane == 0 && todo) atomicAdd(&g.dbg[3], (uint32_t)__popcll(todo));
   }
   return certified;
+}
+
+// ------------------------------------------------------------------ k-NN by histogram selection
+// The k-NN stage is VALU-bound: keeping a sorted k-list per lane costs ~100 instructions per inserted candidate.
+// wave_knn_hist instead walks the candidate stream TWICE (16 queries x 4 candidate sub-slots per wave, same clusters
+// and stream as wave_search):
+//   pass 1  histogram of the squared distances per query in LDS, bins = the top 11 bits of the f32 pattern
+//           (8 bins per octave), 62 regular bins below (2 r)^2, one underflow bin;
+//   tau     the upper edge of the first bin whose cumulative count reaches k: at least k and typically k + 1..3
+//           candidates lie below it, and the k nearest are certainly among them;
+//   pass 2  the candidates below tau are appended to a short per-query list in LDS (<= QN_HCAP);
+//   rank    each list entry's rank = number of smaller (d2, idx) keys in the list; rank < k -> output slot `rank`.
+// Exact: the output is the k smallest keys of the scanned box in ascending (d2, idx) order, certified against the
+// nearest unseen box face exactly as in wave_search.  Queries this scheme does not cover (fewer than k points within
+// 2 r although the whole grid was scanned, more than QN_HCAP candidates below tau, non-finite) return status 2 and
+// go to the general sorted-list path (wave_search + BestK).
+#define QN_HB 64
+#define QN_HCAP 48
+struct WaveLdsH {
+  WaveLds s;
+  union {
+    uint32_t hist[16][QN_HB + 1];                 // +1: the 16 queries' rows start in different banks
+    unsigned long long list[16][QN_HCAP + 1];
+  } u;
+  uint32_t cnt[16];
+  uint32_t kth[16];
+};
+
+// All 64 lanes call; lane l serves query (l & 15) as sub-slot (l >> 4); the 4 lanes of a query pass identical q, r,
+// out pointers.  Returns the query's status in all of its lanes: 0 = done (k indices written, ascending),
+// 1 = not certified within max_rounds (continue from the returned r), 2 = needs the general path.
+__device__ __forceinline__ int wave_knn_hist(const GridView& g, float qx, float qy, float qz, bool active, float& r, int k, int max_rounds,
+                                             WaveLdsH* L, int32_t* __restrict__ idx_out, float* __restrict__ d2_out) {
+  const int lane = threadIdx.x & 63, qs = lane & 15, sub = lane >> 4;
+  WaveLds* lds = &L->s;
+  const int cx = cell_coord(qx, g.ox, g.inv_cell, g.nx);
+  const int cy = cell_coord(qy, g.oy, g.inv_cell, g.ny);
+  const int cz = cell_coord(qz, g.oz, g.inv_cell, g.nz);
+  const float INF = __int_as_float(0x7f800000);
+  int status = active ? 1 : 0;
+  unsigned long long todo = __ballot(active);
+  for (int round = 0; todo != 0 && round < max_rounds; round++) {
+    const bool mine = (todo >> lane) & 1ull;
+    uint32_t cid; int ncl; uint32_t nseg_all;
+    build_clusters<4>(g, lds, todo, cx, cy, cz, qx, qy, qz, r, cid, ncl, nseg_all);
+    // ---- pass 1: histogram
+    { uint32_t* hz = &L->u.hist[0][0];
+      for (int e = lane; e < 16 * (QN_HB + 1); e += 64) hz[e] = 0; }
+    wave_lds_fence();
+    const int base = (int)(__float_as_uint(4.f * r * r) >> 20) - (QN_HB - 2);      // bin QN_HB-2 ends at (2 r)^2, bin QN_HB-1 = beyond (not counted)
+    const uint32_t ncand = stream_clusters<4>(g, lds, ncl, nseg_all, [&](const float4& cp, bool in_tile, uint32_t ccid) __attribute__((always_inline)) {
+      const uint32_t bits = __float_as_uint(sqdist(qx, qy, qz, cp.x, cp.y, cp.z));
+      const int bin = max((int)(bits >> 20) - base, 0);
+      if (mine && in_tile && ccid == cid && bin < QN_HB - 1) atomicAdd(&L->u.hist[qs][bin], 1u);
+    });
+    wave_lds_fence();
+    // ---- tau: sub-slot s sums bins [16 s, 16 s + 16), then looks for the crossing in its own range
+    uint32_t hv[16], mysum = 0;
+#pragma unroll
+    for (int j = 0; j < 16; j++) { hv[j] = L->u.hist[qs][sub * 16 + j]; mysum += hv[j]; }
+    const uint32_t s0 = __shfl(mysum, qs), s1 = __shfl(mysum, qs + 16), s2 = __shfl(mysum, qs + 32), s3 = __shfl(mysum, qs + 48);
+    uint32_t run = (sub > 0 ? s0 : 0u) + (sub > 1 ? s1 : 0u) + (sub > 2 ? s2 : 0u);
+    const bool enough = s0 + s1 + s2 + s3 >= (uint32_t)k;
+    int cross = 1 << 20;
+#pragma unroll
+    for (int j = 0; j < 16; j++) { run += hv[j]; if (cross == (1 << 20) && run >= (uint32_t)k) cross = sub * 16 + j; }
+    cross = min(cross, __shfl_xor(cross, 16)); cross = min(cross, __shfl_xor(cross, 32));
+    const uint32_t tau_bits = (uint32_t)(base + cross + 1) << 20;                  // d2 bit patterns below this pass
+    wave_lds_fence();                                                               // hist is dead: the list shares its storage
+    if (lane < 16) { L->cnt[lane] = 0; L->kth[lane] = 0x7f800000u; }
+    wave_lds_fence();
+    // ---- pass 2: collect the candidates below tau
+    const bool collect = mine && enough;
+    stream_clusters<4>(g, lds, ncl, nseg_all, [&](const float4& cp, bool in_tile, uint32_t ccid) __attribute__((always_inline)) {
+      const float d2 = sqdist(qx, qy, qz, cp.x, cp.y, cp.z);
+      if (collect && in_tile && ccid == cid && __float_as_uint(d2) < tau_bits) {
+        const uint32_t pos = atomicAdd(&L->cnt[qs], 1u);
+        if (pos < QN_HCAP) L->u.list[qs][pos] = pack_key(d2, __float_as_uint(cp.w));
+      }
+    });
+    wave_lds_fence();
+    const uint32_t P = L->cnt[qs];
+    const bool ok = collect && P <= QN_HCAP;                                        // (P >= k by construction)
+    // ---- rank: own entries sub, sub + 4, ...; every entry of the query's list is compared against them
+    const int maxP = wave_max_i(ok ? (int)P : 0);
+    unsigned long long own[QN_HCAP / 4]; int rank[QN_HCAP / 4];
+#pragma unroll
+    for (int j = 0; j < QN_HCAP / 4; j++) { own[j] = (ok && (uint32_t)(sub + 4 * j) < P) ? L->u.list[qs][sub + 4 * j] : QN_INF_KEY; rank[j] = 0; }
+    if (maxP <= 32) {
+      for (int f = 0; f < maxP; f++) {
+        const unsigned long long kf = (ok && (uint32_t)f < P) ? L->u.list[qs][f] : QN_INF_KEY;
+#pragma unroll
+        for (int j = 0; j < 8; j++) rank[j] += kf < own[j] ? 1 : 0;
+      }
+    } else {
+      for (int f = 0; f < maxP; f++) {
+        const unsigned long long kf = (ok && (uint32_t)f < P) ? L->u.list[qs][f] : QN_INF_KEY;
+#pragma unroll
+        for (int j = 0; j < QN_HCAP / 4; j++) rank[j] += kf < own[j] ? 1 : 0;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < QN_HCAP / 4; j++) if (own[j] != QN_INF_KEY && rank[j] == k - 1) L->kth[qs] = (uint32_t)(own[j] >> 32);
+    wave_lds_fence();
+    const float kth_d2 = __uint_as_float(L->kth[qs]);
+    if (g.dbg && lane == 0) { atomicAdd(&g.dbg[0], (uint32_t)ncl); atomicAdd(&g.dbg[1], ncand); }
+    // ---- certification (as in wave_search)
+    bool retry = false;
+    if (mine) {
+      const int* b = lds->box[cid];
+      const int ex0 = b[0], ex1 = b[1], ey0 = b[2], ey1 = b[3], ez0 = b[4], ez1 = b[5];
+      float d = INF;
+      if (ex0 > 0) d = fminf(d, qx - (g.ox + ex0 * g.cell));
+      if (ex1 < g.nx - 1) d = fminf(d, (g.ox + (ex1 + 1) * g.cell) - qx);
+      if (ey0 > 0) d = fminf(d, qy - (g.oy + ey0 * g.cell));
+      if (ey1 < g.ny - 1) d = fminf(d, (g.oy + (ey1 + 1) * g.cell) - qy);
+      if (ez0 > 0) d = fminf(d, qz - (g.oz + ez0 * g.cell));
+      if (ez1 < g.nz - 1) d = fminf(d, (g.oz + (ez1 + 1) * g.cell) - qz);
+      const bool whole = d == INF || !(r == r);
+      if (!enough) {
+        if (whole) status = 2;                                                      // fewer than k points within 2 r of the whole cloud
+        else { r = 2.f * r + g.cell; retry = true; }
+      } else if (!ok) status = 2;                                                   // list overflow
+      else {
+        d -= g.eps;
+        if (whole || (d > 0.f && kth_d2 < d * d)) {
+          status = 0;
+#pragma unroll
+          for (int j = 0; j < QN_HCAP / 4; j++) if (own[j] != QN_INF_KEY && rank[j] < k) {
+            idx_out[rank[j]] = (int32_t)key_idx(own[j]);
+            if (d2_out) d2_out[rank[j]] = key_d2(own[j]);
+          }
+        } else { r = fmaxf(sqrtf(kth_d2) * 1.000001f + g.eps, r); retry = true; }
+      }
+    }
+    todo = __ballot(retry && round + 1 < max_rounds);
+    if (g.dbg && lane == 0 && todo) atomicAdd(&g.dbg[3], (uint32_t)__popcll(todo));
+  }
+  return status;
 }
 
 // ------------------------------------------------------------------ single-query search: one query per WAVE

@@ -102,6 +102,8 @@ extern "C" int qn_ctx_create(int device, uint32_t max_points, qn_ctx** out) {
   CA(hipMalloc(&c->nn_idx, sizeof(int32_t) * max_points));
   CA(hipMalloc(&c->knn_idx, sizeof(int32_t) * (size_t)max_points * 32));
   CA(hipMalloc(&c->nn_ref, sizeof(float4) * max_points));
+  CA(hipMalloc(&c->cov_s_sorted, sizeof(double) * 6 * max_points));
+  CA(hipMalloc(&c->tgt_rec, sizeof(TargetRec) * max_points));
   CA(hipMalloc(&c->fit_psum, sizeof(double) * QN_FIT_BLOCKS));
   CA(hipMalloc(&c->fit_pcnt, sizeof(uint32_t) * QN_FIT_BLOCKS));
   CA(hipMalloc(&c->trace, sizeof(qn_iter_trace) * QN_MAX_TRACE));
@@ -110,7 +112,7 @@ extern "C" int qn_ctx_create(int device, uint32_t max_points, qn_ctx** out) {
   CA(hipMalloc(&c->sqd_fit, sizeof(float) * max_points));
   CA(hipMalloc(&c->fb_list, sizeof(uint2) * max_points));
   CA(hipMalloc(&c->big_list, sizeof(uint2) * max_points));
-  CA(hipMalloc(&c->fb_count2, sizeof(uint32_t)));
+  CA(hipMalloc(&c->fb_count2, 2 * sizeof(uint32_t)));
   CA(hipMalloc(&c->aligned, sizeof(float4) * max_points));
   CA(hipMalloc(&c->pose_tmp, sizeof(double) * 16));
   CA(hipMalloc(&c->guess_tmp, sizeof(float) * 16));
@@ -131,7 +133,7 @@ extern "C" void qn_ctx_destroy(qn_ctx* c) {
   c->prof_collect();
   for (int w = 0; w < 2; w++) { CloudBuf& b = c->cloud[w]; hipFree(b.raw); hipFree(b.sorted); hipFree(b.cell_of_pt); hipFree(b.cell_start); hipFree(b.counts); hipFree(b.cov); }
   hipFree(c->staging); hipFree(c->scan_sums); hipFree(c->bbox); hipFree(c->state); hipFree(c->partials); hipFree(c->trace);
-  hipFree(c->nn_idx); hipFree(c->knn_idx); hipFree(c->nn_ref); hipFree(c->fit_psum); hipFree(c->fit_pcnt); hipFree(c->corr); hipFree(c->sqd); hipFree(c->sqd_fit); hipFree(c->fb_list); hipFree(c->big_list); hipFree(c->fb_count2); hipFree(c->aligned);
+  hipFree(c->nn_idx); hipFree(c->knn_idx); hipFree(c->nn_ref); hipFree(c->cov_s_sorted); hipFree(c->tgt_rec); hipFree(c->fit_psum); hipFree(c->fit_pcnt); hipFree(c->corr); hipFree(c->sqd); hipFree(c->sqd_fit); hipFree(c->fb_list); hipFree(c->big_list); hipFree(c->fb_count2); hipFree(c->aligned);
   for (int w = 0; w < 2; w++) { hipFree(c->q_normals[w]); hipFree(c->q_spfh[w]); hipFree(c->q_fpfh_s[w]); hipFree(c->q_fpfh[w]); hipFree(c->q_key[w]); }
   hipFree(c->q_hit); hipFree(c->q_list); hipFree(c->q_pairs); hipFree(c->q_counts); hipFree(c->q_T);
   hipFree(c->pose_tmp); hipFree(c->guess_tmp); hipFree(c->dbg_knn_idx); hipFree(c->dbg_knn_d2); hipFree(c->dbg_counters);
@@ -254,6 +256,18 @@ static void launch_knn_cov(qn_ctx* c, CloudBuf& b, int k, int32_t* kidx, float* 
   hipStream_t s = c->stream;
   const float r0 = c->margin_knn * b.grid.cell;
   ProfScope ps(c, QN_K_KNN_COV);
+  if (c->knn_hist) {                        // histogram selection (default); its leftovers -> hist list pass -> general sorted-list pass
+    const uint32_t nb = (b.n + QN_BLOCK / 4 - 1) / (QN_BLOCK / 4);
+    uint32_t* genc = c->fb_count2 + 1;
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_knn_hist<false>), dim3(nb), dim3(QN_BLOCK), 0, s, b.grid, k, r0, c->knn_rounds, kidx, kd2, c->fb_list, c->fb_count2, c->big_list, genc);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_knn_hist<true>), dim3(std::min<uint32_t>((b.n + 63) / 64, 512)), dim3(QN_BLOCK), 0, s, b.grid, k, r0, 64, kidx, kd2, c->fb_list, c->fb_count2, c->big_list, genc);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_knn_cov<KMAX, true, 4>), dim3(std::min<uint32_t>((b.n + 63) / 64, 64)), dim3(QN_BLOCK), 0, s, b.grid, b.raw, k, r0, 64, b.cov, kidx, kd2, c->big_list, genc);
+    const uint32_t nbp = (b.n + QN_BLOCK - 1) / QN_BLOCK;
+    hipLaunchKernelGGL(k_cov_from_idx, dim3(nbp), dim3(QN_BLOCK), 0, s, b.raw, b.n, k, kidx, b.cov);
+    if (&b == &c->cloud[0]) hipLaunchKernelGGL(k_sort_cov, dim3(nbp), dim3(QN_BLOCK), 0, s, b.sorted, b.cov, b.n, c->cov_s_sorted);
+    else hipLaunchKernelGGL(k_build_target_rec, dim3(nbp), dim3(QN_BLOCK), 0, s, b.raw, b.cov, b.n, c->tgt_rec);
+    return;
+  }
   if (c->knn_lanes_per_query == 1) {        // one query per lane: fewest wave-instructions per query
     const uint32_t nb = (b.n + QN_BLOCK - 1) / QN_BLOCK;
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_knn_cov<KMAX, false, 1>), dim3(nb), dim3(QN_BLOCK), 0, s, b.grid, b.raw, k, r0, 2, b.cov, kidx, kd2, c->fb_list, c->fb_count2);
@@ -265,7 +279,11 @@ static void launch_knn_cov(qn_ctx* c, CloudBuf& b, int k, int32_t* kidx, float* 
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_knn_cov<KMAX, false, 4>), dim3(nb), dim3(QN_BLOCK), 0, s, b.grid, b.raw, k, r0, 2, b.cov, kidx, kd2, c->fb_list, c->fb_count2);
   }
   hipLaunchKernelGGL(HIP_KERNEL_NAME(k_knn_cov<KMAX, true, 4>), dim3(std::min<uint32_t>((b.n + 63) / 64, 512)), dim3(QN_BLOCK), 0, s, b.grid, b.raw, k, r0, 64, b.cov, kidx, kd2, c->fb_list, c->fb_count2);
-  hipLaunchKernelGGL(k_cov_from_idx, dim3((b.n + QN_BLOCK - 1) / QN_BLOCK), dim3(QN_BLOCK), 0, s, b.raw, b.n, k, kidx, b.cov);
+  const uint32_t nbp = (b.n + QN_BLOCK - 1) / QN_BLOCK;
+  hipLaunchKernelGGL(k_cov_from_idx, dim3(nbp), dim3(QN_BLOCK), 0, s, b.raw, b.n, k, kidx, b.cov);
+  // layouts for the fused optimiser ticks: source covariances in cell-sorted order, target point + covariance in one 64-byte record
+  if (&b == &c->cloud[0]) hipLaunchKernelGGL(k_sort_cov, dim3(nbp), dim3(QN_BLOCK), 0, s, b.sorted, b.cov, b.n, c->cov_s_sorted);
+  else hipLaunchKernelGGL(k_build_target_rec, dim3(nbp), dim3(QN_BLOCK), 0, s, b.raw, b.cov, b.n, c->tgt_rec);
 }
 static int compute_cov(qn_ctx* c, int which, int32_t* kidx, float* kd2) {
   if (!c || (which != 0 && which != 1)) return QN_ERR_INVALID_ARG;
@@ -273,7 +291,7 @@ static int compute_cov(qn_ctx* c, int which, int32_t* kidx, float* kd2) {
   if (!b.has_grid) return b.n == 0 ? QN_ERR_EMPTY_CLOUD : QN_ERR_NOT_READY;
   HIPCHK(c, hipSetDevice(c->device));
   const int k = c->params.k_correspondences;
-  HIPCHK(c, hipMemsetAsync(c->fb_count2, 0, sizeof(uint32_t), c->stream));
+  HIPCHK(c, hipMemsetAsync(c->fb_count2, 0, 2 * sizeof(uint32_t), c->stream));
   if (k <= 16) launch_knn_cov<16>(c, b, k, kidx, kd2);
   else if (k <= 20) launch_knn_cov<20>(c, b, k, kidx, kd2);
   else if (k <= 24) launch_knn_cov<24>(c, b, k, kidx, kd2);
@@ -331,7 +349,7 @@ static void enqueue_tick_fused(qn_ctx* c) {
   const double thr2 = c->params.max_corr_dist * c->params.max_corr_dist;
   { ProfScope ps(c, QN_K_NN_SEARCH);
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_nn_track<0, true>), dim3(nbt), dim3(QN_BLOCK), 0, s, S.grid, T.grid, T.raw, c->state, thr2, c->corr, c->sqd, c->nn_idx, c->nn_ref,
-                       c->fb_list, &c->state->fb_count, c->big_list, &c->state->big_count, S.cov, T.cov, c->partials); }
+                       c->fb_list, &c->state->fb_count, c->big_list, &c->state->big_count, c->cov_s_sorted, c->tgt_rec, c->partials); }
   enqueue_solve(c, 0);
 }
 static void enqueue_tick(qn_ctx* c, bool seeded, int tick) {
@@ -553,6 +571,8 @@ extern "C" int qn_debug_set(qn_ctx* c, const char* key, double v) {
   if (k == "cell") { c->cell_override = v; c->cloud[0].has_grid = c->cloud[1].has_grid = false; }
   else if (k == "margin_nn") c->margin_nn = (float)v;
   else if (k == "margin_knn") c->margin_knn = (float)v;
+  else if (k == "knn_hist") c->knn_hist = v != 0;
+  else if (k == "knn_rounds") c->knn_rounds = v < 1 ? 1 : (int)v;
   else if (k == "knn_lanes_per_query") c->knn_lanes_per_query = v == 1 ? 1 : (v == 2 ? 2 : 4);
   else if (k == "fused_ticks") c->fused_ticks = v != 0;
   else if (k == "big_ratio") c->big_ratio = (float)v;

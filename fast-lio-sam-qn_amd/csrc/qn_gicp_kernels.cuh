@@ -153,6 +153,27 @@ __global__ void __launch_bounds__(QN_BLOCK) k_cov_from_idx(const float4* __restr
     }
 }
 
+// Target-side record for the fused optimiser ticks: point and covariance of a target point in ONE 64-byte line
+// (a correspondence then costs one scattered cache line instead of two).
+struct __attribute__((aligned(64))) TargetRec { float4 p; double cov[6]; };
+static_assert(sizeof(TargetRec) == 64, "TargetRec is one 64-byte line");
+__global__ void k_build_target_rec(const float4* __restrict__ raw, const double* __restrict__ cov, uint32_t n, TargetRec* __restrict__ rec) {
+  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  TargetRec r; r.p = raw[j];
+#pragma unroll
+  for (int u = 0; u < 6; u++) r.cov[u] = cov[(size_t)j * 6 + u];
+  rec[j] = r;
+}
+// source covariances in the source's cell-sorted order (the order the NN kernels walk the queries in)
+__global__ void k_sort_cov(const float4* __restrict__ sorted, const double* __restrict__ cov, uint32_t n, double* __restrict__ cov_sorted) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  const uint32_t i = __float_as_uint(sorted[t].w);
+#pragma unroll
+  for (int u = 0; u < 6; u++) cov_sorted[(size_t)t * 6 + u] = cov[(size_t)i * 6 + u];
+}
+
 // One kernel body for both passes.  LIST = false: query t = global query slot, radius margin * cell, two
 // rounds, leftovers appended to fb_list with the radius to continue from.  LIST = true: the queries are
 // the fb_list entries of the first pass (16 per wave, wave-stride), rounds until exact.
@@ -185,6 +206,36 @@ __global__ void __launch_bounds__(QN_BLOCK, 3) k_knn_cov(GridView g, const float
   }
 }
 
+// k-NN by histogram selection (wave_knn_hist), 16 queries per wave.  LIST = false: every point, radius margin * cell,
+// `max_rounds` rounds, leftovers appended to fb_list as (t, r) with the sign bit of r set when the query needs the
+// general path.  LIST = true: the fb_list entries, rounds until exact; general-path entries are passed on to gen_list
+// (served by k_knn_cov<KMAX, true, 4> afterwards).
+template <bool LIST>
+__global__ void __launch_bounds__(QN_BLOCK, 3) k_knn_hist(GridView g, int k, float r0, int max_rounds, int32_t* __restrict__ knn_idx, float* __restrict__ knn_d2,
+                                                       uint2* __restrict__ fb_list, uint32_t* __restrict__ fb_count, uint2* __restrict__ gen_list, uint32_t* __restrict__ gen_count) {
+  __shared__ WaveLdsH lds[QN_BLOCK / 64];
+  WaveLdsH* my = &lds[threadIdx.x >> 6];
+  const uint32_t nq = LIST ? *fb_count : g.n;
+  if (LIST && g.dbg && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&g.dbg[4], nq);
+  const uint32_t wave0 = blockIdx.x * (QN_BLOCK / 64) + (threadIdx.x >> 6), nwaves = gridDim.x * (QN_BLOCK / 64);
+  for (uint32_t base = wave0 * 16; base < nq; base += nwaves * 16) {
+    const uint32_t slot = base + (threadIdx.x & 15);
+    bool active = slot < nq;
+    uint32_t t = slot; float r = r0; bool general = false;
+    if (LIST && active) { const uint2 rec = fb_list[slot]; t = rec.x; r = __uint_as_float(rec.y & 0x7fffffffu); general = (rec.y >> 31) != 0; }
+    const float4 q = active ? g.pts[t] : make_float4(0, 0, 0, 0);
+    const uint32_t i = __float_as_uint(q.w);
+    int status = 2;
+    {
+      const int st = wave_knn_hist(g, q.x, q.y, q.z, active && !general, r, k, max_rounds, my, knn_idx + (size_t)i * k, knn_d2 ? knn_d2 + (size_t)i * k : nullptr);
+      if (!general) status = st;
+    }
+    if (!active || (threadIdx.x & 63) >= 16 || status == 0) continue;
+    if (LIST) { const uint32_t fs = atomicAdd(gen_count, 1u); gen_list[fs] = make_uint2(t, __float_as_uint(r)); }
+    else { const uint32_t fs = atomicAdd(fb_count, 1u); fb_list[fs] = make_uint2(t, __float_as_uint(r) | (status == 2 ? 0x80000000u : 0u)); }
+  }
+}
+
 // ------------------------------------------------------------------ K4a nearest-neighbour search
 // MODE 0: update_correspondences: q = T_f * p in f32, Eigen order ((c0 x + c1 y) + c2 z) + c3.
 // MODE 1: getFitnessScore: q = pcl::transformPointCloud, SSE order c0 x + (c1 y + (c2 z + c3)).
@@ -201,10 +252,12 @@ __device__ __forceinline__ void xform_query(const float Tf[12], float x, float y
   }
 }
 
+// corr / sqd are indexed by the ORIGINAL source index i (API order); the tracking state (nn_idx, nn_ref) by the source's
+// cell-sorted position t, the order every NN kernel walks the queries in - coalesced.
 template <int MODE>
-__device__ __forceinline__ void store_nn(unsigned long long key, uint32_t i, double thr2, int32_t* __restrict__ corr, float* __restrict__ sqd, int32_t* __restrict__ nn_idx) {
+__device__ __forceinline__ void store_nn(unsigned long long key, uint32_t i, uint32_t t, double thr2, int32_t* __restrict__ corr, float* __restrict__ sqd, int32_t* __restrict__ nn_idx) {
   const float d2 = key_d2(key);
-  if (MODE == 0 && key != QN_INF_KEY) nn_idx[i] = (int32_t)key_idx(key);        // ungated NN: next iteration's search seed (k_nn_track)
+  if (MODE == 0 && key != QN_INF_KEY) nn_idx[t] = (int32_t)key_idx(key);        // ungated NN: next iteration's search seed (k_nn_track)
   if (MODE == 0) {
     const bool found = key != QN_INF_KEY;
     sqd[i] = found ? d2 : 0.f;
@@ -244,8 +297,8 @@ __global__ void __launch_bounds__(QN_BLOCK) k_nn_search(GridView src, GridView t
       unsigned long long key; float second, d_unseen;
       wave_search_single(tgt, qx, qy, qz, r, __int_as_float(0x7f800000), key, second, d_unseen, &lds[threadIdx.x >> 6]);
       if ((threadIdx.x & 63) == 0) {
-        store_nn<MODE>(key, __float_as_uint(p.w), thr2, corr, sqd, nn_idx);
-        if (MODE == 0) nn_ref[__float_as_uint(p.w)] = make_float4(qx, qy, qz, fminf(sqrtf(second), d_unseen));
+        store_nn<MODE>(key, __float_as_uint(p.w), rec.x, thr2, corr, sqd, nn_idx);
+        if (MODE == 0) nn_ref[rec.x] = make_float4(qx, qy, qz, fminf(sqrtf(second), d_unseen));
       }
     }
     return;
@@ -269,9 +322,9 @@ __global__ void __launch_bounds__(QN_BLOCK) k_nn_search(GridView src, GridView t
     const bool cert = wave_search<4>(tgt, qx, qy, qz, active, r, r_cap, max_rounds, sink, &lds[threadIdx.x >> 6], d_unseen);
     if (!active || (threadIdx.x & 48) != 0) continue;
     if (cert || LIST) {
-      store_nn<MODE>(sink.key, __float_as_uint(p.w), thr2, corr, sqd, nn_idx);
+      store_nn<MODE>(sink.key, __float_as_uint(p.w), t, thr2, corr, sqd, nn_idx);
       // bound-pruning reference: where this query was scanned and how far away every other point is at least
-      if (MODE == 0) nn_ref[__float_as_uint(p.w)] = make_float4(qx, qy, qz, fminf(sqrtf(sink.second), d_unseen));
+      if (MODE == 0) nn_ref[t] = make_float4(qx, qy, qz, fminf(sqrtf(sink.second), d_unseen));
     }
     else if (r > big_ratio * r0) { const uint32_t fs = atomicAdd(big_count, 1u); big_list[fs] = make_uint2(t, __float_as_uint(-r)); }   // far: one query per wave
     else { const uint32_t fs = atomicAdd(fb_count, 1u); fb_list[fs] = make_uint2(t, __float_as_uint(-r)); }                         // continue from r
@@ -390,7 +443,7 @@ __global__ void __launch_bounds__(QN_BLOCK) k_nn_track(GridView src, GridView tg
                                                        double thr2, int32_t* __restrict__ corr, float* __restrict__ sqd, int32_t* __restrict__ nn_idx,
                                                        float4* __restrict__ nn_ref, uint2* __restrict__ fb_list, uint32_t* __restrict__ fb_count,
                                                        uint2* __restrict__ big_list, uint32_t* __restrict__ big_count,
-                                                       const double* __restrict__ cov_s, const double* __restrict__ cov_t, double* __restrict__ partials) {
+                                                       const double* __restrict__ cov_s_sorted, const TargetRec* __restrict__ tgt_rec, double* __restrict__ partials) {
   __shared__ WaveLds lds[FUSED ? QN_BLOCK / 64 : 1];
   __shared__ double red[FUSED ? QN_BLOCK / 64 : 1][QN_NPART];
   if (MODE == 0 && st->phase != 0) return;
@@ -409,9 +462,9 @@ __global__ void __launch_bounds__(QN_BLOCK) k_nn_track(GridView src, GridView tg
   bool rescanned = false, big = false;
   float r = 0.f, delta = 0.f;
   if (valid) {
-    const int32_t j0 = nn_idx[i];
-    const float4 ref = nn_ref[i];
-    const float4 p0 = tgt_raw[j0];
+    const int32_t j0 = nn_idx[t];
+    const float4 ref = nn_ref[t];
+    const float4 p0 = FUSED ? tgt_rec[j0].p : tgt_raw[j0];          // FUSED: point and covariance of a target point share one 64-byte line
     const float d0 = sqdist(qx, qy, qz, p0.x, p0.y, p0.z);
     best = pack_key(d0, (uint32_t)j0);
     delta = sqrtf(sqdist(qx, qy, qz, ref.x, ref.y, ref.z));
@@ -478,8 +531,9 @@ __global__ void __launch_bounds__(QN_BLOCK) k_nn_track(GridView src, GridView tg
     }
   }
   if (valid) {
-    store_nn<MODE>(best, i, thr2, corr, sqd, nn_idx);
-    if (MODE == 0 && rescanned) nn_ref[i] = make_float4(qx, qy, qz, fminf(sqrtf(second), d_unseen));
+    if (!FUSED) store_nn<MODE>(best, i, t, thr2, corr, sqd, nn_idx);          // FUSED ticks feed the accumulation directly: corr / sqd are not needed
+    else if (best != QN_INF_KEY) nn_idx[t] = (int32_t)key_idx(best);
+    if (MODE == 0 && rescanned) nn_ref[t] = make_float4(qx, qy, qz, fminf(sqrtf(second), d_unseen));
   }
   if (FUSED) {
     double R[3][3], T[3][4];
@@ -491,8 +545,8 @@ __global__ void __launch_bounds__(QN_BLOCK) k_nn_track(GridView src, GridView tg
 #pragma unroll
     for (int u = 0; u < QN_NPART; u++) acc[u] = 0;
     if (valid && best != QN_INF_KEY && (double)key_d2(best) < thr2) {
-      const uint32_t j = key_idx(best);
-      accumulate_point(R, T, make_float4(p.x, p.y, p.z, 1.f), tgt_raw[j], cov_s + (size_t)i * 6, cov_t + (size_t)j * 6, true, acc);
+      const TargetRec* rec = tgt_rec + key_idx(best);
+      accumulate_point(R, T, make_float4(p.x, p.y, p.z, 1.f), rec->p, cov_s_sorted + (size_t)t * 6, rec->cov, true, acc);
     }
     reduce_block_partials(acc, true, partials, red);
   }
