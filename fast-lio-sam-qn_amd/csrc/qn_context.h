@@ -46,6 +46,9 @@ struct qn_ctx {
   double cell_override = 0.0;
   float big_ratio = 2.5f;               // first-search leftovers whose next radius exceeds big_ratio * r0 go one-per-wave
   bool fused_ticks = true;              // GN ticks >= 3: tracking + leftovers + accumulation in one kernel
+  int nn_rounds = 1;                    // rounds of an unseeded NN search before a query goes to the list pass
+  int track_from_tick = 3;              // NN passes before this tick search unseeded (ball around the query) instead of tracking the previous neighbour
+  int fused_from_tick = 3;
   int knn_rounds = 2;                   // rounds of the first k-NN pass before a query goes to the list pass
   int knn_hist = 1;                     // 1: k-NN by histogram selection (wave_knn_hist), 0: sorted-list sink (wave_search + BestK)
   int knn_lanes_per_query = 4;          // 4: latency-optimal k-NN layout, 1: throughput-optimal (see wave_search)

@@ -117,6 +117,18 @@ __device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v, int lane) {
 // DS operations of one wave execute in issue order; this only stops the compiler from reordering.
 __device__ __forceinline__ void wave_lds_fence() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); }
 
+// Wave-aggregated list append: one atomic per wave, the wave's entries land contiguously and in lane order (so the
+// list keeps the spatial coherence of the cell-sorted query order).  Must be called by the wave convergently.
+__device__ __forceinline__ void wave_append(uint2* __restrict__ list, uint32_t* __restrict__ count, bool want, uint2 rec) {
+  const unsigned long long mask = __ballot(want);
+  if (mask == 0) return;
+  const int lane = threadIdx.x & 63, leader = __ffsll((long long)mask) - 1;
+  uint32_t base = 0;
+  if (lane == leader) base = atomicAdd(count, (uint32_t)__popcll(mask));
+  base = rflu(__shfl(base, leader));
+  if (want) list[base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = rec;
+}
+
 // ------------------------------------------------------------------ wave-private LDS scratch
 #define QN_PEND_CAP 16
 struct WaveLds {                        // per-wave scratch: candidate tile + segment table + cluster boxes (~4 KiB)

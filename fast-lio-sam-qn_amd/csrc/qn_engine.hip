@@ -320,7 +320,7 @@ static void enqueue_nn(qn_ctx* c, int mode /*0 align, 1 fitness*/, float* sqd_ou
   if (mode == 0) {
     { ProfScope ps(c, QN_K_NN_SEARCH);
       if (seeded) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_nn_track<0, false>), dim3(nbt), dim3(QN_BLOCK), 0, s, S.grid, T.grid, T.raw, c->state, thr2, c->corr, sqd_out, c->nn_idx, c->nn_ref, c->fb_list, fbc, c->big_list, bgc, nullptr, nullptr, nullptr);
-      else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_nn_search<0, false>), dim3(nb), dim3(QN_BLOCK), 0, s, S.grid, T.grid, c->state, thr2, r0, 1, c->corr, sqd_out, c->nn_idx, c->nn_ref, c->fb_list, fbc, c->big_list, bgc, 0, c->big_ratio); }
+      else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_nn_search<0, false>), dim3(nb), dim3(QN_BLOCK), 0, s, S.grid, T.grid, c->state, thr2, r0, c->nn_rounds, c->corr, sqd_out, c->nn_idx, c->nn_ref, c->fb_list, fbc, c->big_list, bgc, 0, c->big_ratio); }
     { ProfScope ps(c, QN_K_NN_FALLBACK);
       hipLaunchKernelGGL(HIP_KERNEL_NAME(k_nn_search<0, true>), dim3(fbb + big_blocks), dim3(QN_BLOCK), 0, s, S.grid, T.grid, c->state, thr2, r0, 64, c->corr, sqd_out, c->nn_idx, c->nn_ref, c->fb_list, fbc, c->big_list, bgc, big_blocks, c->big_ratio); }
   } else {
@@ -353,7 +353,8 @@ static void enqueue_tick_fused(qn_ctx* c) {
   enqueue_solve(c, 0);
 }
 static void enqueue_tick(qn_ctx* c, bool seeded, int tick) {
-  if (seeded && tick >= 3 && c->fused_ticks && c->params.optimizer == QN_OPT_GN && acc_blocks(c) == (c->cloud[0].n + QN_BLOCK - 1) / QN_BLOCK) { enqueue_tick_fused(c); return; }
+  if (tick < c->track_from_tick) seeded = false;
+  if (seeded && tick >= c->fused_from_tick && c->fused_ticks && c->params.optimizer == QN_OPT_GN && acc_blocks(c) == (c->cloud[0].n + QN_BLOCK - 1) / QN_BLOCK) { enqueue_tick_fused(c); return; }
   enqueue_nn(c, 0, c->sqd, seeded, tick); enqueue_accumulate(c); enqueue_solve(c, 0);
 }
 static void enqueue_epilogue(qn_ctx* c, double max_range, bool seeded) {       // fitness + output cloud; each kernel is a no-op until phase == done
@@ -572,6 +573,9 @@ extern "C" int qn_debug_set(qn_ctx* c, const char* key, double v) {
   else if (k == "margin_nn") c->margin_nn = (float)v;
   else if (k == "margin_knn") c->margin_knn = (float)v;
   else if (k == "knn_hist") c->knn_hist = v != 0;
+  else if (k == "nn_rounds") c->nn_rounds = v < 1 ? 1 : (int)v;
+  else if (k == "track_from_tick") c->track_from_tick = v < 1 ? 1 : (int)v;
+  else if (k == "fused_from_tick") c->fused_from_tick = v < 1 ? 1 : (int)v;
   else if (k == "knn_rounds") c->knn_rounds = v < 1 ? 1 : (int)v;
   else if (k == "knn_lanes_per_query") c->knn_lanes_per_query = v == 1 ? 1 : (v == 2 ? 2 : 4);
   else if (k == "fused_ticks") c->fused_ticks = v != 0;

@@ -320,14 +320,18 @@ __global__ void __launch_bounds__(QN_BLOCK) k_nn_search(GridView src, GridView t
     Best1 sink; sink.init();
     float d_unseen;
     const bool cert = wave_search<4>(tgt, qx, qy, qz, active, r, r_cap, max_rounds, sink, &lds[threadIdx.x >> 6], d_unseen);
-    if (!active || (threadIdx.x & 48) != 0) continue;
-    if (cert || LIST) {
+    const bool mine = active && (threadIdx.x & 48) == 0;
+    const bool done = cert || LIST;
+    if (mine && done) {
       store_nn<MODE>(sink.key, __float_as_uint(p.w), t, thr2, corr, sqd, nn_idx);
       // bound-pruning reference: where this query was scanned and how far away every other point is at least
       if (MODE == 0) nn_ref[t] = make_float4(qx, qy, qz, fminf(sqrtf(sink.second), d_unseen));
     }
-    else if (r > big_ratio * r0) { const uint32_t fs = atomicAdd(big_count, 1u); big_list[fs] = make_uint2(t, __float_as_uint(-r)); }   // far: one query per wave
-    else { const uint32_t fs = atomicAdd(fb_count, 1u); fb_list[fs] = make_uint2(t, __float_as_uint(-r)); }                         // continue from r
+    if (!LIST) {
+      const bool far = r > big_ratio * r0;
+      wave_append(big_list, big_count, mine && !done && far, make_uint2(t, __float_as_uint(-r)));     // far: one query per wave
+      wave_append(fb_list, fb_count, mine && !done && !far, make_uint2(t, __float_as_uint(-r)));      // continue from r
+    }
   }
 }
 
@@ -514,20 +518,27 @@ __global__ void __launch_bounds__(QN_BLOCK) k_nn_track(GridView src, GridView tg
     }
   }
   if (!FUSED) {
-    if (big) {   // list passes, seeded with the bound.  tight seed (the query barely moved since it was scanned) AND far neighbour: one query per wave
-      if (r > 2.5f * tgt.cell && delta < 0.25f * r) { const uint32_t slot = atomicAdd(big_count, 1u); big_list[slot] = make_uint2(t, __float_as_uint(r)); }
-      else { const uint32_t slot = atomicAdd(fb_count, 1u); fb_list[slot] = make_uint2(t, __float_as_uint(r)); }   // r is NaN for a non-finite query: resolved at once
-      return;
-    }
-  } else {       // resolve the wave's big-ball queries here, one after the other, all 64 lanes on each
+    // list passes, seeded with the bound.  tight seed (the query barely moved since it was scanned) AND far neighbour: one query per wave
+    const bool tight_far = r > 2.5f * tgt.cell && delta < 0.25f * r;
+    wave_append(big_list, big_count, big && tight_far, make_uint2(t, __float_as_uint(r)));
+    wave_append(fb_list, fb_count, big && !tight_far, make_uint2(t, __float_as_uint(r)));    // r is NaN for a non-finite query: resolved at once
+    if (big) return;
+  } else {       // resolve the wave's big-ball queries here, 16 at a time, cooperatively (neighbouring queries' balls overlap: one shared candidate stream)
     const int lane = threadIdx.x & 63;
-    for (unsigned long long pending = __ballot(big); pending != 0; pending &= pending - 1) {
-      const int L = __ffsll((long long)pending) - 1;
-      const float ax = __shfl(qx, L), ay = __shfl(qy, L), az = __shfl(qz, L), ar = __shfl(r, L), ad = __shfl(delta, L);
-      const float rs = (ad < 0.25f * ar) ? ar * 1.1f + 0.5f * tgt.cell : ar;     // tight seed: scan a little wider (bound pruning next time)
-      unsigned long long key; float sec, du;
-      wave_search_single(tgt, ax, ay, az, rs, INF, key, sec, du, &lds[threadIdx.x >> 6]);
-      if (lane == L) { best = key; second = sec; d_unseen = du; rescanned = true; }
+    for (unsigned long long pending = __ballot(big); pending != 0;) {
+      unsigned long long grp = 0, tmp = pending; int srcl = -1;
+      for (int sl = 0; sl < 16 && tmp != 0; sl++) { const int L = __ffsll((long long)tmp) - 1; if (sl == (lane & 15)) srcl = L; grp |= 1ull << L; tmp &= tmp - 1; }
+      pending &= ~grp;
+      const bool act = srcl >= 0;
+      const int sl_ = act ? srcl : 0;
+      const float ax = __shfl(qx, sl_), ay = __shfl(qy, sl_), az = __shfl(qz, sl_), ar = __shfl(r, sl_), ad = __shfl(delta, sl_);
+      float rs = (ad < 0.25f * ar) ? ar * 1.1f + 0.5f * tgt.cell : ar;           // tight seed: scan a little wider (bound pruning next time)
+      Best1 sink; sink.init();
+      float du = INF;
+      wave_search<4>(tgt, ax, ay, az, act, rs, INF, 64, sink, &lds[threadIdx.x >> 6], du);
+      const int slot = __popcll(grp & ((1ull << lane) - 1ull));                   // my query's slot in the group (results sit in lanes 0..15)
+      const unsigned long long rk = __shfl(sink.key, slot); const float rsec = __shfl(sink.second, slot), rdu = __shfl(du, slot);
+      if ((grp >> lane) & 1ull) { best = rk; second = rsec; d_unseen = rdu; rescanned = true; }
     }
   }
   if (valid) {

@@ -5,13 +5,12 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "fast-lio-sam-qn
 import numpy as np, torch
 from qn_amd import engine, synth
 KNOB = float(sys.argv[1]) if len(sys.argv) > 1 else 4
-for N in (100000,):
+for N in (100000, 25000, 6000):
     src, tgt, T = synth.make_pair(0, N, extent=120.0 if N >= 30000 else 40.0)
     s = torch.from_numpy(src).cuda(); t = torch.from_numpy(tgt).cuda(); torch.cuda.synchronize()
-    for C_ in (1, 4, 6):
+    for C_ in (1, 4):
         ctxs = [engine.Context(N + 1024) for _ in range(C_)]
         for cx in ctxs:
-            cx.debug_set('knn_lanes_per_query', KNOB)
             g = engine.NanoGICP(cx); g.setCorrespondenceRandomness(20); g.setMaximumIterations(20); g.setMaxCorrespondenceDistance(52.5); g.setOptimizer("gn"); g.setForceIterations(20)
         descs = [(s.data_ptr(), N, t.data_ptr(), N, 12, 1)] * 24
         engine.icp_alignment_batch(ctxs, descs[:8])
