@@ -159,16 +159,17 @@ def main():
         ctx.synchronize(); ctx.prof_enable(False)
         stats = ctx.prof_stats()
         fam_ms = {k: v[0] / nprof for k, v in stats.items() if v[1] > 0}             # ms per registration
-        fam_launches = {k: v[1] / nprof for k, v in stats.items() if v[1] > 0}
+        fam_avg = {k: v[0] / v[1] for k, v in stats.items() if v[1] > 0}             # ms per profiled span (= one launch for the single-kernel families)
         ab = algorithmic_bytes()
-        dom = max(fam_ms, key=fam_ms.get)
-        # algorithmic bytes one launch-group of the dominant family moves
-        per_launch_bytes = {"knn_cov": ab["knn_cov"], "nn_search": ab["gn_iteration"], "nn_fallback": ab["gn_iteration"],
-                            "accumulate": ab["gn_iteration"], "grid_build": ab["grid_build"], "fitness": ab["fitness"],
-                            "transform": ab["transform"], "solve": 28 * 8 * 256}.get(dom, ab["gn_iteration"])
-        groups = {"knn_cov": 2, "grid_build": 2, "nn_search": GN_ITERS, "nn_fallback": GN_ITERS, "accumulate": GN_ITERS,
-                  "solve": GN_ITERS, "fitness": 1, "transform": 1}.get(dom, 1)
-        dom_ms = fam_ms[dom] / groups
+        # kernel families timed as ONE kernel per span, with the rocprofv3 name of that kernel and its algorithmic bytes per launch
+        single = {"knn_select": ("k_knn_hist<false>", N_PTS * (16 + 16 * K_COV)),          # k-NN selection of one cloud: point + k neighbour points
+                  "gn_tick_fused": ("k_nn_track<0, true>", ab["gn_iteration"]),              # one whole GN iteration (NN + accumulate + solve)
+                  "nn_search": ("k_nn_search<0, false>", ab["gn_iteration"]),                # first (unseeded) NN passes of an align
+                  "nn_fallback": ("k_nn_search<0, true>", ab["gn_iteration"]),
+                  "accumulate": ("k_accumulate", ab["gn_iteration"]), "solve": ("k_solve", 28 * 8 * 512)}
+        dom = max((k for k in fam_ms if k in single), key=fam_ms.get)
+        dom_kernel, per_launch_bytes = single[dom]
+        dom_ms = fam_avg[dom]
         achieved = per_launch_bytes / (dom_ms * 1e-3) / 1e9
         pmc = None
         pmc_path = os.path.join(ROOT, "profiles", "pmc_latest.json")
@@ -178,7 +179,10 @@ def main():
             except Exception:
                 pmc = None
         traffic = pmc.get("hbm_bytes_per_launch") if isinstance(pmc, dict) else None
-        roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        kernels = {k: {"kernel": single[k][0], "avg_launch_ms": round(fam_avg[k], 5), "launches_per_registration": round(stats[k][1] / nprof, 2),
+                       "algorithmic_bytes_per_launch": single[k][1], "achieved_GBs": round(single[k][1] / (fam_avg[k] * 1e-3) / 1e9, 2),
+                       "frac": round(single[k][1] / (fam_avg[k] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)} for k in single if k in fam_avg}
+        roofline = {"bound": "hbm", "kernel": dom_kernel, "family": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_detail": pmc,
                     "avg_launch_ms": round(dom_ms, 5), "algorithmic_bytes_per_launch": per_launch_bytes,
                     "whole_registration": {"algorithmic_bytes": ab["full"], "achieved": round(ab["full"] / (ms_step * 1e-3) / 1e9, 2),
@@ -186,7 +190,7 @@ def main():
                                            "note": "amortised over the registrations in flight"},
                     "align_only": {"algorithmic_bytes": ab["align"], "ms": round(align_ms, 4),
                                    "frac": round(ab["align"] / (align_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)},
-                    "family_ms_per_registration": {k: round(v, 4) for k, v in fam_ms.items()},
+                    "family_ms_per_registration": {k: round(v, 4) for k, v in fam_ms.items()}, "kernels": kernels,
                     "note": "working set (<=20 MB) is L2/MALL resident: nominal HBM yardstick (SURVEY 8d)"}
 
         # ---- Quatro coarse stage (BASELINE configs[2]): FPFH + optimizedMatching (cap 200) + GNC solve, 30k-point pair from the host

@@ -51,7 +51,6 @@ struct qn_ctx {
   int fused_from_tick = 3;
   int knn_rounds = 2;                   // rounds of the first k-NN pass before a query goes to the list pass
   int knn_hist = 1;                     // 1: k-NN by histogram selection (wave_knn_hist), 0: sorted-list sink (wave_search + BestK)
-  int knn_lanes_per_query = 4;          // 4: latency-optimal k-NN layout, 1: throughput-optimal (see wave_search)
   float margin_nn = 1.f, margin_knn = 2.f;   // first search radius in cells (1-NN of the first tick / k-NN of the covariances)
   int margin_nn_cap = 3, margin_knn_cap = 5, ticks_per_chunk = 8;
   uint32_t* dbg_counters = nullptr;

@@ -10,7 +10,7 @@
 #include <vector>
 #include <atomic>
 #include <thread>
-#include "qn_gicp_kernels.cuh"
+#include "qn_instances.h"      // heavy template kernels: declared here, compiled in qn_inst.hip (one TU per group)
 #include "qn_context.h"
 
 using namespace qn;
@@ -255,12 +255,14 @@ template <int KMAX>
 static void launch_knn_cov(qn_ctx* c, CloudBuf& b, int k, int32_t* kidx, float* kd2) {
   hipStream_t s = c->stream;
   const float r0 = c->margin_knn * b.grid.cell;
-  ProfScope ps(c, QN_K_KNN_COV);
   if (c->knn_hist) {                        // histogram selection (default); its leftovers -> hist list pass -> general sorted-list pass
     const uint32_t nb = (b.n + QN_BLOCK / 4 - 1) / (QN_BLOCK / 4);
     uint32_t* genc = c->fb_count2 + 1;
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_knn_hist<false>), dim3(nb), dim3(QN_BLOCK), 0, s, b.grid, k, r0, c->knn_rounds, kidx, kd2, c->fb_list, c->fb_count2, c->big_list, genc);
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_knn_hist<true>), dim3(std::min<uint32_t>((b.n + 63) / 64, 512)), dim3(QN_BLOCK), 0, s, b.grid, k, r0, 64, kidx, kd2, c->fb_list, c->fb_count2, c->big_list, genc);
+    constexpr int HCAP = KMAX <= 24 ? 32 : 48;      // pass-2 list capacity: 32 keeps the selection kernel at 4 waves/SIMD
+    { ProfScope sel(c, QN_K_KNN_SELECT);
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(k_knn_hist<false, HCAP>), dim3(nb), dim3(QN_BLOCK), 0, s, b.grid, k, r0, c->knn_rounds, kidx, kd2, c->fb_list, c->fb_count2, c->big_list, genc); }
+    ProfScope ps(c, QN_K_KNN_COV);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_knn_hist<true, HCAP>), dim3(std::min<uint32_t>((b.n + 63) / 64, 512)), dim3(QN_BLOCK), 0, s, b.grid, k, r0, 64, kidx, kd2, c->fb_list, c->fb_count2, c->big_list, genc);
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_knn_cov<KMAX, true, 4>), dim3(std::min<uint32_t>((b.n + 63) / 64, 64)), dim3(QN_BLOCK), 0, s, b.grid, b.raw, k, r0, 64, b.cov, kidx, kd2, c->big_list, genc);
     const uint32_t nbp = (b.n + QN_BLOCK - 1) / QN_BLOCK;
     hipLaunchKernelGGL(k_cov_from_idx, dim3(nbp), dim3(QN_BLOCK), 0, s, b.raw, b.n, k, kidx, b.cov);
@@ -268,13 +270,8 @@ static void launch_knn_cov(qn_ctx* c, CloudBuf& b, int k, int32_t* kidx, float* 
     else hipLaunchKernelGGL(k_build_target_rec, dim3(nbp), dim3(QN_BLOCK), 0, s, b.raw, b.cov, b.n, c->tgt_rec);
     return;
   }
-  if (c->knn_lanes_per_query == 1) {        // one query per lane: fewest wave-instructions per query
-    const uint32_t nb = (b.n + QN_BLOCK - 1) / QN_BLOCK;
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_knn_cov<KMAX, false, 1>), dim3(nb), dim3(QN_BLOCK), 0, s, b.grid, b.raw, k, r0, 2, b.cov, kidx, kd2, c->fb_list, c->fb_count2);
-  } else if (c->knn_lanes_per_query == 2) { // 32 queries per wave x 2 candidate sub-slots
-    const uint32_t nb = (b.n + QN_BLOCK / 2 - 1) / (QN_BLOCK / 2);
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_knn_cov<KMAX, false, 2>), dim3(nb), dim3(QN_BLOCK), 0, s, b.grid, b.raw, k, r0, 2, b.cov, kidx, kd2, c->fb_list, c->fb_count2);
-  } else {                                  // 16 queries per wave x 4 candidate sub-slots: shortest critical path
+  ProfScope ps(c, QN_K_KNN_COV);
+  {                                         // sorted-list sink, 16 queries per wave x 4 candidate sub-slots (knn_hist = 0)
     const uint32_t nb = (b.n + QN_BLOCK / 4 - 1) / (QN_BLOCK / 4);
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_knn_cov<KMAX, false, 4>), dim3(nb), dim3(QN_BLOCK), 0, s, b.grid, b.raw, k, r0, 2, b.cov, kidx, kd2, c->fb_list, c->fb_count2);
   }
@@ -347,7 +344,7 @@ static void enqueue_tick_fused(qn_ctx* c) {
   CloudBuf &S = c->cloud[0], &T = c->cloud[1];
   const uint32_t nbt = (S.n + QN_BLOCK - 1) / QN_BLOCK;
   const double thr2 = c->params.max_corr_dist * c->params.max_corr_dist;
-  { ProfScope ps(c, QN_K_NN_SEARCH);
+  { ProfScope ps(c, QN_K_GN_TICK_FUSED);        // tracking NN + in-kernel leftovers + accumulation in one kernel (an in-kernel last-block solver was measured slower than k_solve: DESIGN.md section 4)
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_nn_track<0, true>), dim3(nbt), dim3(QN_BLOCK), 0, s, S.grid, T.grid, T.raw, c->state, thr2, c->corr, c->sqd, c->nn_idx, c->nn_ref,
                        c->fb_list, &c->state->fb_count, c->big_list, &c->state->big_count, c->cov_s_sorted, c->tgt_rec, c->partials); }
   enqueue_solve(c, 0);
@@ -577,7 +574,6 @@ extern "C" int qn_debug_set(qn_ctx* c, const char* key, double v) {
   else if (k == "track_from_tick") c->track_from_tick = v < 1 ? 1 : (int)v;
   else if (k == "fused_from_tick") c->fused_from_tick = v < 1 ? 1 : (int)v;
   else if (k == "knn_rounds") c->knn_rounds = v < 1 ? 1 : (int)v;
-  else if (k == "knn_lanes_per_query") c->knn_lanes_per_query = v == 1 ? 1 : (v == 2 ? 2 : 4);
   else if (k == "fused_ticks") c->fused_ticks = v != 0;
   else if (k == "big_ratio") c->big_ratio = (float)v;
   else if (k == "margin_nn_cap") c->margin_nn_cap = (int)v;

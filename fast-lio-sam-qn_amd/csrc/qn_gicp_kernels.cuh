@@ -4,6 +4,7 @@
 // contraction - it is gather / scan / reduce work bound by memory latency and LDS bandwidth.
 #pragma once
 #include "qn_device.cuh"
+#include "qn_knn_hist.cuh"
 #include "../../include/qn_engine.h"
 #include "qn_util_kernels.cuh"
 
@@ -34,7 +35,7 @@ struct GicpConfig {                                 // by-value kernel argument
 };
 
 // ------------------------------------------------------------------ K1 grid build (utility kernels: qn_util_kernels.cuh)
-__global__ void k_cell_count(const float4* __restrict__ pts, uint32_t n, GridView g, uint32_t* __restrict__ counts, uint32_t* __restrict__ cell_of_pt) {
+static __global__ void k_cell_count(const float4* __restrict__ pts, uint32_t n, GridView g, uint32_t* __restrict__ counts, uint32_t* __restrict__ cell_of_pt) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   float4 p = pts[i];
@@ -47,7 +48,7 @@ __global__ void k_cell_count(const float4* __restrict__ pts, uint32_t n, GridVie
 // counting-sort scatter: counts[] still holds the per-cell population; slots are handed out from the
 // back of each cell's run.  Order inside a cell is arbitrary - every consumer is order independent
 // (ties resolve on the original index carried in .w).
-__global__ void k_scatter(const float4* __restrict__ pts, uint32_t n, const uint32_t* __restrict__ cell_of_pt,
+static __global__ void k_scatter(const float4* __restrict__ pts, uint32_t n, const uint32_t* __restrict__ cell_of_pt,
                           const uint32_t* __restrict__ cell_start, uint32_t* __restrict__ counts, float4* __restrict__ sorted) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -58,68 +59,10 @@ __global__ void k_scatter(const float4* __restrict__ pts, uint32_t n, const uint
   sorted[slot] = p;
 }
 
-// ------------------------------------------------------------------ K2+K3 k-NN + covariance
+// ------------------------------------------------------------------ K2+K3 k-NN + covariance (k-NN selection: k_knn_hist below, k_knn_cov in qn_knn_kernels.cuh)
 // k nearest (self included), mean/cov in f64 (cov = X X^T / k), PLANE regularisation:
-// C = V diag(1, 1, 1e-3) V^T with V the eigenvectors of cov (eigenvalues descending).
-template <int KMAX>
-__device__ __forceinline__ void cov_from_knn(const BestK<KMAX>& sink, const float4* __restrict__ raw, double* __restrict__ cov_out,
-                                             int32_t* __restrict__ knn_idx, float* __restrict__ knn_d2) {
-  const int k = sink.k;
-  int found = 0;
-  double mean[3] = {0, 0, 0};
-#pragma unroll
-  for (int j = 0; j < KMAX; j++) if (sink.slot_valid(j)) {
-    float4 p = raw[key_idx(sink.a[j])];
-    mean[0] += (double)p.x; mean[1] += (double)p.y; mean[2] += (double)p.z; found++;
-  }
-  if (knn_idx) {
-#pragma unroll
-    for (int j = 0; j < KMAX; j++) if (j >= KMAX - k) {
-      const bool ok = sink.a[j] != QN_INF_KEY;
-      knn_idx[j - (KMAX - k)] = ok ? (int32_t)key_idx(sink.a[j]) : -1; knn_d2[j - (KMAX - k)] = ok ? key_d2(sink.a[j]) : 0.f;
-    }
-  }
-  if (found == 0) { for (int t = 0; t < 6; t++) cov_out[t] = 0; return; }
-  mean[0] /= found; mean[1] /= found; mean[2] /= found;
-  double c[6] = {0, 0, 0, 0, 0, 0};
-#pragma unroll
-  for (int j = 0; j < KMAX; j++) if (sink.slot_valid(j)) {
-    float4 p = raw[key_idx(sink.a[j])];
-    double dx = (double)p.x - mean[0], dy = (double)p.y - mean[1], dz = (double)p.z - mean[2];
-    c[0] += dx * dx; c[1] += dx * dy; c[2] += dx * dz; c[3] += dy * dy; c[4] += dy * dz; c[5] += dz * dz;
-  }
-#pragma unroll
-  for (int t = 0; t < 6; t++) c[t] /= found;
-  double w[3], V[3][3];
-  sym_eig3(c, w, V);
-  const double vals[3] = {1.0, 1.0, 1e-3};
-  int t = 0;
-#pragma unroll
-  for (int a = 0; a < 3; a++)
-#pragma unroll
-    for (int b = a; b < 3; b++, t++) {
-      double s = 0;
-#pragma unroll
-      for (int e = 0; e < 3; e++) s += V[a][e] * vals[e] * V[b][e];
-      cov_out[t] = s;
-    }
-}
-
-// k-NN selection and covariance are separate kernels: the selection keeps a 2k-register list alive, the
-// covariance needs ~40 f64 registers for the Jacobi sweep - fused, the kernel sat at 2 waves/SIMD.
-template <int KMAX>
-__device__ __forceinline__ void store_knn(const BestK<KMAX>& sink, int32_t* __restrict__ knn_idx, float* __restrict__ knn_d2) {
-  const int k = sink.k;
-#pragma unroll
-  for (int j = 0; j < KMAX; j++) if (j >= KMAX - k) {
-    const bool ok = sink.a[j] != QN_INF_KEY;
-    knn_idx[j - (KMAX - k)] = ok ? (int32_t)key_idx(sink.a[j]) : -1;
-    if (knn_d2) knn_d2[j - (KMAX - k)] = ok ? key_d2(sink.a[j]) : 0.f;
-  }
-}
-
-// SURVEY A.1.3 from stored neighbour indices (ascending (d2, idx) order, -1 = missing): one point per lane.
-__global__ void __launch_bounds__(QN_BLOCK) k_cov_from_idx(const float4* __restrict__ raw, uint32_t n, int k, const int32_t* __restrict__ knn_idx, double* __restrict__ cov) {
+// C = V diag(1, 1, 1e-3) V^T with V the eigenvectors of cov (eigenvalues descending); from stored neighbour indices (ascending (d2, idx) order, -1 = missing): one point per lane.
+static __global__ void __launch_bounds__(QN_BLOCK) k_cov_from_idx(const float4* __restrict__ raw, uint32_t n, int k, const int32_t* __restrict__ knn_idx, double* __restrict__ cov) {
   const uint32_t i = blockIdx.x * QN_BLOCK + threadIdx.x;
   if (i >= n) return;
   const int32_t* nb = knn_idx + (size_t)i * k;
@@ -157,7 +100,7 @@ __global__ void __launch_bounds__(QN_BLOCK) k_cov_from_idx(const float4* __restr
 // (a correspondence then costs one scattered cache line instead of two).
 struct __attribute__((aligned(64))) TargetRec { float4 p; double cov[6]; };
 static_assert(sizeof(TargetRec) == 64, "TargetRec is one 64-byte line");
-__global__ void k_build_target_rec(const float4* __restrict__ raw, const double* __restrict__ cov, uint32_t n, TargetRec* __restrict__ rec) {
+static __global__ void k_build_target_rec(const float4* __restrict__ raw, const double* __restrict__ cov, uint32_t n, TargetRec* __restrict__ rec) {
   const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= n) return;
   TargetRec r; r.p = raw[j];
@@ -166,7 +109,7 @@ __global__ void k_build_target_rec(const float4* __restrict__ raw, const double*
   rec[j] = r;
 }
 // source covariances in the source's cell-sorted order (the order the NN kernels walk the queries in)
-__global__ void k_sort_cov(const float4* __restrict__ sorted, const double* __restrict__ cov, uint32_t n, double* __restrict__ cov_sorted) {
+static __global__ void k_sort_cov(const float4* __restrict__ sorted, const double* __restrict__ cov, uint32_t n, double* __restrict__ cov_sorted) {
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= n) return;
   const uint32_t i = __float_as_uint(sorted[t].w);
@@ -174,47 +117,17 @@ __global__ void k_sort_cov(const float4* __restrict__ sorted, const double* __re
   for (int u = 0; u < 6; u++) cov_sorted[(size_t)t * 6 + u] = cov[(size_t)i * 6 + u];
 }
 
-// One kernel body for both passes.  LIST = false: query t = global query slot, radius margin * cell, two
-// rounds, leftovers appended to fb_list with the radius to continue from.  LIST = true: the queries are
-// the fb_list entries of the first pass (16 per wave, wave-stride), rounds until exact.
-template <int KMAX, bool LIST, int S>
-__global__ void __launch_bounds__(QN_BLOCK, 3) k_knn_cov(GridView g, const float4* __restrict__ raw, int k, float r0, int max_rounds,
-                                                      double* __restrict__ cov, int32_t* __restrict__ knn_idx, float* __restrict__ knn_d2,
-                                                      uint2* __restrict__ fb_list, uint32_t* __restrict__ fb_count) {
-  __shared__ WaveLdsK lds[QN_BLOCK / 64];
-  WaveLdsK* my = &lds[threadIdx.x >> 6];
-  const uint32_t nq = LIST ? *fb_count : g.n;
-  if (LIST && g.dbg && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&g.dbg[4], nq);
-  const uint32_t wave0 = blockIdx.x * (QN_BLOCK / 64) + (threadIdx.x >> 6), nwaves = gridDim.x * (QN_BLOCK / 64);
-  constexpr uint32_t QPW = 64 / S;                                          // queries per wave
-  for (uint32_t base = wave0 * QPW; base < nq; base += nwaves * QPW) {      // (non-LIST grids cover nq in one trip)
-    const uint32_t slot = base + (threadIdx.x & (QPW - 1));
-    const bool active = slot < nq;
-    uint32_t t = slot; float r = r0;
-    if (LIST && active) { const uint2 rec = fb_list[slot]; t = rec.x; r = __uint_as_float(rec.y); }   // continue from r
-    const float4 q = active ? g.pts[t] : make_float4(0, 0, 0, 0);
-    BestK<KMAX> sink; sink.init(k, my->pend, g.dbg);
-    float d_unseen;
-    const bool cert = wave_search<S>(g, q.x, q.y, q.z, active, r, __int_as_float(0x7f800000), max_rounds, sink, &my->s, d_unseen);
-    if (!active || (threadIdx.x & 63) >= QPW) continue;             // sub-slot 0 of each query finishes the job
-    const uint32_t i = __float_as_uint(q.w);
-    if (cert || LIST) store_knn(sink, knn_idx + (size_t)i * k, knn_d2 ? knn_d2 + (size_t)i * k : nullptr);
-    else {
-      const uint32_t fs = atomicAdd(fb_count, 1u);
-      fb_list[fs] = make_uint2(t, __float_as_uint(r));
-    }
-  }
-}
-
 // k-NN by histogram selection (wave_knn_hist), 16 queries per wave.  LIST = false: every point, radius margin * cell,
 // `max_rounds` rounds, leftovers appended to fb_list as (t, r) with the sign bit of r set when the query needs the
 // general path.  LIST = true: the fb_list entries, rounds until exact; general-path entries are passed on to gen_list
 // (served by k_knn_cov<KMAX, true, 4> afterwards).
-template <bool LIST>
-__global__ void __launch_bounds__(QN_BLOCK, 3) k_knn_hist(GridView g, int k, float r0, int max_rounds, int32_t* __restrict__ knn_idx, float* __restrict__ knn_d2,
+// HCAP = capacity of the per-query candidate list of pass 2 (>= k + the few extras below tau): 32 for k <= 24 keeps the
+// kernel at 4 waves/SIMD (LDS 34 KB/block, <= 128 VGPRs), 48 serves k <= 32 at 3 waves/SIMD.
+template <bool LIST, int HCAP>
+__global__ void __launch_bounds__(QN_BLOCK, HCAP <= 32 ? 4 : 3) k_knn_hist(GridView g, int k, float r0, int max_rounds, int32_t* __restrict__ knn_idx, float* __restrict__ knn_d2,
                                                        uint2* __restrict__ fb_list, uint32_t* __restrict__ fb_count, uint2* __restrict__ gen_list, uint32_t* __restrict__ gen_count) {
-  __shared__ WaveLdsH lds[QN_BLOCK / 64];
-  WaveLdsH* my = &lds[threadIdx.x >> 6];
+  __shared__ WaveLdsH<HCAP> lds[QN_BLOCK / 64];
+  WaveLdsH<HCAP>* my = &lds[threadIdx.x >> 6];
   const uint32_t nq = LIST ? *fb_count : g.n;
   if (LIST && g.dbg && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&g.dbg[4], nq);
   const uint32_t wave0 = blockIdx.x * (QN_BLOCK / 64) + (threadIdx.x >> 6), nwaves = gridDim.x * (QN_BLOCK / 64);
@@ -227,7 +140,7 @@ __global__ void __launch_bounds__(QN_BLOCK, 3) k_knn_hist(GridView g, int k, flo
     const uint32_t i = __float_as_uint(q.w);
     int status = 2;
     {
-      const int st = wave_knn_hist(g, q.x, q.y, q.z, active && !general, r, k, max_rounds, my, knn_idx + (size_t)i * k, knn_d2 ? knn_d2 + (size_t)i * k : nullptr);
+      const int st = wave_knn_hist<HCAP>(g, q.x, q.y, q.z, active && !general, r, k, max_rounds, my, knn_idx + (size_t)i * k, knn_d2 ? knn_d2 + (size_t)i * k : nullptr);
       if (!general) status = st;
     }
     if (!active || (threadIdx.x & 63) >= 16 || status == 0) continue;
@@ -401,7 +314,7 @@ __device__ __forceinline__ void reduce_block_partials(const double acc[QN_NPART]
   }
 }
 
-__global__ void __launch_bounds__(QN_BLOCK) k_accumulate(const float4* __restrict__ src_raw, uint32_t ns, const float4* __restrict__ tgt_raw,
+static __global__ void __launch_bounds__(QN_BLOCK) k_accumulate(const float4* __restrict__ src_raw, uint32_t ns, const float4* __restrict__ tgt_raw,
                                                          const double* __restrict__ cov_s, const double* __restrict__ cov_t,
                                                          const int32_t* __restrict__ corr, const GicpState* __restrict__ st,
                                                          double* __restrict__ partials) {
@@ -772,7 +685,7 @@ __device__ inline void solve_controller(GicpState* st, const double* sums, const
 
 
 #define QN_SOLVE_THREADS 1024
-__global__ void __launch_bounds__(QN_SOLVE_THREADS) k_solve(GicpState* gst, const double* __restrict__ partials, int nblk, GicpConfig cfg, qn_iter_trace* trace, int mode) {
+static __global__ void __launch_bounds__(QN_SOLVE_THREADS) k_solve(GicpState* gst, const double* __restrict__ partials, int nblk, GicpConfig cfg, qn_iter_trace* trace, int mode) {
   __shared__ double sums[QN_NPART];
   __shared__ double part32[QN_NPART][33];
   __shared__ GicpState sh;                       // the controller works on an LDS copy: one coalesced read, one coalesced write-back
@@ -801,7 +714,7 @@ __global__ void __launch_bounds__(QN_SOLVE_THREADS) k_solve(GicpState* gst, cons
   for (int i = threadIdx.x; i < (int)(sizeof(GicpState) / 8); i += QN_SOLVE_THREADS) ((unsigned long long*)gst)[i] = ((const unsigned long long*)&sh)[i];
 }
 
-__global__ void k_init_state(GicpState* st, const float* __restrict__ guess /* 16 or null */, int has_guess, int phase) {
+static __global__ void k_init_state(GicpState* st, const float* __restrict__ guess /* 16 or null */, int has_guess, int phase) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   for (int i = 0; i < 16; i++) { double v = has_guess ? (double)guess[i] : ((i % 5 == 0) ? 1.0 : 0.0); st->x0[i] = v; st->xi[i] = v; st->delta[i] = (i % 5 == 0) ? 1.0 : 0.0; }
   for (int i = 0; i < 36; i++) { st->H[i] = 0; st->final_H[i] = (i % 7 == 0) ? 1.0 : 0.0; }
@@ -809,7 +722,7 @@ __global__ void k_init_state(GicpState* st, const float* __restrict__ guess /* 1
   st->y0 = st->yi = st->den = 0; st->lambda = -1.0; st->nu = 2.0; st->fitness = 0;
   st->outer = st->inner = 0; st->phase = phase; st->converged = 0; st->lm_failed = 0; st->fb_count = 0; st->big_count = 0; st->trace_len = 0;
 }
-__global__ void k_set_pose(GicpState* st, const double* __restrict__ T, int which /*0 x0, 1 xi, 2 neither*/, int phase) {
+static __global__ void k_set_pose(GicpState* st, const double* __restrict__ T, int which /*0 x0, 1 xi, 2 neither*/, int phase) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   for (int i = 0; i < 16; i++) { if (which == 0) st->x0[i] = T[i]; else if (which == 1) st->xi[i] = T[i]; }
   st->phase = phase; st->fb_count = 0; st->big_count = 0;
@@ -818,7 +731,7 @@ __global__ void k_set_pose(GicpState* st, const double* __restrict__ T, int whic
 // ------------------------------------------------------------------ K7 fitness reduce, K8 transform
 // pcl getFitnessScore: mean of the f32 squared NN distances <= max_range, summed in f64.
 #define QN_FIT_BLOCKS 128
-__global__ void __launch_bounds__(QN_BLOCK) k_fitness_partial(const float* __restrict__ sqd, uint32_t n, double max_range, const GicpState* __restrict__ st,
+static __global__ void __launch_bounds__(QN_BLOCK) k_fitness_partial(const float* __restrict__ sqd, uint32_t n, double max_range, const GicpState* __restrict__ st,
                                                               double* __restrict__ psum, uint32_t* __restrict__ pcnt, int require_done) {
   __shared__ double ssum[QN_BLOCK / 64]; __shared__ uint32_t scnt[QN_BLOCK / 64];
   if (require_done && st->phase != 2) return;
@@ -835,7 +748,7 @@ __global__ void __launch_bounds__(QN_BLOCK) k_fitness_partial(const float* __res
     psum[blockIdx.x] = t; pcnt[blockIdx.x] = tc;
   }
 }
-__global__ void __launch_bounds__(QN_FIT_BLOCKS) k_fitness_final(const double* __restrict__ psum, const uint32_t* __restrict__ pcnt, GicpState* st, int require_done) {
+static __global__ void __launch_bounds__(QN_FIT_BLOCKS) k_fitness_final(const double* __restrict__ psum, const uint32_t* __restrict__ pcnt, GicpState* st, int require_done) {
   __shared__ double ssum[QN_FIT_BLOCKS]; __shared__ uint32_t scnt[QN_FIT_BLOCKS];
   if (require_done && st->phase != 2) return;
   ssum[threadIdx.x] = psum[threadIdx.x]; scnt[threadIdx.x] = pcnt[threadIdx.x];
@@ -850,7 +763,7 @@ __global__ void __launch_bounds__(QN_FIT_BLOCKS) k_fitness_final(const double* _
 
 // pcl::transformPointCloud(*input_, output, final_transformation_) inside align(); also used for the
 // Quatro -> GICP hand-over transformPcd(src, T_q) (loop_closure.cpp:152, utilities.hpp:164-175) in f64 mode.
-__global__ void k_transform_cloud(const float4* __restrict__ in, uint32_t n, const GicpState* __restrict__ st, float4* __restrict__ out, int require_done) {
+static __global__ void k_transform_cloud(const float4* __restrict__ in, uint32_t n, const GicpState* __restrict__ st, float4* __restrict__ out, int require_done) {
   if (require_done && st->phase != 2) return;
   float Tf[12];
 #pragma unroll
@@ -864,7 +777,7 @@ __global__ void k_transform_cloud(const float4* __restrict__ in, uint32_t n, con
 
 struct ResultBlock { qn_gicp_result r; int32_t phase; uint32_t trace_len; };
 
-__global__ void k_finalize(const GicpState* __restrict__ st, ResultBlock* out) {   // out lives in pinned host memory
+static __global__ void k_finalize(const GicpState* __restrict__ st, ResultBlock* out) {   // out lives in pinned host memory
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   for (int i = 0; i < 16; i++) { out->r.T64[i] = st->x0[i]; out->r.T[i] = (float)st->x0[i]; }
   for (int i = 0; i < 36; i++) out->r.H[i] = st->final_H[i];

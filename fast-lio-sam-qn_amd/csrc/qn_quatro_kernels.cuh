@@ -49,7 +49,7 @@ __device__ __forceinline__ void for_each_in_ball_cells(const GridView& g, float 
 }
 
 // K9: PCL NormalEstimation, radius search.  normals[t] = (nx, ny, nz, 1) or NaNs.
-__global__ void __launch_bounds__(QN_BLOCK) k_normals(GridView g, float r, float r2, float4* __restrict__ normals) {
+static __global__ void __launch_bounds__(QN_BLOCK) k_normals(GridView g, float r, float r2, float4* __restrict__ normals) {
   const uint32_t t = blockIdx.x * QN_BLOCK + threadIdx.x;
   if (t >= g.n) return;
   const float4 p = g.pts[t];
@@ -92,7 +92,7 @@ __device__ __forceinline__ bool pair_features(const float4 p1, const float4 n1, 
 }
 
 // K10: SPFH - 3 x 11-bin histograms of (theta, alpha, phi) over the r_f neighbourhood; bin = count * 100 / (n_nbrs - 1)
-__global__ void __launch_bounds__(QN_BLOCK) k_spfh(GridView g, float r, float r2, const float4* __restrict__ normals, float* __restrict__ spfh) {
+static __global__ void __launch_bounds__(QN_BLOCK) k_spfh(GridView g, float r, float r2, const float4* __restrict__ normals, float* __restrict__ spfh) {
   const uint32_t t = blockIdx.x * QN_BLOCK + threadIdx.x;
   if (t >= g.n) return;
   const float4 p = g.pts[t], np = normals[t];
@@ -124,7 +124,7 @@ __global__ void __launch_bounds__(QN_BLOCK) k_spfh(GridView g, float r, float r2
 }
 
 // K11: FPFH(p) = sum_q SPFH(q) / d2(p, q) over the r_f neighbourhood (d2 > 0), each 11-bin group normalised to 100
-__global__ void __launch_bounds__(QN_BLOCK) k_fpfh(GridView g, float r, float r2, const float4* __restrict__ normals, const float* __restrict__ spfh, float* __restrict__ fpfh) {
+static __global__ void __launch_bounds__(QN_BLOCK) k_fpfh(GridView g, float r, float r2, const float4* __restrict__ normals, const float* __restrict__ spfh, float* __restrict__ fpfh) {
   const uint32_t t = blockIdx.x * QN_BLOCK + threadIdx.x;
   if (t >= g.n) return;
   const float4 p = g.pts[t], np = normals[t];
@@ -159,7 +159,7 @@ __global__ void __launch_bounds__(QN_BLOCK) k_fpfh(GridView g, float r, float r2
 }
 
 // sorted-position rows -> original-index rows (rows of `w` floats)
-__global__ void k_rows_to_original(const float4* __restrict__ pts, uint32_t n, const float* __restrict__ in, float* __restrict__ out, int w_in, int w_out) {
+static __global__ void k_rows_to_original(const float4* __restrict__ pts, uint32_t n, const float* __restrict__ in, float* __restrict__ out, int w_in, int w_out) {
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= n) return;
   const uint32_t i = __float_as_uint(pts[t].w);
@@ -170,7 +170,7 @@ __global__ void k_rows_to_original(const float4* __restrict__ pts, uint32_t n, c
 // grid.x tiles the queries (256 per block), grid.y splits the candidates; partial winners meet in a 64-bit
 // atomicMin on (distance bits << 32 | index).  Queries optionally come through an index list.
 #define QN_FM_TILE 64
-__global__ void __launch_bounds__(QN_BLOCK) k_feat_nn(const float* __restrict__ Q, uint32_t nq, const uint32_t* __restrict__ qlist, const uint32_t* __restrict__ qlist_n,
+static __global__ void __launch_bounds__(QN_BLOCK) k_feat_nn(const float* __restrict__ Q, uint32_t nq, const uint32_t* __restrict__ qlist, const uint32_t* __restrict__ qlist_n,
                                                       const float* __restrict__ Cn, uint32_t nc, uint32_t chunk, unsigned long long* __restrict__ best_key) {
   __shared__ float4 tile[QN_FM_TILE * 9];
   const uint32_t nqueries = qlist ? *qlist_n : nq;
@@ -207,21 +207,21 @@ __global__ void __launch_bounds__(QN_BLOCK) k_feat_nn(const float* __restrict__ 
   if (qok && bi != 0xffffffffu) atomicMin(&best_key[qi], ((unsigned long long)__float_as_uint(best) << 32) | bi);
 }
 
-__global__ void k_fill_u64(unsigned long long* p, uint32_t n, unsigned long long v) { uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; if (i < n) p[i] = v; }
+static __global__ void k_fill_u64(unsigned long long* p, uint32_t n, unsigned long long v) { uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; if (i < n) p[i] = v; }
 
 // mark the candidates that were somebody's nearest neighbour and compact them into a query list
-__global__ void k_mark_hits(const unsigned long long* __restrict__ j_key, uint32_t nj, uint32_t* __restrict__ hit) {
+static __global__ void k_mark_hits(const unsigned long long* __restrict__ j_key, uint32_t nj, uint32_t* __restrict__ hit) {
   const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= nj) return;
   const unsigned long long k = j_key[j];
   if (k != QN_INF_KEY) hit[(uint32_t)k] = 1u;
 }
-__global__ void k_compact_hits(const uint32_t* __restrict__ hit, uint32_t ni, uint32_t* __restrict__ list, uint32_t* __restrict__ count) {
+static __global__ void k_compact_hits(const uint32_t* __restrict__ hit, uint32_t ni, uint32_t* __restrict__ list, uint32_t* __restrict__ count) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < ni && hit[i]) list[atomicAdd(count, 1u)] = i;
 }
 // cross-check: keep (i, j) when i's own nearest neighbour is j
-__global__ void k_mutual(const unsigned long long* __restrict__ j_key, uint32_t nj, const unsigned long long* __restrict__ i_key,
+static __global__ void k_mutual(const unsigned long long* __restrict__ j_key, uint32_t nj, const unsigned long long* __restrict__ i_key,
                          uint2* __restrict__ pairs, uint32_t* __restrict__ count) {
   const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= nj) return;
@@ -234,7 +234,7 @@ __global__ void k_mutual(const unsigned long long* __restrict__ j_key, uint32_t 
 
 // transformPcd(src, T_q): pcl::transformPointCloud with a Matrix4d on f32 points (utilities.hpp:164-175,
 // loop_closure.cpp:152): double arithmetic ((t0 x + t1 y) + t2 z) + t3, rounded to f32
-__global__ void k_transform_cloud_f64(const float4* __restrict__ in, uint32_t n, const double* __restrict__ T, float4* __restrict__ out) {
+static __global__ void k_transform_cloud_f64(const float4* __restrict__ in, uint32_t n, const double* __restrict__ T, float4* __restrict__ out) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const float4 p = in[i];

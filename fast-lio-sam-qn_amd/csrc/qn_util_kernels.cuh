@@ -5,7 +5,9 @@
 
 namespace qn {
 
+#ifndef QN_BLOCK
 #define QN_BLOCK 256
+#endif
 
 struct BBoxOut { int mn[3], mx[3]; uint32_t nonfinite; };
 

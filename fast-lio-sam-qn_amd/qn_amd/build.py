@@ -14,6 +14,9 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fP
          "-Wno-unused-result", "-Wno-unused-value", "-Wno-pass-failed", "-I" + os.path.join(ROOT, "include")]
 
 
+N_INST_GROUPS = 9      # = QN_NUM_INST_GROUPS in csrc/qn_instances.h
+
+
 def sources():
     return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip"))
 
@@ -26,25 +29,50 @@ def needs_build():
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    return any(os.path.getmtime(d) > t for d in sources() + _deps())
+    return any(_stale(src, obj) or os.path.getmtime(obj) > t for src, obj, _ in _units())
 
 
-def build(force=False, verbose=False):
-    """One object per .hip translation unit (cached by mtime: qn_cloud.hip pulls in hipCUB's radix sort, minutes to
-    compile), then one link into the in-tree libqn_engine.so."""
+def _units():
+    """(source, object, extra flags): qn_inst.hip is compiled once per instantiation group (csrc/qn_instances.h)."""
+    units = []
+    for src in sources():
+        if os.path.basename(src) == "qn_inst.hip":
+            units += [(src, src[:-4] + "_g%d.o" % g, ["-DQN_INST_GROUP=%d" % g]) for g in range(1, N_INST_GROUPS + 1)]
+        else:
+            units.append((src, src[:-4] + ".o", []))
+    return units
+
+
+def _stale(src, obj):
+    """Per-unit dependencies from the compiler's own -MD file (so the minutes-long k-NN units are rebuilt only when
+    qn_knn_kernels.cuh / qn_device.cuh change)."""
+    if not os.path.exists(obj) or not os.path.exists(obj + ".d"):
+        return True
+    t = os.path.getmtime(obj)
+    deps = [w for w in open(obj + ".d").read().replace("\\\n", " ").split()[1:] if os.path.abspath(w).startswith(ROOT)]
+    return any((not os.path.exists(d)) or os.path.getmtime(d) > t for d in [src] + deps)
+
+
+def build(force=False, verbose=False, jobs=None):
+    """One object per translation unit, compiled in parallel (the search kernels take minutes each; they are split into
+    explicit-instantiation units for that reason), cached by mtime, then one link into the in-tree libqn_engine.so."""
     if not force and not needs_build():
         return LIB
-    objs = []
+    from concurrent.futures import ThreadPoolExecutor
     cflags = [f for f in FLAGS if f != "-shared"]
-    for src in sources():
-        obj = src[:-4] + ".o"
-        stale = force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(p) for p in [src] + _deps())
-        if stale:
-            cmd = [HIPCC] + cflags + ["-c", src, "-o", obj]
-            if verbose:
-                print(" ".join(cmd))
-            subprocess.check_call(cmd)
+    todo, objs = [], []
+    for src, obj, extra in _units():
         objs.append(obj)
+        if force or _stale(src, obj):
+            todo.append([HIPCC] + cflags + extra + ["-MD", "-MF", obj + ".d", "-c", src, "-o", obj])
+
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+
+    with ThreadPoolExecutor(max_workers=jobs or max(1, min(len(todo), os.cpu_count() or 1))) as ex:
+        list(ex.map(run, todo))
     cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-pthread"] + objs + ["-o", LIB]
     if verbose:
         print(" ".join(cmd))

@@ -84,6 +84,8 @@ enum {                     /* kernel families for qn_prof_get */
   QN_K_GRID_BUILD = 0, QN_K_KNN_COV = 1, QN_K_NN_SEARCH = 2, QN_K_NN_FALLBACK = 3,
   QN_K_ACCUMULATE = 4, QN_K_SOLVE = 5, QN_K_FITNESS = 6, QN_K_TRANSFORM = 7,
   QN_K_FPFH_NORMALS = 8, QN_K_FPFH_SPFH = 9, QN_K_FPFH_FPFH = 10, QN_K_FEAT_MATCH = 11,
+  QN_K_GN_TICK_FUSED = 12,   /* fused Gauss-Newton tick: tracking NN + leftovers + accumulation in one kernel       */
+  QN_K_KNN_SELECT = 13,      /* k-NN selection kernel alone (QN_K_KNN_COV then holds its list tail + covariances)  */
   QN_K_COUNT = 16
 };
 
