@@ -152,11 +152,12 @@ struct Best1 {                         // 1-NN, plus the squared distance of the
   float second;                        // smallest d2 among scanned points other than `key`'s point
   __device__ __forceinline__ void init() { key = QN_INF_KEY; second = __int_as_float(0x7f800000); }
   __device__ __forceinline__ void consider(bool on, float d2, uint32_t idx) {
-    const unsigned long long k = pack_key(d2, idx);
-    if (on) {
-      if (k < key) { if (key != QN_INF_KEY) second = key_d2(key); key = k; }
-      else if (k != key && d2 < second) second = d2;
-    }
+    const unsigned long long k = pack_key(d2, idx);                   // branch-free (selects): no exec-mask region for the scheduler to sink loads into
+    const bool lt = on && k < key;
+    const bool mid = on && !lt && k != key && d2 < second;
+    const float s_lt = key != QN_INF_KEY ? key_d2(key) : second;
+    second = lt ? s_lt : (mid ? d2 : second);
+    key = lt ? k : key;
   }
   template <int S>
   __device__ __forceinline__ void finish(bool on) {                   // combine the S candidate sub-slots of a query
@@ -392,11 +393,16 @@ __device__ __forceinline__ uint32_t stream_clusters(const GridView& g, WaveLds* 
       wave_lds_fence();
       if (slot < total) { lds->tile[lane] = g.pts[lds->seg_start[j] + (slot - lds->seg_excl[j])]; lds->tile_cid[lane] = lds->seg_cid[j]; }
       wave_lds_fence();
-#pragma unroll 2
-      for (uint32_t c = 0; c < cnt; c += S) {                               // S candidates per step: one per sub-slot
-        const uint32_t ci = c + (uint32_t)(S == 1 ? 0 : lane / (64 / S));
-        const float4 cp = lds->tile[ci & 63];                               // ds_read_b128, S distinct addresses per wave
-        fn(cp, ci < cnt, lds->tile_cid[ci & 63]);
+      // S candidates per step (one per sub-slot), 4 steps per trip with the four ds_read_b128 issued BEFORE any scoring: with
+      // the read inside a predicated body every step paid the LDS latency in full (read -> wait -> score -> branch).
+      // fn must tolerate in_tile == false (it is then handed a stale tile entry; tile[ci & 63] is always in bounds).
+      const uint32_t sub_off = (uint32_t)(S == 1 ? 0 : lane / (64 / S));
+      for (uint32_t c = 0; c < cnt; c += 4 * S) {
+        float4 cp[4]; uint32_t cc[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) { const uint32_t ci = (c + (uint32_t)(S * u) + sub_off) & 63u; cp[u] = lds->tile[ci]; cc[u] = lds->tile_cid[ci]; }
+#pragma unroll
+        for (int u = 0; u < 4; u++) fn(cp[u], c + (uint32_t)(S * u) + sub_off < cnt, cc[u]);
       }
     }
     ncand += total;

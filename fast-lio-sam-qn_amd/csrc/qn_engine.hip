@@ -256,13 +256,13 @@ static void launch_knn_cov(qn_ctx* c, CloudBuf& b, int k, int32_t* kidx, float* 
   hipStream_t s = c->stream;
   const float r0 = c->margin_knn * b.grid.cell;
   if (c->knn_hist) {                        // histogram selection (default); its leftovers -> hist list pass -> general sorted-list pass
-    const uint32_t nb = (b.n + QN_BLOCK / 4 - 1) / (QN_BLOCK / 4);
+    const uint32_t nb = (b.n + QN_KNN_BLOCK / 4 - 1) / (QN_KNN_BLOCK / 4);     // 16 queries per wave
     uint32_t* genc = c->fb_count2 + 1;
     constexpr int HCAP = KMAX <= 24 ? 32 : 48;      // pass-2 list capacity: 32 keeps the selection kernel at 4 waves/SIMD
     { ProfScope sel(c, QN_K_KNN_SELECT);
-      hipLaunchKernelGGL(HIP_KERNEL_NAME(k_knn_hist<false, HCAP>), dim3(nb), dim3(QN_BLOCK), 0, s, b.grid, k, r0, c->knn_rounds, kidx, kd2, c->fb_list, c->fb_count2, c->big_list, genc); }
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(k_knn_hist<false, HCAP>), dim3(nb), dim3(QN_KNN_BLOCK), 0, s, b.grid, k, r0, c->knn_rounds, kidx, kd2, c->fb_list, c->fb_count2, c->big_list, genc); }
     ProfScope ps(c, QN_K_KNN_COV);
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_knn_hist<true, HCAP>), dim3(std::min<uint32_t>((b.n + 63) / 64, 512)), dim3(QN_BLOCK), 0, s, b.grid, k, r0, 64, kidx, kd2, c->fb_list, c->fb_count2, c->big_list, genc);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_knn_hist<true, HCAP>), dim3(std::min<uint32_t>((b.n + 63) / 64, 512) * (QN_BLOCK / QN_KNN_BLOCK)), dim3(QN_KNN_BLOCK), 0, s, b.grid, k, r0, 64, kidx, kd2, c->fb_list, c->fb_count2, c->big_list, genc);
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_knn_cov<KMAX, true, 4>), dim3(std::min<uint32_t>((b.n + 63) / 64, 64)), dim3(QN_BLOCK), 0, s, b.grid, b.raw, k, r0, 64, b.cov, kidx, kd2, c->big_list, genc);
     const uint32_t nbp = (b.n + QN_BLOCK - 1) / QN_BLOCK;
     hipLaunchKernelGGL(k_cov_from_idx, dim3(nbp), dim3(QN_BLOCK), 0, s, b.raw, b.n, k, kidx, b.cov);
@@ -307,24 +307,25 @@ extern "C" int qn_gicp_compute_covariances(qn_ctx* c, int which) { return comput
 static void enqueue_nn(qn_ctx* c, int mode /*0 align, 1 fitness*/, float* sqd_out, bool seeded, int tick = 0) {
   hipStream_t s = c->stream;
   CloudBuf &S = c->cloud[0], &T = c->cloud[1];
-  const uint32_t nb = (S.n + QN_BLOCK / 4 - 1) / (QN_BLOCK / 4);      // 16 queries per wave, 64 per block
+  const uint32_t nb = (S.n + QN_NN_BLOCK / 4 - 1) / (QN_NN_BLOCK / 4);   // grid passes: 16 queries per wave
+  const uint32_t nb4 = (S.n + QN_BLOCK / 4 - 1) / (QN_BLOCK / 4);       // list passes: 4 waves per block
   const uint32_t nbt = (S.n + QN_BLOCK - 1) / QN_BLOCK;               // tracking: one query per lane
   const double thr2 = c->params.max_corr_dist * c->params.max_corr_dist;
   uint32_t* fbc = &c->state->fb_count; uint32_t* bgc = &c->state->big_count;
   const int big_blocks = tick == 0 ? 1024 : (tick == 1 ? 256 : (tick == 2 ? 512 : 64));   // waves with one far query each (idle blocks exit at once)
-  const uint32_t fbb = std::min<uint32_t>(nb, tick <= 1 ? 512 : (tick == 2 ? 128 : 64));  // list pass: wave-stride over the leftovers
+  const uint32_t fbb = std::min<uint32_t>(nb4, tick <= 1 ? 512 : (tick == 2 ? 128 : 64));  // list pass: wave-stride over the leftovers
   const float r0 = c->margin_nn * T.grid.cell;
   if (mode == 0) {
     { ProfScope ps(c, QN_K_NN_SEARCH);
       if (seeded) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_nn_track<0, false>), dim3(nbt), dim3(QN_BLOCK), 0, s, S.grid, T.grid, T.raw, c->state, thr2, c->corr, sqd_out, c->nn_idx, c->nn_ref, c->fb_list, fbc, c->big_list, bgc, nullptr, nullptr, nullptr);
-      else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_nn_search<0, false>), dim3(nb), dim3(QN_BLOCK), 0, s, S.grid, T.grid, c->state, thr2, r0, c->nn_rounds, c->corr, sqd_out, c->nn_idx, c->nn_ref, c->fb_list, fbc, c->big_list, bgc, 0, c->big_ratio); }
+      else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_nn_search<0, false, QN_NN_BLOCK>), dim3(nb), dim3(QN_NN_BLOCK), 0, s, S.grid, T.grid, c->state, thr2, r0, c->nn_rounds, c->corr, sqd_out, c->nn_idx, c->nn_ref, c->fb_list, fbc, c->big_list, bgc, 0, c->big_ratio); }
     { ProfScope ps(c, QN_K_NN_FALLBACK);
-      hipLaunchKernelGGL(HIP_KERNEL_NAME(k_nn_search<0, true>), dim3(fbb + big_blocks), dim3(QN_BLOCK), 0, s, S.grid, T.grid, c->state, thr2, r0, 64, c->corr, sqd_out, c->nn_idx, c->nn_ref, c->fb_list, fbc, c->big_list, bgc, big_blocks, c->big_ratio); }
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(k_nn_search<0, true, QN_BLOCK>), dim3(fbb + big_blocks), dim3(QN_BLOCK), 0, s, S.grid, T.grid, c->state, thr2, r0, 64, c->corr, sqd_out, c->nn_idx, c->nn_ref, c->fb_list, fbc, c->big_list, bgc, big_blocks, c->big_ratio); }
   } else {
     ProfScope ps(c, QN_K_FITNESS);
     if (seeded) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_nn_track<1, false>), dim3(nbt), dim3(QN_BLOCK), 0, s, S.grid, T.grid, T.raw, c->state, thr2, c->corr, sqd_out, c->nn_idx, c->nn_ref, c->fb_list, fbc, c->big_list, bgc, nullptr, nullptr, nullptr);
-    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_nn_search<1, false>), dim3(nb), dim3(QN_BLOCK), 0, s, S.grid, T.grid, c->state, thr2, r0, 1, c->corr, sqd_out, c->nn_idx, c->nn_ref, c->fb_list, fbc, c->big_list, bgc, 0, c->big_ratio);
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_nn_search<1, true>), dim3(fbb + big_blocks), dim3(QN_BLOCK), 0, s, S.grid, T.grid, c->state, thr2, r0, 64, c->corr, sqd_out, c->nn_idx, c->nn_ref, c->fb_list, fbc, c->big_list, bgc, big_blocks, c->big_ratio);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_nn_search<1, false, QN_NN_BLOCK>), dim3(nb), dim3(QN_NN_BLOCK), 0, s, S.grid, T.grid, c->state, thr2, r0, 1, c->corr, sqd_out, c->nn_idx, c->nn_ref, c->fb_list, fbc, c->big_list, bgc, 0, c->big_ratio);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_nn_search<1, true, QN_BLOCK>), dim3(fbb + big_blocks), dim3(QN_BLOCK), 0, s, S.grid, T.grid, c->state, thr2, r0, 64, c->corr, sqd_out, c->nn_idx, c->nn_ref, c->fb_list, fbc, c->big_list, bgc, big_blocks, c->big_ratio);
   }
 }
 static uint32_t acc_blocks(const qn_ctx* c) { return std::min<uint32_t>((c->cloud[0].n + QN_BLOCK - 1) / QN_BLOCK, QN_ACC_MAX_BLOCKS); }

@@ -123,14 +123,19 @@ static __global__ void k_sort_cov(const float4* __restrict__ sorted, const doubl
 // (served by k_knn_cov<KMAX, true, 4> afterwards).
 // HCAP = capacity of the per-query candidate list of pass 2 (>= k + the few extras below tau): 32 for k <= 24 keeps the
 // kernel at 4 waves/SIMD (LDS 34 KB/block, <= 128 VGPRs), 48 serves k <= 32 at 3 waves/SIMD.
+// QN_KNN_BLOCK: threads per block of the selection kernel (one wave serves 16 queries; smaller blocks refill the CUs at a
+// finer grain, which shortens the tail of the 6250-wave launch)
+#ifndef QN_KNN_BLOCK
+#define QN_KNN_BLOCK 64
+#endif
 template <bool LIST, int HCAP>
-__global__ void __launch_bounds__(QN_BLOCK, HCAP <= 32 ? 4 : 3) k_knn_hist(GridView g, int k, float r0, int max_rounds, int32_t* __restrict__ knn_idx, float* __restrict__ knn_d2,
+__global__ void __launch_bounds__(QN_KNN_BLOCK, HCAP <= 32 ? 4 : 3) k_knn_hist(GridView g, int k, float r0, int max_rounds, int32_t* __restrict__ knn_idx, float* __restrict__ knn_d2,
                                                        uint2* __restrict__ fb_list, uint32_t* __restrict__ fb_count, uint2* __restrict__ gen_list, uint32_t* __restrict__ gen_count) {
-  __shared__ WaveLdsH<HCAP> lds[QN_BLOCK / 64];
+  __shared__ WaveLdsH<HCAP> lds[QN_KNN_BLOCK / 64];
   WaveLdsH<HCAP>* my = &lds[threadIdx.x >> 6];
   const uint32_t nq = LIST ? *fb_count : g.n;
   if (LIST && g.dbg && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&g.dbg[4], nq);
-  const uint32_t wave0 = blockIdx.x * (QN_BLOCK / 64) + (threadIdx.x >> 6), nwaves = gridDim.x * (QN_BLOCK / 64);
+  const uint32_t wave0 = blockIdx.x * (QN_KNN_BLOCK / 64) + (threadIdx.x >> 6), nwaves = gridDim.x * (QN_KNN_BLOCK / 64);
   for (uint32_t base = wave0 * 16; base < nq; base += nwaves * 16) {
     const uint32_t slot = base + (threadIdx.x & 15);
     bool active = slot < nq;
@@ -184,12 +189,13 @@ __device__ __forceinline__ void store_nn(unsigned long long key, uint32_t i, uin
 // leftovers to fb_list.  LIST = true: the fb_list entries (leftovers of the first search, or the big-ball
 // queries of k_nn_track with their seed radius), 16 per wave, rounds until exact.
 // In the LIST launch the last `big_blocks` blocks serve big_list instead, one query per wave (wave_search_single).
-template <int MODE, bool LIST>
-__global__ void __launch_bounds__(QN_BLOCK) k_nn_search(GridView src, GridView tgt, const GicpState* __restrict__ st, double thr2, float r0, int max_rounds,
+// BLOCK = threads per block: the grid passes run one wave per block (finer refill of the CUs), the list passes four.
+template <int MODE, bool LIST, int BLOCK>
+__global__ void __launch_bounds__(BLOCK) k_nn_search(GridView src, GridView tgt, const GicpState* __restrict__ st, double thr2, float r0, int max_rounds,
                                                         int32_t* __restrict__ corr, float* __restrict__ sqd, int32_t* __restrict__ nn_idx, float4* __restrict__ nn_ref,
                                                         uint2* __restrict__ fb_list, uint32_t* __restrict__ fb_count,
                                                         uint2* __restrict__ big_list, uint32_t* __restrict__ big_count, int big_blocks, float big_ratio) {
-  __shared__ WaveLds lds[QN_BLOCK / 64];
+  __shared__ WaveLds lds[BLOCK / 64];
   if (MODE == 0 && st->phase != 0) return;
   if (MODE == 1 && st->phase != 2) return;
   float Tf[12];
@@ -198,7 +204,7 @@ __global__ void __launch_bounds__(QN_BLOCK) k_nn_search(GridView src, GridView t
   if (LIST && (int)blockIdx.x >= (int)gridDim.x - big_blocks) {            // ---- big entries: one query per wave
     const uint32_t nbig = *big_count;
     if (tgt.dbg && blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) atomicAdd(&tgt.dbg[7], nbig);
-    const uint32_t bw0 = (blockIdx.x - (gridDim.x - big_blocks)) * (QN_BLOCK / 64) + (threadIdx.x >> 6), nbw = big_blocks * (QN_BLOCK / 64);
+    const uint32_t bw0 = (blockIdx.x - (gridDim.x - big_blocks)) * (BLOCK / 64) + (threadIdx.x >> 6), nbw = big_blocks * (BLOCK / 64);
     for (uint32_t w = bw0; w < nbig; w += nbw) {
       const uint2 rec = big_list[w];
       const float4 p = src.pts[rec.x];
@@ -218,7 +224,7 @@ __global__ void __launch_bounds__(QN_BLOCK) k_nn_search(GridView src, GridView t
   }
   const uint32_t nq = LIST ? *fb_count : src.n;
   if (LIST && tgt.dbg && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&tgt.dbg[5], nq);
-  const uint32_t wave0 = blockIdx.x * (QN_BLOCK / 64) + (threadIdx.x >> 6), nwaves = (gridDim.x - (LIST ? big_blocks : 0)) * (QN_BLOCK / 64);
+  const uint32_t wave0 = blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6), nwaves = (gridDim.x - (LIST ? big_blocks : 0)) * (BLOCK / 64);
   for (uint32_t base = wave0 * 16; base < nq; base += nwaves * 16) {
     const uint32_t slot = base + (threadIdx.x & 15);
     const bool active = slot < nq;

@@ -15,6 +15,7 @@
 
 namespace qn {
 
+#define QN_NN_BLOCK 256        // threads per block of the grid-form 1-NN passes (16 queries per wave)
 #define QN_KNN_HIST_ARGS (GridView, int, float, int, int32_t*, float*, uint2*, uint32_t*, uint2*, uint32_t*)
 #define QN_NN_SEARCH_ARGS (GridView, GridView, const GicpState*, double, float, int, int32_t*, float*, int32_t*, float4*, uint2*, uint32_t*, uint2*, uint32_t*, int, float)
 #define QN_NN_TRACK_ARGS (GridView, GridView, const float4*, const GicpState*, double, int32_t*, float*, int32_t*, float4*, uint2*, uint32_t*, uint2*, uint32_t*, const double*, const TargetRec*, double*)
@@ -23,10 +24,10 @@ QN_G1 __global__ void k_knn_hist<false, 32> QN_KNN_HIST_ARGS;
 QN_G1 __global__ void k_knn_hist<true, 32> QN_KNN_HIST_ARGS;
 QN_G1 __global__ void k_knn_hist<false, 48> QN_KNN_HIST_ARGS;
 QN_G1 __global__ void k_knn_hist<true, 48> QN_KNN_HIST_ARGS;
-QN_G1 __global__ void k_nn_search<0, false> QN_NN_SEARCH_ARGS;
-QN_G1 __global__ void k_nn_search<0, true> QN_NN_SEARCH_ARGS;
-QN_G1 __global__ void k_nn_search<1, false> QN_NN_SEARCH_ARGS;
-QN_G1 __global__ void k_nn_search<1, true> QN_NN_SEARCH_ARGS;
+QN_G1 __global__ void k_nn_search<0, false, QN_NN_BLOCK> QN_NN_SEARCH_ARGS;
+QN_G1 __global__ void k_nn_search<0, true, QN_BLOCK> QN_NN_SEARCH_ARGS;
+QN_G1 __global__ void k_nn_search<1, false, QN_NN_BLOCK> QN_NN_SEARCH_ARGS;
+QN_G1 __global__ void k_nn_search<1, true, QN_BLOCK> QN_NN_SEARCH_ARGS;
 QN_G1 __global__ void k_nn_track<0, false> QN_NN_TRACK_ARGS;
 QN_G1 __global__ void k_nn_track<1, false> QN_NN_TRACK_ARGS;
 QN_G1 __global__ void k_nn_track<0, true> QN_NN_TRACK_ARGS;

@@ -19,11 +19,12 @@ namespace qn {
 // 2 r although the whole grid was scanned, more than HCAP candidates below tau, non-finite) return status 2 and
 // go to the general sorted-list path (wave_search + BestK).
 #define QN_HB 64
+#define QN_HW (QN_HB + 5)
 template <int HCAP>
 struct WaveLdsH {
   WaveLds s;
   union {
-    uint32_t hist[16][QN_HB + 1];                 // +1: the 16 queries' rows start in different banks
+    uint32_t hist[16][QN_HW];                     // 64 bins + 4 reject columns (one per sub-slot) + 1: rows start in different banks
     unsigned long long list[16][HCAP + 1];
   } u;
   uint32_t cnt[16];
@@ -50,13 +51,14 @@ __device__ __forceinline__ int wave_knn_hist(const GridView& g, float qx, float 
     build_clusters<4>(g, lds, todo, cx, cy, cz, qx, qy, qz, r, cid, ncl, nseg_all);
     // ---- pass 1: histogram
     { uint32_t* hz = &L->u.hist[0][0];
-      for (int e = lane; e < 16 * (QN_HB + 1); e += 64) hz[e] = 0; }
+      for (int e = lane; e < 16 * QN_HW; e += 64) hz[e] = 0; }
     wave_lds_fence();
     const int base = (int)(__float_as_uint(4.f * r * r) >> 20) - (QN_HB - 2);      // bin QN_HB-2 ends at (2 r)^2, bin QN_HB-1 = beyond (not counted)
     const uint32_t ncand = stream_clusters<4>(g, lds, ncl, nseg_all, [&](const float4& cp, bool in_tile, uint32_t ccid) __attribute__((always_inline)) {
       const uint32_t bits = __float_as_uint(sqdist(qx, qy, qz, cp.x, cp.y, cp.z));
       const int bin = max((int)(bits >> 20) - base, 0);
-      if (mine && in_tile && ccid == cid && bin < QN_HB - 1) atomicAdd(&L->u.hist[qs][bin], 1u);
+      const bool ok = mine && in_tile && ccid == cid && bin < QN_HB - 1;
+      atomicAdd(&L->u.hist[qs][ok ? bin : QN_HB + sub], 1u);                      // branch-free: rejected candidates land in the sub-slot's reject column
     });
     wave_lds_fence();
     // ---- tau: sub-slot s sums bins [16 s, 16 s + 16), then looks for the crossing in its own range
@@ -91,17 +93,21 @@ __device__ __forceinline__ int wave_knn_hist(const GridView& g, float qx, float 
     unsigned long long own[HCAP / 4]; int rank[HCAP / 4];
 #pragma unroll
     for (int j = 0; j < HCAP / 4; j++) { own[j] = (ok && (uint32_t)(sub + 4 * j) < P) ? L->u.list[qs][sub + 4 * j] : QN_INF_KEY; rank[j] = 0; }
-    if (maxP <= 32) {
-      for (int f = 0; f < maxP; f++) {
-        const unsigned long long kf = (ok && (uint32_t)f < P) ? L->u.list[qs][f] : QN_INF_KEY;
+    // 4 list entries per step, all four LDS reads issued before the compares (the entry -> compare chain was latency-bound)
+    for (int f = 0; f < maxP; f += 4) {
+      unsigned long long kf[4];
 #pragma unroll
-        for (int j = 0; j < 8; j++) rank[j] += kf < own[j] ? 1 : 0;
-      }
-    } else {
-      for (int f = 0; f < maxP; f++) {
-        const unsigned long long kf = (ok && (uint32_t)f < P) ? L->u.list[qs][f] : QN_INF_KEY;
+      for (int u = 0; u < 4; u++) kf[u] = L->u.list[qs][min(f + u, HCAP)];
 #pragma unroll
-        for (int j = 0; j < HCAP / 4; j++) rank[j] += kf < own[j] ? 1 : 0;
+      for (int u = 0; u < 4; u++) {
+        const unsigned long long kv = (ok && (uint32_t)(f + u) < P) ? kf[u] : QN_INF_KEY;
+        if (HCAP > 32 && maxP > 32) {
+#pragma unroll
+          for (int j = 0; j < HCAP / 4; j++) rank[j] += kv < own[j] ? 1 : 0;
+        } else {
+#pragma unroll
+          for (int j = 0; j < 8; j++) rank[j] += kv < own[j] ? 1 : 0;
+        }
       }
     }
 #pragma unroll
