@@ -83,6 +83,10 @@ def main():
         gg.setOptimizer("gn"); gg.setForceIterations(GN_ITERS)
         gs.append(gg)
     ctx, g = ctxs[0], gs[0]
+    knobs = json.loads(os.environ.get("QN_DEBUG_KNOBS", "{}"))     # developer tuning only (qn_debug_set); empty in every reported run
+    for cx in ctxs:
+        for kk, vv in knobs.items():
+            cx.debug_set(kk, float(vv))
 
     # candidate pairs of this rank: pair_id = rank + world * j   (pair i -> rank i mod N)
     pairs = []
@@ -173,10 +177,10 @@ def main():
         fam_avg = {k: v[0] / v[1] for k, v in stats.items() if v[1] > 0}             # ms per profiled span (= one launch for the single-kernel families)
         ab = algorithmic_bytes()
         # kernel families timed as ONE kernel per span, with the rocprofv3 name of that kernel and its algorithmic bytes per launch
-        single = {"knn_select": ("k_knn_hist<false>", N_PTS * (16 + 16 * K_COV)),          # k-NN selection of one cloud: point + k neighbour points
+        single = {"knn_select": ("k_knn_hist<false, 32>", N_PTS * (16 + 16 * K_COV)),          # k-NN selection of one cloud: point + k neighbour points
                   "gn_tick_fused": ("k_nn_track<0, true>", ab["gn_iteration"]),              # one whole GN iteration (NN + accumulate + solve)
-                  "nn_search": ("k_nn_search<0, false>", ab["gn_iteration"]),                # first (unseeded) NN passes of an align
-                  "nn_fallback": ("k_nn_search<0, true>", ab["gn_iteration"]),
+                  "nn_search": ("k_nn_search<0, false, 256>", ab["gn_iteration"]),                # first (unseeded) NN passes of an align
+                  "nn_fallback": ("k_nn_search<0, true, 256>", ab["gn_iteration"]),
                   "accumulate": ("k_accumulate", ab["gn_iteration"]), "solve": ("k_solve", 28 * 8 * 512)}
         dom = max((k for k in fam_ms if k in single), key=fam_ms.get)
         dom_kernel, per_launch_bytes = single[dom]

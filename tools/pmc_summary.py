@@ -9,8 +9,8 @@ bench.py reads the committed copy (profiles/pmc_latest.json) for the `roofline.t
 import csv, json, os, sys
 from collections import defaultdict
 
-FAMILY = [("k_knn_hist<false>", "knn_select"), ("k_nn_track<0, true>", "gn_tick_fused"), ("k_nn_track<0, false>", "nn_track"),
-          ("k_nn_search<0, false>", "nn_search"), ("k_nn_search<0, true>", "nn_fallback"), ("k_accumulate", "accumulate"),
+FAMILY = [("k_knn_hist<false, 32>", "knn_select"), ("k_nn_track<0, true>", "gn_tick_fused"), ("k_nn_track<0, false>", "nn_track"),
+          ("k_nn_search<0, false,", "nn_search"), ("k_nn_search<0, true,", "nn_fallback"), ("k_accumulate", "accumulate"),
           ("k_solve", "solve"), ("k_cov_from_idx", "cov_from_idx"), ("k_scatter", "grid_scatter"), ("k_fitness_partial", "fitness")]
 
 
