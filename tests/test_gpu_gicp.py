@@ -28,11 +28,26 @@ def test_knn_bit_exact(eng, oracle):
     src = src.copy(); src[200:215] = src[100]          # exact duplicates: ties must resolve to the lowest index
     g = engine.NanoGICP(ctx); g.setInputSource(src)
     o = oracle.GicpOracle(); o.set_source(src)
-    for k in (1, 15, 20, 32):
+    for k in (1, 15, 16, 17, 20, 24, 25, 32):      # both histogram list capacities (k <= 24 / k > 24) and every BestK<KMAX> tail
         idx, d2 = g.knn(0, k)
         oi, od = o.knn(0, src, k)
         assert np.array_equal(idx, oi), k
         assert np.array_equal(d2, od), k
+
+
+def test_knn_sorted_list_path_bit_exact(oracle):
+    """The general k-NN path (wave_search + BestK<KMAX>, knn_hist = 0: the tail the histogram path falls back on) alone."""
+    from qn_amd import engine
+    ctx = engine.Context(8192)
+    src, _, _ = _pair_small()
+    ctx.debug_set("knn_hist", 0)
+    g = engine.NanoGICP(ctx); g.setInputSource(src)
+    o = oracle.GicpOracle(); o.set_source(src)
+    for k in (15, 20, 24, 32):
+        idx, d2 = g.knn(0, k)
+        oi, od = o.knn(0, src, k)
+        assert np.array_equal(idx, oi) and np.array_equal(d2, od), k
+    ctx.close()
 
 
 def test_knn_bit_exact_sparse_and_tiny(eng, oracle):
