@@ -346,6 +346,15 @@ __device__ __forceinline__ void build_clusters(const GridView& g, WaveLds* lds, 
   wave_lds_fence();
 }
 
+// Exact n / d and n % d for 0 <= n < 2^22, 1 <= d < 2^22 from one v_rcp_f32 and a +-1 correction (the generic u32 division
+// is ~25 VALU instructions, and the segment tables need four of them per lane and pass).
+__device__ __forceinline__ void divmod_small(int n, int d, int& q, int& r) {
+  q = (int)((float)n * __builtin_amdgcn_rcpf((float)d));
+  r = n - q * d;
+  if (r < 0) { q--; r += d; }
+  if (r >= d) { q++; r -= d; }
+}
+
 // Step (4): the points of all cluster boxes as one dense candidate stream.  fn(cp, in_tile, ccid) is called once per
 // step by all 64 lanes; the S sub-slots see S consecutive candidates (cp = point, .w = original index bits; in_tile =
 // the slot holds a real candidate; ccid = the cluster whose box the candidate came from).  Returns the stream length.
@@ -364,14 +373,16 @@ __device__ __forceinline__ uint32_t stream_clusters(const GridView& g, WaveLds* 
       const int x0 = b[0], x1 = b[1], y0 = b[2], y1 = b[3], z0 = b[4];
       const int tx0 = x0 >> 3, ntr = (x1 >> 3) - tx0 + 1;
       const int li = (int)(sidx - lds->cl_seg0[c]);
-      const int t = li % ntr, rr = li / ntr;
+      int t, rr; divmod_small(li, ntr, rr, t);
       if (lds->cl_tile_mode[c]) {                  // segment = one whole tile
         const int ty0 = y0 >> 2, ntyr = (y1 >> 2) - ty0 + 1;
-        const uint32_t tile = ((uint32_t)((z0 >> 2) + rr / ntyr) * g.nty + (ty0 + rr % ntyr)) * g.ntx + (tx0 + t);
+        int qz_, ry_; divmod_small(rr, ntyr, qz_, ry_);
+        const uint32_t tile = ((uint32_t)((z0 >> 2) + qz_) * g.nty + (ty0 + ry_)) * g.ntx + (tx0 + t);
         s = g.cell_start[tile << 7]; len = g.cell_start[(tile + 1) << 7] - s;
       } else {                                     // segment = cells [xa..xb] of row (ry, rz) inside tile tx
         const int nyr = y1 - y0 + 1;
-        const int ry = y0 + rr % nyr, rz = z0 + rr / nyr, tx = tx0 + t;
+        int qz_, ry_; divmod_small(rr, nyr, qz_, ry_);
+        const int ry = y0 + ry_, rz = z0 + qz_, tx = tx0 + t;
         const int xa = max(x0, tx << 3), xb = min(x1, (tx << 3) + 7);
         const uint32_t k0 = cell_key(g, xa, ry, rz);
         s = g.cell_start[k0]; len = g.cell_start[k0 + (xb - xa) + 1] - s;
@@ -391,18 +402,19 @@ __device__ __forceinline__ uint32_t stream_clusters(const GridView& g, WaveLds* 
       for (int step = 32; step > 0; step >>= 1) { const int t = j + step; if (t < 64 && lds->seg_excl[t] <= slot) j = t; }
       const uint32_t cnt = min(64u, total - cb);
       wave_lds_fence();
-      if (slot < total) { lds->tile[lane] = g.pts[lds->seg_start[j] + (slot - lds->seg_excl[j])]; lds->tile_cid[lane] = lds->seg_cid[j]; }
+      if (slot < total) lds->tile[lane] = g.pts[lds->seg_start[j] + (slot - lds->seg_excl[j])];
+      lds->tile_cid[lane] = slot < total ? lds->seg_cid[j] : 0xffffffffu;   // empty slots belong to no cluster: the `ccid == cid` test of the scorers rejects them
       wave_lds_fence();
       // S candidates per step (one per sub-slot), 4 steps per trip with the four ds_read_b128 issued BEFORE any scoring: with
       // the read inside a predicated body every step paid the LDS latency in full (read -> wait -> score -> branch).
-      // fn must tolerate in_tile == false (it is then handed a stale tile entry; tile[ci & 63] is always in bounds).
+      // Slots past the chunk's end hold stale points with cluster id ~0 (tile[ci & 63] is always in bounds).
       const uint32_t sub_off = (uint32_t)(S == 1 ? 0 : lane / (64 / S));
       for (uint32_t c = 0; c < cnt; c += 4 * S) {
         float4 cp[4]; uint32_t cc[4];
 #pragma unroll
         for (int u = 0; u < 4; u++) { const uint32_t ci = (c + (uint32_t)(S * u) + sub_off) & 63u; cp[u] = lds->tile[ci]; cc[u] = lds->tile_cid[ci]; }
 #pragma unroll
-        for (int u = 0; u < 4; u++) fn(cp[u], c + (uint32_t)(S * u) + sub_off < cnt, cc[u]);
+        for (int u = 0; u < 4; u++) fn(cp[u], true, cc[u]);
       }
     }
     ncand += total;
