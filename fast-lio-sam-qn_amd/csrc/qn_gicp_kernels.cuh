@@ -34,6 +34,15 @@ struct GicpConfig {                                 // by-value kernel argument
   double max_corr_dist_sq, transformation_epsilon, rotation_epsilon, lm_init_lambda_factor;
 };
 
+// XCD-aware block order.  The hardware deals consecutive workgroups round-robin to the 8 XCDs, each with its own L2; the
+// queries are in tile-major cell order, so with the identity mapping every XCD touches the whole target cloud.  Remapped,
+// XCD x serves one contiguous eighth of the (spatially sorted) queries and its L2 only has to hold that region of the
+// target grid.  Bijection on [0, nb): logical block = first block of XCD (b & 7) + (b >> 3).
+__device__ __forceinline__ uint32_t xcd_block(uint32_t b, uint32_t nb) {
+  const uint32_t per = nb >> 3, rem = nb & 7u, x = b & 7u;
+  return x * per + min(x, rem) + (b >> 3);
+}
+
 // ------------------------------------------------------------------ K1 grid build (utility kernels: qn_util_kernels.cuh)
 static __global__ void k_cell_count(const float4* __restrict__ pts, uint32_t n, GridView g, uint32_t* __restrict__ counts, uint32_t* __restrict__ cell_of_pt) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -135,7 +144,7 @@ __global__ void __launch_bounds__(QN_KNN_BLOCK, HCAP <= 32 ? 4 : 3) k_knn_hist(G
   WaveLdsH<HCAP>* my = &lds[threadIdx.x >> 6];
   const uint32_t nq = LIST ? *fb_count : g.n;
   if (LIST && g.dbg && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&g.dbg[4], nq);
-  const uint32_t wave0 = blockIdx.x * (QN_KNN_BLOCK / 64) + (threadIdx.x >> 6), nwaves = gridDim.x * (QN_KNN_BLOCK / 64);
+  const uint32_t wave0 = (LIST ? blockIdx.x : xcd_block(blockIdx.x, gridDim.x)) * (QN_KNN_BLOCK / 64) + (threadIdx.x >> 6), nwaves = gridDim.x * (QN_KNN_BLOCK / 64);
   for (uint32_t base = wave0 * 16; base < nq; base += nwaves * 16) {
     const uint32_t slot = base + (threadIdx.x & 15);
     bool active = slot < nq;
@@ -224,7 +233,7 @@ __global__ void __launch_bounds__(BLOCK) k_nn_search(GridView src, GridView tgt,
   }
   const uint32_t nq = LIST ? *fb_count : src.n;
   if (LIST && tgt.dbg && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&tgt.dbg[5], nq);
-  const uint32_t wave0 = blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6), nwaves = (gridDim.x - (LIST ? big_blocks : 0)) * (BLOCK / 64);
+  const uint32_t wave0 = blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6), nwaves = (gridDim.x - (LIST ? big_blocks : 0)) * (BLOCK / 64);   // (XCD remap measured slower here: the leftover lists lose their locality)
   for (uint32_t base = wave0 * 16; base < nq; base += nwaves * 16) {
     const uint32_t slot = base + (threadIdx.x & 15);
     const bool active = slot < nq;
@@ -302,7 +311,7 @@ __device__ __forceinline__ void accumulate_point(const double R[3][3], const dou
 }
 
 // block-level reduction of the 28 per-thread sums (DPP row sums + 2 cross-row shuffles per wave, then the 4 waves in order)
-__device__ __forceinline__ void reduce_block_partials(const double acc[QN_NPART], const bool lin, double* __restrict__ partials, double (*red)[QN_NPART]) {
+__device__ __forceinline__ void reduce_block_partials(const double acc[QN_NPART], const bool lin, double* __restrict__ partials, double (*red)[QN_NPART], const uint32_t blk) {
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   if (lin) {
 #pragma unroll
@@ -316,7 +325,7 @@ __device__ __forceinline__ void reduce_block_partials(const double acc[QN_NPART]
     double s = 0;
 #pragma unroll
     for (int w = 0; w < QN_BLOCK / 64; w++) s += red[w][threadIdx.x];
-    partials[(size_t)blockIdx.x * QN_NPART + threadIdx.x] = s;
+    partials[(size_t)blk * QN_NPART + threadIdx.x] = s;   // blk = LOGICAL block: the reduction tree does not depend on the block order
   }
 }
 
@@ -340,7 +349,7 @@ static __global__ void __launch_bounds__(QN_BLOCK) k_accumulate(const float4* __
     if (j < 0) continue;
     accumulate_point(R, T, src_raw[i], tgt_raw[j], cov_s + (size_t)i * 6, cov_t + (size_t)j * 6, phase == 0, acc);
   }
-  reduce_block_partials(acc, phase == 0, partials, red);
+  reduce_block_partials(acc, phase == 0, partials, red, blockIdx.x);
 }
 
 // ------------------------------------------------------------------ K4a', temporal tracking
@@ -374,7 +383,8 @@ __global__ void __launch_bounds__(QN_BLOCK) k_nn_track(GridView src, GridView tg
   float Tf[12];
 #pragma unroll
   for (int j = 0; j < 12; j++) Tf[j] = (float)st->x0[j];
-  const uint32_t t = blockIdx.x * QN_BLOCK + threadIdx.x;
+  const uint32_t lblk = xcd_block(blockIdx.x, gridDim.x);          // XCD x tracks one contiguous eighth of the sorted queries
+  const uint32_t t = lblk * QN_BLOCK + threadIdx.x;
   const bool valid = t < src.n;
   if (!FUSED && !valid) return;
   const float INF = __int_as_float(0x7f800000);
@@ -478,7 +488,7 @@ __global__ void __launch_bounds__(QN_BLOCK) k_nn_track(GridView src, GridView tg
       const TargetRec* rec = tgt_rec + key_idx(best);
       accumulate_point(R, T, make_float4(p.x, p.y, p.z, 1.f), rec->p, cov_s_sorted + (size_t)t * 6, rec->cov, true, acc);
     }
-    reduce_block_partials(acc, true, partials, red);
+    reduce_block_partials(acc, true, partials, red, lblk);
   }
 }
 
