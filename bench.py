@@ -113,6 +113,10 @@ def main():
 
     if args.warmup > 0:
         batch(args.warmup)
+    if dist is not None:          # untimed: bring up the communicator's channels (RCCL connects lazily on the first collective)
+        wtmp = torch.zeros(19, dtype=torch.float64, device=cdev)
+        dist.all_gather([torch.empty_like(wtmp) for _ in range(world)], wtmp)
+        dist.all_reduce(torch.zeros(1, dtype=torch.float64, device=cdev), op=dist.ReduceOp.MAX)
     barrier()
     t0 = time.perf_counter()
     results, valid, status = batch(args.steps)                      # EXACTLY `steps` registrations
