@@ -45,8 +45,8 @@ def algorithmic_bytes():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-quatro", action="store_true")
     ap.add_argument("--pairs", type=int, default=2, help="distinct synthetic pairs per rank, cycled over the steps")

@@ -226,6 +226,19 @@ struct BestK {
   // One-directional merge: lanes whose `recv` is true insert the k real entries of lane ^ lane_xor;
   // the sending lanes insert the +inf key (a no-op), so their lists stay intact while being read.
   __device__ __forceinline__ void merge_from(int lane_xor, bool recv) {
+    if (KMAX > 24) {                 // fully unrolled, the KMAX x KMAX merge takes ~6 MINUTES to compile at KMAX = 32 (3 s rolled); k > 24 is off the hot path
+      unsigned long long tmp[KMAX];
+#pragma unroll
+      for (int j = 0; j < KMAX; j++) tmp[j] = __shfl_xor(a[j], lane_xor);
+#pragma unroll 1
+      for (int j = 0; j < KMAX; j++) {
+        unsigned long long other = QN_INF_KEY;
+#pragma unroll
+        for (int u = 0; u < KMAX; u++) other = (u == j) ? tmp[u] : other;      // select chain instead of a runtime-indexed register array
+        if (__any(j >= KMAX - k)) insert((recv && j >= KMAX - k) ? other : QN_INF_KEY);
+      }
+      return;
+    }
 #pragma unroll
     for (int j = 0; j < KMAX; j++) {
       const unsigned long long other = __shfl_xor(a[j], lane_xor);

@@ -1,6 +1,5 @@
 // qn_instances_knn.h - explicit instantiations (group g) / declarations (every other unit) of the sorted-list k-NN kernel
-// k_knn_cov<KMAX, LIST, 4>.  One unit per instantiation: the register-resident BestK<32> variants take ~6 minutes each
-// to compile, the others ~15 s.  These units include only qn_knn_kernels.cuh + qn_device.cuh (see qn_instances.h).
+// k_knn_cov<KMAX, LIST, 4>.  One unit per instantiation (~15 s each for the fully unrolled BestK<24> merges).  These units include only qn_knn_kernels.cuh + qn_device.cuh (see qn_instances.h).
 #pragma once
 #include "qn_knn_kernels.cuh"
 

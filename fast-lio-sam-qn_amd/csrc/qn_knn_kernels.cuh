@@ -1,6 +1,6 @@
 // qn_knn_kernels.cuh - general sorted-list k-NN kernel (register-resident BestK<KMAX> sink) of calculateSource/
-// TargetCovariances (loop_closure.cpp:121,123).  Its own header because the KMAX = 32 instantiations
-// take minutes to compile: the units that instantiate it (qn_instances.h groups 2-9) depend on nothing but this
+// TargetCovariances (loop_closure.cpp:121,123).  Its own header because its instantiations are the
+// slowest units to compile (unrolled BestK merges): the units that instantiate it (qn_instances.h groups 2-9) depend on nothing but this
 // file and qn_device.cuh, so edits to the align kernels do not rebuild them.
 #pragma once
 #include "qn_device.cuh"
