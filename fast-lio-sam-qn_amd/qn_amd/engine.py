@@ -291,6 +291,24 @@ def icp_alignment(ctx, src, dst, *, k=15, max_iter=32, max_corr_dist=52.5, trans
                 T=np.array(res.T, dtype=np.float32).reshape(4, 4).astype(np.float64), iterations=res.iterations)
 
 
+def fpfh(ctx, xyz):
+    """qn_fpfh: n x 33 FPFH descriptors (NaN rows where PCL yields none), radii from the context's Quatro parameters."""
+    a, n, stride = _cloud_arg(xyz)
+    out = np.zeros((n, 33), dtype=np.float32)
+    ctx.check(ctx._l.qn_fpfh(ctx.h, _p(a), C.c_uint32(n), C.c_uint32(stride), _p(out)))
+    return out
+
+
+def match_optimized(ctx, src, dst, fs, ft, thr_dist=35.0, num_max_corres=200, tuple_scale=0.95):
+    """qn_match_optimized: Matcher::optimizedMatching on two clouds and their descriptors -> (m, 2) int32 pairs (src idx, dst idx)."""
+    a, ns, stride = _cloud_arg(src); b, nt, _ = _cloud_arg(dst)
+    fs = np.ascontiguousarray(fs, dtype=np.float32); ft = np.ascontiguousarray(ft, dtype=np.float32)
+    pairs = np.zeros((num_max_corres, 2), dtype=np.int32); n = C.c_uint32()
+    ctx.check(ctx._l.qn_match_optimized(ctx.h, _p(a), C.c_uint32(ns), _p(b), C.c_uint32(nt), C.c_uint32(stride), _p(fs), _p(ft),
+                                        C.c_float(thr_dist), C.c_int(num_max_corres), C.c_float(tuple_scale), _p(pairs), C.c_uint32(num_max_corres), C.byref(n)))
+    return pairs[:min(n.value, num_max_corres)].copy()
+
+
 # ---------------------------------------------------------------------------------------- Quatro
 class QuatroParams(C.Structure):
     _fields_ = [("fpfh_normal_radius", C.c_double), ("fpfh_radius", C.c_double), ("noise_bound", C.c_double),

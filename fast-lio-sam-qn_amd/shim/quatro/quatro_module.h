@@ -5,8 +5,10 @@
 // std::shared_ptr at include/loop_closure.h:76) and
 //   Eigen::Matrix4d align(const pcl::PointCloud<PointType>& src, const pcl::PointCloud<PointType>& dst, bool& is_converged)
 // (loop_closure.cpp:144).  Header-only over the C-ABI of include/qn_engine.h; link with -lqn_engine.
-// The upstream class also exposes the matcher's optimizedMatching(thr_dist, num_max_corres, tuple_scale);
-// here it is a public method with the same arguments that stores them for the next align().
+// The upstream package also has the matcher on its own: teaser::Matcher with
+//   void optimizedMatching(float thr_dist, int num_max_corres, float tuple_scale)      (result in corres_)
+// on two clouds and their 33-D FPFH sets; `quatro_matcher` below keeps that signature over qn_fpfh / qn_match_optimized.
+// quatro<>::optimizedMatching(...) with the same arguments stores them for the next align().
 #pragma once
 #include <cstdint>
 #include <cstdio>
@@ -14,6 +16,41 @@
 #include <pcl/point_types.h>
 #include <Eigen/Core>
 #include "qn_engine.h"
+
+#include <utility>
+#include <vector>
+
+// teaser::Matcher as Quatro uses it: holds the two clouds and their descriptors, optimizedMatching fills corres_.
+template <typename PointType>
+class quatro_matcher {
+ public:
+  typedef std::vector<std::vector<float>> Feature;                       // upstream: vector of 33-float descriptors
+  explicit quatro_matcher(qn_ctx* ctx) : ctx_(ctx) {}
+  // FPFH of a cloud with the context's radii (upstream FPFHEstimation::computeFPFHFeatures); rows of NaN where PCL yields none
+  int computeFPFH(const pcl::PointCloud<PointType>& cloud, std::vector<float>& fpfh33) {
+    fpfh33.assign(cloud.size() * 33, 0.f);
+    return cloud.size() == 0 ? QN_ERR_EMPTY_CLOUD : qn_fpfh(ctx_, &cloud.points[0].x, (uint32_t)cloud.size(), (uint32_t)sizeof(PointType), fpfh33.data());
+  }
+  void setInput(const pcl::PointCloud<PointType>& src, const pcl::PointCloud<PointType>& dst, const std::vector<float>& src_fpfh33, const std::vector<float>& dst_fpfh33) {
+    src_ = &src; dst_ = &dst; fs_ = &src_fpfh33; ft_ = &dst_fpfh33;
+  }
+  void optimizedMatching(float thr_dist, int num_max_corres, float tuple_scale) {
+    corres_.clear();
+    if (!src_ || !dst_ || src_->size() == 0 || dst_->size() == 0) return;
+    std::vector<int32_t> pairs(2 * (size_t)num_max_corres); uint32_t n = 0;
+    status_ = qn_match_optimized(ctx_, &src_->points[0].x, (uint32_t)src_->size(), &dst_->points[0].x, (uint32_t)dst_->size(), (uint32_t)sizeof(PointType),
+                                 fs_->data(), ft_->data(), thr_dist, num_max_corres, tuple_scale, pairs.data(), (uint32_t)num_max_corres, &n);
+    if (status_ != QN_OK) return;
+    for (uint32_t e = 0; e < n && e < (uint32_t)num_max_corres; e++) corres_.emplace_back(pairs[2 * e], pairs[2 * e + 1]);
+  }
+  std::vector<std::pair<int, int>> corres_;
+  int lastStatus() const { return status_; }
+ private:
+  qn_ctx* ctx_;
+  const pcl::PointCloud<PointType>* src_ = nullptr; const pcl::PointCloud<PointType>* dst_ = nullptr;
+  const std::vector<float>* fs_ = nullptr; const std::vector<float>* ft_ = nullptr;
+  int status_ = QN_OK;
+};
 
 template <typename PointType>
 class quatro {

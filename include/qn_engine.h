@@ -157,6 +157,15 @@ int  qn_quatro_align(qn_ctx*, const float* src, uint32_t ns, const float* dst, u
 /* LoopClosure::coarseToFineAlignment, loop_closure.cpp:138-159: Quatro, transformPcd, icpAlignment, T_gicp * T_quatro */
 int  qn_coarse_to_fine_alignment(qn_ctx*, const float* src, uint32_t ns, const float* dst, uint32_t nt, uint32_t stride_bytes, double score_thr,
                                  qn_gicp_result* gicp_out, double T_total[16], double T_quatro[16], int* valid);
+/* The two stages upstream Quatro exposes on its own:
+ *  qn_fpfh            = FPFH descriptors of one cloud (pcl::FPFHEstimationOMP with the context's radii): n x 33 f32, caller order
+ *  qn_match_optimized = teaser::Matcher::optimizedMatching(thr_dist, num_max_corres, tuple_scale) on two clouds + their
+ *                       descriptors: mutual 33-D NN (GPU), distance gate, tuple test, cap; pairs = (src idx, dst idx)            */
+int  qn_fpfh(qn_ctx*, const float* xyz, uint32_t n, uint32_t stride_bytes, float* fpfh33_out);
+int  qn_match_optimized(qn_ctx*, const float* src, uint32_t ns, const float* dst, uint32_t nt, uint32_t stride_bytes,
+                        const float* src_fpfh33, const float* dst_fpfh33, float thr_dist, int num_max_corres, float tuple_scale,
+                        int32_t* pairs_out, uint32_t cap, uint32_t* n_out);
+
 /* stages, for the parity tests: descriptors of the last qn_quatro_align (original point order; n x 3, n x 33, n x 33),
  * the align with its intermediate products, and the host solver alone (Matcher + TEASER++/Quatro solve)            */
 int  qn_quatro_get_features(qn_ctx*, int which, float* normals3, float* spfh33, float* fpfh33);

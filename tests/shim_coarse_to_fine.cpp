@@ -1,6 +1,7 @@
 // LoopClosure's constructor and coarseToFineAlignment (fast_lio_sam_qn/src/loop_closure.cpp:3-30, 138-159)
 // written against the two drop-in shims, in the reference's own shape.
 // usage: shim_coarse_to_fine src.bin dst.bin -> prints valid converged score T(16)
+#include <algorithm>
 #include <cstdio>
 #include <limits>
 #include <memory>
@@ -80,6 +81,20 @@ int main(int argc, char** argv) {
   const RegistrationOutput r = lc.coarseToFineAlignment(load(argv[1]), load(argv[2]));
   std::printf("%d %d %.17g", (int)r.is_valid_, (int)r.is_converged_, r.score_);
   for (int a = 0; a < 4; a++) for (int b = 0; b < 4; b++) std::printf(" %.17g", r.pose_between_eig_(a, b));
+  // the matcher on its own, with upstream's optimizedMatching(thr_dist, num_max_corres, tuple_scale) signature
+  {
+    qn_ctx* mctx = nullptr;
+    const pcl::PointCloud<PointType> a = load(argv[1]), b = load(argv[2]);
+    if (qn_ctx_create(0, (uint32_t)(std::max(a.size(), b.size()) + 4096), &mctx) != QN_OK) return 3;
+    quatro_matcher<PointType> matcher(mctx);
+    std::vector<float> fa, fb;
+    if (matcher.computeFPFH(a, fa) != QN_OK || matcher.computeFPFH(b, fb) != QN_OK) return 4;
+    matcher.setInput(a, b, fa, fb);
+    matcher.optimizedMatching(35.0f, 200, 0.95f);
+    long long chk = 0; for (const auto& pr : matcher.corres_) chk += 31LL * pr.first + pr.second;
+    std::printf(" %zu %lld", matcher.corres_.size(), chk);
+    qn_ctx_destroy(mctx);
+  }
   std::printf("\n");
   return 0;
 }

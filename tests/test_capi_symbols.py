@@ -17,7 +17,8 @@ def declared_symbols():
 def test_header_declares_the_reference_surface():
     syms = declared_symbols()
     for s in ["qn_ctx_create", "qn_gicp_set_source", "qn_gicp_set_target", "qn_gicp_compute_covariances",
-              "qn_gicp_align", "qn_gicp_fitness", "qn_gicp_transformed_source", "qn_icp_alignment"]:
+              "qn_gicp_align", "qn_gicp_fitness", "qn_gicp_transformed_source", "qn_icp_alignment",
+              "qn_quatro_set_params", "qn_quatro_align", "qn_fpfh", "qn_match_optimized", "qn_coarse_to_fine_alignment", "qn_icp_alignment_batch"]:
         assert s in syms
 
 

@@ -57,6 +57,27 @@ def test_feature_matching_and_solution_parity(eng, oracle, pair):
     assert np.abs(r["T"] - o["T"]).max() < 1e-9
 
 
+def test_standalone_fpfh_and_optimized_matching(eng, oracle, pair):
+    """The two stages upstream exposes on their own (qn_fpfh, qn_match_optimized = Matcher::optimizedMatching with its
+    three arguments), on descriptors handed in by the caller - here the ORACLE's, so only the GPU matcher is under test."""
+    engine, ctx = eng
+    src, tgt, _ = pair
+    # qn_fpfh alone == the descriptors quatro::align computes internally
+    q = engine.Quatro(ctx); q.align(src, tgt)
+    _, _, fp_src = q.features(0)
+    f = engine.fpfh(ctx, src)
+    assert np.array_equal(np.isnan(f), np.isnan(fp_src)) and np.array_equal(np.nan_to_num(f), np.nan_to_num(fp_src))
+    _, _, ofs = oracle.quatro_fpfh(src, 0.9, 1.5); _, _, oft = oracle.quatro_fpfh(tgt, 0.9, 1.5)
+    for thr, cap, scale in ((35.0, 200, 0.95), (20.0, 50, 0.9)):
+        got = engine.match_optimized(ctx, src, tgt, ofs, oft, thr_dist=thr, num_max_corres=cap, tuple_scale=scale)
+        _, corres = oracle.quatro_match(src, tgt, ofs, oft, oracle.QuatroParams(distance_threshold=thr, max_num_corres=cap, tuple_scale=scale))
+        assert np.array_equal(got, corres)
+    # swapped roles (the matcher searches from the smaller set): fewer source than target points
+    got = engine.match_optimized(ctx, src[:5000], tgt, ofs[:5000], oft)
+    _, corres = oracle.quatro_match(src[:5000], tgt, ofs[:5000], oft)
+    assert np.array_equal(got, corres)
+
+
 @pytest.mark.parametrize("pair_id", [311, 312, 313])
 def test_quatro_align_parity_end_to_end(eng, oracle, pair_id):
     """Whole coarse stage, GPU descriptors vs oracle descriptors: same correspondences, same transform."""

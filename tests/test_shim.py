@@ -44,6 +44,13 @@ def test_shims_reproduce_coarse_to_fine(tmp_path, oracle):
     assert abs(score - o["score"]) <= 1e-6 * o["score"]
     dt, dr = synth.pose_error(Tm, o["T"])
     assert dt <= 1e-4 and dr <= 1e-4
+    # quatro_matcher<>::optimizedMatching(35, 200, 0.95) on its own FPFH sets == the oracle matcher on the same descriptors
+    from qn_amd import engine
+    ctx = engine.Context(8192)
+    fs, ft = engine.fpfh(ctx, src), engine.fpfh(ctx, tgt)
+    ctx.close()
+    _, corres = oracle.quatro_match(src, tgt, fs, ft)
+    assert int(out[19]) == len(corres) and int(out[20]) == int((31 * corres[:, 0].astype(np.int64) + corres[:, 1]).sum())
 
 
 @pytest.mark.gpu
