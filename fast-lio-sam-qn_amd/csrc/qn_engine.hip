@@ -265,7 +265,7 @@ static void launch_knn_cov(qn_ctx* c, CloudBuf& b, int k, int32_t* kidx, float* 
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_knn_hist<true, HCAP>), dim3(std::min<uint32_t>((b.n + 63) / 64, 512) * (QN_BLOCK / QN_KNN_BLOCK)), dim3(QN_KNN_BLOCK), 0, s, b.grid, k, r0, 64, kidx, kd2, c->fb_list, c->fb_count2, c->big_list, genc);
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_knn_cov<KMAX, true, 4>), dim3(std::min<uint32_t>((b.n + 63) / 64, 64)), dim3(QN_BLOCK), 0, s, b.grid, b.raw, k, r0, 64, b.cov, kidx, kd2, c->big_list, genc);
     const uint32_t nbp = (b.n + QN_BLOCK - 1) / QN_BLOCK;
-    hipLaunchKernelGGL(k_cov_from_idx, dim3(nbp), dim3(QN_BLOCK), 0, s, b.raw, b.n, k, kidx, b.cov);
+    hipLaunchKernelGGL(k_cov_from_idx, dim3(nbp), dim3(QN_BLOCK), 0, s, b.raw, b.sorted, b.n, k, kidx, b.cov);
     if (&b == &c->cloud[0]) hipLaunchKernelGGL(k_sort_cov, dim3(nbp), dim3(QN_BLOCK), 0, s, b.sorted, b.cov, b.n, c->cov_s_sorted);
     else hipLaunchKernelGGL(k_build_target_rec, dim3(nbp), dim3(QN_BLOCK), 0, s, b.raw, b.cov, b.n, c->tgt_rec);
     return;
@@ -277,7 +277,7 @@ static void launch_knn_cov(qn_ctx* c, CloudBuf& b, int k, int32_t* kidx, float* 
   }
   hipLaunchKernelGGL(HIP_KERNEL_NAME(k_knn_cov<KMAX, true, 4>), dim3(std::min<uint32_t>((b.n + 63) / 64, 512)), dim3(QN_BLOCK), 0, s, b.grid, b.raw, k, r0, 64, b.cov, kidx, kd2, c->fb_list, c->fb_count2);
   const uint32_t nbp = (b.n + QN_BLOCK - 1) / QN_BLOCK;
-  hipLaunchKernelGGL(k_cov_from_idx, dim3(nbp), dim3(QN_BLOCK), 0, s, b.raw, b.n, k, kidx, b.cov);
+  hipLaunchKernelGGL(k_cov_from_idx, dim3(nbp), dim3(QN_BLOCK), 0, s, b.raw, b.sorted, b.n, k, kidx, b.cov);
   // layouts for the fused optimiser ticks: source covariances in cell-sorted order, target point + covariance in one 64-byte record
   if (&b == &c->cloud[0]) hipLaunchKernelGGL(k_sort_cov, dim3(nbp), dim3(QN_BLOCK), 0, s, b.sorted, b.cov, b.n, c->cov_s_sorted);
   else hipLaunchKernelGGL(k_build_target_rec, dim3(nbp), dim3(QN_BLOCK), 0, s, b.raw, b.cov, b.n, c->tgt_rec);

@@ -71,9 +71,12 @@ static __global__ void k_scatter(const float4* __restrict__ pts, uint32_t n, con
 // ------------------------------------------------------------------ K2+K3 k-NN + covariance (k-NN selection: k_knn_hist below, k_knn_cov in qn_knn_kernels.cuh)
 // k nearest (self included), mean/cov in f64 (cov = X X^T / k), PLANE regularisation:
 // C = V diag(1, 1, 1e-3) V^T with V the eigenvectors of cov (eigenvalues descending); from stored neighbour indices (ascending (d2, idx) order, -1 = missing): one point per lane.
-static __global__ void __launch_bounds__(QN_BLOCK) k_cov_from_idx(const float4* __restrict__ raw, uint32_t n, int k, const int32_t* __restrict__ knn_idx, double* __restrict__ cov) {
-  const uint32_t i = blockIdx.x * QN_BLOCK + threadIdx.x;
-  if (i >= n) return;
+// Threads walk the points in cell-sorted order (a block's points are spatial neighbours, so their k-NN gathers overlap in
+// L1/L2), blocks in XCD-aware order.
+static __global__ void __launch_bounds__(QN_BLOCK) k_cov_from_idx(const float4* __restrict__ raw, const float4* __restrict__ sorted, uint32_t n, int k, const int32_t* __restrict__ knn_idx, double* __restrict__ cov) {
+  const uint32_t spos = xcd_block(blockIdx.x, gridDim.x) * QN_BLOCK + threadIdx.x;
+  if (spos >= n) return;
+  const uint32_t i = __float_as_uint(sorted[spos].w);
   const int32_t* nb = knn_idx + (size_t)i * k;
   int found = 0;
   double mean[3] = {0, 0, 0};
