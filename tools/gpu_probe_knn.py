@@ -4,7 +4,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "fast-lio-sam-qn_amd"))
 import numpy as np
 from qn_amd import engine, synth
-N = 100000
+N = int(os.environ.get("N", "100000"))
 src, tgt, T = synth.make_pair(0, N)
 ctx = engine.Context(N + 1024)
 g = engine.NanoGICP(ctx)
@@ -26,6 +26,12 @@ def run(label, **kn):
         for _ in range(20): g.calculateSourceCovariances()
         ctx.synchronize(); best = min(best, (time.perf_counter() - t0) / 20 * 1e3)
     print("%-44s %.3f ms  clusters %6d cand %9d retries %6d list %6d" % (label, best, c[0], c[1], c[3], c[4]))
-for cf in (0.8, 0.9, 1.0, 1.15, 1.3):
-    for m in (1.5, 1.75, 2.0, 2.25, 2.5):
-        run("cell x%.2f margin %.2f" % (cf, m), cell=cell0 * cf, knn_hist=1, margin_knn=m * 1.0, knn_rounds=2)
+if os.environ.get("SWEEP"):
+    for cf in (0.8, 0.9, 1.0, 1.15, 1.3):
+        for m in (1.5, 1.75, 2.0, 2.25, 2.5):
+            run("cell x%.2f margin %.2f" % (cf, m), cell=cell0 * cf, knn_hist=1, margin_knn=m * 1.0, knn_rounds=2)
+else:
+    run("default", knn_hist=1)
+    for m in (2.0, 2.5, 3.0):
+        for rd in (2, 3):
+            run("margin %.2f rounds %d" % (m, rd), knn_hist=1, margin_knn=m, knn_rounds=rd)
