@@ -312,8 +312,8 @@ static void enqueue_nn(qn_ctx* c, int mode /*0 align, 1 fitness*/, float* sqd_ou
   const uint32_t nbt = (S.n + QN_BLOCK - 1) / QN_BLOCK;               // tracking: one query per lane
   const double thr2 = c->params.max_corr_dist * c->params.max_corr_dist;
   uint32_t* fbc = &c->state->fb_count; uint32_t* bgc = &c->state->big_count;
-  const int big_blocks = tick == 0 ? 1024 : (tick == 1 ? 256 : (tick == 2 ? 512 : 64));   // waves with one far query each (idle blocks exit at once)
-  const uint32_t fbb = std::min<uint32_t>(nb4, tick <= 1 ? 512 : (tick == 2 ? 128 : 64));  // list pass: wave-stride over the leftovers
+  const int big_blocks = tick <= 2 ? 4096 : 64;                                            // waves with one far query each (idle blocks exit at once)
+  const uint32_t fbb = std::min<uint32_t>(nb4, tick <= 2 ? 512 : 64);                      // list pass: wave-stride over the leftovers
   const float r0 = c->margin_nn * T.grid.cell;
   if (mode == 0) {
     { ProfScope ps(c, QN_K_NN_SEARCH);
