@@ -263,7 +263,7 @@ static void launch_knn_cov(qn_ctx* c, CloudBuf& b, int k, int32_t* kidx, float* 
       hipLaunchKernelGGL(HIP_KERNEL_NAME(k_knn_hist<false, HCAP>), dim3(nb), dim3(QN_KNN_BLOCK), 0, s, b.grid, k, r0, c->knn_rounds, kidx, kd2, c->fb_list, c->fb_count2, c->big_list, genc); }
     ProfScope ps(c, QN_K_KNN_COV);
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_knn_hist<true, HCAP>), dim3(std::min<uint32_t>((b.n + 63) / 64, 512) * (QN_BLOCK / QN_KNN_BLOCK)), dim3(QN_KNN_BLOCK), 0, s, b.grid, k, r0, 64, kidx, kd2, c->fb_list, c->fb_count2, c->big_list, genc);
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_knn_cov<KMAX, true, 4>), dim3(std::min<uint32_t>((b.n + 63) / 64, 64)), dim3(QN_BLOCK), 0, s, b.grid, b.raw, k, r0, 64, b.cov, kidx, kd2, c->big_list, genc);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_knn_cov<KMAX, true, 4>), dim3(std::min<uint32_t>((b.n + 63) / 64, 1024)), dim3(QN_BLOCK), 0, s, b.grid, b.raw, k, r0, 64, b.cov, kidx, kd2, c->big_list, genc);
     const uint32_t nbp = (b.n + QN_BLOCK - 1) / QN_BLOCK;
     hipLaunchKernelGGL(k_cov_from_idx, dim3(nbp), dim3(QN_BLOCK), 0, s, b.raw, b.sorted, b.n, k, kidx, b.cov);
     if (&b == &c->cloud[0]) hipLaunchKernelGGL(k_sort_cov, dim3(nbp), dim3(QN_BLOCK), 0, s, b.sorted, b.cov, b.n, c->cov_s_sorted);
@@ -312,8 +312,8 @@ static void enqueue_nn(qn_ctx* c, int mode /*0 align, 1 fitness*/, float* sqd_ou
   const uint32_t nbt = (S.n + QN_BLOCK - 1) / QN_BLOCK;               // tracking: one query per lane
   const double thr2 = c->params.max_corr_dist * c->params.max_corr_dist;
   uint32_t* fbc = &c->state->fb_count; uint32_t* bgc = &c->state->big_count;
-  const int big_blocks = tick <= 2 ? 4096 : 64;                                            // waves with one far query each (idle blocks exit at once)
-  const uint32_t fbb = std::min<uint32_t>(nb4, tick <= 2 ? 512 : 64);                      // list pass: wave-stride over the leftovers
+  const int big_blocks = tick <= 2 ? 4096 : 1024;                                           // waves with one far query each (idle blocks exit at once)
+  const uint32_t fbb = std::min<uint32_t>(nb4, tick <= 2 ? 512 : 256);                     // list pass: wave-stride over the leftovers
   const float r0 = c->margin_nn * T.grid.cell;
   if (mode == 0) {
     { ProfScope ps(c, QN_K_NN_SEARCH);
