@@ -282,3 +282,29 @@ def test_lm_path_with_rejections(eng, oracle):
     o.set_source(src); o.compute_covariances(0); o.set_target(tgt); o.compute_covariances(1)
     ro = o.align(guess.astype(np.float64))
     _check_parity(r, ro)
+
+
+def test_randomized_configurations(eng, oracle):
+    """Seeded sweep over sizes, k (all list capacities / BestK tails), optimizer, iteration cap, epsilon and ragged target
+    sizes: same iteration count, same convergence flag, transform within the north-star tolerance, same score.
+    (tools/gpu_parity_sweep.py is the long version: 60 cases up to 60k points.)"""
+    engine, ctx = eng
+    rng = np.random.default_rng(77)
+    for case in range(10):
+        n = int(rng.choice([300, 1500, 4000, 9000])); k = int(rng.choice([10, 15, 20, 24, 27, 32]))
+        opt = str(rng.choice(["lm", "gn"])); max_iter = int(rng.choice([8, 32])); eps = float(rng.choice([0.01, 5e-4]))
+        src, tgt, _ = synth.make_pair(7000 + case, n, extent=45.0 if n > 4000 else float(rng.choice([25.0, 45.0])))
+        if case % 3 == 0:
+            tgt = tgt[: int(0.7 * n)]
+        g = engine.NanoGICP(ctx)
+        g.setCorrespondenceRandomness(k); g.setMaximumIterations(max_iter); g.setMaxCorrespondenceDistance(52.5)
+        g.setTransformationEpsilon(eps); g.setOptimizer(opt)
+        g.setInputSource(src); g.calculateSourceCovariances(); g.setInputTarget(tgt); g.calculateTargetCovariances()
+        g.align(); r = g.result_dict()
+        o = oracle.GicpOracle(k=k, max_iter=max_iter, max_corr_dist=52.5, trans_eps=eps, optimizer=opt)
+        o.set_source(src); o.compute_covariances(0); o.set_target(tgt); o.compute_covariances(1)
+        ro = o.align()
+        dt, dr = synth.pose_error(r["T"], ro["T"])
+        assert r["iterations"] == ro["iterations"] and r["converged"] == ro["converged"], (case, n, k, opt)
+        assert dt <= TOL_T and dr <= TOL_R, (case, dt, dr)
+        assert abs(r["fitness"] - ro["fitness"]) <= 1e-6 * max(ro["fitness"], 1e-12)
