@@ -174,6 +174,8 @@ struct Best1 {                         // 1-NN, plus the squared distance of the
   __device__ __forceinline__ void reset() { key = QN_INF_KEY; second = __int_as_float(0x7f800000); }
   __device__ __forceinline__ bool full() const { return key != QN_INF_KEY; }
   __device__ __forceinline__ float worst_d2() const { return key_d2(key); }
+  __device__ __forceinline__ int found() const { return key != QN_INF_KEY ? 1 : 0; }
+  __device__ __forceinline__ int wanted() const { return 1; }
 };
 
 // k-NN: ascending (d2, idx) list in registers.  Inserting costs a KMAX-long compare-exchange chain
@@ -260,6 +262,13 @@ struct BestK {
   }
   __device__ __forceinline__ bool full() const { return w != QN_INF_KEY; }
   __device__ __forceinline__ float worst_d2() const { return key_d2(w); }
+  __device__ __forceinline__ int found() const {                       // real entries in the (merged) list
+    int f = 0;
+#pragma unroll
+    for (int j = 0; j < KMAX; j++) f += (j >= KMAX - k && a[j] != QN_INF_KEY) ? 1 : 0;
+    return f;
+  }
+  __device__ __forceinline__ int wanted() const { return k; }
 };
 
 // ------------------------------------------------------------------ dense candidate stream over a cell box
@@ -489,7 +498,11 @@ __device__ __forceinline__ bool wave_search(const GridView& g, float qx, float q
       if (d == INF || !(r == r)) { certified = true; d_unseen = INF; }   // the whole grid was scanned (or a non-finite query: nothing to find)
       else { d -= g.eps; d_unseen = d; certified = d > 0.f && sink.full() && sink.worst_d2() < d * d; }
       if (!certified) {
-        r = sink.full() ? fmaxf(sqrtf(sink.worst_d2()) * 1.000001f + g.eps, r) : 2.f * r + g.cell;
+        if (sink.full()) r = fmaxf(sqrtf(sink.worst_d2()) * 1.000001f + g.eps, r);
+        else {                                                // fewer than k points in the box: extrapolate from the count (surface-like data: count ~ r^2)
+          const int f = sink.found();                         // instead of doubling blindly (a sparse-region k-NN query then re-scans far less)
+          r = f > 0 ? fmaxf(r * sqrtf((float)sink.wanted() / (float)f) * 1.25f, r + g.cell) : 2.f * r + g.cell;
+        }
         r = fminf(r, r_cap);                                 // r_cap: a proven upper bound on the (k-th) NN distance, +inf if none
         if (round + 1 < max_rounds) { retry = true; sink.reset(); }
       }

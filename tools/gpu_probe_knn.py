@@ -5,7 +5,8 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "fast-lio-sam-qn
 import numpy as np
 from qn_amd import engine, synth
 N = int(os.environ.get("N", "100000"))
-src, tgt, T = synth.make_pair(0, N)
+src, tgt, T = synth.make_pair(int(os.environ.get("PAIR", "0")), N)
+if os.environ.get("WHICH") == "tgt": src = tgt
 ctx = engine.Context(N + 1024)
 g = engine.NanoGICP(ctx)
 g.setCorrespondenceRandomness(int(os.environ.get("K", "20")))
