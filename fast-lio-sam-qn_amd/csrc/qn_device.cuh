@@ -275,20 +275,29 @@ struct BestK {
 // Calls body(p, valid, cnt) once per 64-candidate chunk with one candidate per lane (`valid` = lane
 // holds a real one, `cnt` = candidates in this chunk, wave-uniform).  All 64 lanes must call.
 template <class Body>
-__device__ __forceinline__ uint32_t stream_box(const GridView& g, int x0, int x1, int y0, int y1, int z0, int z1, WaveLds* lds, Body&& body) {
+__device__ __forceinline__ uint32_t stream_box(const GridView& g, int x0, int x1, int y0, int y1, int z0, int z1, const bool tile_mode, WaveLds* lds, Body&& body) {
+  // tile_mode: the box has been widened to whole 8x4x4-cell tiles by the caller and is enumerated tile by tile (a tile's 128
+  // cells are one contiguous run of pts[]) - a big ball is mostly empty space, row-wise enumeration would spend its time on
+  // cell_start look-ups of empty rows.
   const int lane = threadIdx.x & 63;
   const int tx0 = x0 >> 3, ntr = (x1 >> 3) - tx0 + 1, nyr = y1 - y0 + 1;
-  const int nseg = ntr * nyr * (z1 - z0 + 1);
+  const int ty0 = y0 >> 2, ntyr = (y1 >> 2) - ty0 + 1;
+  const int nseg = tile_mode ? ntr * ntyr * ((z1 >> 2) - (z0 >> 2) + 1) : ntr * nyr * (z1 - z0 + 1);
   uint32_t grand = 0;
   for (int sb = 0; sb < nseg; sb += 64) {
     const int sidx = sb + lane;
     uint32_t s = 0, len = 0;
     if (sidx < nseg) {
       const int t = sidx % ntr, r = sidx / ntr;
-      const int ry = y0 + r % nyr, rz = z0 + r / nyr, tx = tx0 + t;
-      const int xa = max(x0, tx << 3), xb = min(x1, (tx << 3) + 7);
-      const uint32_t k0 = cell_key(g, xa, ry, rz);
-      s = g.cell_start[k0]; len = g.cell_start[k0 + (xb - xa) + 1] - s;
+      if (tile_mode) {
+        const uint32_t tile = ((uint32_t)((z0 >> 2) + r / ntyr) * g.nty + (ty0 + r % ntyr)) * g.ntx + (tx0 + t);
+        s = g.cell_start[tile << 7]; len = g.cell_start[(tile + 1) << 7] - s;
+      } else {
+        const int ry = y0 + r % nyr, rz = z0 + r / nyr, tx = tx0 + t;
+        const int xa = max(x0, tx << 3), xb = min(x1, (tx << 3) + 7);
+        const uint32_t k0 = cell_key(g, xa, ry, rz);
+        s = g.cell_start[k0]; len = g.cell_start[k0 + (xb - xa) + 1] - s;
+      }
     }
     const uint32_t incl = wave_incl_scan_u32(len, lane);
     const uint32_t total = rflu(__shfl(incl, 63));

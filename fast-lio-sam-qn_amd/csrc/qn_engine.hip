@@ -112,7 +112,7 @@ extern "C" int qn_ctx_create(int device, uint32_t max_points, qn_ctx** out) {
   CA(hipMalloc(&c->sqd_fit, sizeof(float) * max_points));
   CA(hipMalloc(&c->fb_list, sizeof(uint2) * max_points));
   CA(hipMalloc(&c->big_list, sizeof(uint2) * max_points));
-  CA(hipMalloc(&c->fb_count2, 2 * sizeof(uint32_t)));
+  CA(hipMalloc(&c->fb_count2, 4 * sizeof(uint32_t)));
   CA(hipMalloc(&c->aligned, sizeof(float4) * max_points));
   CA(hipMalloc(&c->pose_tmp, sizeof(double) * 16));
   CA(hipMalloc(&c->guess_tmp, sizeof(float) * 16));
@@ -263,7 +263,9 @@ static void launch_knn_cov(qn_ctx* c, CloudBuf& b, int k, int32_t* kidx, float* 
       hipLaunchKernelGGL(HIP_KERNEL_NAME(k_knn_hist<false, HCAP>), dim3(nb), dim3(QN_KNN_BLOCK), 0, s, b.grid, k, r0, c->knn_rounds, kidx, kd2, c->fb_list, c->fb_count2, c->big_list, genc); }
     ProfScope ps(c, QN_K_KNN_COV);
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_knn_hist<true, HCAP>), dim3(std::min<uint32_t>((b.n + 63) / 64, 512) * (QN_BLOCK / QN_KNN_BLOCK)), dim3(QN_KNN_BLOCK), 0, s, b.grid, k, r0, 64, kidx, kd2, c->fb_list, c->fb_count2, c->big_list, genc);
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_knn_cov<KMAX, true, 4>), dim3(std::min<uint32_t>((b.n + 63) / 64, 1024)), dim3(QN_BLOCK), 0, s, b.grid, b.raw, k, r0, 64, b.cov, kidx, kd2, c->big_list, genc);
+    // far / overflowing queries (isolated points, sparse far field): one per wave; its leftovers -> the sorted-list kernel (fb_list is free again)
+    hipLaunchKernelGGL(k_knn_single, dim3(std::min<uint32_t>((b.n + 3) / 4, 2048)), dim3(QN_BLOCK), 0, s, b.grid, k, kidx, kd2, c->big_list, genc, c->fb_list, c->fb_count2 + 2);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_knn_cov<KMAX, true, 4>), dim3(std::min<uint32_t>((b.n + 63) / 64, 1024)), dim3(QN_BLOCK), 0, s, b.grid, b.raw, k, r0, 64, b.cov, kidx, kd2, c->fb_list, c->fb_count2 + 2);
     const uint32_t nbp = (b.n + QN_BLOCK - 1) / QN_BLOCK;
     hipLaunchKernelGGL(k_cov_from_idx, dim3(nbp), dim3(QN_BLOCK), 0, s, b.raw, b.sorted, b.n, k, kidx, b.cov);
     if (&b == &c->cloud[0]) hipLaunchKernelGGL(k_sort_cov, dim3(nbp), dim3(QN_BLOCK), 0, s, b.sorted, b.cov, b.n, c->cov_s_sorted);
@@ -288,7 +290,7 @@ static int compute_cov(qn_ctx* c, int which, int32_t* kidx, float* kd2) {
   if (!b.has_grid) return b.n == 0 ? QN_ERR_EMPTY_CLOUD : QN_ERR_NOT_READY;
   HIPCHK(c, hipSetDevice(c->device));
   const int k = c->params.k_correspondences;
-  HIPCHK(c, hipMemsetAsync(c->fb_count2, 0, 2 * sizeof(uint32_t), c->stream));
+  HIPCHK(c, hipMemsetAsync(c->fb_count2, 0, 4 * sizeof(uint32_t), c->stream));
   if (k <= 16) launch_knn_cov<16>(c, b, k, kidx, kd2);
   else if (k <= 20) launch_knn_cov<20>(c, b, k, kidx, kd2);
   else if (k <= 24) launch_knn_cov<24>(c, b, k, kidx, kd2);

@@ -162,7 +162,25 @@ __global__ void __launch_bounds__(QN_KNN_BLOCK, HCAP <= 32 ? 4 : 3) k_knn_hist(G
     }
     if (!active || (threadIdx.x & 63) >= 16 || status == 0) continue;
     if (LIST) { const uint32_t fs = atomicAdd(gen_count, 1u); gen_list[fs] = make_uint2(t, __float_as_uint(r)); }
-    else { const uint32_t fs = atomicAdd(fb_count, 1u); fb_list[fs] = make_uint2(t, __float_as_uint(r) | (status == 2 ? 0x80000000u : 0u)); }
+    else if (status == 2 || r > 2.5f * r0) { const uint32_t fs = atomicAdd(gen_count, 1u); gen_list[fs] = make_uint2(t, __float_as_uint(r)); }   // far or overflowing: one query per wave (k_knn_single)
+    else { const uint32_t fs = atomicAdd(fb_count, 1u); fb_list[fs] = make_uint2(t, __float_as_uint(r)); }
+  }
+}
+
+// The far / overflowing k-NN queries, one per wave (wave_knn_single); what it cannot finish goes to the sorted-list kernel.
+static __global__ void __launch_bounds__(QN_BLOCK) k_knn_single(GridView g, int k, int32_t* __restrict__ knn_idx, float* __restrict__ knn_d2,
+                                                                const uint2* __restrict__ list, const uint32_t* __restrict__ count, uint2* __restrict__ gen_list, uint32_t* __restrict__ gen_count) {
+  __shared__ WaveLdsH1 lds[QN_BLOCK / 64];
+  WaveLdsH1* my = &lds[threadIdx.x >> 6];
+  const uint32_t nq = *count;
+  if (g.dbg && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&g.dbg[8], nq);
+  const uint32_t wave0 = blockIdx.x * (QN_BLOCK / 64) + (threadIdx.x >> 6), nwaves = gridDim.x * (QN_BLOCK / 64);
+  for (uint32_t e = wave0; e < nq; e += nwaves) {
+    const uint2 rec = list[e];
+    const float4 q = g.pts[rec.x];
+    const uint32_t i = __float_as_uint(q.w);
+    const int st = wave_knn_single(g, q.x, q.y, q.z, __uint_as_float(rec.y & 0x7fffffffu), k, my, knn_idx + (size_t)i * k, knn_d2 ? knn_d2 + (size_t)i * k : nullptr);
+    if (st != 0 && (threadIdx.x & 63) == 0) { if (g.dbg) atomicAdd(&g.dbg[9], 1u); const uint32_t fs = atomicAdd(gen_count, 1u); gen_list[fs] = make_uint2(rec.x, rec.y & 0x7fffffffu); }
   }
 }
 

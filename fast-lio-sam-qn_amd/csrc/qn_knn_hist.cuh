@@ -151,4 +151,109 @@ __device__ __forceinline__ int wave_knn_hist(const GridView& g, float qx, float 
 }
 
 
+// ------------------------------------------------------------------ one k-NN query per WAVE
+// For the queries whose k-th neighbour is far away (isolated points, sparse far field of a real scan): in the 16-query layout
+// such queries form 16 disjoint clusters per wave and every lane walks all 16 candidate streams.  Here all 64 lanes score ONE
+// query's candidates (stream_box: one candidate per lane and step) with the same histogram selection: pass 1 bins the squared
+// distances into one LDS histogram, tau = first bin edge whose cumulative count reaches k, pass 2 collects the candidates below
+// tau (<= QN_HCAP1), each lane ranks up to two of them.  Same exactness argument and certification as wave_knn_hist.
+// Returns 0 = done (k indices written in ascending (d2, idx) order), 2 = hand over to the sorted-list path.
+#define QN_HCAP1 128
+struct WaveLdsH1 {
+  WaveLds s;
+  uint32_t hist[QN_HB];
+  unsigned long long list[QN_HCAP1];
+  uint32_t cnt, kth;
+};
+
+__device__ __forceinline__ int wave_knn_single(const GridView& g, float qx, float qy, float qz, float r, int k, WaveLdsH1* L,
+                                               int32_t* __restrict__ idx_out, float* __restrict__ d2_out) {
+  const int lane = threadIdx.x & 63;
+  const float INF = __int_as_float(0x7f800000);
+  if (!(qx == qx) || !(qy == qy) || !(qz == qz) || !(r == r)) return 2;
+  for (int round = 0; round < 64; round++) {
+    int x0 = rfl(cell_coord(qx - r, g.ox, g.inv_cell, g.nx)), x1 = rfl(cell_coord(qx + r, g.ox, g.inv_cell, g.nx));
+    int y0 = rfl(cell_coord(qy - r, g.oy, g.inv_cell, g.ny)), y1 = rfl(cell_coord(qy + r, g.oy, g.inv_cell, g.ny));
+    int z0 = rfl(cell_coord(qz - r, g.oz, g.inv_cell, g.nz)), z1 = rfl(cell_coord(qz + r, g.oz, g.inv_cell, g.nz));
+    const bool tile_mode = ((x1 >> 3) - (x0 >> 3) + 1) * (y1 - y0 + 1) * (z1 - z0 + 1) > 128;
+    if (tile_mode) {                                                          // whole tiles: the certification below sees the larger scanned box
+      x0 = (x0 >> 3) << 3; x1 = min(((x1 >> 3) << 3) + 7, g.nx - 1);
+      y0 = (y0 >> 2) << 2; y1 = min(((y1 >> 2) << 2) + 3, g.ny - 1);
+      z0 = (z0 >> 2) << 2; z1 = min(((z1 >> 2) << 2) + 3, g.nz - 1);
+    }
+    wave_lds_fence();
+    L->hist[lane] = 0; if (lane == 0) { L->cnt = 0; L->kth = 0x7f800000u; }
+    wave_lds_fence();
+    const int base = (int)(__float_as_uint(4.f * r * r) >> 20) - (QN_HB - 2);
+    stream_box(g, x0, x1, y0, y1, z0, z1, tile_mode, &L->s, [&](const float4& p, bool valid, uint32_t) __attribute__((always_inline)) {
+      const int bin = max((int)(__float_as_uint(sqdist(qx, qy, qz, p.x, p.y, p.z)) >> 20) - base, 0);
+      if (valid && bin < QN_HB - 1) atomicAdd(&L->hist[bin], 1u);
+    });
+    wave_lds_fence();
+    const uint32_t hv = lane < QN_HB - 1 ? L->hist[lane] : 0u;
+    const uint32_t cum = wave_incl_scan_u32(hv, lane);
+    const uint32_t total = rflu(__shfl(cum, 63));
+    const bool enough = total >= (uint32_t)k;
+    const unsigned long long reach = __ballot(cum >= (uint32_t)k);
+    const int cross = reach ? __ffsll((long long)reach) - 1 : QN_HB - 2;
+    uint32_t tau_bits = (uint32_t)(base + cross + 1) << 20;
+    // A far query's crossing bin can hold hundreds of points (the bins are 9 % wide in d2): refine it with 64 linear sub-bins
+    // (bits 14..19 of the f32 pattern) so that the list of pass 2 stays short.
+    if (enough && rflu(__shfl(cum, cross)) > (uint32_t)QN_HCAP1 && cross > 0) {
+      const uint32_t below = rflu(__shfl(cum, cross - 1)), need = (uint32_t)k - below;       // below < k: all of them are among the k nearest
+      const uint32_t hi20 = (uint32_t)(base + cross);
+      wave_lds_fence();
+      L->hist[lane] = 0;
+      wave_lds_fence();
+      stream_box(g, x0, x1, y0, y1, z0, z1, tile_mode, &L->s, [&](const float4& p, bool valid, uint32_t) __attribute__((always_inline)) {
+        const uint32_t bits = __float_as_uint(sqdist(qx, qy, qz, p.x, p.y, p.z));
+        if (valid && (bits >> 20) == hi20) atomicAdd(&L->hist[(bits >> 14) & 63u], 1u);
+      });
+      wave_lds_fence();
+      const uint32_t cum2 = wave_incl_scan_u32(L->hist[lane], lane);
+      const unsigned long long reach2 = __ballot(cum2 >= need);
+      const int sub = reach2 ? __ffsll((long long)reach2) - 1 : 63;
+      tau_bits = (hi20 << 20) + ((uint32_t)(sub + 1) << 14);
+    }
+    float d = INF;                                                          // nearest face of the scanned box with unseen cells behind it
+    if (x0 > 0) d = fminf(d, qx - (g.ox + x0 * g.cell));
+    if (x1 < g.nx - 1) d = fminf(d, (g.ox + (x1 + 1) * g.cell) - qx);
+    if (y0 > 0) d = fminf(d, qy - (g.oy + y0 * g.cell));
+    if (y1 < g.ny - 1) d = fminf(d, (g.oy + (y1 + 1) * g.cell) - qy);
+    if (z0 > 0) d = fminf(d, qz - (g.oz + z0 * g.cell));
+    if (z1 < g.nz - 1) d = fminf(d, (g.oz + (z1 + 1) * g.cell) - qz);
+    const bool whole = d == INF;
+    if (!enough) {
+      if (whole) return 2;                                                   // fewer than k points within 2 r of the whole cloud: general path
+      r = total > 0 ? fmaxf(2.f * r * sqrtf((float)k / (float)total) * 1.1f, r + g.cell) : 2.f * r + g.cell;
+      continue;
+    }
+    stream_box(g, x0, x1, y0, y1, z0, z1, tile_mode, &L->s, [&](const float4& p, bool valid, uint32_t) __attribute__((always_inline)) {
+      const float d2 = sqdist(qx, qy, qz, p.x, p.y, p.z);
+      if (valid && __float_as_uint(d2) < tau_bits) {
+        const uint32_t pos = atomicAdd(&L->cnt, 1u);
+        if (pos < QN_HCAP1) L->list[pos] = pack_key(d2, __float_as_uint(p.w));
+      }
+    });
+    wave_lds_fence();
+    const uint32_t P = L->cnt;
+    if (P > QN_HCAP1) return 2;                                             // too many ties below tau: general path
+    const unsigned long long own0 = (uint32_t)lane < P ? L->list[lane] : QN_INF_KEY, own1 = (uint32_t)lane + 64u < P ? L->list[lane + 64] : QN_INF_KEY;
+    int rank0 = 0, rank1 = 0;
+    for (uint32_t f = 0; f < P; f++) { const unsigned long long kf = L->list[f]; rank0 += kf < own0 ? 1 : 0; rank1 += kf < own1 ? 1 : 0; }
+    if (own0 != QN_INF_KEY && rank0 == k - 1) L->kth = (uint32_t)(own0 >> 32);
+    if (own1 != QN_INF_KEY && rank1 == k - 1) L->kth = (uint32_t)(own1 >> 32);
+    wave_lds_fence();
+    const float kth_d2 = __uint_as_float(L->kth);
+    const float df = d - g.eps;
+    if (whole || (df > 0.f && kth_d2 < df * df)) {
+      if (own0 != QN_INF_KEY && rank0 < k) { idx_out[rank0] = (int32_t)key_idx(own0); if (d2_out) d2_out[rank0] = key_d2(own0); }
+      if (own1 != QN_INF_KEY && rank1 < k) { idx_out[rank1] = (int32_t)key_idx(own1); if (d2_out) d2_out[rank1] = key_d2(own1); }
+      return 0;
+    }
+    r = fmaxf(sqrtf(kth_d2) * 1.000001f + g.eps, r);                        // the k-th best is known: the next ball certifies
+  }
+  return 2;
+}
+
 }  // namespace qn

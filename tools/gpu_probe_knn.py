@@ -7,6 +7,9 @@ from qn_amd import engine, synth
 N = int(os.environ.get("N", "100000"))
 src, tgt, T = synth.make_pair(int(os.environ.get("PAIR", "0")), N)
 if os.environ.get("WHICH") == "tgt": src = tgt
+if os.environ.get("OUTLIERS"):
+    rng = np.random.default_rng(3); m = int(float(os.environ["OUTLIERS"]) * N); lo, hi = src.min(0), src.max(0); hi[2] = lo[2] + 25.0
+    src = src.copy(); src[rng.choice(N, m, replace=False)] = rng.uniform(lo, hi, size=(m, 3)).astype(np.float32)
 ctx = engine.Context(N + 1024)
 g = engine.NanoGICP(ctx)
 g.setCorrespondenceRandomness(int(os.environ.get("K", "20")))
@@ -26,7 +29,7 @@ def run(label, **kn):
         ctx.synchronize(); t0 = time.perf_counter()
         for _ in range(20): g.calculateSourceCovariances()
         ctx.synchronize(); best = min(best, (time.perf_counter() - t0) / 20 * 1e3)
-    print("%-44s %.3f ms  clusters %6d cand %9d retries %6d list %6d" % (label, best, c[0], c[1], c[3], c[4]))
+    print("%-44s %.3f ms  clusters %6d cand %9d retries %6d list %6d  dbg8-11 %s" % (label, best, c[0], c[1], c[3], c[4], c[8:12]))
 if os.environ.get("SWEEP"):
     for cf in (0.8, 0.9, 1.0, 1.15, 1.3):
         for m in (1.5, 1.75, 2.0, 2.25, 2.5):
