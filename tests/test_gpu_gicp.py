@@ -50,6 +50,26 @@ def test_knn_sorted_list_path_bit_exact(oracle):
     ctx.close()
 
 
+def test_knn_bit_exact_with_isolated_points_and_ties(eng, oracle):
+    """Far queries (isolated points scattered in the bounding volume: the one-query-per-wave path with its second-level
+    histogram and tile-wise box enumeration) and a regular lattice (every distance tied many times: list overflows fall back
+    to the sorted-list kernel, ties must still resolve to the lowest index)."""
+    engine, ctx = eng
+    src, _, _ = synth.make_pair(43, 20000)
+    rng = np.random.default_rng(9)
+    lo, hi = src.min(0), src.max(0); hi[2] = lo[2] + 25.0
+    src = src.copy(); sel = rng.choice(len(src), 600, replace=False)
+    src[sel] = rng.uniform(lo, hi, size=(600, 3)).astype(np.float32)
+    gx, gy = np.meshgrid(np.arange(60, dtype=np.float32) * 0.5, np.arange(60, dtype=np.float32) * 0.5)
+    lattice = np.stack([gx.ravel() + 200.0, gy.ravel(), np.zeros(3600, np.float32)], 1).astype(np.float32)
+    for cloud, ks in ((src, (15, 20, 32)), (lattice, (20,))):
+        g = engine.NanoGICP(ctx); g.setInputSource(cloud)
+        o = oracle.GicpOracle(); o.set_source(cloud)
+        for k in ks:
+            idx, d2 = g.knn(0, k); oi, od = o.knn(0, cloud, k)
+            assert np.array_equal(idx, oi) and np.array_equal(d2, od), k
+
+
 def test_knn_bit_exact_sparse_and_tiny(eng, oracle):
     """Sparse cloud (most queries leave the LDS-staged stencil -> exact ball fallback) and n < k."""
     engine, ctx = eng
