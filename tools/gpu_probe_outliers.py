@@ -24,3 +24,9 @@ for frac in (0.0, 0.01, 0.05, 0.2):
     ctx.prof_reset(); ctx.prof_enable(True); engine.icp_alignment(ctx, src, tgt); ctx.synchronize(); ctx.prof_enable(False)
     st = {k: round(v[0], 3) for k, v in ctx.prof_stats().items() if v[1]}
     print("outliers %4.0f%%: icpAlignment %.3f ms iters=%d valid=%s  %s" % (100 * frac, dt, r["iterations"], r["valid"], st))
+    g = engine.NanoGICP(ctx); g.setCorrespondenceRandomness(20); g.setMaximumIterations(20); g.setMaxCorrespondenceDistance(52.5); g.setOptimizer("gn"); g.setForceIterations(20)
+    g.setInputSource(src); g.calculateSourceCovariances(); g.setInputTarget(tgt); g.calculateTargetCovariances()
+    for _ in range(2): g.align()
+    t = time.perf_counter()
+    for _ in range(5): g.align()
+    print("               GN x20 align only: %.3f ms" % ((time.perf_counter() - t) / 5 * 1e3))
