@@ -130,7 +130,12 @@ __device__ __forceinline__ int wave_knn_hist(const GridView& g, float qx, float 
       const bool whole = d == INF || !(r == r);
       if (!enough) {
         if (whole) status = 2;                                                      // fewer than k points within 2 r of the whole cloud
-        else { r = 2.f * r + g.cell; retry = true; }
+        else {
+          const uint32_t tot = s0 + s1 + s2 + s3;
+          if (4u * tot < (uint32_t)k) {                                           // an isolated point (a quarter of k within 2 r): do not drag the wave through a
+            r = tot > 0 ? 2.f * r * sqrtf((float)k / (float)tot) * 1.1f : 4.f * r + g.cell;   // big-box round - hand it over with an extrapolated radius (count ~ r^2);
+          } else { r = 2.f * r + g.cell; retry = true; }                          // the caller sends radii beyond 2.5 r0 to the one-query-per-wave pass
+        }
       } else if (!ok) status = 2;                                                   // list overflow
       else {
         d -= g.eps;
