@@ -25,6 +25,11 @@ for case in range(ncases):
     except RuntimeError:
         src, tgt, T = synth.make_pair(pid, n)
     if rng.random() < 0.25: tgt = tgt[: int(0.7 * n)]                      # ragged sizes
+    if rng.random() < 0.35:                                                 # isolated points scattered in the bounding volume (far-query k-NN / 1-NN paths)
+        frac = float(rng.choice([0.005, 0.02, 0.1]))
+        for c in (src, tgt):
+            m = max(1, int(frac * len(c))); lo, hi = c.min(0), c.max(0); hi[2] = lo[2] + 20.0
+            c[rng.choice(len(c), m, replace=False)] = rng.uniform(lo, hi, size=(m, 3)).astype(np.float32)
     g = engine.NanoGICP(ctx)
     g.setCorrespondenceRandomness(k); g.setMaximumIterations(max_iter); g.setMaxCorrespondenceDistance(52.5)
     g.setTransformationEpsilon(eps); g.setOptimizer(opt)
