@@ -267,9 +267,8 @@ static void launch_knn_cov(qn_ctx* c, CloudBuf& b, int k, int32_t* kidx, float* 
     hipLaunchKernelGGL(k_knn_single, dim3(std::min<uint32_t>((b.n + 3) / 4, 2048)), dim3(QN_BLOCK), 0, s, b.grid, k, kidx, kd2, c->big_list, genc, c->fb_list, c->fb_count2 + 2);
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_knn_cov<KMAX, true, 4>), dim3(std::min<uint32_t>((b.n + 63) / 64, 1024)), dim3(QN_BLOCK), 0, s, b.grid, b.raw, k, r0, 64, b.cov, kidx, kd2, c->fb_list, c->fb_count2 + 2);
     const uint32_t nbp = (b.n + QN_BLOCK - 1) / QN_BLOCK;
-    hipLaunchKernelGGL(k_cov_from_idx, dim3(nbp), dim3(QN_BLOCK), 0, s, b.raw, b.sorted, b.n, k, kidx, b.cov);
-    if (&b == &c->cloud[0]) hipLaunchKernelGGL(k_sort_cov, dim3(nbp), dim3(QN_BLOCK), 0, s, b.sorted, b.cov, b.n, c->cov_s_sorted);
-    else hipLaunchKernelGGL(k_build_target_rec, dim3(nbp), dim3(QN_BLOCK), 0, s, b.raw, b.cov, b.n, c->tgt_rec);
+    hipLaunchKernelGGL(k_cov_from_idx, dim3(nbp), dim3(QN_BLOCK), 0, s, b.raw, b.sorted, b.n, k, kidx, b.cov,
+                       &b == &c->cloud[0] ? c->cov_s_sorted : (double*)nullptr, &b == &c->cloud[0] ? (TargetRec*)nullptr : c->tgt_rec);   // + the fused ticks' layouts
     return;
   }
   ProfScope ps(c, QN_K_KNN_COV);
@@ -279,10 +278,8 @@ static void launch_knn_cov(qn_ctx* c, CloudBuf& b, int k, int32_t* kidx, float* 
   }
   hipLaunchKernelGGL(HIP_KERNEL_NAME(k_knn_cov<KMAX, true, 4>), dim3(std::min<uint32_t>((b.n + 63) / 64, 512)), dim3(QN_BLOCK), 0, s, b.grid, b.raw, k, r0, 64, b.cov, kidx, kd2, c->fb_list, c->fb_count2);
   const uint32_t nbp = (b.n + QN_BLOCK - 1) / QN_BLOCK;
-  hipLaunchKernelGGL(k_cov_from_idx, dim3(nbp), dim3(QN_BLOCK), 0, s, b.raw, b.sorted, b.n, k, kidx, b.cov);
-  // layouts for the fused optimiser ticks: source covariances in cell-sorted order, target point + covariance in one 64-byte record
-  if (&b == &c->cloud[0]) hipLaunchKernelGGL(k_sort_cov, dim3(nbp), dim3(QN_BLOCK), 0, s, b.sorted, b.cov, b.n, c->cov_s_sorted);
-  else hipLaunchKernelGGL(k_build_target_rec, dim3(nbp), dim3(QN_BLOCK), 0, s, b.raw, b.cov, b.n, c->tgt_rec);
+  hipLaunchKernelGGL(k_cov_from_idx, dim3(nbp), dim3(QN_BLOCK), 0, s, b.raw, b.sorted, b.n, k, kidx, b.cov,
+                     &b == &c->cloud[0] ? c->cov_s_sorted : (double*)nullptr, &b == &c->cloud[0] ? (TargetRec*)nullptr : c->tgt_rec);   // + the fused ticks' layouts
 }
 static int compute_cov(qn_ctx* c, int which, int32_t* kidx, float* kd2) {
   if (!c || (which != 0 && which != 1)) return QN_ERR_INVALID_ARG;

@@ -71,9 +71,14 @@ static __global__ void k_scatter(const float4* __restrict__ pts, uint32_t n, con
 // ------------------------------------------------------------------ K2+K3 k-NN + covariance (k-NN selection: k_knn_hist below, k_knn_cov in qn_knn_kernels.cuh)
 // k nearest (self included), mean/cov in f64 (cov = X X^T / k), PLANE regularisation:
 // C = V diag(1, 1, 1e-3) V^T with V the eigenvectors of cov (eigenvalues descending); from stored neighbour indices (ascending (d2, idx) order, -1 = missing): one point per lane.
+// Target-side record for the fused optimiser ticks: point and covariance of a target point in ONE 64-byte line
+// (a correspondence then costs one scattered cache line instead of two).
+struct __attribute__((aligned(64))) TargetRec { float4 p; double cov[6]; };
+static_assert(sizeof(TargetRec) == 64, "TargetRec is one 64-byte line");
 // Threads walk the points in cell-sorted order (a block's points are spatial neighbours, so their k-NN gathers overlap in
 // L1/L2), blocks in XCD-aware order.
-static __global__ void __launch_bounds__(QN_BLOCK) k_cov_from_idx(const float4* __restrict__ raw, const float4* __restrict__ sorted, uint32_t n, int k, const int32_t* __restrict__ knn_idx, double* __restrict__ cov) {
+static __global__ void __launch_bounds__(QN_BLOCK) k_cov_from_idx(const float4* __restrict__ raw, const float4* __restrict__ sorted, uint32_t n, int k, const int32_t* __restrict__ knn_idx, double* __restrict__ cov,
+                                                                  double* __restrict__ cov_sorted, TargetRec* __restrict__ rec) {
   const uint32_t spos = xcd_block(blockIdx.x, gridDim.x) * QN_BLOCK + threadIdx.x;
   if (spos >= n) return;
   const uint32_t i = __float_as_uint(sorted[spos].w);
@@ -82,7 +87,21 @@ static __global__ void __launch_bounds__(QN_BLOCK) k_cov_from_idx(const float4* 
   double mean[3] = {0, 0, 0};
   for (int j = 0; j < k; j++) { const int32_t u = nb[j]; if (u < 0) continue; const float4 p = raw[u]; mean[0] += (double)p.x; mean[1] += (double)p.y; mean[2] += (double)p.z; found++; }
   double* cov_out = cov + (size_t)i * 6;
-  if (found == 0) { for (int t = 0; t < 6; t++) cov_out[t] = 0; return; }
+  double co[6] = {0, 0, 0, 0, 0, 0};
+  // the layouts of the fused optimiser ticks are written here as well (cov_sorted: source, cell-sorted order; rec: target, 64-byte records)
+  auto store = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int u = 0; u < 6; u++) cov_out[u] = co[u];
+    if (cov_sorted) {
+#pragma unroll
+      for (int u = 0; u < 6; u++) cov_sorted[(size_t)spos * 6 + u] = co[u];
+    }
+    if (rec) { TargetRec r; r.p = raw[i];
+#pragma unroll
+      for (int u = 0; u < 6; u++) r.cov[u] = co[u];
+      rec[i] = r; }
+  };
+  if (found == 0) { store(); return; }
   mean[0] /= found; mean[1] /= found; mean[2] /= found;
   double c[6] = {0, 0, 0, 0, 0, 0};
   for (int j = 0; j < k; j++) {
@@ -104,35 +123,16 @@ static __global__ void __launch_bounds__(QN_BLOCK) k_cov_from_idx(const float4* 
       double s = 0;
 #pragma unroll
       for (int e = 0; e < 3; e++) s += V[a][e] * vals[e] * V[b][e];
-      cov_out[t] = s;
+      co[t] = s;
     }
+  store();
 }
 
-// Target-side record for the fused optimiser ticks: point and covariance of a target point in ONE 64-byte line
-// (a correspondence then costs one scattered cache line instead of two).
-struct __attribute__((aligned(64))) TargetRec { float4 p; double cov[6]; };
-static_assert(sizeof(TargetRec) == 64, "TargetRec is one 64-byte line");
-static __global__ void k_build_target_rec(const float4* __restrict__ raw, const double* __restrict__ cov, uint32_t n, TargetRec* __restrict__ rec) {
-  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= n) return;
-  TargetRec r; r.p = raw[j];
-#pragma unroll
-  for (int u = 0; u < 6; u++) r.cov[u] = cov[(size_t)j * 6 + u];
-  rec[j] = r;
-}
-// source covariances in the source's cell-sorted order (the order the NN kernels walk the queries in)
-static __global__ void k_sort_cov(const float4* __restrict__ sorted, const double* __restrict__ cov, uint32_t n, double* __restrict__ cov_sorted) {
-  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= n) return;
-  const uint32_t i = __float_as_uint(sorted[t].w);
-#pragma unroll
-  for (int u = 0; u < 6; u++) cov_sorted[(size_t)t * 6 + u] = cov[(size_t)i * 6 + u];
-}
 
 // k-NN by histogram selection (wave_knn_hist), 16 queries per wave.  LIST = false: every point, radius margin * cell,
-// `max_rounds` rounds, leftovers appended to fb_list as (t, r) with the sign bit of r set when the query needs the
-// general path.  LIST = true: the fb_list entries, rounds until exact; general-path entries are passed on to gen_list
-// (served by k_knn_cov<KMAX, true, 4> afterwards).
+// `max_rounds` rounds; near leftovers are appended to fb_list as (t, r), far ones (next radius > 2.5 r0) and list overflows to
+// gen_list.  LIST = true: the fb_list entries, rounds until exact; what it cannot finish is passed on to gen_list as well
+// (served by k_knn_single, then k_knn_cov<KMAX, true, 4>).
 // HCAP = capacity of the per-query candidate list of pass 2 (>= k + the few extras below tau): 32 for k <= 24 keeps the
 // kernel at 4 waves/SIMD (LDS 34 KB/block, <= 128 VGPRs), 48 serves k <= 32 at 3 waves/SIMD.
 // QN_KNN_BLOCK: threads per block of the selection kernel (one wave serves 16 queries; smaller blocks refill the CUs at a
