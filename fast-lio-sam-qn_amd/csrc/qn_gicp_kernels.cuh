@@ -221,7 +221,7 @@ __device__ __forceinline__ void store_nn(unsigned long long key, uint32_t i, uin
 // In the LIST launch the last `big_blocks` blocks serve big_list instead, one query per wave (wave_search_single).
 // BLOCK = threads per block: the grid passes run one wave per block (finer refill of the CUs), the list passes four.
 template <int MODE, bool LIST, int BLOCK>
-__global__ void __launch_bounds__(BLOCK) k_nn_search(GridView src, GridView tgt, const GicpState* __restrict__ st, double thr2, float r0, int max_rounds,
+__global__ void __launch_bounds__(BLOCK, 6) k_nn_search(GridView src, GridView tgt, const GicpState* __restrict__ st, double thr2, float r0, int max_rounds,
                                                         int32_t* __restrict__ corr, float* __restrict__ sqd, int32_t* __restrict__ nn_idx, float4* __restrict__ nn_ref,
                                                         uint2* __restrict__ fb_list, uint32_t* __restrict__ fb_count,
                                                         uint2* __restrict__ big_list, uint32_t* __restrict__ big_count, int big_blocks, float big_ratio) {
@@ -392,7 +392,7 @@ static __global__ void __launch_bounds__(QN_BLOCK) k_accumulate(const float4* __
 // partial sums - no list pass and no separate accumulate kernel in that tick.
 #define QN_TRACK_SEG 8
 template <int MODE, bool FUSED>
-__global__ void __launch_bounds__(QN_BLOCK) k_nn_track(GridView src, GridView tgt, const float4* __restrict__ tgt_raw, const GicpState* __restrict__ st,
+__global__ void __launch_bounds__(QN_BLOCK, 6) k_nn_track(GridView src, GridView tgt, const float4* __restrict__ tgt_raw, const GicpState* __restrict__ st,
                                                        double thr2, int32_t* __restrict__ corr, float* __restrict__ sqd, int32_t* __restrict__ nn_idx,
                                                        float4* __restrict__ nn_ref, uint2* __restrict__ fb_list, uint32_t* __restrict__ fb_count,
                                                        uint2* __restrict__ big_list, uint32_t* __restrict__ big_count,
