@@ -394,6 +394,7 @@ extern "C" int qn_gicp_align(qn_ctx* c, const float guess[16], qn_gicp_result* o
     HIPCHK(c, hipStreamSynchronize(s));
     budget -= chunk;
     if (c->result_host->phase == 2) break;
+    if (p.force_iterations <= 0) chunk = std::max(2 * per_outer, c->ticks_per_chunk / 2);   // convergence is usually near after the first chunk: ticks past it are ~8 wasted launches each
     if (budget <= 0) { c->last_error = "align: device state machine did not terminate"; return QN_ERR_HIP; }
   }
   c->prof_collect();
