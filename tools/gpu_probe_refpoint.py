@@ -8,6 +8,8 @@ from qn_amd import engine, synth
 for N in (10000, 30000, 100000):
     src, tgt, T = synth.make_pair(5, N)
     ctx = engine.Context(N + 1024)
+    import json
+    for kk, vv in json.loads(os.environ.get("QN_DEBUG_KNOBS", "{}")).items(): ctx.debug_set(kk, float(vv))
     for _ in range(3): r = engine.icp_alignment(ctx, src, tgt)
     t = time.perf_counter()
     for _ in range(20): r = engine.icp_alignment(ctx, src, tgt)
