@@ -198,7 +198,18 @@ extern "C" int qn_kf_assemble(qn_kf_store* s, const int32_t* ids, const double* 
     vd.minb[d] = (int)std::floor(mn * vd.inv); const int maxb = (int)std::floor(mx * vd.inv);
     divb[d] = maxb - vd.minb[d] + 1; cells *= divb[d];
   }
-  if (cells > (long long)INT32_MAX) { s->last_error = "leaf size too small for the cloud extent (PCL would warn and skip the filter)"; return QN_ERR_CAPACITY; }
+  {  // pcl::VoxelGrid::applyFilter's overflow guard in PCL's own arithmetic (f32 product, int64 cast): it warns and sets output = *input_
+    long long pd = 1;
+    for (int d = 0; d < 3; d++) { const float mn = qn::ord2f(s->bbox_host->mn[d]), mx = qn::ord2f(s->bbox_host->mx[d]); pd *= (long long)((mx - mn) * vd.inv) + 1; }
+    if (pd > (long long)INT32_MAX || cells > (long long)INT32_MAX) {
+      s->last_error = "warning: leaf size is too small for the input dataset, integer indices would overflow: cloud passed through unfiltered (as pcl::VoxelGrid does)";
+      if (n > s->out_cap[slot]) { (void)hipFree(s->out[slot]); s->out[slot] = nullptr; s->out_cap[slot] = 0; KFCHK(s, hipMalloc(&s->out[slot], sizeof(float4) * (n + n / 2))); s->out_cap[slot] = n + n / 2; }
+      KFCHK(s, hipMemcpyAsync(s->out[slot], s->concat, sizeof(float4) * n, hipMemcpyDeviceToDevice, st));
+      KFCHK(s, hipStreamSynchronize(st));
+      s->out_n[slot] = n; *d_xyz_out = (const float*)s->out[slot]; *n_out = n;
+      return QN_OK;
+    }
+  }
   vd.div0 = divb[0]; vd.div01 = divb[0] * divb[1];
   const uint32_t nb = (n + 255) / 256;
   hipLaunchKernelGGL(qn::k_voxel_keys, dim3(nb), dim3(256), 0, st, s->concat, n, vd, s->keys);

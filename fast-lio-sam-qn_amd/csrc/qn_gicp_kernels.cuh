@@ -205,7 +205,7 @@ __device__ __forceinline__ void xform_query(const float Tf[12], float x, float y
 template <int MODE>
 __device__ __forceinline__ void store_nn(unsigned long long key, uint32_t i, uint32_t t, double thr2, int32_t* __restrict__ corr, float* __restrict__ sqd, int32_t* __restrict__ nn_idx) {
   const float d2 = key_d2(key);
-  if (MODE == 0 && key != QN_INF_KEY) nn_idx[t] = (int32_t)key_idx(key);        // ungated NN: next iteration's search seed (k_nn_track)
+  if (MODE == 0) nn_idx[t] = key != QN_INF_KEY ? (int32_t)key_idx(key) : -1;     // ungated NN: next iteration's search seed (k_nn_track); -1 = none (non-finite query): never a stale index
   if (MODE == 0) {
     const bool found = key != QN_INF_KEY;
     sqd[i] = found ? d2 : 0.f;
@@ -391,6 +391,18 @@ static __global__ void __launch_bounds__(QN_BLOCK) k_accumulate(const float4* __
 // time by the whole wave (wave_search_single), and every lane adds its correspondence's contribution to the block's 28
 // partial sums - no list pass and no separate accumulate kernel in that tick.
 #define QN_TRACK_SEG 8
+// The pruning inequality  d(q, p_j0) + |q - q_ref| < d_other  evaluated in f32 with a margin that dominates every rounding
+// error involved.  Exact quantities: D0 = |q - p_j0|, DELTA = |q - q_ref|, B = the stored bound.  Computed: d0 (3 subtractions,
+// 3 products, 2 sums: relative error <= 3.5 u with u = 2^-24 - the subtractions of f32 coordinates are exact to 1 ulp of the
+// DIFFERENCE), its sqrtf (<= 0.5 u more after halving), the same for delta, one f32 sum (1 u).  So
+// sqrt(d0) + delta >= (D0 + DELTA) (1 - 4 u) and the stored bound B was itself rounded DOWN from a quantity with the same
+// error budget (<= 4 u); a factor 1 + 2^-18 (= 1 + 64 u) on the left covers both with a 8x reserve.  The bound B is a lower
+// bound on the distance from q_ref to every OTHER target point in exact arithmetic up to those 4 u, so the triangle
+// inequality gives  |q - p| >= B - DELTA > D0  for every other p: j0 stays the unique nearest neighbour, ties included
+// (strict inequality).  tests/test_gpu_adversarial.py exercises it on lattices and at +8 km offsets against a fresh search.
+__device__ __forceinline__ bool track_bound_holds(float d0, float delta, float bound) {
+  return (sqrtf(d0) + delta) * 1.000004f < bound;
+}
 template <int MODE, bool FUSED>
 __global__ void __launch_bounds__(QN_BLOCK, 6) k_nn_track(GridView src, GridView tgt, const float4* __restrict__ tgt_raw, const GicpState* __restrict__ st,
                                                        double thr2, int32_t* __restrict__ corr, float* __restrict__ sqd, int32_t* __restrict__ nn_idx,
@@ -415,14 +427,20 @@ __global__ void __launch_bounds__(QN_BLOCK, 6) k_nn_track(GridView src, GridView
   unsigned long long best = QN_INF_KEY; float second = INF, d_unseen = INF;
   bool rescanned = false, big = false;
   float r = 0.f, delta = 0.f;
-  if (valid) {
-    const int32_t j0 = nn_idx[t];
+  bool noseed = false;                                              // no usable seed (nn_idx = -1 after a non-finite pose, or an index from another target): unseeded search
+  const bool finite_q = (qx - qx == 0.f) && (qy - qy == 0.f) && (qz - qz == 0.f);   // a non-finite query has no neighbour: corr = -1, like the first search
+  if (valid && finite_q) {
+    const uint32_t j0 = (uint32_t)nn_idx[t];
+    if (j0 >= tgt.n) { noseed = true; big = true; r = tgt.cell; }
+  }
+  if (valid && finite_q && !noseed) {
+    const uint32_t j0 = (uint32_t)nn_idx[t];
     const float4 ref = nn_ref[t];
     const float4 p0 = FUSED ? tgt_rec[j0].p : tgt_raw[j0];          // FUSED: point and covariance of a target point share one 64-byte line
     const float d0 = sqdist(qx, qy, qz, p0.x, p0.y, p0.z);
-    best = pack_key(d0, (uint32_t)j0);
+    best = pack_key(d0, j0);
     delta = sqrtf(sqdist(qx, qy, qz, ref.x, ref.y, ref.z));
-    if ((sqrtf(d0) + delta) * 1.000004f < ref.w) {                  // proven: j0 is still the unique NN (the factor covers f32 rounding)
+    if (track_bound_holds(d0, delta, ref.w)) {                      // proven: j0 is still the unique NN
       if (tgt.dbg && (threadIdx.x & 63) == 0) atomicAdd(&tgt.dbg[6], (uint32_t)__popcll(__ballot(1)));
     } else {
       r = sqrtf(d0) * 1.000001f + tgt.eps;
@@ -471,7 +489,7 @@ __global__ void __launch_bounds__(QN_BLOCK, 6) k_nn_track(GridView src, GridView
     // list passes, seeded with the bound.  tight seed (the query barely moved since it was scanned) AND far neighbour: one query per wave
     const bool tight_far = r > 2.5f * tgt.cell && delta < 0.25f * r;
     wave_append(big_list, big_count, big && tight_far, make_uint2(t, __float_as_uint(r)));
-    wave_append(fb_list, fb_count, big && !tight_far, make_uint2(t, __float_as_uint(r)));    // r is NaN for a non-finite query: resolved at once
+    wave_append(fb_list, fb_count, big && !tight_far, make_uint2(t, __float_as_uint(noseed ? -r : r)));    // negative: unseeded, continue from |r|
     if (big) return;
   } else {       // resolve the wave's big-ball queries here, 16 at a time, cooperatively (neighbouring queries' balls overlap: one shared candidate stream)
     const int lane = threadIdx.x & 63;
@@ -493,7 +511,7 @@ __global__ void __launch_bounds__(QN_BLOCK, 6) k_nn_track(GridView src, GridView
   }
   if (valid) {
     if (!FUSED) store_nn<MODE>(best, i, t, thr2, corr, sqd, nn_idx);          // FUSED ticks feed the accumulation directly: corr / sqd are not needed
-    else if (best != QN_INF_KEY) nn_idx[t] = (int32_t)key_idx(best);
+    else nn_idx[t] = best != QN_INF_KEY ? (int32_t)key_idx(best) : -1;
     if (MODE == 0 && rescanned) nn_ref[t] = make_float4(qx, qy, qz, fminf(sqrtf(second), d_unseen));
   }
   if (FUSED) {

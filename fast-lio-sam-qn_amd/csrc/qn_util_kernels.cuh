@@ -48,7 +48,9 @@ static __global__ void __launch_bounds__(QN_BLOCK) k_bbox(const float4* __restri
 
 // exclusive scan of counts[0..m) -> out[0..m], out[m] = total.  3 kernels, 4096 items per block.
 #define QN_SCAN_ITEMS 16
-static __global__ void k_scan_block(const uint32_t* __restrict__ in, uint32_t m, uint32_t* __restrict__ out, uint32_t* __restrict__ block_sums) {
+// `in` and `out` may alias (the radix-sort histograms are scanned in place): no __restrict__ on them; every thread loads
+// its QN_SCAN_ITEMS inputs before it stores any output and blocks own disjoint ranges, so in-place is well defined.
+static __global__ void k_scan_block(const uint32_t* in, uint32_t m, uint32_t* out, uint32_t* __restrict__ block_sums) {
   __shared__ uint32_t wsum[QN_BLOCK / 64];
   const uint32_t base = (blockIdx.x * QN_BLOCK + threadIdx.x) * QN_SCAN_ITEMS;
   uint32_t v[QN_SCAN_ITEMS], s = 0;

@@ -51,12 +51,12 @@ class NanoGICP {
     status_ = cloud->size() ? qn_gicp_set_source(ctx_, &cloud->points[0].x, (uint32_t)cloud->size(), (uint32_t)sizeof(PointSource)) : QN_ERR_EMPTY_CLOUD;
   }
   void setInputTarget(const PointCloudTargetConstPtr& cloud) {
-    target_ = cloud; has_result_ = false;
+    target_ = cloud; has_result_ = false; tgt_cov_done_ = false;
     if (!prepare(cloud ? cloud->size() : 0, true)) return;
     status_ = cloud->size() ? qn_gicp_set_target(ctx_, &cloud->points[0].x, (uint32_t)cloud->size(), (uint32_t)sizeof(PointTarget)) : QN_ERR_EMPTY_CLOUD;
   }
-  bool calculateSourceCovariances() { src_cov_done_ = ctx_ && push() && qn_gicp_compute_covariances(ctx_, QN_SOURCE) == QN_OK; return src_cov_done_; }
-  bool calculateTargetCovariances() { return ctx_ && push() && qn_gicp_compute_covariances(ctx_, QN_TARGET) == QN_OK; }
+  bool calculateSourceCovariances() { src_cov_done_ = ctx_ && push() && cov(QN_SOURCE); return src_cov_done_; }
+  bool calculateTargetCovariances() { tgt_cov_done_ = ctx_ && push() && cov(QN_TARGET); return tgt_cov_done_; }
 
   // ---- loop_closure.cpp:124: pcl::Registration::align(output) == align(output, Identity)
   void align(PointCloudSource& output) { align_impl(output, nullptr); }
@@ -88,18 +88,27 @@ class NanoGICP {
       if (ctx_) { qn_ctx_destroy(ctx_); ctx_ = nullptr; }
       capacity_ = n + n / 2 + 4096;
       if (source_ && source_->size() + 4096 > capacity_) capacity_ = source_->size() + 4096;
+      if (target_ && target_->size() + 4096 > capacity_) capacity_ = target_->size() + 4096;
       status_ = qn_ctx_create(0, (uint32_t)capacity_, &ctx_);
       if (status_ != QN_OK) { std::fprintf(stderr, "[nano_gicp shim] %s\n", qn_status_str(status_)); ctx_ = nullptr; capacity_ = 0; return false; }
       dirty_ = true;
       if (!push()) return false;
-      // the source (already set, maybe with covariances) lived in the old context: restore it
+      // the OTHER cloud (already set, maybe with covariances) lived in the old context: restore it, whichever order the
+      // caller uses (LoopClosure sets the source first, loop_closure.cpp:120-123; PCL code usually the target first)
       if (for_target && source_ && source_->size()) {
-        qn_gicp_set_source(ctx_, &source_->points[0].x, (uint32_t)source_->size(), (uint32_t)sizeof(PointSource));
-        if (src_cov_done_) qn_gicp_compute_covariances(ctx_, QN_SOURCE);
+        int rc = qn_gicp_set_source(ctx_, &source_->points[0].x, (uint32_t)source_->size(), (uint32_t)sizeof(PointSource));
+        if (rc == QN_OK && src_cov_done_) rc = qn_gicp_compute_covariances(ctx_, QN_SOURCE);
+        if (rc != QN_OK) { status_ = rc; src_cov_done_ = false; std::fprintf(stderr, "[nano_gicp shim] restoring the source after a regrow failed: %s\n", qn_status_str(rc)); return false; }
+      }
+      if (!for_target && target_ && target_->size()) {
+        int rc = qn_gicp_set_target(ctx_, &target_->points[0].x, (uint32_t)target_->size(), (uint32_t)sizeof(PointTarget));
+        if (rc == QN_OK && tgt_cov_done_) rc = qn_gicp_compute_covariances(ctx_, QN_TARGET);
+        if (rc != QN_OK) { status_ = rc; tgt_cov_done_ = false; std::fprintf(stderr, "[nano_gicp shim] restoring the target after a regrow failed: %s\n", qn_status_str(rc)); return false; }
       }
     }
     return push();
   }
+  bool cov(int which) { status_ = qn_gicp_compute_covariances(ctx_, which); return status_ == QN_OK; }
   bool push() { if (dirty_ && ctx_) { status_ = qn_gicp_set_params(ctx_, &params_); dirty_ = status_ != QN_OK; } return !dirty_; }
   void align_impl(PointCloudSource& output, const float* guess) {
     has_result_ = false;
@@ -108,14 +117,14 @@ class NanoGICP {
     if (status_ != QN_OK) return;
     has_result_ = true;
     output = *source_;                                               // keeps intensity etc.; xyz(+1) are overwritten below
-    if (output.size()) qn_gicp_transformed_source(ctx_, &output.points[0].x, (uint32_t)sizeof(PointSource));
+    if (output.size()) status_ = qn_gicp_transformed_source(ctx_, &output.points[0].x, (uint32_t)sizeof(PointSource));
   }
 
   qn_ctx* ctx_ = nullptr;
   size_t capacity_ = 0;
   qn_gicp_params params_;
   qn_gicp_result result_;
-  bool dirty_ = true, has_result_ = false, src_cov_done_ = false;
+  bool dirty_ = true, has_result_ = false, src_cov_done_ = false, tgt_cov_done_ = false;
   int status_ = QN_OK;
   PointCloudSourceConstPtr source_;
   PointCloudTargetConstPtr target_;

@@ -23,7 +23,7 @@ void orc_transform_pcd(const float* xyz, int n, const double* T, float* out) {
   }
 }
 
-// returns the number of output points (<= n); -1 when the leaf grid would overflow 2^31 cells (PCL warns and copies the input)
+// returns the number of output points (<= n); when the leaf grid would overflow 2^31 cells PCL warns and passes the input through unfiltered
 int orc_voxel_grid(const float* xyz, int n, float leaf, float* out) {
   if (n == 0) return 0;
   const float inv = 1.0f / leaf;
@@ -31,7 +31,12 @@ int orc_voxel_grid(const float* xyz, int n, float leaf, float* out) {
   for (int i = 0; i < n; i++) for (int d = 0; d < 3; d++) { mn[d] = std::min(mn[d], xyz[3 * i + d]); mx[d] = std::max(mx[d], xyz[3 * i + d]); }
   int minb[3], divb[3];
   for (int d = 0; d < 3; d++) { minb[d] = (int)std::floor(mn[d] * inv); const int maxb = (int)std::floor(mx[d] * inv); divb[d] = maxb - minb[d] + 1; }
-  if ((int64_t)divb[0] * divb[1] * divb[2] > (int64_t)INT32_MAX) return -1;
+  // pcl::VoxelGrid::applyFilter's overflow guard, in PCL's own arithmetic: dx = int64((max - min) * inverse_leaf) + 1 per axis (f32
+  // product), "Leaf size is too small for the input dataset. Integer indices would overflow." -> output = *input_ (unfiltered).
+  {
+    const int64_t dx = (int64_t)((mx[0] - mn[0]) * inv) + 1, dy = (int64_t)((mx[1] - mn[1]) * inv) + 1, dz = (int64_t)((mx[2] - mn[2]) * inv) + 1;
+    if (dx * dy * dz > (int64_t)INT32_MAX) { std::memcpy(out, xyz, sizeof(float) * 3 * (size_t)n); return n; }
+  }
   std::vector<uint64_t> key(n);
   for (int i = 0; i < n; i++) {
     const int i0 = (int)(std::floor(xyz[3 * i] * inv) - (float)minb[0]);

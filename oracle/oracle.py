@@ -227,8 +227,6 @@ def transform_pcd(xyz, T):
 def voxel_grid(xyz, leaf):
     xyz = _f32(xyz); out = np.zeros_like(xyz)
     m = lib().orc_voxel_grid(_p(xyz), C.c_int(len(xyz)), C.c_float(leaf), _p(out))
-    if m < 0:
-        raise OverflowError("leaf grid exceeds 2^31 cells")
     return out[:m].copy()
 
 

@@ -305,6 +305,8 @@ void solve(const float* src, const float* dst, const std::vector<std::pair<int, 
   std::vector<std::array<double, 3>> A(m), B(m);
   for (int i = 0; i < m; i++) { const int root = C[i], leaf = C[(i + 1) % m]; for (int d = 0; d < 3; d++) { A[i][d] = S[leaf][d] - S[root][d]; B[i][d] = D[leaf][d] - D[root][d]; } }
   // Quatro rotation: GNC-TLS restricted to yaw
+  // TEASER++ RobustRegistrationSolver::solve(): "params.noise_bound *= (2 / solution_.scale)" on the rotation solver's params
+  // before solveForRotation (TIMs are differences of two bounded measurements), which then uses pow(params_.noise_bound, 2).
   double nb2 = (2.0 * p.noise_bound) * (2.0 * p.noise_bound); if (nb2 < 1e-16) nb2 = 1e-2;
   std::vector<double> wgt(m, 1.0), res(m);
   double mu = 1.0, prev_cost = std::numeric_limits<double>::infinity(), c = 1.0, s = 0.0;

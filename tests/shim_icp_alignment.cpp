@@ -1,6 +1,6 @@
 // LoopClosure::icpAlignment (fast_lio_sam_qn/src/loop_closure.cpp:110-136) written against the drop-in
 // shim exactly as the reference writes it against nano_gicp - proves the shim's surface is sufficient.
-// usage: shim_icp_alignment src.bin dst.bin   (raw float32 xyz triplets) -> prints valid converged score T(16)
+// usage: shim_icp_alignment src.bin dst.bin [t]  (raw float32 xyz triplets; t = set the target first) -> prints valid converged score T(16)
 #include <cstdio>
 #include <vector>
 #include <limits>
@@ -42,10 +42,17 @@ int main(int argc, char** argv) {
   pcl::PointCloud<PointType>::Ptr dst_cloud(new pcl::PointCloud<PointType>());
   *src_cloud = src;
   *dst_cloud = dst;
+  if (argc > 3 && argv[3][0] == 't') {   // the usual PCL order (target first); with a larger source this regrows the shim's context AFTER the target was set
+    nano_gicp_.setInputTarget(dst_cloud);
+    nano_gicp_.calculateTargetCovariances();
+    nano_gicp_.setInputSource(src_cloud);
+    nano_gicp_.calculateSourceCovariances();
+  } else {
   nano_gicp_.setInputSource(src_cloud);
   nano_gicp_.calculateSourceCovariances();
   nano_gicp_.setInputTarget(dst_cloud);
   nano_gicp_.calculateTargetCovariances();
+  }
   nano_gicp_.align(aligned_);
   reg_output.score_ = nano_gicp_.getFitnessScore();
   if (nano_gicp_.hasConverged() && reg_output.score_ < 1.5) {

@@ -72,3 +72,24 @@ def test_shim_reproduces_icp_alignment(tmp_path, oracle):
     n_out, x0, inten = int(out[19]), float(out[20]), float(out[21])
     assert n_out == len(src) and inten == 42.0                     # output cloud: source fields kept, xyz transformed
     assert abs(x0 - ro["raw"]["Tf"][0] @ np.r_[src[0], 1.0]) < 1e-3
+
+
+@pytest.mark.gpu
+def test_shim_target_first_regrow(tmp_path, oracle):
+    """Target set first, then a source large enough to make the shim regrow its context: the target and its covariances
+    must survive (they were silently lost and align() read as hasConverged() == false)."""
+    from qn_amd import synth
+    if not os.path.exists(BIN):
+        build_shim_program()
+    src, tgt, T = synth.make_pair(71, 14000, extent=45.0)
+    tgt = np.ascontiguousarray(tgt[::4])
+    a, b = tmp_path / "src.bin", tmp_path / "dst.bin"
+    src.tofile(a); tgt.tofile(b)
+    out = subprocess.check_output([BIN, str(a), str(b), "t"]).decode().split()
+    valid, conv, score = int(out[0]), int(out[1]), float(out[2])
+    Tm = np.array([float(x) for x in out[3:19]]).reshape(4, 4)
+    ro = oracle.icp_alignment(src, tgt)
+    assert bool(conv) == ro["converged"] and bool(valid) == ro["valid"]
+    assert abs(score - ro["score"]) <= 1e-6 * ro["score"]
+    dt, dr = synth.pose_error(Tm, ro["T"])
+    assert dt <= 1e-4 and dr <= 1e-4
