@@ -41,7 +41,8 @@ struct qn_ctx {
   qn_quatro_params qparams{}; bool qparams_set = false, q_ready = false;
   float4* q_normals[2] = {nullptr, nullptr}; float* q_spfh[2] = {nullptr, nullptr}; float* q_fpfh_s[2] = {nullptr, nullptr}; float* q_fpfh[2] = {nullptr, nullptr};
   unsigned long long* q_key[2] = {nullptr, nullptr};
-  uint32_t* q_hit = nullptr; uint32_t* q_list = nullptr; uint2* q_pairs = nullptr; uint32_t* q_counts = nullptr; double* q_T = nullptr;
+  uint32_t* q_hit = nullptr; uint32_t* q_list = nullptr; uint32_t* q_sel = nullptr; uint2* q_pairs = nullptr; uint32_t* q_counts = nullptr; double* q_T = nullptr;
+  float* q_mean = nullptr; double* q_mean_psum = nullptr; void* q_host = nullptr;   // Matcher tail: cloud means, pinned hand-over block (header + one record per selected correspondence)
   // tuning knobs
   double cell_override = 0.0;
   float big_ratio = 2.5f;               // first-search leftovers whose next radius exceeds big_ratio * r0 go one-per-wave
@@ -54,6 +55,8 @@ struct qn_ctx {
   float margin_nn = 1.f, margin_knn = 2.f;   // first search radius in cells (1-NN of the first tick / k-NN of the covariances)
   int margin_nn_cap = 3, margin_knn_cap = 5, ticks_per_chunk = 8;
   uint32_t* dbg_counters = nullptr;
+  // verify_track (debug): scratch of the fresh search every tracked pass is compared with
+  bool verify_track = false; int32_t* v_corr = nullptr; int32_t* v_nn_idx = nullptr; float* v_sqd = nullptr; float4* v_nn_ref = nullptr; uint32_t* v_counters = nullptr;
   // profiling
   bool prof_on = false;
   std::vector<ProfSpan> spans;

@@ -135,8 +135,10 @@ extern "C" void qn_ctx_destroy(qn_ctx* c) {
   hipFree(c->staging); hipFree(c->scan_sums); hipFree(c->bbox); hipFree(c->state); hipFree(c->partials); hipFree(c->trace);
   hipFree(c->nn_idx); hipFree(c->knn_idx); hipFree(c->nn_ref); hipFree(c->cov_s_sorted); hipFree(c->tgt_rec); hipFree(c->fit_psum); hipFree(c->fit_pcnt); hipFree(c->corr); hipFree(c->sqd); hipFree(c->sqd_fit); hipFree(c->fb_list); hipFree(c->big_list); hipFree(c->fb_count2); hipFree(c->aligned);
   for (int w = 0; w < 2; w++) { hipFree(c->q_normals[w]); hipFree(c->q_spfh[w]); hipFree(c->q_fpfh_s[w]); hipFree(c->q_fpfh[w]); hipFree(c->q_key[w]); }
-  hipFree(c->q_hit); hipFree(c->q_list); hipFree(c->q_pairs); hipFree(c->q_counts); hipFree(c->q_T);
+  hipFree(c->q_hit); hipFree(c->q_list); hipFree(c->q_sel); hipFree(c->q_pairs); hipFree(c->q_counts); hipFree(c->q_T); hipFree(c->q_mean); hipFree(c->q_mean_psum);
+  if (c->q_host) hipHostFree(c->q_host);
   hipFree(c->pose_tmp); hipFree(c->guess_tmp); hipFree(c->dbg_knn_idx); hipFree(c->dbg_knn_d2); hipFree(c->dbg_counters);
+  hipFree(c->v_corr); hipFree(c->v_nn_idx); hipFree(c->v_sqd); hipFree(c->v_nn_ref); hipFree(c->v_counters);
   if (c->result_host) hipHostFree(c->result_host);
   if (c->bbox_host) hipHostFree(c->bbox_host);
   if (c->scalar_host) hipHostFree(c->scalar_host);
@@ -327,6 +329,21 @@ static void enqueue_nn(qn_ctx* c, int mode /*0 align, 1 fitness*/, float* sqd_ou
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_nn_search<1, true, QN_BLOCK>), dim3(fbb + big_blocks), dim3(QN_BLOCK), 0, s, S.grid, T.grid, c->state, thr2, r0, 64, c->corr, sqd_out, c->nn_idx, c->nn_ref, c->fb_list, fbc, c->big_list, bgc, big_blocks, c->big_ratio);
   }
 }
+// debug knob "verify_track": a fresh, unseeded search of the current pose into scratch buffers, compared query by query with what
+// the tracked / bound-pruned pass just produced (tests/test_gpu_adversarial.py)
+static void enqueue_verify(qn_ctx* c, bool fused) {
+  hipStream_t s = c->stream;
+  CloudBuf &S = c->cloud[0], &T = c->cloud[1];
+  const uint32_t nb = (S.n + QN_NN_BLOCK / 4 - 1) / (QN_NN_BLOCK / 4), nb4 = (S.n + QN_BLOCK / 4 - 1) / (QN_BLOCK / 4);
+  const double thr2 = c->params.max_corr_dist * c->params.max_corr_dist;
+  uint32_t* fbc = &c->state->fb_count; uint32_t* bgc = &c->state->big_count;
+  const float r0 = c->margin_nn * T.grid.cell;
+  hipLaunchKernelGGL(k_reset_lists, dim3(1), dim3(64), 0, s, c->state);
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_nn_search<0, false, QN_NN_BLOCK>), dim3(nb), dim3(QN_NN_BLOCK), 0, s, S.grid, T.grid, c->state, thr2, r0, c->nn_rounds, c->v_corr, c->v_sqd, c->v_nn_idx, c->v_nn_ref, c->fb_list, fbc, c->big_list, bgc, 0, c->big_ratio);
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_nn_search<0, true, QN_BLOCK>), dim3(std::min<uint32_t>(nb4, 512) + 4096), dim3(QN_BLOCK), 0, s, S.grid, T.grid, c->state, thr2, r0, 64, c->v_corr, c->v_sqd, c->v_nn_idx, c->v_nn_ref, c->fb_list, fbc, c->big_list, bgc, 4096, c->big_ratio);
+  hipLaunchKernelGGL(k_verify_nn, dim3((S.n + 255) / 256), dim3(256), 0, s, S.n, c->state, c->nn_idx, c->v_nn_idx, fused ? (const float*)nullptr : c->sqd, c->v_sqd, c->corr, c->v_corr, c->v_counters);
+  hipLaunchKernelGGL(k_reset_lists, dim3(1), dim3(64), 0, s, c->state);
+}
 static uint32_t acc_blocks(const qn_ctx* c) { return std::min<uint32_t>((c->cloud[0].n + QN_BLOCK - 1) / QN_BLOCK, QN_ACC_MAX_BLOCKS); }
 static void enqueue_accumulate(qn_ctx* c) {
   ProfScope ps(c, QN_K_ACCUMULATE);
@@ -347,12 +364,15 @@ static void enqueue_tick_fused(qn_ctx* c) {
   { ProfScope ps(c, QN_K_GN_TICK_FUSED);        // tracking NN + in-kernel leftovers + accumulation in one kernel (an in-kernel last-block solver was measured slower than k_solve: DESIGN.md section 4)
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_nn_track<0, true>), dim3(nbt), dim3(QN_BLOCK), 0, s, S.grid, T.grid, T.raw, c->state, thr2, c->corr, c->sqd, c->nn_idx, c->nn_ref,
                        c->fb_list, &c->state->fb_count, c->big_list, &c->state->big_count, c->cov_s_sorted, c->tgt_rec, c->partials); }
+  if (c->verify_track) enqueue_verify(c, true);
   enqueue_solve(c, 0);
 }
 static void enqueue_tick(qn_ctx* c, bool seeded, int tick) {
   if (tick < c->track_from_tick) seeded = false;
   if (seeded && tick >= c->fused_from_tick && c->fused_ticks && c->params.optimizer == QN_OPT_GN && acc_blocks(c) == (c->cloud[0].n + QN_BLOCK - 1) / QN_BLOCK) { enqueue_tick_fused(c); return; }
-  enqueue_nn(c, 0, c->sqd, seeded, tick); enqueue_accumulate(c); enqueue_solve(c, 0);
+  enqueue_nn(c, 0, c->sqd, seeded, tick);
+  if (c->verify_track && seeded) enqueue_verify(c, false);
+  enqueue_accumulate(c); enqueue_solve(c, 0);
 }
 static void enqueue_epilogue(qn_ctx* c, double max_range, bool seeded) {       // fitness + output cloud; each kernel is a no-op until phase == done
   enqueue_nn(c, 1, c->sqd_fit, seeded, 1);
@@ -440,7 +460,8 @@ extern "C" int qn_gicp_get_trace(qn_ctx* c, qn_iter_trace* out, uint32_t cap, ui
 }
 
 // LoopClosure::icpAlignment (loop_closure.cpp:110-136).  where: 0 = both clouds on the host, 1 = both on the device,
-// 2 = source on the device as packed float4 (the coarse-aligned cloud of coarseToFineAlignment), target on the host.
+// 2 = source on the device as packed float4 (the coarse-aligned cloud of coarseToFineAlignment), target on the host,
+// 3 = like 2 with the target on the device too.
 static int icp_alignment(qn_ctx* c, const float* src, uint32_t ns, const float* dst, uint32_t nt, uint32_t stride, double thr,
                          qn_gicp_result* out, int* valid, int where) {
   if (!c || !out || !valid) return QN_ERR_INVALID_ARG;
@@ -448,9 +469,9 @@ static int icp_alignment(qn_ctx* c, const float* src, uint32_t ns, const float* 
   memset(out, 0, sizeof(*out)); out->fitness = DBL_MAX;
   for (int i = 0; i < 4; i++) { out->T[5 * i] = 1.f; out->T64[5 * i] = 1.0; }
   int rc;
-  if ((rc = set_cloud(c, QN_SOURCE, src, ns, where == 2 ? 16 : stride, where != 0)) != QN_OK) return rc;   // :120
+  if ((rc = set_cloud(c, QN_SOURCE, src, ns, where >= 2 ? 16 : stride, where != 0)) != QN_OK) return rc;   // :120
   if ((rc = qn_gicp_compute_covariances(c, QN_SOURCE)) != QN_OK) return rc;         // :121
-  if ((rc = set_cloud(c, QN_TARGET, dst, nt, stride, where == 1)) != QN_OK) return rc;     // :122
+  if ((rc = set_cloud(c, QN_TARGET, dst, nt, stride, where == 1 || where == 3)) != QN_OK) return rc;     // :122
   if ((rc = qn_gicp_compute_covariances(c, QN_TARGET)) != QN_OK) return rc;         // :123
   if ((rc = qn_gicp_align(c, nullptr, out)) != QN_OK) return rc;                    // :124, :127
   *valid = (out->converged && out->fitness < thr) ? 1 : 0;                          // :129
@@ -586,6 +607,15 @@ extern "C" int qn_debug_set(qn_ctx* c, const char* key, double v) {
     for (int w = 0; w < 2; w++) c->cloud[w].grid.dbg = c->dbg_counters;
   }
   else if (k == "ticks_per_chunk") c->ticks_per_chunk = std::max(1, (int)v);
+  else if (k == "verify_track") {
+    if (v != 0 && !c->v_counters) {
+      const size_t n = c->max_points;
+      if (hipMalloc(&c->v_corr, 4 * n) != hipSuccess || hipMalloc(&c->v_nn_idx, 4 * n) != hipSuccess || hipMalloc(&c->v_sqd, 4 * n) != hipSuccess ||
+          hipMalloc(&c->v_nn_ref, 16 * n) != hipSuccess || hipMalloc(&c->v_counters, 16) != hipSuccess) return QN_ERR_HIP;
+    }
+    if (c->v_counters) (void)hipMemset(c->v_counters, 0, 16);
+    c->verify_track = v != 0;
+  }
   else return QN_ERR_INVALID_ARG;
   return QN_OK;
 }
@@ -594,6 +624,18 @@ extern "C" int qn_debug_get_counters(qn_ctx* c, uint32_t out[16]) {
   if (hipStreamSynchronize(c->stream) != hipSuccess) return QN_ERR_HIP;
   if (hipMemcpy(out, c->dbg_counters, 16 * sizeof(uint32_t), hipMemcpyDeviceToHost) != hipSuccess) return QN_ERR_HIP;
   return QN_OK;
+}
+extern "C" int qn_debug_get(qn_ctx* c, const char* key, double* value) {
+  if (!c || !key || !value) return QN_ERR_INVALID_ARG;
+  const std::string k(key);
+  if (k == "verify_mismatches" || k == "verify_passes" || k == "verify_first") {
+    if (!c->v_counters) return QN_ERR_NOT_READY;
+    uint32_t h[4];
+    if (hipStreamSynchronize(c->stream) != hipSuccess || hipMemcpy(h, c->v_counters, 16, hipMemcpyDeviceToHost) != hipSuccess) return QN_ERR_HIP;
+    *value = k == "verify_mismatches" ? h[0] : (k == "verify_passes" ? h[1] : h[2]);
+    return QN_OK;
+  }
+  return QN_ERR_INVALID_ARG;
 }
 extern "C" int qn_debug_get_grid(qn_ctx* c, int which, double out[8]) {
   if (!c || (which != 0 && which != 1) || !c->cloud[which].has_grid) return QN_ERR_INVALID_ARG;

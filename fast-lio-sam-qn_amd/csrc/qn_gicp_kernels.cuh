@@ -531,6 +531,22 @@ __global__ void __launch_bounds__(QN_BLOCK, 6) k_nn_track(GridView src, GridView
   }
 }
 
+// ------------------------------------------------------------------ verification of the tracked passes (debug knob "verify_track")
+// After a tracked / bound-pruned NN pass, a FRESH unseeded search of the same pose runs into scratch buffers and every query is
+// compared: nn_idx (ungated NN per cell-sorted position) and, where the pass wrote them, the f32 squared distances bit for bit.
+static __global__ void k_reset_lists(GicpState* st) { if (threadIdx.x == 0 && blockIdx.x == 0) { st->fb_count = 0; st->big_count = 0; } }
+static __global__ void k_verify_nn(uint32_t n, const GicpState* __restrict__ st, const int32_t* __restrict__ nn_a, const int32_t* __restrict__ nn_b,
+                                   const float* __restrict__ sqd_a, const float* __restrict__ sqd_b, const int32_t* __restrict__ corr_a, const int32_t* __restrict__ corr_b,
+                                   uint32_t* __restrict__ counters /* [0] mismatching queries, [1] verified passes, [2] first mismatching position + 1 */) {
+  if (st->phase != 0) return;
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t == 0) atomicAdd(&counters[1], 1u);
+  if (t >= n) return;
+  bool bad = nn_a[t] != nn_b[t];
+  if (sqd_a) bad = bad || __float_as_uint(sqd_a[t]) != __float_as_uint(sqd_b[t]) || corr_a[t] != corr_b[t];   // these two are indexed by original point: any bijection of [0, n) will do
+  if (bad) { atomicAdd(&counters[0], 1u); atomicCAS(&counters[2], 0u, t + 1u); }
+}
+
 // ------------------------------------------------------------------ K6 solver / LM-GN controller
 __device__ inline void d_so3_exp(const double om[3], double R[3][3]) {
   double theta_sq = om[0] * om[0] + om[1] * om[1] + om[2] * om[2];

@@ -220,16 +220,139 @@ static __global__ void k_compact_hits(const uint32_t* __restrict__ hit, uint32_t
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < ni && hit[i]) list[atomicAdd(count, 1u)] = i;
 }
-// cross-check: keep (i, j) when i's own nearest neighbour is j
-static __global__ void k_mutual(const unsigned long long* __restrict__ j_key, uint32_t nj, const unsigned long long* __restrict__ i_key,
-                         uint2* __restrict__ pairs, uint32_t* __restrict__ count) {
+// ------------------------------------------------------------------ K13: the Matcher tail on the device
+// (cross-check, distance gate, seeded tuple test, cap - Matcher::optimizedMatching / advancedMatching).
+// Everything that is O(N) or O(ncorr x 100) stays on the GPU; what crosses PCIe at the end is one record per SELECTED
+// correspondence (<= ~203 x 32 bytes with the reference's cap).
+
+// normalizePoints (absolute scale): each cloud's own mean, f64 sums in a fixed tree, rounded to f32
+#define QN_MEAN_BLOCKS 64
+static __global__ void __launch_bounds__(QN_BLOCK) k_mean_partial(const float4* __restrict__ pts, uint32_t n, double* __restrict__ psum) {
+  __shared__ double sh[QN_BLOCK / 64][3];
+  double s[3] = {0, 0, 0};
+  for (uint32_t i = blockIdx.x * QN_BLOCK + threadIdx.x; i < n; i += QN_MEAN_BLOCKS * QN_BLOCK) { const float4 p = pts[i]; s[0] += (double)p.x; s[1] += (double)p.y; s[2] += (double)p.z; }
+#pragma unroll
+  for (int d = 0; d < 3; d++) s[d] = wave_sum_f64_dpp(s[d]);
+  if ((threadIdx.x & 63) == 0) { for (int d = 0; d < 3; d++) sh[threadIdx.x >> 6][d] = s[d]; }
+  __syncthreads();
+  if (threadIdx.x < 3) { double t = 0; for (int w = 0; w < QN_BLOCK / 64; w++) t += sh[w][threadIdx.x]; psum[blockIdx.x * 3 + threadIdx.x] = t; }
+}
+static __global__ void k_mean_final(const double* __restrict__ psum, uint32_t n, float* __restrict__ mean3) {
+  if (threadIdx.x >= 3 || blockIdx.x != 0) return;
+  double t = 0; for (int b = 0; b < QN_MEAN_BLOCKS; b++) t += psum[b * 3 + threadIdx.x];
+  mean3[threadIdx.x] = (float)(t / (double)n);
+}
+
+__device__ __forceinline__ float norm_dist(const float4 a, const float* __restrict__ ma, const float4 b, const float* __restrict__ mb) {
+  const float x = (a.x - ma[0]) - (b.x - mb[0]), y = (a.y - ma[1]) - (b.y - mb[1]), z = (a.z - ma[2]) - (b.z - mb[2]);
+  return sqrtf((x * x + y * y) + z * z);
+}
+
+// cross-check + distance gate: flag[j] = 1 and partner[j] = (i, j) when i's own nearest neighbour is j and (optimizedMatching only)
+// the mean-subtracted points are not further apart than thr.  One thread per j, so the compacted list is in ascending j.
+static __global__ void k_mutual_gate(const unsigned long long* __restrict__ j_key, uint32_t nj, const unsigned long long* __restrict__ i_key,
+                                     const float4* __restrict__ Pi, const float4* __restrict__ Pj, const float* __restrict__ mean_i, const float* __restrict__ mean_j,
+                                     float thr, int gate, uint32_t* __restrict__ flag, uint2* __restrict__ partner) {
   const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= nj) return;
   const unsigned long long kj = j_key[j];
-  if (kj == QN_INF_KEY) return;
-  const uint32_t i = (uint32_t)kj;
-  const unsigned long long ki = i_key[i];
-  if (ki != QN_INF_KEY && (uint32_t)ki == j) pairs[atomicAdd(count, 1u)] = make_uint2(i, j);
+  uint32_t f = 0, i = 0;
+  if (kj != QN_INF_KEY) {
+    i = (uint32_t)kj;
+    const unsigned long long ki = i_key[i];
+    f = (ki != QN_INF_KEY && (uint32_t)ki == j) ? 1u : 0u;
+    if (f && gate && norm_dist(Pi[i], mean_i, Pj[j], mean_j) > thr) f = 0;
+  }
+  flag[j] = f; partner[j] = make_uint2(i, j);
+}
+static __global__ void k_compact_cand(const uint32_t* __restrict__ flag, const uint32_t* __restrict__ pos, const uint2* __restrict__ partner, uint32_t nj, uint2* __restrict__ cand) {
+  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j < nj && flag[j]) cand[pos[j]] = partner[j];
+}
+
+// n steps of the LCG  s <- 1664525 s + 1013904223 (mod 2^32)  as one affine map (A, C): s_n = A s_0 + C
+__device__ __forceinline__ void lcg_jump(unsigned long long n, uint32_t& A, uint32_t& C) {
+  uint32_t am = 1u, ap = 0u, cm = 1664525u, cp = 1013904223u;
+  while (n) { if (n & 1ull) { am *= cm; ap = ap * cm + cp; } cp = (cm + 1u) * cp; cm *= cm; n >>= 1; }
+  A = am; C = ap;
+}
+
+// FGR tuple test with the seeded LCG (trial t consumes draws 3t+1 .. 3t+3 of the sequence, so every trial can be evaluated
+// independently after a jump-ahead): ONE block walks the ncorr * 100 trials 1024 at a time in trial order; accepted trials mark
+// their three correspondences in sel[].  optimizedMatching stops after the accepted trial that pushes 3 * accepted past the cap
+// (`if (corres_tuple.size() > num_max_corres) break`), advancedMatching runs every trial.
+#define QN_TUPLE_THREADS 1024
+static __global__ void __launch_bounds__(QN_TUPLE_THREADS) k_tuple_test(const uint2* __restrict__ cand, const uint32_t* __restrict__ ncand_p,
+                                                                        const float4* __restrict__ Pi, const float4* __restrict__ Pj, const float* __restrict__ mean_i, const float* __restrict__ mean_j,
+                                                                        float scale, uint32_t seed, int capped, int max_corres, uint32_t* __restrict__ sel) {
+  __shared__ uint32_t wcnt[QN_TUPLE_THREADS / 64];
+  __shared__ uint32_t total_sh;
+  const uint32_t ncorr = *ncand_p;
+  if (ncorr < 3) return;
+  const unsigned long long trials = (unsigned long long)ncorr * 100ull;
+  const uint32_t a_max = capped ? (uint32_t)(max_corres / 3 + 1) : 0xffffffffu;      // accepted trials until 3 a > cap
+  uint32_t A, C, As, Cs;
+  lcg_jump(3ull * threadIdx.x, A, C);
+  uint32_t s = A * seed + C;                                                            // state before this thread's first trial
+  lcg_jump(3ull * QN_TUPLE_THREADS, As, Cs);
+  uint32_t accepted = 0;
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  for (unsigned long long base = 0; base < trials; base += QN_TUPLE_THREADS) {
+    const bool live = base + threadIdx.x < trials;
+    uint32_t t = s, r[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) { t = t * 1664525u + 1013904223u; r[k] = (t >> 8) % ncorr; }
+    bool ok = false;
+    if (live) {
+      const uint2 c0 = cand[r[0]], c1 = cand[r[1]], c2 = cand[r[2]];
+      const float4 a0 = Pi[c0.x], a1 = Pi[c1.x], a2 = Pi[c2.x], b0 = Pj[c0.y], b1 = Pj[c1.y], b2 = Pj[c2.y];
+      const float li0 = norm_dist(a0, mean_i, a1, mean_i), li1 = norm_dist(a1, mean_i, a2, mean_i), li2 = norm_dist(a2, mean_i, a0, mean_i);
+      const float lj0 = norm_dist(b0, mean_j, b1, mean_j), lj1 = norm_dist(b1, mean_j, b2, mean_j), lj2 = norm_dist(b2, mean_j, b0, mean_j);
+      ok = (li0 * scale < lj0) && (lj0 < li0 / scale) && (li1 * scale < lj1) && (lj1 < li1 / scale) && (li2 * scale < lj2) && (lj2 < li2 / scale);
+    }
+    const unsigned long long m = __ballot(ok);
+    if (lane == 0) wcnt[wid] = (uint32_t)__popcll(m);
+    __syncthreads();
+    uint32_t before = accepted;
+    for (int w = 0; w < wid; w++) before += wcnt[w];
+    if (threadIdx.x == 0) { uint32_t tot = 0; for (int w = 0; w < QN_TUPLE_THREADS / 64; w++) tot += wcnt[w]; total_sh = tot; }
+    const uint32_t rank = before + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));      // position of this trial among the accepted ones, trial order
+    if (ok && rank < a_max) { sel[r[0]] = 1u; sel[r[1]] = 1u; sel[r[2]] = 1u; }
+    __syncthreads();
+    accepted += total_sh;
+    if (accepted >= a_max) break;
+    __syncthreads();
+    s = As * s + Cs;
+  }
+}
+
+// one 32-byte record per selected correspondence, written straight to pinned host memory in candidate (ascending j) order
+struct QuatroCorr { uint32_t i, j; float pi[3], pj[3]; };
+struct QuatroTailOut { uint32_t n_cand, n_sel, overflow, pad; };
+static __global__ void __launch_bounds__(QN_TUPLE_THREADS) k_collect_corres(const uint2* __restrict__ cand, const uint32_t* __restrict__ ncand_p, const uint32_t* __restrict__ sel,
+                                                                            const float4* __restrict__ Pi, const float4* __restrict__ Pj, uint32_t cap, QuatroTailOut* __restrict__ head, QuatroCorr* __restrict__ out) {
+  __shared__ uint32_t wcnt[QN_TUPLE_THREADS / 64];
+  const uint32_t n = *ncand_p;
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  uint32_t total = 0;
+  for (uint32_t base = 0; base < n; base += QN_TUPLE_THREADS) {
+    const uint32_t e = base + threadIdx.x;
+    const bool on = e < n && sel[e] != 0;
+    const unsigned long long m = __ballot(on);
+    if (lane == 0) wcnt[wid] = (uint32_t)__popcll(m);
+    __syncthreads();
+    uint32_t before = total, tot = 0;
+    for (int w = 0; w < QN_TUPLE_THREADS / 64; w++) { if (w < wid) before += wcnt[w]; tot += wcnt[w]; }
+    const uint32_t slot = before + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+    if (on && slot < cap) {
+      const uint2 c = cand[e]; const float4 a = Pi[c.x], b = Pj[c.y];
+      QuatroCorr rec; rec.i = c.x; rec.j = c.y; rec.pi[0] = a.x; rec.pi[1] = a.y; rec.pi[2] = a.z; rec.pj[0] = b.x; rec.pj[1] = b.y; rec.pj[2] = b.z;
+      out[slot] = rec;
+    }
+    total += tot;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { head->n_cand = n; head->n_sel = total < cap ? total : cap; head->overflow = total > cap ? 1u : 0u; head->pad = 0; }
 }
 
 // transformPcd(src, T_q): pcl::transformPointCloud with a Matrix4d on f32 points (utilities.hpp:164-175,

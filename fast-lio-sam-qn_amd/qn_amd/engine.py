@@ -11,7 +11,7 @@ QN_OK, QN_ERR_INVALID_ARG, QN_ERR_EMPTY_CLOUD, QN_ERR_CAPACITY, QN_ERR_NOT_READY
 QN_SOURCE, QN_TARGET = 0, 1
 FLOAT_MAX = 3.4028234663852886e38
 KERNEL_FAMILIES = ["grid_build", "knn_cov", "nn_search", "nn_fallback", "accumulate", "solve", "fitness", "transform",
-                   "fpfh_normals", "fpfh_spfh", "fpfh_fpfh", "feat_match", "gn_tick_fused", "knn_select"]
+                   "fpfh_normals", "fpfh_spfh", "fpfh_fpfh", "feat_match", "gn_tick_fused", "knn_select", "match_tail"]
 
 
 class GicpParams(C.Structure):
@@ -100,6 +100,11 @@ class Context:
 
     def debug_set(self, key, value):
         self.check(self._l.qn_debug_set(self.h, key.encode(), C.c_double(value)))
+
+    def debug_get(self, key):
+        v = C.c_double()
+        self.check(self._l.qn_debug_get(self.h, key.encode(), C.byref(v)))
+        return v.value
 
     def grid_info(self, which):
         out = np.zeros(8)
@@ -354,6 +359,13 @@ class Quatro:
         return dict(T=T, valid=bool(valid.value), mutual=mutual[:nm.value].copy(), corres=corres[:nc.value].copy(),
                     clique=clique[:nq.value].copy(), rot_iterations=it.value)
 
+    def align_device(self, src_ptr, ns, dst_ptr, nt, stride):
+        """qn_quatro_align_device: both clouds are HIP device pointers (n points, `stride` bytes apart)."""
+        self._n = [ns, nt]
+        T = np.zeros((4, 4)); valid = C.c_int()
+        self.ctx.check(self._l.qn_quatro_align_device(self.ctx.h, C.c_void_p(src_ptr), C.c_uint32(ns), C.c_void_p(dst_ptr), C.c_uint32(nt), C.c_uint32(stride), _p(T), C.byref(valid)))
+        return T, bool(valid.value)
+
     def features(self, which):
         n = self._n[which]
         nrm = np.zeros((n, 3), np.float32); sp = np.zeros((n, 33), np.float32); fp = np.zeros((n, 33), np.float32)
@@ -386,6 +398,18 @@ def coarse_to_fine_alignment(ctx, src, dst, *, quatro=None, k=15, max_iter=32, m
     if st == QN_ERR_EMPTY_CLOUD:
         return dict(valid=False, converged=False, score=1.7976931348623157e308, T=np.eye(4), T_quatro=np.eye(4))
     ctx.check(st)
+    return dict(valid=bool(valid.value), converged=bool(res.converged), score=res.fitness, T=T, T_quatro=Tq, iterations=res.iterations)
+
+
+def coarse_to_fine_alignment_device(ctx, src_ptr, ns, dst_ptr, nt, stride, *, quatro=None, k=15, max_iter=32, max_corr_dist=52.5, trans_eps=0.01, score_thr=1.5):
+    """qn_coarse_to_fine_alignment_device: the same with both clouds resident on the GPU (e.g. KeyframeStore.assemble outputs)."""
+    quatro = quatro or Quatro(ctx)
+    g = NanoGICP(ctx)
+    g.setCorrespondenceRandomness(k); g.setMaximumIterations(max_iter)
+    g.setMaxCorrespondenceDistance(max_corr_dist); g.setTransformationEpsilon(trans_eps)
+    res = GicpResult(); valid = C.c_int(); T = np.zeros((4, 4)); Tq = np.zeros((4, 4))
+    ctx.check(ctx._l.qn_coarse_to_fine_alignment_device(ctx.h, C.c_void_p(src_ptr), C.c_uint32(ns), C.c_void_p(dst_ptr), C.c_uint32(nt), C.c_uint32(stride),
+                                                       C.c_double(score_thr), C.byref(res), _p(T), _p(Tq), C.byref(valid)))
     return dict(valid=bool(valid.value), converged=bool(res.converged), score=res.fitness, T=T, T_quatro=Tq, iterations=res.iterations)
 
 

@@ -86,6 +86,7 @@ enum {                     /* kernel families for qn_prof_get */
   QN_K_FPFH_NORMALS = 8, QN_K_FPFH_SPFH = 9, QN_K_FPFH_FPFH = 10, QN_K_FEAT_MATCH = 11,
   QN_K_GN_TICK_FUSED = 12,   /* fused Gauss-Newton tick: tracking NN + leftovers + accumulation in one kernel       */
   QN_K_KNN_SELECT = 13,      /* k-NN selection kernel alone (QN_K_KNN_COV then holds its list tail + covariances)  */
+  QN_K_MATCH_TAIL = 14,      /* Matcher tail on the device: means, cross-check + gate, tuple test, hand-over        */
   QN_K_COUNT = 16
 };
 
@@ -143,7 +144,7 @@ typedef struct {
   double  rot_cost_diff_thr;       /* :22 */
   int32_t rot_max_iter;            /* :23 */
   int32_t estimate_scale;          /* :24 (must be 0: the reference never enables it) */
-  int32_t use_optimized_matching;  /* :25 */
+  int32_t use_optimized_matching;  /* :25  1: Matcher::optimizedMatching (gate + cap), 0: Matcher::advancedMatching */
   double  distance_threshold;      /* :26 */
   int32_t max_num_corres;          /* :27 */
   uint32_t rng_seed;
@@ -154,9 +155,14 @@ void qn_quatro_default_params(qn_quatro_params* p);                  /* the refe
 int  qn_quatro_set_params(qn_ctx*, const qn_quatro_params*);         /* quatro<PointType> ctor, loop_closure.cpp:18-27 */
 /* quatro<PointType>::align(src, dst, is_converged), loop_closure.cpp:144: T = 4x4 f64 row-major, *valid = is_converged */
 int  qn_quatro_align(qn_ctx*, const float* src, uint32_t ns, const float* dst, uint32_t nt, uint32_t stride_bytes, double T[16], int* valid);
+int  qn_quatro_align_device(qn_ctx*, const float* d_src, uint32_t ns, const float* d_dst, uint32_t nt, uint32_t stride_bytes, double T[16], int* valid);
 /* LoopClosure::coarseToFineAlignment, loop_closure.cpp:138-159: Quatro, transformPcd, icpAlignment, T_gicp * T_quatro */
 int  qn_coarse_to_fine_alignment(qn_ctx*, const float* src, uint32_t ns, const float* dst, uint32_t nt, uint32_t stride_bytes, double score_thr,
                                  qn_gicp_result* gicp_out, double T_total[16], double T_quatro[16], int* valid);
+/* same with both clouds resident on the device (the output of qn_kf_assemble = setSrcAndDstCloud, loop_closure.cpp:177-192):
+ * only the selected correspondences (<= ~6 KB) and the result record cross PCIe                                            */
+int  qn_coarse_to_fine_alignment_device(qn_ctx*, const float* d_src, uint32_t ns, const float* d_dst, uint32_t nt, uint32_t stride_bytes, double score_thr,
+                                        qn_gicp_result* gicp_out, double T_total[16], double T_quatro[16], int* valid);
 /* The two stages upstream Quatro exposes on its own:
  *  qn_fpfh            = FPFH descriptors of one cloud (pcl::FPFHEstimationOMP with the context's radii): n x 33 f32, caller order
  *  qn_match_optimized = teaser::Matcher::optimizedMatching(thr_dist, num_max_corres, tuple_scale) on two clouds + their
@@ -207,6 +213,7 @@ int  qn_prof_get(qn_ctx*, int kernel_family, qn_kernel_stat* out);
 /* developer knobs (cell size, margins, debug counters); not part of the reference surface */
 int  qn_debug_set(qn_ctx*, const char* key, double value);
 int  qn_debug_get_counters(qn_ctx*, uint32_t out[16]);
+int  qn_debug_get(qn_ctx*, const char* key, double* value);   /* "verify_mismatches" / "verify_passes" / "verify_first" after qn_debug_set("verify_track", 1) */
 int  qn_debug_get_grid(qn_ctx*, int which, double out[8]);
 
 #ifdef __cplusplus

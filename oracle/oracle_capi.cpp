@@ -79,7 +79,7 @@ void orc_quatro_feature_nn(const float* q, int nq, const float* c, int nc, int* 
 // returns counts through n_out[0] (mutual), n_out[1] (corres); pair arrays sized min(ns, nt) x 2
 void orc_quatro_match(const float* src, int ns, const float* dst, int nt, const float* fs, const float* ft, const double* dp, const int* ip,
                       int* mutual, int* corres, int* n_out) {
-  std::vector<std::pair<int, int>> m, c; optimized_matching(src, ns, dst, nt, fs, ft, qp_from(dp, ip), m, c);
+  std::vector<std::pair<int, int>> m, c; calculate_correspondences(src, ns, dst, nt, fs, ft, qp_from(dp, ip), m, c);
   for (size_t i = 0; i < m.size(); i++) { mutual[2 * i] = m[i].first; mutual[2 * i + 1] = m[i].second; }
   for (size_t i = 0; i < c.size(); i++) { corres[2 * i] = c[i].first; corres[2 * i + 1] = c[i].second; }
   n_out[0] = (int)m.size(); n_out[1] = (int)c.size();

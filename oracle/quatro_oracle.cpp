@@ -178,8 +178,12 @@ void feature_nn(const float* q, int nq, const float* c, int nc, std::vector<int>
 
 static inline uint32_t lcg(uint32_t& s) { s = s * 1664525u + 1013904223u; return s >> 8; }
 
-void optimized_matching(const float* src, int ns, const float* dst, int nt, const float* fs, const float* ft,
-                        const QuatroParams& p, std::vector<std::pair<int, int>>& mutual, std::vector<std::pair<int, int>>& corres) {
+// optimized = Quatro's Matcher::optimizedMatching(thr_dist, num_max_corres, tuple_scale): distance gate + correspondence cap;
+// !optimized = TEASER++'s Matcher::advancedMatching (the use_optimized_matching_ == false branch, loop_closure.h:40,
+// loop_closure.cpp:25; README.md:21 quotes its cost): the same lazily cross-checked feature matches, no distance gate, and the
+// tuple test runs all ncorr * 100 trials (TEASER++'s matcher has no early exit; SURVEY A.2.3 marks the cap there "believed").
+static void match_impl(const float* src, int ns, const float* dst, int nt, const float* fs, const float* ft, const QuatroParams& p, bool optimized,
+                       std::vector<std::pair<int, int>>& mutual, std::vector<std::pair<int, int>>& corres) {
   mutual.clear(); corres.clear();
   const bool swapped = nt > ns;                          // fi = the larger cloud, fj = the smaller
   const float* Pi = swapped ? dst : src; const float* Pj = swapped ? src : dst;
@@ -205,7 +209,7 @@ void optimized_matching(const float* src, int ns, const float* dst, int nt, cons
     const int i = j_to_i[j];
     if (i < 0 || i_to_j[i] != j) continue;               // cross-check
     float a[3], b[3]; npt(Pi, mi, i, a); npt(Pj, mj, j, b);
-    if (dist(a, b) > (float)p.distance_threshold) continue;
+    if (optimized && dist(a, b) > (float)p.distance_threshold) continue;
     cand.emplace_back(i, j);
   }
   for (auto& c : cand) mutual.emplace_back(swapped ? c.second : c.first, swapped ? c.first : c.second);
@@ -226,11 +230,25 @@ void optimized_matching(const float* src, int ns, const float* dst, int nt, cons
     if ((li0 * scale < lj0) && (lj0 < li0 / scale) && (li1 * scale < lj1) && (lj1 < li1 / scale) && (li2 * scale < lj2) && (lj2 < li2 / scale)) {
       tup.push_back(cand[r0]); tup.push_back(cand[r1]); tup.push_back(cand[r2]);
     }
-    if ((int)tup.size() > p.max_num_corres) break;
+    if (optimized && (int)tup.size() > p.max_num_corres) break;
   }
   for (auto& c : tup) corres.emplace_back(swapped ? c.second : c.first, swapped ? c.first : c.second);
   std::sort(corres.begin(), corres.end());
   corres.erase(std::unique(corres.begin(), corres.end()), corres.end());
+}
+
+void optimized_matching(const float* src, int ns, const float* dst, int nt, const float* fs, const float* ft,
+                        const QuatroParams& p, std::vector<std::pair<int, int>>& mutual, std::vector<std::pair<int, int>>& corres) {
+  match_impl(src, ns, dst, nt, fs, ft, p, true, mutual, corres);
+}
+void advanced_matching(const float* src, int ns, const float* dst, int nt, const float* fs, const float* ft,
+                       const QuatroParams& p, std::vector<std::pair<int, int>>& mutual, std::vector<std::pair<int, int>>& corres) {
+  match_impl(src, ns, dst, nt, fs, ft, p, false, mutual, corres);
+}
+// Matcher::calculateCorrespondences: dispatch on use_optimized_matching
+void calculate_correspondences(const float* src, int ns, const float* dst, int nt, const float* fs, const float* ft,
+                               const QuatroParams& p, std::vector<std::pair<int, int>>& mutual, std::vector<std::pair<int, int>>& corres) {
+  match_impl(src, ns, dst, nt, fs, ft, p, p.use_optimized_matching, mutual, corres);
 }
 
 // ------------------------------------------------------------------ max clique (Bron-Kerbosch with pivot, all maximal cliques)
@@ -352,7 +370,7 @@ void quatro_align(const float* src, int ns, const float* dst, int nt, const Quat
   compute_fpfh(src, ns, p.fpfh_normal_radius, p.fpfh_radius, n1, s1, f1);
   compute_fpfh(dst, nt, p.fpfh_normal_radius, p.fpfh_radius, n2, s2, f2);
   std::vector<std::pair<int, int>> mutual;
-  optimized_matching(src, ns, dst, nt, f1.data(), f2.data(), p, mutual, out->corres);
+  calculate_correspondences(src, ns, dst, nt, f1.data(), f2.data(), p, mutual, out->corres);
   solve(src, dst, out->corres, p, out);
 }
 

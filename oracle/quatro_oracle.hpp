@@ -56,6 +56,12 @@ void feature_nn(const float* q, int nq, const float* c, int nc, std::vector<int>
 // mutual matches + distance gate (before the tuple test), then the seeded tuple test + cap, sorted unique
 void optimized_matching(const float* src, int ns, const float* dst, int nt, const float* fs, const float* ft,
                         const QuatroParams& p, std::vector<std::pair<int, int>>& mutual, std::vector<std::pair<int, int>>& corres);
+// TEASER++ Matcher::advancedMatching (use_optimized_matching == false): no distance gate, no cap
+void advanced_matching(const float* src, int ns, const float* dst, int nt, const float* fs, const float* ft,
+                       const QuatroParams& p, std::vector<std::pair<int, int>>& mutual, std::vector<std::pair<int, int>>& corres);
+// Matcher::calculateCorrespondences: one of the two, by p.use_optimized_matching
+void calculate_correspondences(const float* src, int ns, const float* dst, int nt, const float* fs, const float* ft,
+                               const QuatroParams& p, std::vector<std::pair<int, int>>& mutual, std::vector<std::pair<int, int>>& corres);
 // TEASER++ solve with Quatro rotation on matched points
 void solve(const float* src, const float* dst, const std::vector<std::pair<int, int>>& corres, const QuatroParams& p, QuatroResult* out);
 void quatro_align(const float* src, int ns, const float* dst, int nt, const QuatroParams& p, QuatroResult* out);

@@ -6,7 +6,11 @@ PROVENANCE (read this): the reference's own Nano-GICP / Quatro sources are un-ve
   * gicp_*.npz   - produced by oracle/py_oracle.py, the INDEPENDENT numpy/scipy restatement (cKDTree, numpy.linalg), never
                    by the C++ oracle or the HIP path that are checked against them;
   * cov_plane.npz, so3.npz - closed-form answers (C = I - 0.999 n n^T on an exact plane; Rodrigues), no code under test involved;
-  * voxel.npz    - pcl::VoxelGrid semantics on a hand-checkable cloud, produced by a 20-line pure-numpy restatement below.
+  * voxel.npz    - pcl::VoxelGrid semantics on a hand-checkable cloud, produced by a 20-line pure-numpy restatement below;
+  * quatro_*.npz - the Quatro coarse stage (FPFH, optimizedMatching / advancedMatching, TEASER++ solve with the yaw-only GNC)
+                   produced by oracle/py_quatro.py, the INDEPENDENT numpy/scipy restatement (cKDTree radius / 33-D searches,
+                   numpy.linalg.eigh / svd, libm arctan2) - different code and numerics from oracle/quatro_oracle.cpp and from
+                   the HIP kernels that are both checked against these files.
 Inputs are stored in the files (not regenerated), so the fixtures stay valid if the synthetic generator changes.
 
     python tests/golden/make_golden.py          # rewrites the .npz files next to this script
@@ -16,7 +20,7 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__)); ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "fast-lio-sam-qn_amd"))
 from qn_amd import synth
-from oracle import py_oracle
+from oracle import py_oracle, py_quatro
 
 
 def gicp_case(name, pair_id, n, extent, **kw):
@@ -30,6 +34,25 @@ def gicp_case(name, pair_id, n, extent, **kw):
                         k=kw["k"], max_iter=kw["max_iter"], max_corr_dist=kw["max_corr_dist"], trans_eps=kw["trans_eps"],
                         optimizer=kw["optimizer"])
     print(name, "iters", r["iterations"], "conv", r["converged"], "fitness %.6f" % r["fitness"])
+
+
+def quatro_case(name, pair_id, n, extent, n_tgt=None):
+    src, tgt, T_gt = synth.make_pair(pair_id, n, n_tgt, extent=extent, mode="quatro")
+    p = py_quatro.Params()
+    r = py_quatro.align(src, tgt, p)
+    pa = py_quatro.Params(use_optimized_matching=False)
+    mut_a, cor_a = py_quatro.matching(src, tgt, r["fpfh"][0], r["fpfh"][1], pa)
+    ra = py_quatro.solve(src, tgt, cor_a, pa)
+    np.savez_compressed(os.path.join(HERE, name), src=src, tgt=tgt, T_gt=T_gt,
+                        normals_s=r["normals"][0], normals_t=r["normals"][1], spfh_s=r["spfh"][0], fpfh_s=r["fpfh"][0], fpfh_t=r["fpfh"][1],
+                        mutual=r["mutual"].astype(np.int32), corres=r["corres"].astype(np.int32), clique=np.array(r["clique"], np.int32),
+                        T=r["T"], valid=int(r["valid"]), rot_iterations=r["rot_iterations"],
+                        mutual_adv=mut_a.astype(np.int32), corres_adv=cor_a.astype(np.int32), clique_adv=np.array(ra["clique"], np.int32),
+                        T_adv=ra["T"], valid_adv=int(ra["valid"]), rot_iterations_adv=ra["rot_iterations"],
+                        params=np.array([p.fpfh_normal_radius, p.fpfh_radius, p.noise_bound, p.rot_gnc_factor, p.rot_cost_diff_thr, p.rot_max_iter,
+                                         p.distance_threshold, p.max_num_corres, p.rng_seed, p.tuple_scale]))
+    print(name, "mutual", len(r["mutual"]), "corres", len(r["corres"]), "clique", len(r["clique"]), "valid", r["valid"], "err", synth.pose_error(r["T"], T_gt),
+          "| advanced corres", len(cor_a), "clique", len(ra["clique"]), "err", synth.pose_error(ra["T"], T_gt))
 
 
 def voxel_grid_numpy(xyz, leaf):
@@ -56,6 +79,8 @@ def voxel_grid_numpy(xyz, leaf):
 def main():
     gicp_case("gicp_lm_k15.npz", 101, 1500, 30.0, k=15, max_iter=32, max_corr_dist=52.5, trans_eps=0.01, optimizer="lm")   # reference operating point
     gicp_case("gicp_gn_k20.npz", 102, 1200, 30.0, k=20, max_iter=32, max_corr_dist=52.5, trans_eps=0.01, optimizer="gn")
+    quatro_case("quatro_a.npz", 401, 3000, 30.0)                      # equal sizes
+    quatro_case("quatro_b.npz", 402, 2600, 34.0, n_tgt=3100)          # target larger than source: the matcher's swapped branch
     # exact plane: every covariance is I - 0.999 n n^T
     rng = np.random.default_rng(5)
     n = np.array([0.3, -0.2, 0.933]); n /= np.linalg.norm(n)

@@ -104,3 +104,102 @@ def test_gpu_voxel_grid_golden():
     ptr, n = store.assemble([kid], [np.eye(4)], float(d["leaf"]), 0)
     assert np.array_equal(store.download(0, n), d["out"])
     store.close()
+
+
+# ------------------------------------------------------------------ Quatro fixtures (oracle/py_quatro.py, the second restatement)
+QUATRO_CASES = ["quatro_a.npz", "quatro_b.npz"]
+
+
+def _rows_off(a, b, tol=1e-4):
+    """(#rows whose finiteness differs, #rows with a bin off by more than tol) between two descriptor sets"""
+    fa, fb = np.isfinite(a).all(1), np.isfinite(b).all(1)
+    both = fa & fb
+    off = np.zeros(len(a), bool)
+    off[both] = np.abs(a[both] - b[both]).max(1) > tol
+    return int((fa != fb).sum()), int(off.sum())
+
+
+def _qparams(d, oracle=None, advanced=False):
+    v = d["params"]
+    kw = dict(fpfh_normal_radius=float(v[0]), fpfh_radius=float(v[1]), noise_bound=float(v[2]), rot_gnc_factor=float(v[3]), rot_cost_diff_thr=float(v[4]),
+              rot_max_iter=int(v[5]), distance_threshold=float(v[6]), max_num_corres=int(v[7]), rng_seed=int(v[8]), use_optimized_matching=not advanced)
+    return kw, float(v[9])
+
+
+@pytest.mark.parametrize("name", QUATRO_CASES)
+def test_oracle_reproduces_quatro_golden(oracle, name):
+    """C++ oracle (hash-grid radius search, Jacobi, polynomial atan2, f32 brute-force matcher, running-sum TLS) against the
+    numpy/scipy restatement's fixture (cKDTree, eigh, libm arctan2, KD-tree matcher, direct TLS)."""
+    d = np.load(os.path.join(G, name))
+    kw, tscale = _qparams(d)
+    nrm, sp, fp = oracle.quatro_fpfh(d["src"], kw["fpfh_normal_radius"], kw["fpfh_radius"])
+    assert np.nanmax(np.abs(nrm - d["normals_s"])) < 1e-6
+    assert _rows_off(sp, d["spfh_s"]) == (0, 0), "SPFH: bins moved by the polynomial atan2 / f32 op order"
+    nf, off = _rows_off(fp, d["fpfh_s"])
+    assert nf == 0 and off == 0, (nf, off)                                   # <= 1e-4 per bin, every point
+    _, _, fpt = oracle.quatro_fpfh(d["tgt"], kw["fpfh_normal_radius"], kw["fpfh_radius"])
+    assert _rows_off(fpt, d["fpfh_t"]) == (0, 0)
+    # matcher on the FIXTURE's descriptors: same cross-checked matches, same correspondences (optimized and advanced)
+    for adv, mk, ck, qk, tk in ((False, "mutual", "corres", "clique", "T"), (True, "mutual_adv", "corres_adv", "clique_adv", "T_adv")):
+        kw2, _ = _qparams(d, advanced=adv)
+        p = oracle.QuatroParams(tuple_scale=tscale, **kw2)
+        mutual, corres = oracle.quatro_match(d["src"], d["tgt"], d["fpfh_s"], d["fpfh_t"], p)
+        assert np.array_equal(mutual, d[mk]) and np.array_equal(corres, d[ck])
+        r = oracle.quatro_solve(d["src"], d["tgt"], corres, p)
+        assert r["clique"].tolist() == d[qk].tolist() and r["valid"] == bool(d["valid_adv" if adv else "valid"])
+        assert np.abs(r["T"] - d[tk]).max() < 1e-9
+        assert r["rot_iterations"] == int(d["rot_iterations_adv" if adv else "rot_iterations"])
+    # end to end
+    r = oracle.quatro_align(d["src"], d["tgt"], oracle.QuatroParams(tuple_scale=tscale, **kw))
+    assert np.array_equal(r["corres"], d["corres"]) and np.abs(r["T"] - d["T"]).max() < 1e-9
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", QUATRO_CASES)
+def test_gpu_reproduces_quatro_golden(name):
+    """The HIP path, through the C-ABI, against the same fixture: qn_fpfh, qn_match_optimized on the fixture's descriptors,
+    qn_quatro_solve, and quatro<>::align end to end for both matchers."""
+    from qn_amd import engine
+    d = np.load(os.path.join(G, name))
+    kw, tscale = _qparams(d)
+    ctx = engine.Context(8192)
+    q = engine.Quatro(ctx, **kw)
+    n = len(d["src"])
+    fp = engine.fpfh(ctx, d["src"])
+    nf, off = _rows_off(fp, d["fpfh_s"])
+    print("%s: FPFH rows off by > 1e-4: %d of %d (finiteness differs: %d)" % (name, off, n, nf))
+    assert nf == 0 and off <= max(2, n // 500)          # a last-bit f32 normal (different f64 summation order) can move a pair across a bin edge
+    corres = engine.match_optimized(ctx, d["src"], d["tgt"], d["fpfh_s"], d["fpfh_t"], kw["distance_threshold"], kw["max_num_corres"], tscale)
+    assert np.array_equal(corres, d["corres"])
+    s = engine.quatro_solve(d["src"], d["tgt"], d["corres"], q.p)
+    assert s["clique"].tolist() == d["clique"].tolist() and np.abs(s["T"] - d["T"]).max() < 1e-9
+    r = q.align(d["src"], d["tgt"], debug=True)
+    if off == 0:
+        assert np.array_equal(r["mutual"], d["mutual"]) and np.array_equal(r["corres"], d["corres"])
+        assert r["clique"].tolist() == d["clique"].tolist() and np.abs(r["T"] - d["T"]).max() < 1e-9 and r["rot_iterations"] == int(d["rot_iterations"])
+    dt, dr = synth.pose_error(r["T"], d["T"])
+    assert r["valid"] == bool(d["valid"]) and (off > 0 or (dt <= 1e-4 and dr <= 1e-4))
+    kwa, _ = _qparams(d, advanced=True)
+    qa = engine.Quatro(ctx, **kwa)
+    ra = qa.align(d["src"], d["tgt"], debug=True)
+    if off == 0:
+        assert np.array_equal(ra["corres"], d["corres_adv"]) and np.abs(ra["T"] - d["T_adv"]).max() < 1e-9
+    # device-pointer entry point: same answer with both clouds resident in HBM
+    import torch
+    s_d = torch.from_numpy(np.ascontiguousarray(d["src"])).cuda(); t_d = torch.from_numpy(np.ascontiguousarray(d["tgt"])).cuda()
+    Td, vd = q.align_device(s_d.data_ptr(), len(d["src"]), t_d.data_ptr(), len(d["tgt"]), 12)
+    assert vd == r["valid"] and np.array_equal(Td, r["T"])
+    ctx.close()
+
+
+@pytest.mark.gpu
+def test_gpu_quatro_params_are_not_silently_ignored():
+    """estimate_scale has no implementation: refused (QN_ERR_INVALID_ARG), never accepted and ignored; use_optimized_matching = 0
+    selects advancedMatching (covered above)."""
+    from qn_amd import engine
+    ctx = engine.Context(1024)
+    with pytest.raises(engine.EngineError) as ei:
+        engine.Quatro(ctx, estimate_scale=True)
+    assert ei.value.status == engine.QN_ERR_INVALID_ARG
+    engine.Quatro(ctx, use_optimized_matching=False)
+    ctx.close()
