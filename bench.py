@@ -7,13 +7,18 @@ setInputTarget + calculateTargetCovariances + align + getFitnessScore, on BASELI
 configs[1]: 100k x 100k points, k = 20 covariances, 20 forced Gauss-Newton iterations.
 The raw clouds are resident in HBM when the timed region starts (device-pointer entry points).
 
-N > 1: one process per GPU, candidate pairs sharded pair i -> rank i mod N (no data-path
-collective; independent registrations), one RCCL all_gather of the fixed-size result records at the
-end so rank 0 can pick the winning loop.  Weak scaling: every rank runs K steps.
+`--gpus N`: one process per GPU.  Launched by torchrun (RANK / WORLD_SIZE in the environment) the script is one rank; launched
+plainly with N > 1 it starts the N ranks itself (and refuses when fewer than N GPUs are visible - there is no GPU sharing and no
+CPU fallback).  Candidate pairs are sharded pair i -> rank i mod N with no data-path collective (independent registrations); one
+RCCL all_gather of the fixed-size best-result records at the end lets rank 0 pick the winning loop.  Weak
+scaling: every rank runs K steps.  The same line also carries BASELINE configs[3] literally (`batch64`: 64 distinct pairs sharded
+over the ranks through qn_multi_align_best + the gather), the reference's operating point (configs[0], `reference_operating_point`)
+and the Quatro stage (configs[2], `quatro`).
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -26,20 +31,49 @@ import torch
 
 N_PTS, K_COV, GN_ITERS = 100000, 20, 20
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec (MI355X_MICROARCH.md); 6290 GB/s measured-achievable
+FP32_VALU_PEAK_TF = 157.3    # f32 vector peak with FMA (MI355X_MICROARCH.md); 78.6 without FMA contraction
 
 
-def algorithmic_bytes():
+def algorithmic_bytes(n=N_PTS, k=K_COV, it=GN_ITERS):
     """SURVEY.md 8(d) accounting, compact fp32 layouts (point 16 B, covariance 24 B)."""
-    n, k, it = N_PTS, K_COV, GN_ITERS
     return {
         "grid_build": 36 * n,                       # per cloud
         "knn_cov": n * (16 + 16 * k + 24),          # per cloud
         "gn_iteration": 80 * n,                     # NN search + accumulate of one iteration
+        "lm_error_pass": 56 * n,
         "fitness": 32 * n,
         "transform": 32 * n,
         "align": 80 * it * n + 32 * n,
         "full": 36 * 2 * n + (40 + 16 * k) * 2 * n + 80 * it * n + 64 * n,
     }
+
+
+def pct(xs):
+    xs = np.sort(np.asarray(xs, dtype=np.float64))
+    return {"median": round(float(np.median(xs)), 4), "p10": round(float(np.percentile(xs, 10)), 4), "p90": round(float(np.percentile(xs, 90)), 4), "n": int(len(xs))}
+
+
+def spawn_ranks(args):
+    """plain `python bench.py --gpus N`: start the N ranks (one process per GPU) and relay rank 0's JSON line."""
+    n = args.gpus
+    backend = os.environ.get("QN_BENCH_BACKEND", "nccl")
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if backend == "nccl" and have < n:
+        raise SystemExit("bench.py --gpus %d needs %d GPUs, %d visible: refusing to run fewer ranks or to share a GPU (QN_BENCH_BACKEND=gloo is the 1-GPU plumbing test)" % (n, n, have))
+    if have < 1:
+        raise SystemExit("bench.py needs a GPU: the engine has no CPU fallback")
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out, _ = procs[0].communicate()
+    rcs = [p.wait() for p in procs]
+    sys.stdout.write(out.decode()); sys.stdout.flush()
+    if any(rcs):
+        raise SystemExit("bench.py: rank exit codes %s" % rcs)
 
 
 def main():
@@ -49,17 +83,25 @@ def main():
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-quatro", action="store_true")
-    ap.add_argument("--pairs", type=int, default=2, help="distinct synthetic pairs per rank, cycled over the steps")
+    ap.add_argument("--no-extras", action="store_true", help="only the headline measurement (profiling runs)")
+    ap.add_argument("--pairs", type=int, default=8, help="distinct synthetic pairs (scenes) per rank, cycled over the steps (>= 2 x in-flight)")
     ap.add_argument("--in-flight", type=int, default=4, help="candidate pairs registered concurrently per GPU (one context = one hipStream each)")
+    ap.add_argument("--batch-pairs", type=int, default=64, help="BASELINE configs[3]: candidate pairs of one query, sharded over the ranks")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        return spawn_ranks(args)
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d: launch one rank per GPU (torchrun --nproc-per-node %d)" % (args.gpus, world, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the engine has no CPU fallback")
     # one process per GPU (RCCL over xGMI).  QN_BENCH_BACKEND=gloo lets the N > 1 code path be exercised on a 1-GPU box
     # (all ranks share cuda:0, collectives on host tensors) - a plumbing test, not a measurement.
     backend = os.environ.get("QN_BENCH_BACKEND", "nccl")
+    if backend == "nccl" and torch.cuda.device_count() <= local:
+        raise SystemExit("bench.py: rank %d has no GPU of its own (%d visible)" % (rank, torch.cuda.device_count()))
     local = local % torch.cuda.device_count() if backend != "nccl" else local
     torch.cuda.set_device(local)
     cdev = "cuda" if backend == "nccl" else "cpu"
@@ -88,21 +130,23 @@ def main():
         for kk, vv in knobs.items():
             cx.debug_set(kk, float(vv))
 
-    # candidate pairs of this rank: pair_id = rank + world * j   (pair i -> rank i mod N)
+    # candidate pairs of this rank: pair_id = rank + world * j   (pair i -> rank i mod N); distinct scenes, distinct device buffers
+    npairs = max(args.pairs, 1)
     pairs = []
-    for j in range(args.pairs):
+    for j in range(npairs):
         src, tgt, T = synth.make_pair(rank + world * j, N_PTS)
         pairs.append((torch.from_numpy(src).cuda(), torch.from_numpy(tgt).cuda(), T))
     torch.cuda.synchronize()
 
-    def register(j):
+    def register(j, gg=g):
         s, t, _ = pairs[j % len(pairs)]
-        g.setInputSourceDevice(s.data_ptr(), N_PTS, 12); g.calculateSourceCovariances()
-        g.setInputTargetDevice(t.data_ptr(), N_PTS, 12); g.calculateTargetCovariances()
-        return g.align()
+        gg.setInputSourceDevice(s.data_ptr(), N_PTS, 12); gg.calculateSourceCovariances()
+        gg.setInputTargetDevice(t.data_ptr(), N_PTS, 12); gg.calculateTargetCovariances()
+        return gg.align()
 
-    def batch(n):
-        descs = [(pairs[j % len(pairs)][0].data_ptr(), N_PTS, pairs[j % len(pairs)][1].data_ptr(), N_PTS, 12, 1) for j in range(n)]
+    def batch(n, plist=None):
+        plist = plist or pairs
+        descs = [(plist[j % len(plist)][0].data_ptr(), N_PTS, plist[j % len(plist)][1].data_ptr(), N_PTS, 12, 1) for j in range(n)]
         return engine.icp_alignment_batch(ctxs, descs, score_thr=1.5)
 
     def barrier():
@@ -111,11 +155,19 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def gather_best(best):
+        """the one exchange step: all_gather of every rank's best record (RCCL when backend = nccl) -> the winning loop"""
+        if dist is None:
+            return best
+        mine = torch.tensor(best, dtype=torch.float64, device=cdev)
+        allrec = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(allrec, mine)
+        return min((a.tolist() for a in allrec), key=lambda a: (a[2], a[0]))
+
     if args.warmup > 0:
         batch(args.warmup)
     if dist is not None:          # untimed: bring up the communicator's channels (RCCL connects lazily on the first collective)
-        wtmp = torch.zeros(19, dtype=torch.float64, device=cdev)
-        dist.all_gather([torch.empty_like(wtmp) for _ in range(world)], wtmp)
+        gather_best([0.0] * 19)
         dist.all_reduce(torch.zeros(1, dtype=torch.float64, device=cdev), op=dist.ReduceOp.MAX)
     barrier()
     t0 = time.perf_counter()
@@ -126,13 +178,7 @@ def main():
         rec = [float(rank + world * (j % len(pairs))), float(r.converged), r.fitness] + list(r.T)
         if best is None or rec[2] < best[2]:
             best = rec
-    if dist is not None:          # the one exchange step: gather every rank's best record to pick the winning loop
-        mine = torch.tensor(best, dtype=torch.float64, device=cdev)
-        allrec = [torch.empty_like(mine) for _ in range(world)]
-        dist.all_gather(allrec, mine)
-        winner = min((a.tolist() for a in allrec), key=lambda a: a[2])
-    else:
-        winner = best
+    winner = gather_best(best)
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
@@ -140,16 +186,51 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
+    # ---- BASELINE configs[3], literally: ONE query with `batch_pairs` (64) DISTINCT candidate pairs, pair i -> rank i mod N, each rank
+    # through qn_multi_align_best (its GPU, `in_flight` streams, the RCCL gather of its record table inside the C-ABI), then the
+    # all_gather of the per-rank winners; pairs/s = 64 / wall.  The 64 pairs = the rank's scenes x rigid re-poses of the target.
+    batch64 = None
+    if not args.no_extras:
+        nb = args.batch_pairs
+        my_ids = [i for i in range(nb) if i % world == rank]
+        bpairs = []
+        for i in my_ids:
+            s, t, _ = pairs[(i // world) % len(pairs)]
+            v = i // (world * len(pairs))                              # variant: re-pose the target (distinct coordinates, distinct ground truth)
+            if v:
+                a = 0.01 * v; ca, sa = float(np.cos(a)), float(np.sin(a))
+                R = torch.tensor([[ca, -sa, 0.0], [sa, ca, 0.0], [0.0, 0.0, 1.0]], dtype=torch.float32, device=t.device)
+                t = (t @ R.T + torch.tensor([0.05 * v, -0.03 * v, 0.0], dtype=torch.float32, device=t.device)).contiguous()
+            bpairs.append((s, t))
+        mg = engine.MultiGpu(1, N_PTS + 1024, in_flight=len(ctxs), device_ids=[local])
+        mg.set_params(g.p)
+        descs = [(s.data_ptr(), N_PTS, t.data_ptr(), N_PTS, 12, 1) for s, t in bpairs]
+        mg.align_best(descs[:min(len(descs), 4)])                     # untimed warm-up of the new contexts
+        barrier()
+        tb = time.perf_counter()
+        recs, bestrec = mg.align_best(descs)
+        mine = [float(my_ids[bestrec.pair_id]), float(bestrec.converged), bestrec.fitness] + list(bestrec.T) if bestrec is not None else [-1.0, 0.0, 1.7e308] + [0.0] * 16
+        bwin = gather_best(mine)
+        barrier()
+        bwall = time.perf_counter() - tb
+        if dist is not None:
+            tmax = torch.tensor([bwall], dtype=torch.float64, device=cdev); dist.all_reduce(tmax, op=dist.ReduceOp.MAX); bwall = float(tmax.item())
+        assert all(r.status == 0 for r in recs), [r.status for r in recs]
+        batch64 = {"pairs": nb, "distinct_pairs": nb, "wall_ms": round(1e3 * bwall, 3), "pairs_per_s": round(nb / bwall, 2), "ms_per_pair": round(1e3 * bwall / nb, 4),
+                   "winner_pair": int(bwin[0]), "winner_score": bwin[2], "sharding": "pair i -> rank i mod %d; qn_multi_align_best per rank (RCCL all-gather of the 96-byte records inside), all_gather of the rank winners" % world,
+                   "valid_pairs_this_rank": int(sum(r.valid for r in recs))}
+        mg.close()
+
     out = None
     if rank == 0:
         ms_step = 1e3 * elapsed / args.steps
-        # ---- one registration at a time on one stream (latency view)
+        # ---- one registration at a time on one stream (latency view): median / p10 / p90 over distinct pairs
         for j in range(2):
             register(j)
-        tl = time.perf_counter()
-        for j in range(10):
-            register(j)
-        single_ms = 1e3 * (time.perf_counter() - tl) / 10
+        lat = []
+        for j in range(30):
+            tl = time.perf_counter(); register(j); lat.append(1e3 * (time.perf_counter() - tl))
+        single = pct(lat)
         # ---- PCIe-inclusive view: the same registration with the clouds handed over as HOST buffers (never `value`)
         s_host, t_host = pairs[0][0].cpu().numpy(), pairs[0][1].cpu().numpy()
         def register_host():
@@ -157,22 +238,20 @@ def main():
             g.setInputTarget(t_host); g.calculateTargetCovariances()
             return g.align()
         register_host()
-        th = time.perf_counter()
-        for _ in range(5):
-            register_host()
-        host_ms = 1e3 * (time.perf_counter() - th) / 5
+        lat = []
+        for _ in range(10):
+            th = time.perf_counter(); register_host(); lat.append(1e3 * (time.perf_counter() - th))
+        host = pct(lat)
         # ---- align-only timing (clouds + covariances resident): BASELINE's "ms/align"
-        reps = max(5, args.steps // 2)
         register(0); ctx.synchronize(); torch.cuda.synchronize()
-        ta = time.perf_counter()
-        for _ in range(reps):
-            g.align()
-        torch.cuda.synchronize()
-        align_ms = 1e3 * (time.perf_counter() - ta) / reps
+        lat = []
+        for _ in range(max(30, args.steps // 4)):
+            ta = time.perf_counter(); g.align(); lat.append(1e3 * (time.perf_counter() - ta))
+        align = pct(lat); align_ms = align["median"]
 
         # ---- roofline leg: per-kernel-family device time from hipEvents on the engine's stream
         ctx.prof_reset(); ctx.prof_enable(True)
-        nprof = 3
+        nprof = 4
         for j in range(nprof):
             register(j)
         ctx.synchronize(); ctx.prof_enable(False)
@@ -181,29 +260,32 @@ def main():
         fam_avg = {k: v[0] / v[1] for k, v in stats.items() if v[1] > 0}             # ms per profiled span (= one launch for the single-kernel families)
         ab = algorithmic_bytes()
         # kernel families timed as ONE kernel per span, with the rocprofv3 name of that kernel and its algorithmic bytes per launch
-        single = {"knn_select": ("k_knn_hist<false, 32>", N_PTS * (16 + 16 * K_COV)),          # k-NN selection of one cloud: point + k neighbour points
-                  "gn_tick_fused": ("k_nn_track<0, true>", ab["gn_iteration"]),              # one whole GN iteration (NN + accumulate + solve)
-                  "nn_search": ("k_nn_search<0, false, 256>", ab["gn_iteration"]),                # first (unseeded) NN passes of an align
-                  "nn_fallback": ("k_nn_search<0, true, 256>", ab["gn_iteration"]),
-                  "accumulate": ("k_accumulate", ab["gn_iteration"]), "solve": ("k_solve", 28 * 8 * 512)}
-        dom = max((k for k in fam_ms if k in single), key=fam_ms.get)
-        dom_kernel, per_launch_bytes = single[dom]
+        single_k = {"knn_select": ("k_knn_hist<false, 32>", N_PTS * (16 + 16 * K_COV)),          # k-NN selection of one cloud: point + k neighbour points
+                    "gn_tick_fused": ("k_nn_track<0, true>", ab["gn_iteration"]),              # one whole GN iteration (NN + accumulate + solve)
+                    "nn_search": ("k_nn_search<0, false, 256>", ab["gn_iteration"]),                # first (unseeded) NN passes of an align
+                    "nn_fallback": ("k_nn_search<0, true, 256>", ab["gn_iteration"]),
+                    "accumulate": ("k_accumulate", ab["gn_iteration"]), "solve": ("k_solve", 28 * 8 * 512)}
+        dom = max((k for k in fam_ms if k in single_k), key=fam_ms.get)
+        dom_kernel, per_launch_bytes = single_k[dom]
         dom_ms = fam_avg[dom]
         achieved = per_launch_bytes / (dom_ms * 1e-3) / 1e9
-        pmc = None
+        pmc, pmc_all = None, None
         pmc_path = os.path.join(ROOT, "profiles", "pmc_latest.json")
         if os.path.exists(pmc_path):
             try:
-                pmc = json.load(open(pmc_path)).get(dom)
+                pmc_all = json.load(open(pmc_path)); pmc = pmc_all.get(dom)
             except Exception:
                 pmc = None
         traffic = pmc.get("hbm_bytes_per_launch") if isinstance(pmc, dict) else None
-        kernels = {k: {"kernel": single[k][0], "avg_launch_ms": round(fam_avg[k], 5), "launches_per_registration": round(stats[k][1] / nprof, 2),
-                       "algorithmic_bytes_per_launch": single[k][1], "achieved_GBs": round(single[k][1] / (fam_avg[k] * 1e-3) / 1e9, 2),
-                       "frac": round(single[k][1] / (fam_avg[k] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)} for k in single if k in fam_avg}
+        kernels = {k: {"kernel": single_k[k][0], "avg_launch_ms": round(fam_avg[k], 5), "launches_per_registration": round(stats[k][1] / nprof, 2),
+                       "algorithmic_bytes_per_launch": single_k[k][1], "achieved_GBs": round(single_k[k][1] / (fam_avg[k] * 1e-3) / 1e9, 2),
+                       "frac": round(single_k[k][1] / (fam_avg[k] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                       "traffic": (pmc_all or {}).get(k, {}).get("hbm_bytes_per_launch") if isinstance(pmc_all, dict) else None} for k in single_k if k in fam_avg}
         roofline = {"bound": "hbm", "kernel": dom_kernel, "family": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_detail": pmc,
-                    "avg_launch_ms": round(dom_ms, 5), "algorithmic_bytes_per_launch": per_launch_bytes,
+                    "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                    "traffic_source": "NOT measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the same workload (tools/gpu_round.sh <tag> pmc), stored in profiles/pmc_latest.json",
+                    "stale_from": (pmc_all or {}).get("_meta", {}).get("tag", "profiles/pmc_latest.json") if isinstance(pmc_all, dict) else None,
+                    "traffic_detail": pmc, "avg_launch_ms": round(dom_ms, 5), "algorithmic_bytes_per_launch": per_launch_bytes,
                     "whole_registration": {"algorithmic_bytes": ab["full"], "achieved": round(ab["full"] / (ms_step * 1e-3) / 1e9, 2),
                                            "frac": round(ab["full"] / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
                                            "note": "amortised over the registrations in flight"},
@@ -212,16 +294,63 @@ def main():
                     "family_ms_per_registration": {k: round(v, 4) for k, v in fam_ms.items()}, "kernels": kernels,
                     "note": "working set (<=20 MB) is L2/MALL resident: nominal HBM yardstick (SURVEY 8d)"}
 
-        # ---- Quatro coarse stage (BASELINE configs[2]): FPFH + optimizedMatching (cap 200) + GNC solve, 30k-point pair from the host
+        extras = {}
+        if not args.no_extras:
+            # ---- a less favourable pair: 80 % overlap (target window shifted 24 m; the default pairs overlap ~96 %), same workload
+            s80, t80, _ = synth.make_pair(9000, N_PTS, shift=24.0)
+            p80 = [(torch.from_numpy(s80).cuda(), torch.from_numpy(t80).cuda(), None)]
+            batch(8, p80); torch.cuda.synchronize()
+            t8 = time.perf_counter(); batch(40, p80); torch.cuda.synchronize()
+            extras["overlap80"] = {"registrations_per_s": round(40 / (time.perf_counter() - t8), 2), "note": "one pair with 80 % overlap cycled, same in-flight setting"}
+            # ---- BASELINE configs[0]: the reference's operating point: k = 15, LM, <= 32 iterations, real stopping rule,
+            # clouds handed over as HOST buffers through qn_icp_alignment (PCIe inclusive), 30k and 100k points; CPU oracle beside it
+            rop = {}
+            for npts in (30000, N_PTS):
+                sr, tr_, _ = synth.make_pair(700 + npts // 1000, npts)
+                engine.icp_alignment(ctx, sr, tr_)
+                lat = []
+                for _ in range(15):
+                    tq = time.perf_counter(); rr = engine.icp_alignment(ctx, sr, tr_); lat.append(1e3 * (time.perf_counter() - tq))
+                e = {"gpu_ms_from_host_buffers": pct(lat), "iterations": rr["iterations"], "converged": rr["converged"], "score": rr["score"]}
+                if not args.no_cpu_baseline:
+                    from oracle import oracle as orc
+                    tc = time.perf_counter(); ro = orc.icp_alignment(sr, tr_); c1 = time.perf_counter() - tc
+                    reps = max(1, min(5, int(4.0 / max(c1, 1e-3)))); tc = time.perf_counter()
+                    for _ in range(reps):
+                        orc.icp_alignment(sr, tr_)
+                    e["cpu_oracle_ms"] = round(1e3 * (time.perf_counter() - tc) / reps, 2); e["cpu_threads"] = orc.num_threads()
+                    e["same_iterations_as_oracle"] = bool(ro["iterations"] == rr["iterations"])
+                rop["%dk" % (npts // 1000)] = e
+            extras["reference_operating_point"] = {"config": "k=15, LM, max 32 iterations, eps_t 0.01, eps_r 2e-3, max_corr_dist 52.5 m, score thr 1.5 (SURVEY App. C)", **rop}
+
+        # ---- Quatro coarse stage (BASELINE configs[2]): FPFH + optimizedMatching (cap 200) + GNC solve, 30k and 100k pairs from the host
         quatro = None
-        if world == 1 and not args.no_quatro:
-            qs, qt, _ = synth.make_pair(400, 30000, mode="quatro")
-            q = engine.Quatro(ctx)
-            q.align(qs, qt)
-            tq = time.perf_counter()
-            for _ in range(3):
-                Tq, qvalid = q.align(qs, qt)
-            quatro = {"ms_per_align_30k": round(1e3 * (time.perf_counter() - tq) / 3, 3), "valid": bool(qvalid)}
+        if world == 1 and not args.no_quatro and not args.no_extras:
+            from scipy.spatial import cKDTree
+            quatro = {}
+            for npts in (30000, N_PTS):
+                qs, qt, _ = synth.make_pair(400 + npts // 1000, npts, mode="quatro")
+                q = engine.Quatro(ctx)
+                q.align(qs, qt)
+                lat = []
+                for _ in range(5):
+                    tq = time.perf_counter(); Tq, qvalid = q.align(qs, qt); lat.append(1e3 * (time.perf_counter() - tq))
+                ctx.prof_reset(); ctx.prof_enable(True); q.align(qs, qt); ctx.synchronize(); ctx.prof_enable(False)
+                st = ctx.prof_stats()
+                stage = {k: round(st[k][0], 4) for k in ("grid_build", "fpfh_normals", "fpfh_spfh", "fpfh_fpfh", "feat_match", "match_tail") if st[k][1] > 0}
+                tree = cKDTree(qs.astype(np.float64)); sel = np.random.default_rng(0).choice(len(qs), 4000, replace=False)
+                m_n = float(np.mean(tree.query_ball_point(qs[sel].astype(np.float64), 0.9, return_length=True)))
+                m_f = float(np.mean(tree.query_ball_point(qs[sel].astype(np.float64), 1.5, return_length=True)))
+                ab_q = {"normals": npts * (16 + 16 * m_n + 12), "spfh": npts * (28 + 28 * m_f + 132), "fpfh": npts * (136 * m_f + 132)}     # per cloud, SURVEY 8d
+                fm_ms = stage.get("feat_match", 0.0)
+                flops = 2.0 * 33 * npts * npts                                   # forward direction; the lazy reverse search adds the hit fraction
+                e = {"ms_per_align": pct(lat), "valid": bool(qvalid), "stage_ms": stage, "m_n": round(m_n, 1), "m_f": round(m_f, 1),
+                     "algorithmic_bytes_per_cloud": {k: int(v) for k, v in ab_q.items()},
+                     "frac_hbm": {k: round(ab_q[k] * 2 / (stage[s] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) for k, s in (("normals", "fpfh_normals"), ("spfh", "fpfh_spfh"), ("fpfh", "fpfh_fpfh")) if s in stage},
+                     "feat_match": {"flops_forward": flops, "achieved_TF_lower_bound": round(flops / (fm_ms * 1e-3) / 1e12, 2) if fm_ms else None,
+                                    "frac_of_f32_valu_peak": round(flops / (fm_ms * 1e-3) / 1e12 / FP32_VALU_PEAK_TF, 4) if fm_ms else None,
+                                    "peak_TF": FP32_VALU_PEAK_TF, "note": "2*33*Ns*Nt flop (sub+fma counted as 2) over BOTH searches' time: a lower bound"}}
+                quatro["%dk" % (npts // 1000)] = e
 
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
@@ -234,13 +363,13 @@ def main():
                 return o.align()
             tc = time.perf_counter(); ro = cpu_once(); first = time.perf_counter() - tc
             nrep = max(1, min(8, int(15.0 / max(first, 1e-3))))
-            tc = time.perf_counter()
+            times = []
             for _ in range(nrep):
-                cpu_once()
-            cpu_s = (time.perf_counter() - tc) / nrep
+                tc = time.perf_counter(); cpu_once(); times.append(time.perf_counter() - tc)
+            cpu_s = float(np.median(times))
             cpu = {"value": round(1.0 / cpu_s, 4), "unit": "registrations/s", "cores": nthreads, "kind": "port",
-                   "ms_per_registration": round(cpu_s * 1e3, 2),
-                   "sample": "%d full registrations of pair 0 (100k x 100k, k=20, 20 GN iterations) with the OpenMP C++ oracle" % nrep}
+                   "ms_per_registration": round(cpu_s * 1e3, 2), "ms_range": [round(1e3 * min(times), 2), round(1e3 * max(times), 2)],
+                   "sample": "%d full registrations of pair 0 (100k x 100k, k=20, 20 GN iterations) with the OpenMP C++ oracle; shared host, wall time varies run to run" % nrep}
             # parity spot check of the benched workload against the oracle
             r = register(0)
             dtp = float(np.abs(np.array(r.T64).reshape(4, 4) - ro["T"]).max())
@@ -251,11 +380,13 @@ def main():
                "unit": "registrations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(ms_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                "dtype": "f32 search / f64 accumulate", "data": "synthetic",
-               "config": {"workload": "Nano-GICP icpAlignment, synthetic 100k x 100k street-scene pair, k=20 covariances, 20 forced GN iterations (BASELINE configs[1])",
+               "config": {"workload": "Nano-GICP icpAlignment, synthetic 100k x 100k street-scene pairs, k=20 covariances, 20 forced GN iterations (BASELINE configs[1])",
                           "points": N_PTS, "k": K_COV, "gn_iterations": GN_ITERS, "sharding": "pair i -> rank i mod N, all_gather of best record",
-                          "in_flight": len(ctxs), "ms_per_registration_single_stream": round(single_ms, 4), "ms_per_registration_from_host_buffers": round(host_ms, 4),
-                          "ms_per_align": round(align_ms, 4), "winner_pair": int(winner[0]), "winner_score": winner[2],
-                          "max_abs_T_diff_vs_oracle": dtp, "quatro": quatro},
+                          "in_flight": len(ctxs), "distinct_pairs_per_rank": len(pairs),
+                          "ms_per_registration_single_stream": single["median"], "ms_per_registration_single_stream_stats": single,
+                          "ms_per_registration_from_host_buffers": host["median"], "ms_per_registration_from_host_buffers_stats": host,
+                          "ms_per_align": align_ms, "ms_per_align_stats": align, "winner_pair": int(winner[0]), "winner_score": winner[2],
+                          "max_abs_T_diff_vs_oracle": dtp, "batch64": batch64, "quatro": quatro, **extras},
                "roofline": roofline, "cpu_baseline": cpu}
         print(json.dumps(out))
     if dist is not None:

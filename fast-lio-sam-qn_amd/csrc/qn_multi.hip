@@ -1,0 +1,186 @@
+// qn_multi.hip - candidate pairs of one loop-closure query sharded over the GPUs of a node (BASELINE configs[3]).
+//
+// Every candidate pair is an independent LoopClosure::icpAlignment (fast_lio_sam_qn/src/loop_closure.cpp:116-123 rebuilds trees and
+// covariances per call; the fan-out point in the reference is fast_lio_sam_qn.cpp:213-219, where ONE candidate is registered per timer
+// tick), so the data path needs no collective: pair i runs on GPU i mod N, on one of `in_flight` contexts (= hipStreams) of that GPU.
+// The single exchange step is the gather of the fixed-size result records (<= 96 bytes each) so that the host can pick the winning
+// loop: ONE ncclAllGather over xGMI.  Point clouds never move between GPUs.  Single process, all GPUs (ncclCommInitAll) - the
+// reference is a single process too.  Host code only: this unit launches no kernel of its own; it drives the C-ABI of qn_engine.h.
+//
+// RCCL is loaded with dlopen at qn_multi_init, so libqn_engine.so itself carries no load-time dependency on librccl: the single-GPU
+// entry points work on a box without RCCL, qn_multi_init fails loudly there.
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+#include <dlfcn.h>
+#include <atomic>
+#include <cfloat>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+#include "../../include/qn_engine.h"
+
+static_assert(sizeof(qn_pair_record) == 96, "result records are 96 bytes (SURVEY 8e)");
+
+struct qn_multi {
+  int n_gpus = 0, in_flight = 1;
+  uint32_t max_points = 0;
+  std::vector<int> dev;
+  std::vector<std::vector<qn_ctx*>> ctx;          // [gpu][slot]
+  std::vector<ncclComm_t> comm;
+  std::vector<hipStream_t> stream;
+  std::vector<qn_pair_record*> d_send, d_recv;    // per GPU: its own records / everybody's
+  uint32_t rec_cap = 0;                           // records per GPU the device buffers hold
+  qn_pair_record* h_all = nullptr;                // pinned: gathered table as GPU 0 received it
+  void* rccl = nullptr;
+  decltype(&ncclCommInitAll) p_init_all = nullptr;
+  decltype(&ncclCommDestroy) p_destroy = nullptr;
+  decltype(&ncclAllGather) p_all_gather = nullptr;
+  decltype(&ncclGroupStart) p_group_start = nullptr;
+  decltype(&ncclGroupEnd) p_group_end = nullptr;
+  decltype(&ncclGetErrorString) p_err = nullptr;
+  std::string last_error;
+};
+
+static thread_local std::string g_init_error;
+extern "C" const char* qn_multi_last_error(const qn_multi* m) { return m ? m->last_error.c_str() : g_init_error.c_str(); }
+
+extern "C" void qn_multi_destroy(qn_multi* m) {
+  if (!m) return;
+  for (int g = 0; g < (int)m->ctx.size(); g++) for (qn_ctx* c : m->ctx[g]) qn_ctx_destroy(c);
+  for (int g = 0; g < (int)m->comm.size(); g++) if (m->comm[g] && m->p_destroy) { hipSetDevice(m->dev[g]); m->p_destroy(m->comm[g]); }
+  for (int g = 0; g < (int)m->dev.size(); g++) {
+    hipSetDevice(m->dev[g]);
+    if (g < (int)m->d_send.size()) { hipFree(m->d_send[g]); hipFree(m->d_recv[g]); }
+    if (g < (int)m->stream.size() && m->stream[g]) hipStreamDestroy(m->stream[g]);
+  }
+  if (m->h_all) hipHostFree(m->h_all);
+  if (m->rccl) dlclose(m->rccl);
+  delete m;
+}
+
+static int multi_reserve(qn_multi* m, uint32_t per_gpu) {
+  if (per_gpu <= m->rec_cap) return QN_OK;
+  const uint32_t cap = per_gpu + 8;
+  for (int g = 0; g < m->n_gpus; g++) {
+    if (hipSetDevice(m->dev[g]) != hipSuccess) return QN_ERR_HIP;
+    hipFree(m->d_send[g]); hipFree(m->d_recv[g]); m->d_send[g] = m->d_recv[g] = nullptr;
+    if (hipMalloc(&m->d_send[g], sizeof(qn_pair_record) * cap) != hipSuccess || hipMalloc(&m->d_recv[g], sizeof(qn_pair_record) * cap * m->n_gpus) != hipSuccess) { m->last_error = "hipMalloc of the record buffers failed"; return QN_ERR_HIP; }
+  }
+  if (m->h_all) hipHostFree(m->h_all);
+  m->h_all = nullptr;
+  if (hipHostMalloc(&m->h_all, sizeof(qn_pair_record) * cap * m->n_gpus, hipHostMallocDefault) != hipSuccess) { m->last_error = "hipHostMalloc failed"; return QN_ERR_HIP; }
+  m->rec_cap = cap;
+  return QN_OK;
+}
+
+extern "C" int qn_multi_init(int n_gpus, const int* device_ids, uint32_t max_points, int in_flight, qn_multi** out) {
+  if (!out || n_gpus < 1 || max_points == 0 || in_flight < 1 || in_flight > 64) return QN_ERR_INVALID_ARG;
+  *out = nullptr;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < n_gpus) {
+    char buf[160]; snprintf(buf, sizeof(buf), "qn_multi_init: %d GPUs requested, %d visible (no CPU fallback, no GPU sharing between ranks)", n_gpus, ndev < 0 ? 0 : ndev);
+    g_init_error = buf; return QN_ERR_NO_DEVICE;
+  }
+  qn_multi* m = new qn_multi();
+  m->n_gpus = n_gpus; m->in_flight = in_flight; m->max_points = max_points;
+  for (int g = 0; g < n_gpus; g++) {
+    const int d = device_ids ? device_ids[g] : g;
+    if (d < 0 || d >= ndev) { g_init_error = "qn_multi_init: device id out of range"; qn_multi_destroy(m); return QN_ERR_NO_DEVICE; }
+    for (int e : m->dev) if (e == d) { g_init_error = "qn_multi_init: the same device listed twice (one rank per GPU)"; qn_multi_destroy(m); return QN_ERR_INVALID_ARG; }
+    m->dev.push_back(d);
+  }
+  auto fail = [&](int code, const std::string& why) { g_init_error = why; qn_multi_destroy(m); return code; };
+  m->rccl = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+  if (!m->rccl) m->rccl = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
+  if (!m->rccl) m->rccl = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+  if (!m->rccl) return fail(QN_ERR_HIP, std::string("qn_multi_init: cannot load RCCL: ") + dlerror());
+#define QN_SYM(field, name) m->field = (decltype(m->field))dlsym(m->rccl, name); if (!m->field) return fail(QN_ERR_HIP, std::string("qn_multi_init: RCCL lacks ") + name)
+  QN_SYM(p_init_all, "ncclCommInitAll"); QN_SYM(p_destroy, "ncclCommDestroy"); QN_SYM(p_all_gather, "ncclAllGather");
+  QN_SYM(p_group_start, "ncclGroupStart"); QN_SYM(p_group_end, "ncclGroupEnd"); QN_SYM(p_err, "ncclGetErrorString");
+#undef QN_SYM
+  m->ctx.resize(n_gpus); m->stream.assign(n_gpus, nullptr); m->d_send.assign(n_gpus, nullptr); m->d_recv.assign(n_gpus, nullptr);
+  for (int g = 0; g < n_gpus; g++) {
+    if (hipSetDevice(m->dev[g]) != hipSuccess || hipStreamCreateWithFlags(&m->stream[g], hipStreamNonBlocking) != hipSuccess) return fail(QN_ERR_HIP, "qn_multi_init: stream creation failed");
+    for (int s = 0; s < in_flight; s++) {
+      qn_ctx* c = nullptr;
+      const int rc = qn_ctx_create(m->dev[g], max_points, &c);
+      if (rc != QN_OK) return fail(rc, std::string("qn_multi_init: qn_ctx_create: ") + qn_status_str(rc));
+      m->ctx[g].push_back(c);
+    }
+  }
+  m->comm.assign(n_gpus, nullptr);
+  const ncclResult_t nr = m->p_init_all(m->comm.data(), n_gpus, m->dev.data());      // one communicator over the node's GPUs (xGMI)
+  if (nr != ncclSuccess) return fail(QN_ERR_HIP, std::string("qn_multi_init: ncclCommInitAll: ") + m->p_err(nr));
+  const int rc = multi_reserve(m, 64);
+  if (rc != QN_OK) return fail(rc, m->last_error);
+  *out = m;
+  return QN_OK;
+}
+
+extern "C" int qn_multi_set_params(qn_multi* m, const qn_gicp_params* p) {
+  if (!m || !p) return QN_ERR_INVALID_ARG;
+  for (auto& v : m->ctx) for (qn_ctx* c : v) { const int rc = qn_gicp_set_params(c, p); if (rc != QN_OK) return rc; }
+  return QN_OK;
+}
+
+extern "C" int qn_multi_gpu_count(const qn_multi* m) { return m ? m->n_gpus : 0; }
+
+// pair i -> GPU i mod N (clouds are read where the caller put them: host memory, or - on_device - memory of THAT GPU); every GPU
+// registers its pairs on `in_flight` streams; one ncclAllGather of the per-GPU record tables; the winner is the valid record
+// (converged && score < score_thr, loop_closure.cpp:129) with the smallest score, ties to the lowest pair id.
+extern "C" int qn_multi_align_best(qn_multi* m, const qn_pair_desc* pairs, uint32_t n_pairs, double score_thr,
+                                   qn_pair_record* records, qn_pair_record* best, int* best_found) {
+  if (!m || (n_pairs && !pairs) || !best || !best_found) return QN_ERR_INVALID_ARG;
+  *best_found = 0; memset(best, 0, sizeof(*best)); best->pair_id = -1; best->fitness = DBL_MAX;
+  if (n_pairs == 0) return QN_OK;
+  const int N = m->n_gpus;
+  const uint32_t per = (n_pairs + N - 1) / N;
+  int rc = multi_reserve(m, per);
+  if (rc != QN_OK) return rc;
+  // ---- the data path: independent registrations, no collective
+  std::vector<std::vector<qn_pair_record>> mine(N, std::vector<qn_pair_record>(per));
+  for (int g = 0; g < N; g++) for (uint32_t l = 0; l < per; l++) { qn_pair_record& r = mine[g][l]; memset(&r, 0, sizeof(r)); r.pair_id = -1; r.status = QN_ERR_EMPTY_CLOUD; r.fitness = DBL_MAX; }
+  std::vector<std::atomic<uint32_t>> next(N);
+  for (auto& a : next) a.store(0);
+  auto worker = [&](int g, qn_ctx* c) {
+    for (;;) {
+      const uint32_t l = next[g].fetch_add(1);
+      const uint64_t i = (uint64_t)g + (uint64_t)l * N;
+      if (l >= per || i >= n_pairs) break;
+      const qn_pair_desc& p = pairs[i];
+      qn_gicp_result res; int valid = 0;
+      const int st = p.on_device ? qn_icp_alignment_device(c, p.src, p.ns, p.dst, p.nt, p.stride_bytes, score_thr, &res, &valid)
+                                 : qn_icp_alignment(c, p.src, p.ns, p.dst, p.nt, p.stride_bytes, score_thr, &res, &valid);
+      qn_pair_record& r = mine[g][l];
+      r.pair_id = (int32_t)i; r.status = st; r.valid = (st == QN_OK && valid) ? 1 : 0; r.converged = st == QN_OK ? res.converged : 0;
+      r.iterations = st == QN_OK ? res.iterations : 0; r.fitness = st == QN_OK ? res.fitness : DBL_MAX;
+      if (st == QN_OK) memcpy(r.T, res.T, sizeof(r.T)); else for (int k = 0; k < 16; k++) r.T[k] = (k % 5 == 0) ? 1.f : 0.f;
+    }
+  };
+  std::vector<std::thread> th;
+  for (int g = 0; g < N; g++) for (int s = 0; s < m->in_flight; s++) th.emplace_back(worker, g, m->ctx[g][s]);
+  for (auto& t : th) t.join();
+  // ---- the one exchange step: gather the record tables (N x per x 96 bytes: latency-bound, ring or tree does not matter at this size)
+  for (int g = 0; g < N; g++) {
+    if (hipSetDevice(m->dev[g]) != hipSuccess || hipMemcpyAsync(m->d_send[g], mine[g].data(), sizeof(qn_pair_record) * per, hipMemcpyHostToDevice, m->stream[g]) != hipSuccess) { m->last_error = "upload of the record table failed"; return QN_ERR_HIP; }
+  }
+  ncclResult_t nr = m->p_group_start();
+  for (int g = 0; g < N && nr == ncclSuccess; g++) nr = m->p_all_gather(m->d_send[g], m->d_recv[g], sizeof(qn_pair_record) * per, ncclChar, m->comm[g], m->stream[g]);
+  const ncclResult_t ne = m->p_group_end();
+  if (nr == ncclSuccess) nr = ne;
+  if (nr != ncclSuccess) { m->last_error = std::string("ncclAllGather: ") + m->p_err(nr); return QN_ERR_HIP; }
+  if (hipSetDevice(m->dev[0]) != hipSuccess || hipMemcpyAsync(m->h_all, m->d_recv[0], sizeof(qn_pair_record) * per * N, hipMemcpyDeviceToHost, m->stream[0]) != hipSuccess) { m->last_error = "download of the gathered table failed"; return QN_ERR_HIP; }
+  for (int g = 0; g < N; g++) { if (hipSetDevice(m->dev[g]) != hipSuccess || hipStreamSynchronize(m->stream[g]) != hipSuccess) { m->last_error = "stream synchronisation after the gather failed"; return QN_ERR_HIP; } }
+  // ---- the winner, from the GATHERED table (what rank 0 sees after the collective)
+  int status = QN_OK;
+  for (uint32_t e = 0; e < per * (uint32_t)N; e++) {
+    const qn_pair_record& r = m->h_all[e];
+    if (r.pair_id < 0) continue;
+    if (records) records[r.pair_id] = r;
+    if (r.status != QN_OK && r.status != QN_ERR_EMPTY_CLOUD) status = r.status;
+    if (r.valid && (r.fitness < best->fitness || (r.fitness == best->fitness && r.pair_id < best->pair_id) || !*best_found)) { *best = r; *best_found = 1; }
+  }
+  return status;
+}

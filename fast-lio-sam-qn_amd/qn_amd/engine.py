@@ -438,6 +438,56 @@ def icp_alignment_batch(contexts, pairs, score_thr=1.5):
     return results, list(valid), list(status)
 
 
+class PairRecord(C.Structure):
+    _fields_ = [("pair_id", C.c_int32), ("status", C.c_int32), ("valid", C.c_int32), ("converged", C.c_int32), ("iterations", C.c_int32),
+                ("reserved", C.c_int32), ("fitness", C.c_double), ("T", C.c_float * 16)]
+
+
+class MultiGpu:
+    """qn_multi_*: candidate pairs sharded pair i -> GPU i mod N inside one process, one RCCL all-gather of the result records."""
+
+    def __init__(self, n_gpus, max_points, in_flight=4, device_ids=None):
+        self._l = lib(); h = C.c_void_p()
+        self._l.qn_multi_last_error.restype = C.c_char_p; self._l.qn_multi_last_error.argtypes = [C.c_void_p]
+        self._l.qn_multi_destroy.argtypes = [C.c_void_p]
+        ids = None if device_ids is None else (C.c_int * n_gpus)(*device_ids)
+        st = self._l.qn_multi_init(C.c_int(n_gpus), ids, C.c_uint32(max_points), C.c_int(in_flight), C.byref(h))
+        if st != QN_OK:
+            raise EngineError(st, self._l.qn_status_str(st).decode() + ": " + self._l.qn_multi_last_error(None).decode())
+        self.h = h; self.n_gpus = n_gpus
+
+    def close(self):
+        if getattr(self, "h", None):
+            self._l.qn_multi_destroy(self.h); self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, st):
+        if st != QN_OK:
+            raise EngineError(st, self._l.qn_status_str(st).decode() + ": " + self._l.qn_multi_last_error(self.h).decode())
+
+    def set_params(self, p):
+        self._check(self._l.qn_multi_set_params(self.h, C.byref(p)))
+
+    def align_best(self, pairs, score_thr=1.5):
+        """pairs as for icp_alignment_batch.  -> (records[n], best or None)"""
+        n = len(pairs)
+        descs = (PairDesc * max(n, 1))(); keep = []
+        for i, (s, ns, d, nt, stride, dev) in enumerate(pairs):
+            if not dev:
+                s = np.ascontiguousarray(s, dtype=np.float32); d = np.ascontiguousarray(d, dtype=np.float32); keep += [s, d]
+                descs[i] = PairDesc(s.ctypes.data, ns, d.ctypes.data, nt, stride, 0)
+            else:
+                descs[i] = PairDesc(s, ns, d, nt, stride, 1)
+        recs = (PairRecord * max(n, 1))(); best = PairRecord(); found = C.c_int()
+        self._check(self._l.qn_multi_align_best(self.h, descs, C.c_uint32(n), C.c_double(score_thr), recs, C.byref(best), C.byref(found)))
+        return list(recs[:n]), (best if found.value else None)
+
+
 # ---------------------------------------------------------------------------------------- keyframe store / cloud assembly
 class KeyframeStore:
     """Device-resident keyframe clouds + LoopClosure::setSrcAndDstCloud on the GPU (loop_closure.cpp:58-108)."""

@@ -132,6 +132,33 @@ typedef struct {
 int  qn_icp_alignment_batch(qn_ctx* const* ctxs, uint32_t n_ctx, const qn_pair_desc* pairs, uint32_t n_pairs, double score_thr,
                             qn_gicp_result* results, int* valid, int* status);
 
+/* ---- candidate pairs sharded over the GPUs of one node (BASELINE "batch of 64 candidate keyframe pairs sharded
+ * across 8 MI355X, RCCL gather of best loop").  The reference registers ONE candidate per timer tick
+ * (fast_lio_sam_qn.cpp:213-219 -> loop_closure.cpp:168-205); the generalisation keeps every registration independent: pair i runs on
+ * GPU i mod N on one of `in_flight` contexts, no data-path collective, then ONE ncclAllGather (RCCL over xGMI) of the fixed-size
+ * records below and the host picks the valid record with the smallest score.  Single process, all GPUs (ncclCommInitAll), like the
+ * reference's single process.  qn_multi_init fails with QN_ERR_NO_DEVICE when fewer than n_gpus devices are visible.              */
+typedef struct qn_multi qn_multi;
+typedef struct {            /* 96 bytes */
+  int32_t pair_id;          /* index into `pairs`; -1 = padding slot of the gathered table                    */
+  int32_t status;           /* qn status of this pair's icpAlignment                                            */
+  int32_t valid;            /* is_valid_ (converged && score < score_thr, loop_closure.cpp:129)                 */
+  int32_t converged;        /* hasConverged()                                                                   */
+  int32_t iterations;
+  int32_t reserved;
+  double  fitness;          /* getFitnessScore()                                                                */
+  float   T[16];            /* getFinalTransformation(), row-major                                              */
+} qn_pair_record;
+int  qn_multi_init(int n_gpus, const int* device_ids /* NULL: 0 .. n_gpus-1 */, uint32_t max_points, int in_flight, qn_multi** out);
+void qn_multi_destroy(qn_multi*);
+const char* qn_multi_last_error(const qn_multi*);    /* NULL argument: why the last qn_multi_init on this thread failed */
+int  qn_multi_gpu_count(const qn_multi*);
+int  qn_multi_set_params(qn_multi*, const qn_gicp_params*);            /* loop_closure.cpp:9-16, on every context */
+/* pairs[i].src/dst: host buffers, or (on_device) buffers resident on GPU device_ids[i mod n_gpus].  records (optional, n_pairs
+ * entries) receives every pair's record as rank 0 holds them after the gather; *best / *best_found the winning loop.             */
+int  qn_multi_align_best(qn_multi*, const qn_pair_desc* pairs, uint32_t n_pairs, double score_thr,
+                         qn_pair_record* records, qn_pair_record* best, int* best_found);
+
 /* ---- Quatro coarse registration ---------------------------------------------------------- */
 /* The 10 constructor arguments of quatro<PointType>, in the order LoopClosure passes them
  * (loop_closure.cpp:18-27; struct QuatroConfig, include/loop_closure.h:38-50), plus the seed of the

@@ -65,3 +65,71 @@ def test_two_rank_gather_picks_same_winner_as_single_process(oracle):
     assert (w_multi is None) == (w_single is None)
     if w_single is not None:
         assert int(w_multi[0]) == int(w_single[0]) and np.allclose(w_multi[2:], w_single[2:])
+
+
+# ------------------------------------------------------------------ bench.py's own launcher: loud failures, no silent 1-rank runs
+def _run_bench(args, env=None, timeout=600):
+    import subprocess
+    e = dict(os.environ); e.pop("WORLD_SIZE", None); e.pop("RANK", None); e.pop("LOCAL_RANK", None)
+    e.update(env or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=e, capture_output=True, text=True, timeout=timeout)
+
+
+def test_bench_refuses_more_ranks_than_gpus():
+    """`--gpus N` used to be parsed and ignored.  Now a plain launch starts N ranks itself and, with fewer than N GPUs
+    visible, fails loudly instead of measuring one rank."""
+    ngpu = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    r = _run_bench(["--gpus", str(ngpu + 2), "--steps", "4", "--warmup", "1"])
+    assert r.returncode != 0 and ("needs %d GPUs" % (ngpu + 2)) in (r.stderr + r.stdout)
+
+
+def test_bench_refuses_world_size_mismatch():
+    r = _run_bench(["--gpus", "1", "--steps", "4"], env={"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"})
+    assert r.returncode != 0 and "WORLD_SIZE=2" in (r.stderr + r.stdout)
+
+
+# ------------------------------------------------------------------ GPU: the N > 1 path THROUGH THE ENGINE
+@pytest.mark.gpu
+def test_bench_two_ranks_on_one_gpu_through_the_engine():
+    """2 ranks (gloo for the collectives, both on cuda:0) run bench.py's own sharding / gather / arg-min with real registrations."""
+    import json
+    r = _run_bench(["--gpus", "2", "--steps", "8", "--warmup", "2", "--pairs", "4", "--in-flight", "2", "--batch-pairs", "8", "--no-cpu-baseline", "--no-quatro"],
+                   env={"QN_BENCH_BACKEND": "gloo"}, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    j = json.loads(line)
+    assert j["n_gpus"] == 2 and j["value"] > 0 and j["steps"] == 8
+    b = j["config"]["batch64"]
+    assert b["pairs"] == 8 and b["pairs_per_s"] > 0 and 0 <= b["winner_pair"] < 8
+
+
+@pytest.mark.gpu
+def test_qn_multi_align_best_matches_single_context(oracle):
+    """qn_multi_init / qn_multi_align_best (single process, RCCL communicator, one all-gather of the 96-byte records) on the GPUs of
+    this box: every record equals a plain qn_icp_alignment of that pair, the winner is the arg-min over valid records."""
+    from qn_amd import engine, synth
+    ngpu = torch.cuda.device_count()
+    mg = engine.MultiGpu(ngpu, 8192, in_flight=2)
+    gg = engine.GicpParams(); engine.lib().qn_gicp_default_params(__import__("ctypes").byref(gg))
+    gg.k_correspondences = 15; gg.max_iterations = 32; gg.max_corr_dist = 52.5; gg.transformation_epsilon = 0.01
+    mg.set_params(gg)
+    clouds = [synth.make_pair(220 + pid, 3000 + 100 * pid, extent=36.0, shift=1.0 + 3.0 * pid)[:2] for pid in range(7)]
+    recs, best = mg.align_best([(s, len(s), t, len(t), 12, 0) for s, t in clouds] + [(np.zeros((0, 3), np.float32), 0, clouds[0][1], len(clouds[0][1]), 12, 0)])
+    ctx = engine.Context(8192)
+    ref = [engine.icp_alignment(ctx, s, t) for s, t in clouds]
+    for pid, (r, e) in enumerate(zip(recs, ref)):
+        assert r.pair_id == pid and r.status == 0 and bool(r.valid) == e["valid"] and bool(r.converged) == e["converged"] and r.iterations == e["iterations"]
+        assert r.fitness == e["score"] and np.array_equal(np.array(r.T, dtype=np.float32).reshape(4, 4).astype(np.float64), e["T"])
+        o = oracle.icp_alignment(*clouds[pid])
+        assert bool(r.valid) == o["valid"] and abs(r.fitness - o["score"]) <= 1e-6 * o["score"]
+    assert recs[7].status == engine.QN_ERR_EMPTY_CLOUD and not recs[7].valid           # an empty candidate is an invalid registration, not a failure
+    ok = [r for r in recs[:7] if r.valid]
+    if ok:
+        w = min(ok, key=lambda r: (r.fitness, r.pair_id))
+        assert best is not None and best.pair_id == w.pair_id and best.fitness == w.fitness
+    else:
+        assert best is None
+    with pytest.raises(engine.EngineError) as ei:
+        engine.MultiGpu(ngpu + 1, 1024)
+    assert ei.value.status == engine.QN_ERR_NO_DEVICE
+    mg.close(); ctx.close()
