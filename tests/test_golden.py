@@ -187,6 +187,7 @@ def test_gpu_reproduces_quatro_golden(name):
     # device-pointer entry point: same answer with both clouds resident in HBM
     import torch
     s_d = torch.from_numpy(np.ascontiguousarray(d["src"])).cuda(); t_d = torch.from_numpy(np.ascontiguousarray(d["tgt"])).cuda()
+    q = engine.Quatro(ctx, **kw)                                   # parameters live in the context: back to optimizedMatching
     Td, vd = q.align_device(s_d.data_ptr(), len(d["src"]), t_d.data_ptr(), len(d["tgt"]), 12)
     assert vd == r["valid"] and np.array_equal(Td, r["T"])
     ctx.close()
