@@ -13,7 +13,7 @@ struct CloudBuf {                       // one point cloud, resident in HBM
   uint32_t* cell_of_pt = nullptr;       // [max_points]
   uint32_t* cell_start = nullptr;       // [max_cells + 1]
   uint32_t* counts = nullptr;           // [max_cells + 1] histogram / scatter cursors
-  double* cov = nullptr;                // [max_points][6] xx xy xz yy yz zz (f64), original order
+  double* nrm = nullptr;                // [max_points][3] plane normal (f64), original order: C = I - 0.999 n n^T
   qn::GridView grid{};
 };
 
@@ -28,10 +28,12 @@ struct qn_ctx {
   char* staging = nullptr;              // [max_points * 32] H2D landing zone for strided host clouds
   uint32_t* scan_sums = nullptr;
   qn::BBoxOut* bbox = nullptr; qn::BBoxOut* bbox_host = nullptr;
-  qn::GicpState* state = nullptr;
-  double* partials = nullptr; double* fit_psum = nullptr; uint32_t* fit_pcnt = nullptr;
+  qn::GicpState* state = nullptr;       // [2], double buffered: generation g in state[g & 1] (qn_gicp_kernels.cuh)
+  uint32_t gen = 0; int part_rows = 0;  // current generation; rows of the partial buffer written under it
+  double* partials = nullptr;           // [2][QN_ACC_MAX_BLOCKS][28]
+  double* fit_psum = nullptr; uint32_t* fit_pcnt = nullptr;
   qn_iter_trace* trace = nullptr; uint32_t trace_len = 0;
-  int32_t* corr = nullptr; int32_t* nn_idx = nullptr; int32_t* knn_idx = nullptr; float4* nn_ref = nullptr; double* cov_s_sorted = nullptr; qn::TargetRec* tgt_rec = nullptr; float* sqd = nullptr; float* sqd_fit = nullptr;
+  int32_t* corr = nullptr; int32_t* nn_idx = nullptr; int32_t* knn_idx = nullptr; float4* nn_ref = nullptr; double* nrm_s_sorted = nullptr; qn::TargetRec* tgt_rec = nullptr; float* sqd = nullptr; float* sqd_fit = nullptr;
   uint2* fb_list = nullptr; uint2* big_list = nullptr; uint32_t* fb_count2 = nullptr;
   float4* aligned = nullptr; bool aligned_valid = false;
   double* pose_tmp = nullptr; float* guess_tmp = nullptr;
@@ -54,6 +56,8 @@ struct qn_ctx {
   int knn_hist = 1;                     // 1: k-NN by histogram selection (wave_knn_hist), 0: sorted-list sink (wave_search + BestK)
   float margin_nn = 1.f, margin_knn = 2.f;   // first search radius in cells (1-NN of the first tick / k-NN of the covariances)
   int margin_nn_cap = 3, margin_knn_cap = 5, ticks_per_chunk = 8;
+  uint32_t tick_tb = 512;               // threads per block of k_tick (and of k_solve: both run the same row reduction)
+  int tick_occ = 4;                     // k_tick variant: waves per SIMD the register budget allows (4 = 128 VGPRs: other streams' kernels keep half of the register file)
   uint32_t* dbg_counters = nullptr;
   // verify_track (debug): scratch of the fresh search every tracked pass is compared with
   bool verify_track = false; int32_t* v_corr = nullptr; int32_t* v_nn_idx = nullptr; float* v_sqd = nullptr; float4* v_nn_ref = nullptr; uint32_t* v_counters = nullptr;

@@ -72,7 +72,7 @@ static int alloc_cloud(qn_ctx* c, CloudBuf& b) {
   HIPCHK(c, hipMalloc(&b.cell_of_pt, sizeof(uint32_t) * c->max_points));
   HIPCHK(c, hipMalloc(&b.cell_start, sizeof(uint32_t) * ((size_t)c->max_cells + 1)));
   HIPCHK(c, hipMalloc(&b.counts, sizeof(uint32_t) * ((size_t)c->max_cells + 1)));
-  HIPCHK(c, hipMalloc(&b.cov, sizeof(double) * 6 * c->max_points));
+  HIPCHK(c, hipMalloc(&b.nrm, sizeof(double) * 3 * c->max_points));
   return QN_OK;
 }
 
@@ -97,12 +97,12 @@ extern "C" int qn_ctx_create(int device, uint32_t max_points, qn_ctx** out) {
   CA(hipMalloc(&c->staging, (size_t)max_points * 32));
   CA(hipMalloc(&c->scan_sums, sizeof(uint32_t) * (c->max_cells / (QN_BLOCK * QN_SCAN_ITEMS) + 2)));
   CA(hipMalloc(&c->bbox, sizeof(BBoxOut)));
-  CA(hipMalloc(&c->state, sizeof(GicpState)));
-  CA(hipMalloc(&c->partials, sizeof(double) * QN_ACC_MAX_BLOCKS * QN_NPART));
+  CA(hipMalloc(&c->state, 2 * sizeof(GicpState)));
+  CA(hipMalloc(&c->partials, 2 * sizeof(double) * QN_ACC_MAX_BLOCKS * QN_NPART));
   CA(hipMalloc(&c->nn_idx, sizeof(int32_t) * max_points));
   CA(hipMalloc(&c->knn_idx, sizeof(int32_t) * (size_t)max_points * 32));
   CA(hipMalloc(&c->nn_ref, sizeof(float4) * max_points));
-  CA(hipMalloc(&c->cov_s_sorted, sizeof(double) * 6 * max_points));
+  CA(hipMalloc(&c->nrm_s_sorted, sizeof(double) * 3 * max_points));
   CA(hipMalloc(&c->tgt_rec, sizeof(TargetRec) * max_points));
   CA(hipMalloc(&c->fit_psum, sizeof(double) * QN_FIT_BLOCKS));
   CA(hipMalloc(&c->fit_pcnt, sizeof(uint32_t) * QN_FIT_BLOCKS));
@@ -119,7 +119,7 @@ extern "C" int qn_ctx_create(int device, uint32_t max_points, qn_ctx** out) {
   CA(hipHostMalloc(&c->result_host, sizeof(ResultBlock), hipHostMallocDefault));
   CA(hipHostMalloc(&c->bbox_host, sizeof(BBoxOut), hipHostMallocDefault));
   CA(hipHostMalloc(&c->scalar_host, 64 * sizeof(double), hipHostMallocDefault));
-  CA(hipMemsetAsync(c->state, 0, sizeof(GicpState), c->stream));
+  CA(hipMemsetAsync(c->state, 0, 2 * sizeof(GicpState), c->stream));
   CA(hipStreamSynchronize(c->stream));
 #undef CA
   *out = c;
@@ -131,9 +131,9 @@ extern "C" void qn_ctx_destroy(qn_ctx* c) {
   hipSetDevice(c->device);
   if (c->stream) hipStreamSynchronize(c->stream);
   c->prof_collect();
-  for (int w = 0; w < 2; w++) { CloudBuf& b = c->cloud[w]; hipFree(b.raw); hipFree(b.sorted); hipFree(b.cell_of_pt); hipFree(b.cell_start); hipFree(b.counts); hipFree(b.cov); }
+  for (int w = 0; w < 2; w++) { CloudBuf& b = c->cloud[w]; hipFree(b.raw); hipFree(b.sorted); hipFree(b.cell_of_pt); hipFree(b.cell_start); hipFree(b.counts); hipFree(b.nrm); }
   hipFree(c->staging); hipFree(c->scan_sums); hipFree(c->bbox); hipFree(c->state); hipFree(c->partials); hipFree(c->trace);
-  hipFree(c->nn_idx); hipFree(c->knn_idx); hipFree(c->nn_ref); hipFree(c->cov_s_sorted); hipFree(c->tgt_rec); hipFree(c->fit_psum); hipFree(c->fit_pcnt); hipFree(c->corr); hipFree(c->sqd); hipFree(c->sqd_fit); hipFree(c->fb_list); hipFree(c->big_list); hipFree(c->fb_count2); hipFree(c->aligned);
+  hipFree(c->nn_idx); hipFree(c->knn_idx); hipFree(c->nn_ref); hipFree(c->nrm_s_sorted); hipFree(c->tgt_rec); hipFree(c->fit_psum); hipFree(c->fit_pcnt); hipFree(c->corr); hipFree(c->sqd); hipFree(c->sqd_fit); hipFree(c->fb_list); hipFree(c->big_list); hipFree(c->fb_count2); hipFree(c->aligned);
   for (int w = 0; w < 2; w++) { hipFree(c->q_normals[w]); hipFree(c->q_spfh[w]); hipFree(c->q_fpfh_s[w]); hipFree(c->q_fpfh[w]); hipFree(c->q_key[w]); }
   hipFree(c->q_hit); hipFree(c->q_list); hipFree(c->q_sel); hipFree(c->q_pairs); hipFree(c->q_counts); hipFree(c->q_T); hipFree(c->q_mean); hipFree(c->q_mean_psum);
   if (c->q_host) hipHostFree(c->q_host);
@@ -170,6 +170,12 @@ static GicpConfig make_cfg(const qn_ctx* c) {
   g.transformation_epsilon = p.transformation_epsilon; g.rotation_epsilon = p.rotation_epsilon; g.lm_init_lambda_factor = p.lm_init_lambda_factor;
   return g;
 }
+
+// double-buffered optimiser state / partial rows (qn_gicp_kernels.cuh): generation c->gen
+static inline GicpState* st_cur(qn_ctx* c) { return c->state + (c->gen & 1u); }
+static inline GicpState* st_nxt(qn_ctx* c) { return c->state + ((c->gen + 1u) & 1u); }
+static inline double* part_cur(qn_ctx* c) { return c->partials + (size_t)(c->gen & 1u) * QN_ACC_MAX_BLOCKS * QN_NPART; }
+static inline double* part_nxt(qn_ctx* c) { return c->partials + (size_t)((c->gen + 1u) & 1u) * QN_ACC_MAX_BLOCKS * QN_NPART; }
 
 // ------------------------------------------------------------------ setInputSource / setInputTarget
 // K1: pack -> bbox -> (host picks the cell size) -> count -> exclusive scan -> scatter.
@@ -267,21 +273,21 @@ static void launch_knn_cov(qn_ctx* c, CloudBuf& b, int k, int32_t* kidx, float* 
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_knn_hist<true, HCAP>), dim3(std::min<uint32_t>((b.n + 63) / 64, 512) * (QN_BLOCK / QN_KNN_BLOCK)), dim3(QN_KNN_BLOCK), 0, s, b.grid, k, r0, 64, kidx, kd2, c->fb_list, c->fb_count2, c->big_list, genc);
     // far / overflowing queries (isolated points, sparse far field): one per wave; its leftovers -> the sorted-list kernel (fb_list is free again)
     hipLaunchKernelGGL(k_knn_single, dim3(std::min<uint32_t>((b.n + 3) / 4, 2048)), dim3(QN_BLOCK), 0, s, b.grid, k, kidx, kd2, c->big_list, genc, c->fb_list, c->fb_count2 + 2);
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_knn_cov<KMAX, true, 4>), dim3(std::min<uint32_t>((b.n + 63) / 64, 1024)), dim3(QN_BLOCK), 0, s, b.grid, b.raw, k, r0, 64, b.cov, kidx, kd2, c->fb_list, c->fb_count2 + 2);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_knn_cov<KMAX, true, 4>), dim3(std::min<uint32_t>((b.n + 63) / 64, 1024)), dim3(QN_BLOCK), 0, s, b.grid, b.raw, k, r0, 64, b.nrm, kidx, kd2, c->fb_list, c->fb_count2 + 2);
     const uint32_t nbp = (b.n + QN_BLOCK - 1) / QN_BLOCK;
-    hipLaunchKernelGGL(k_cov_from_idx, dim3(nbp), dim3(QN_BLOCK), 0, s, b.raw, b.sorted, b.n, k, kidx, b.cov,
-                       &b == &c->cloud[0] ? c->cov_s_sorted : (double*)nullptr, &b == &c->cloud[0] ? (TargetRec*)nullptr : c->tgt_rec);   // + the fused ticks' layouts
+    hipLaunchKernelGGL(k_cov_from_idx, dim3(nbp), dim3(QN_BLOCK), 0, s, b.raw, b.sorted, b.n, k, kidx, b.nrm,
+                       &b == &c->cloud[0] ? c->nrm_s_sorted : (double*)nullptr, &b == &c->cloud[0] ? (TargetRec*)nullptr : c->tgt_rec);   // + the optimiser ticks' layouts
     return;
   }
   ProfScope ps(c, QN_K_KNN_COV);
   {                                         // sorted-list sink, 16 queries per wave x 4 candidate sub-slots (knn_hist = 0)
     const uint32_t nb = (b.n + QN_BLOCK / 4 - 1) / (QN_BLOCK / 4);
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_knn_cov<KMAX, false, 4>), dim3(nb), dim3(QN_BLOCK), 0, s, b.grid, b.raw, k, r0, 2, b.cov, kidx, kd2, c->fb_list, c->fb_count2);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_knn_cov<KMAX, false, 4>), dim3(nb), dim3(QN_BLOCK), 0, s, b.grid, b.raw, k, r0, 2, b.nrm, kidx, kd2, c->fb_list, c->fb_count2);
   }
-  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_knn_cov<KMAX, true, 4>), dim3(std::min<uint32_t>((b.n + 63) / 64, 512)), dim3(QN_BLOCK), 0, s, b.grid, b.raw, k, r0, 64, b.cov, kidx, kd2, c->fb_list, c->fb_count2);
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_knn_cov<KMAX, true, 4>), dim3(std::min<uint32_t>((b.n + 63) / 64, 512)), dim3(QN_BLOCK), 0, s, b.grid, b.raw, k, r0, 64, b.nrm, kidx, kd2, c->fb_list, c->fb_count2);
   const uint32_t nbp = (b.n + QN_BLOCK - 1) / QN_BLOCK;
-  hipLaunchKernelGGL(k_cov_from_idx, dim3(nbp), dim3(QN_BLOCK), 0, s, b.raw, b.sorted, b.n, k, kidx, b.cov,
-                     &b == &c->cloud[0] ? c->cov_s_sorted : (double*)nullptr, &b == &c->cloud[0] ? (TargetRec*)nullptr : c->tgt_rec);   // + the fused ticks' layouts
+  hipLaunchKernelGGL(k_cov_from_idx, dim3(nbp), dim3(QN_BLOCK), 0, s, b.raw, b.sorted, b.n, k, kidx, b.nrm,
+                     &b == &c->cloud[0] ? c->nrm_s_sorted : (double*)nullptr, &b == &c->cloud[0] ? (TargetRec*)nullptr : c->tgt_rec);   // + the optimiser ticks' layouts
 }
 static int compute_cov(qn_ctx* c, int which, int32_t* kidx, float* kd2) {
   if (!c || (which != 0 && which != 1)) return QN_ERR_INVALID_ARG;
@@ -312,21 +318,22 @@ static void enqueue_nn(qn_ctx* c, int mode /*0 align, 1 fitness*/, float* sqd_ou
   const uint32_t nb4 = (S.n + QN_BLOCK / 4 - 1) / (QN_BLOCK / 4);       // list passes: 4 waves per block
   const uint32_t nbt = (S.n + QN_BLOCK - 1) / QN_BLOCK;               // tracking: one query per lane
   const double thr2 = c->params.max_corr_dist * c->params.max_corr_dist;
-  uint32_t* fbc = &c->state->fb_count; uint32_t* bgc = &c->state->big_count;
+  GicpState* st = st_cur(c);
+  uint32_t* fbc = &st->fb_count; uint32_t* bgc = &st->big_count;
   const int big_blocks = tick <= 2 ? 4096 : 1024;                                           // waves with one far query each (idle blocks exit at once)
   const uint32_t fbb = std::min<uint32_t>(nb4, tick <= 2 ? 512 : 256);                     // list pass: wave-stride over the leftovers
   const float r0 = c->margin_nn * T.grid.cell;
   if (mode == 0) {
     { ProfScope ps(c, QN_K_NN_SEARCH);
-      if (seeded) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_nn_track<0, false>), dim3(nbt), dim3(QN_BLOCK), 0, s, S.grid, T.grid, T.raw, c->state, thr2, c->corr, sqd_out, c->nn_idx, c->nn_ref, c->fb_list, fbc, c->big_list, bgc, nullptr, nullptr, nullptr);
-      else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_nn_search<0, false, QN_NN_BLOCK>), dim3(nb), dim3(QN_NN_BLOCK), 0, s, S.grid, T.grid, c->state, thr2, r0, c->nn_rounds, c->corr, sqd_out, c->nn_idx, c->nn_ref, c->fb_list, fbc, c->big_list, bgc, 0, c->big_ratio); }
+      if (seeded) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_nn_track<0>), dim3(nbt), dim3(QN_BLOCK), 0, s, S.grid, T.grid, T.raw, st, thr2, c->corr, sqd_out, c->nn_idx, c->nn_ref, c->fb_list, fbc, c->big_list, bgc);
+      else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_nn_search<0, false, QN_NN_BLOCK>), dim3(nb), dim3(QN_NN_BLOCK), 0, s, S.grid, T.grid, st, thr2, r0, c->nn_rounds, c->corr, sqd_out, c->nn_idx, c->nn_ref, c->fb_list, fbc, c->big_list, bgc, 0, c->big_ratio); }
     { ProfScope ps(c, QN_K_NN_FALLBACK);
-      hipLaunchKernelGGL(HIP_KERNEL_NAME(k_nn_search<0, true, QN_BLOCK>), dim3(fbb + big_blocks), dim3(QN_BLOCK), 0, s, S.grid, T.grid, c->state, thr2, r0, 64, c->corr, sqd_out, c->nn_idx, c->nn_ref, c->fb_list, fbc, c->big_list, bgc, big_blocks, c->big_ratio); }
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(k_nn_search<0, true, QN_BLOCK>), dim3(fbb + big_blocks), dim3(QN_BLOCK), 0, s, S.grid, T.grid, st, thr2, r0, 64, c->corr, sqd_out, c->nn_idx, c->nn_ref, c->fb_list, fbc, c->big_list, bgc, big_blocks, c->big_ratio); }
   } else {
     ProfScope ps(c, QN_K_FITNESS);
-    if (seeded) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_nn_track<1, false>), dim3(nbt), dim3(QN_BLOCK), 0, s, S.grid, T.grid, T.raw, c->state, thr2, c->corr, sqd_out, c->nn_idx, c->nn_ref, c->fb_list, fbc, c->big_list, bgc, nullptr, nullptr, nullptr);
-    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_nn_search<1, false, QN_NN_BLOCK>), dim3(nb), dim3(QN_NN_BLOCK), 0, s, S.grid, T.grid, c->state, thr2, r0, 1, c->corr, sqd_out, c->nn_idx, c->nn_ref, c->fb_list, fbc, c->big_list, bgc, 0, c->big_ratio);
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_nn_search<1, true, QN_BLOCK>), dim3(fbb + big_blocks), dim3(QN_BLOCK), 0, s, S.grid, T.grid, c->state, thr2, r0, 64, c->corr, sqd_out, c->nn_idx, c->nn_ref, c->fb_list, fbc, c->big_list, bgc, big_blocks, c->big_ratio);
+    if (seeded) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_nn_track<1>), dim3(nbt), dim3(QN_BLOCK), 0, s, S.grid, T.grid, T.raw, st, thr2, c->corr, sqd_out, c->nn_idx, c->nn_ref, c->fb_list, fbc, c->big_list, bgc);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_nn_search<1, false, QN_NN_BLOCK>), dim3(nb), dim3(QN_NN_BLOCK), 0, s, S.grid, T.grid, st, thr2, r0, 1, c->corr, sqd_out, c->nn_idx, c->nn_ref, c->fb_list, fbc, c->big_list, bgc, 0, c->big_ratio);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_nn_search<1, true, QN_BLOCK>), dim3(fbb + big_blocks), dim3(QN_BLOCK), 0, s, S.grid, T.grid, st, thr2, r0, 64, c->corr, sqd_out, c->nn_idx, c->nn_ref, c->fb_list, fbc, c->big_list, bgc, big_blocks, c->big_ratio);
   }
 }
 // debug knob "verify_track": a fresh, unseeded search of the current pose into scratch buffers, compared query by query with what
@@ -336,52 +343,68 @@ static void enqueue_verify(qn_ctx* c, bool fused) {
   CloudBuf &S = c->cloud[0], &T = c->cloud[1];
   const uint32_t nb = (S.n + QN_NN_BLOCK / 4 - 1) / (QN_NN_BLOCK / 4), nb4 = (S.n + QN_BLOCK / 4 - 1) / (QN_BLOCK / 4);
   const double thr2 = c->params.max_corr_dist * c->params.max_corr_dist;
-  uint32_t* fbc = &c->state->fb_count; uint32_t* bgc = &c->state->big_count;
+  GicpState* st = st_cur(c);
+  uint32_t* fbc = &st->fb_count; uint32_t* bgc = &st->big_count;
   const float r0 = c->margin_nn * T.grid.cell;
-  hipLaunchKernelGGL(k_reset_lists, dim3(1), dim3(64), 0, s, c->state);
-  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_nn_search<0, false, QN_NN_BLOCK>), dim3(nb), dim3(QN_NN_BLOCK), 0, s, S.grid, T.grid, c->state, thr2, r0, c->nn_rounds, c->v_corr, c->v_sqd, c->v_nn_idx, c->v_nn_ref, c->fb_list, fbc, c->big_list, bgc, 0, c->big_ratio);
-  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_nn_search<0, true, QN_BLOCK>), dim3(std::min<uint32_t>(nb4, 512) + 4096), dim3(QN_BLOCK), 0, s, S.grid, T.grid, c->state, thr2, r0, 64, c->v_corr, c->v_sqd, c->v_nn_idx, c->v_nn_ref, c->fb_list, fbc, c->big_list, bgc, 4096, c->big_ratio);
-  hipLaunchKernelGGL(k_verify_nn, dim3((S.n + 255) / 256), dim3(256), 0, s, S.n, c->state, c->nn_idx, c->v_nn_idx, fused ? (const float*)nullptr : c->sqd, c->v_sqd, c->corr, c->v_corr, c->v_counters);
-  hipLaunchKernelGGL(k_reset_lists, dim3(1), dim3(64), 0, s, c->state);
+  hipLaunchKernelGGL(k_reset_lists, dim3(1), dim3(64), 0, s, st);
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_nn_search<0, false, QN_NN_BLOCK>), dim3(nb), dim3(QN_NN_BLOCK), 0, s, S.grid, T.grid, st, thr2, r0, c->nn_rounds, c->v_corr, c->v_sqd, c->v_nn_idx, c->v_nn_ref, c->fb_list, fbc, c->big_list, bgc, 0, c->big_ratio);
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_nn_search<0, true, QN_BLOCK>), dim3(std::min<uint32_t>(nb4, 512) + 4096), dim3(QN_BLOCK), 0, s, S.grid, T.grid, st, thr2, r0, 64, c->v_corr, c->v_sqd, c->v_nn_idx, c->v_nn_ref, c->fb_list, fbc, c->big_list, bgc, 4096, c->big_ratio);
+  hipLaunchKernelGGL(k_verify_nn, dim3((S.n + 255) / 256), dim3(256), 0, s, S.n, st, c->nn_idx, c->v_nn_idx, fused ? (const float*)nullptr : c->sqd, c->v_sqd, c->corr, c->v_corr, c->v_counters);
+  hipLaunchKernelGGL(k_reset_lists, dim3(1), dim3(64), 0, s, st);
 }
 static uint32_t acc_blocks(const qn_ctx* c) { return std::min<uint32_t>((c->cloud[0].n + QN_BLOCK - 1) / QN_BLOCK, QN_ACC_MAX_BLOCKS); }
-static void enqueue_accumulate(qn_ctx* c) {
+static uint32_t tick_ppt(const qn_ctx* c) { return std::max<uint32_t>(1u, (c->cloud[0].n + c->tick_tb * QN_ACC_MAX_BLOCKS - 1) / (c->tick_tb * QN_ACC_MAX_BLOCKS)); }
+static uint32_t tick_blocks(const qn_ctx* c) { const uint32_t per = c->tick_tb * tick_ppt(c); return (c->cloud[0].n + per - 1) / per; }
+static void enqueue_accumulate(qn_ctx* c) {          // partial rows of the CURRENT generation
   ProfScope ps(c, QN_K_ACCUMULATE);
-  CloudBuf &S = c->cloud[0], &T = c->cloud[1];
-  hipLaunchKernelGGL(k_accumulate, dim3(acc_blocks(c)), dim3(QN_BLOCK), 0, c->stream, S.raw, S.n, T.raw, S.cov, T.cov, c->corr, c->state, c->partials);
+  CloudBuf &S = c->cloud[0];
+  hipLaunchKernelGGL(k_accumulate, dim3(acc_blocks(c)), dim3(QN_BLOCK), 0, c->stream, S.raw, S.n, S.nrm, c->tgt_rec, c->corr, st_cur(c), part_cur(c));
+  c->part_rows = (int)acc_blocks(c);
 }
-static void enqueue_solve(qn_ctx* c, int mode) {
+// one controller step as its own launch: generation g -> g + 1 (k_solve)
+static void enqueue_solve(qn_ctx* c, int mode, int will_produce) {
   ProfScope ps(c, QN_K_SOLVE);
-  hipLaunchKernelGGL(k_solve, dim3(1), dim3(QN_SOLVE_THREADS), 0, c->stream, c->state, c->partials, (int)acc_blocks(c), make_cfg(c), c->trace, mode);
+  if (c->tick_tb == 256) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_solve<256>), dim3(1), dim3(256), 0, c->stream, st_cur(c), st_nxt(c), part_cur(c), c->part_rows, make_cfg(c), c->trace, mode, will_produce);
+  else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_solve<512>), dim3(1), dim3(512), 0, c->stream, st_cur(c), st_nxt(c), part_cur(c), c->part_rows, make_cfg(c), c->trace, mode, will_produce);
+  c->gen++;
 }
-// one "tick" of the device-side state machine: [NN pass A, NN pass B, accumulate, solve]
-// Gauss-Newton ticks in the converged regime (tick >= 3): tracking, leftovers and accumulation in ONE kernel, then the solver.
+// One "tick" of the device-side state machine = [controller step on the previous tick's partial rows] + [body under the new state].
+// Tracked regime: ONE kernel (k_tick: controller in the prologue of every block, tracked NN + accumulation, LM trial passes included).
 static void enqueue_tick_fused(qn_ctx* c) {
-  hipStream_t s = c->stream;
   CloudBuf &S = c->cloud[0], &T = c->cloud[1];
-  const uint32_t nbt = (S.n + QN_BLOCK - 1) / QN_BLOCK;
-  const double thr2 = c->params.max_corr_dist * c->params.max_corr_dist;
-  { ProfScope ps(c, QN_K_GN_TICK_FUSED);        // tracking NN + in-kernel leftovers + accumulation in one kernel (an in-kernel last-block solver was measured slower than k_solve: DESIGN.md section 4)
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_nn_track<0, true>), dim3(nbt), dim3(QN_BLOCK), 0, s, S.grid, T.grid, T.raw, c->state, thr2, c->corr, c->sqd, c->nn_idx, c->nn_ref,
-                       c->fb_list, &c->state->fb_count, c->big_list, &c->state->big_count, c->cov_s_sorted, c->tgt_rec, c->partials); }
+  TickArgs a;
+  a.src = S.grid; a.tgt = T.grid; a.st_in = st_cur(c); a.st_out = st_nxt(c); a.part_in = part_cur(c); a.part_out = part_nxt(c); a.rows_in = c->part_rows;
+  a.cfg = make_cfg(c); a.trace = c->trace; a.thr2 = c->params.max_corr_dist * c->params.max_corr_dist;
+  a.nn_idx = c->nn_idx; a.nn_ref = c->nn_ref; a.nrm_s = c->nrm_s_sorted; a.tgt_rec = c->tgt_rec; a.ppt = tick_ppt(c);
+  { ProfScope ps(c, QN_K_GN_TICK_FUSED);
+    const dim3 gr(tick_blocks(c)), bl(c->tick_tb);
+#define QN_TICK_LAUNCH(TB, OCC) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_tick<TB, OCC>), gr, bl, 0, c->stream, a)
+    if (c->tick_tb == 256) { if (c->tick_occ >= 4) QN_TICK_LAUNCH(256, 4); else if (c->tick_occ == 3) QN_TICK_LAUNCH(256, 3); else QN_TICK_LAUNCH(256, 2); }
+    else { if (c->tick_occ >= 4) QN_TICK_LAUNCH(512, 4); else if (c->tick_occ == 3) QN_TICK_LAUNCH(512, 3); else QN_TICK_LAUNCH(512, 2); }
+#undef QN_TICK_LAUNCH
+  }
+  c->gen++; c->part_rows = (int)tick_blocks(c);
   if (c->verify_track) enqueue_verify(c, true);
-  enqueue_solve(c, 0);
 }
-static void enqueue_tick(qn_ctx* c, bool seeded, int tick) {
+// Unseeded regime (the first outer iterations, while the pose still moves by more than a few cells): controller launch, grid search +
+// list passes, accumulation.  `first`: the very first tick of an align has nothing to consume.
+static void enqueue_tick(qn_ctx* c, bool seeded, int tick, bool first) {
   if (tick < c->track_from_tick) seeded = false;
-  if (seeded && tick >= c->fused_from_tick && c->fused_ticks && c->params.optimizer == QN_OPT_GN && acc_blocks(c) == (c->cloud[0].n + QN_BLOCK - 1) / QN_BLOCK) { enqueue_tick_fused(c); return; }
+  if (seeded && tick >= c->fused_from_tick && c->fused_ticks) { enqueue_tick_fused(c); return; }
+  if (!first) enqueue_solve(c, 0, 1);
   enqueue_nn(c, 0, c->sqd, seeded, tick);
   if (c->verify_track && seeded) enqueue_verify(c, false);
-  enqueue_accumulate(c); enqueue_solve(c, 0);
+  enqueue_accumulate(c);
 }
 static void enqueue_epilogue(qn_ctx* c, double max_range, bool seeded) {       // fitness + output cloud; each kernel is a no-op until phase == done
+  GicpState* st = st_cur(c);
   enqueue_nn(c, 1, c->sqd_fit, seeded, 1);
   { ProfScope ps(c, QN_K_FITNESS);
-    hipLaunchKernelGGL(k_fitness_partial, dim3(QN_FIT_BLOCKS), dim3(QN_BLOCK), 0, c->stream, c->sqd_fit, c->cloud[0].n, max_range, c->state, c->fit_psum, c->fit_pcnt, 1);
-    hipLaunchKernelGGL(k_fitness_final, dim3(1), dim3(QN_FIT_BLOCKS), 0, c->stream, c->fit_psum, c->fit_pcnt, c->state, 1); }
+    hipLaunchKernelGGL(k_fitness_partial, dim3(QN_FIT_BLOCKS), dim3(QN_BLOCK), 0, c->stream, c->sqd_fit, c->cloud[0].n, max_range, st, c->fit_psum, c->fit_pcnt, 1);
+    hipLaunchKernelGGL(k_fitness_final, dim3(1), dim3(QN_FIT_BLOCKS), 0, c->stream, c->fit_psum, c->fit_pcnt, st, 1); }
   { ProfScope ps(c, QN_K_TRANSFORM);
-    hipLaunchKernelGGL(k_transform_cloud, dim3((c->cloud[0].n + QN_BLOCK - 1) / QN_BLOCK), dim3(QN_BLOCK), 0, c->stream, c->cloud[0].raw, c->cloud[0].n, c->state, c->aligned, 1); }
-  hipLaunchKernelGGL(k_finalize, dim3(1), dim3(64), 0, c->stream, c->state, c->result_host);
+    hipLaunchKernelGGL(k_transform_cloud, dim3((c->cloud[0].n + QN_BLOCK - 1) / QN_BLOCK), dim3(QN_BLOCK), 0, c->stream, c->cloud[0].raw, c->cloud[0].n, st, c->aligned, 1); }
+  hipLaunchKernelGGL(k_finalize, dim3(1), dim3(64), 0, c->stream, st, c->result_host);
 }
 
 static int ready(qn_ctx* c) {
@@ -397,9 +420,10 @@ extern "C" int qn_gicp_align(qn_ctx* c, const float guess[16], qn_gicp_result* o
   hipStream_t s = c->stream;
   const qn_gicp_params& p = c->params;
   if (guess) HIPCHK(c, hipMemcpyAsync(c->guess_tmp, guess, sizeof(float) * 16, hipMemcpyHostToDevice, s));
-  hipLaunchKernelGGL(k_init_state, dim3(1), dim3(64), 0, s, c->state, c->guess_tmp, guess ? 1 : 0, 0);
+  c->gen = 0; c->part_rows = 0;
+  hipLaunchKernelGGL(k_init_state, dim3(1), dim3(64), 0, s, st_cur(c), c->guess_tmp, guess ? 1 : 0, 0);
   const int maxit = p.force_iterations > 0 ? p.force_iterations : p.max_iterations;
-  if (maxit == 0) hipLaunchKernelGGL(k_set_pose, dim3(1), dim3(64), 0, s, c->state, c->pose_tmp, 2, 2);   // which=2: touch nothing, phase = done
+  if (maxit == 0) hipLaunchKernelGGL(k_set_pose, dim3(1), dim3(64), 0, s, st_cur(c), c->pose_tmp, 2, 2);   // which=2: touch nothing, phase = done
   // Ticks are enqueued in chunks with NO host round trip inside a chunk; kernels of ticks past
   // convergence exit on the `phase` word.  LM needs two ticks per outer iteration (linearize, trial error).
   const int per_outer = p.optimizer == QN_OPT_LM ? 2 : 1;
@@ -408,7 +432,8 @@ extern "C" int qn_gicp_align(qn_ctx* c, const float guess[16], qn_gicp_result* o
   c->result_host->phase = 0;
   bool seeded = false; int tick_no = 0;   // the first linearisation runs the full grid search; every later NN pass tracks from it
   for (;;) {
-    for (int t = 0; t < chunk; t++) { enqueue_tick(c, seeded, tick_no / per_outer); tick_no++; seeded = true; }
+    for (int t = 0; t < chunk; t++) { enqueue_tick(c, seeded, tick_no / per_outer, tick_no == 0); tick_no++; seeded = true; }
+    enqueue_solve(c, 0, 0);                                     // the controller step that consumes the chunk's last partial rows
     enqueue_epilogue(c, DBL_MAX, maxit > 0);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipStreamSynchronize(s));
@@ -429,9 +454,9 @@ extern "C" int qn_gicp_fitness(qn_ctx* c, double max_range, double* score) {
   if (!score) return QN_ERR_INVALID_ARG;
   HIPCHK(c, hipSetDevice(c->device));
   enqueue_nn(c, 1, c->sqd_fit, false);
-  hipLaunchKernelGGL(k_fitness_partial, dim3(QN_FIT_BLOCKS), dim3(QN_BLOCK), 0, c->stream, c->sqd_fit, c->cloud[0].n, max_range, c->state, c->fit_psum, c->fit_pcnt, 1);
-  hipLaunchKernelGGL(k_fitness_final, dim3(1), dim3(QN_FIT_BLOCKS), 0, c->stream, c->fit_psum, c->fit_pcnt, c->state, 1);
-  hipLaunchKernelGGL(k_finalize, dim3(1), dim3(64), 0, c->stream, c->state, c->result_host);
+  hipLaunchKernelGGL(k_fitness_partial, dim3(QN_FIT_BLOCKS), dim3(QN_BLOCK), 0, c->stream, c->sqd_fit, c->cloud[0].n, max_range, st_cur(c), c->fit_psum, c->fit_pcnt, 1);
+  hipLaunchKernelGGL(k_fitness_final, dim3(1), dim3(QN_FIT_BLOCKS), 0, c->stream, c->fit_psum, c->fit_pcnt, st_cur(c), 1);
+  hipLaunchKernelGGL(k_finalize, dim3(1), dim3(64), 0, c->stream, st_cur(c), c->result_host);
   HIPCHK(c, hipGetLastError());
   HIPCHK(c, hipStreamSynchronize(c->stream));
   c->prof_collect();
@@ -512,8 +537,13 @@ extern "C" int qn_gicp_get_covariances(qn_ctx* c, int which, double* out9) {
   if (!b.has_cov) return QN_ERR_NOT_READY;
   HIPCHK(c, hipSetDevice(c->device));
   std::vector<double> h((size_t)b.n * 6);
-  HIPCHK(c, hipMemcpyAsync(h.data(), b.cov, sizeof(double) * 6 * b.n, hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipStreamSynchronize(c->stream));
+  double* d6 = nullptr;                                                 // the engine keeps normals (C = I - 0.999 n n^T): rebuild the matrices for the read-back
+  HIPCHK(c, hipMalloc(&d6, sizeof(double) * 6 * b.n));
+  hipLaunchKernelGGL(k_cov_from_normals, dim3((b.n + 255) / 256), dim3(256), 0, c->stream, b.nrm, b.n, d6);
+  hipError_t ce = hipMemcpyAsync(h.data(), d6, sizeof(double) * 6 * b.n, hipMemcpyDeviceToHost, c->stream);
+  if (ce == hipSuccess) ce = hipStreamSynchronize(c->stream);
+  (void)hipFree(d6);
+  if (ce != hipSuccess) { c->set_error("covariance read-back", ce, __LINE__); return QN_ERR_HIP; }
   for (uint32_t i = 0; i < b.n; i++) {
     const double* s = &h[(size_t)i * 6]; double* o = out9 + (size_t)i * 9;
     o[0] = s[0]; o[1] = s[1]; o[2] = s[2]; o[3] = s[1]; o[4] = s[3]; o[5] = s[4]; o[6] = s[2]; o[7] = s[4]; o[8] = s[5];
@@ -548,10 +578,10 @@ extern "C" int qn_gicp_linearize(qn_ctx* c, const double T[16], double H[36], do
   HIPCHK(c, hipSetDevice(c->device));
   hipStream_t s = c->stream;
   HIPCHK(c, hipMemcpyAsync(c->pose_tmp, T, sizeof(double) * 16, hipMemcpyHostToDevice, s));
-  hipLaunchKernelGGL(k_set_pose, dim3(1), dim3(64), 0, s, c->state, c->pose_tmp, 0, 0);
-  enqueue_nn(c, 0, c->sqd, false); enqueue_accumulate(c); enqueue_solve(c, 1);
+  hipLaunchKernelGGL(k_set_pose, dim3(1), dim3(64), 0, s, st_cur(c), c->pose_tmp, 0, 0);
+  enqueue_nn(c, 0, c->sqd, false); enqueue_accumulate(c); enqueue_solve(c, 1, 0);
   GicpState* hs = (GicpState*)malloc(sizeof(GicpState));
-  hipError_t e = hipMemcpyAsync(hs, c->state, sizeof(GicpState), hipMemcpyDeviceToHost, s);
+  hipError_t e = hipMemcpyAsync(hs, st_cur(c), sizeof(GicpState), hipMemcpyDeviceToHost, s);
   if (e == hipSuccess && corr_out) e = hipMemcpyAsync(corr_out, c->corr, sizeof(int32_t) * c->cloud[0].n, hipMemcpyDeviceToHost, s);
   if (e == hipSuccess && sqd_out) e = hipMemcpyAsync(sqd_out, c->sqd, sizeof(float) * c->cloud[0].n, hipMemcpyDeviceToHost, s);
   if (e == hipSuccess) e = hipStreamSynchronize(s);
@@ -568,9 +598,9 @@ extern "C" int qn_gicp_compute_error(qn_ctx* c, const double T[16], double* err)
   HIPCHK(c, hipSetDevice(c->device));
   hipStream_t s = c->stream;
   HIPCHK(c, hipMemcpyAsync(c->pose_tmp, T, sizeof(double) * 16, hipMemcpyHostToDevice, s));
-  hipLaunchKernelGGL(k_set_pose, dim3(1), dim3(64), 0, s, c->state, c->pose_tmp, 1, 1);
-  enqueue_accumulate(c); enqueue_solve(c, 2);
-  HIPCHK(c, hipMemcpyAsync(c->scalar_host, &c->state->yi, sizeof(double), hipMemcpyDeviceToHost, s));
+  hipLaunchKernelGGL(k_set_pose, dim3(1), dim3(64), 0, s, st_cur(c), c->pose_tmp, 1, 1);
+  enqueue_accumulate(c); enqueue_solve(c, 2, 0);
+  HIPCHK(c, hipMemcpyAsync(c->scalar_host, &st_cur(c)->yi, sizeof(double), hipMemcpyDeviceToHost, s));
   HIPCHK(c, hipStreamSynchronize(s));
   *err = c->scalar_host[0];
   c->prof_collect();
@@ -607,6 +637,8 @@ extern "C" int qn_debug_set(qn_ctx* c, const char* key, double v) {
     for (int w = 0; w < 2; w++) c->cloud[w].grid.dbg = c->dbg_counters;
   }
   else if (k == "ticks_per_chunk") c->ticks_per_chunk = std::max(1, (int)v);
+  else if (k == "tick_occ") c->tick_occ = (int)v;
+  else if (k == "tick_tb") c->tick_tb = v >= 512 ? 512 : 256;
   else if (k == "verify_track") {
     if (v != 0 && !c->v_counters) {
       const size_t n = c->max_points;

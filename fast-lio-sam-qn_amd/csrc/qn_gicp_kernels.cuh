@@ -27,7 +27,12 @@ struct GicpState {
   uint32_t fb_count;                                // 16-query list length
   uint32_t trace_len;
   uint32_t big_count;                               // one-query-per-wave list length
+  int pending;                                      // 1: the partial rows written under THIS state have not been consumed by the controller yet
+  int reserved;
 };
+// The state is double buffered: generation g lives in state[g & 1] and the partial rows produced under it in partials[g & 1].  A
+// controller step (k_solve, or the prologue of k_tick in every block) reads generation g and writes generation g + 1, so no block
+// ever reads what another block of the same launch is writing.
 
 struct GicpConfig {                                 // by-value kernel argument
   int k, max_iterations, optimizer, lm_max_iterations, force_iterations;
@@ -73,12 +78,13 @@ static __global__ void k_scatter(const float4* __restrict__ pts, uint32_t n, con
 // C = V diag(1, 1, 1e-3) V^T with V the eigenvectors of cov (eigenvalues descending); from stored neighbour indices (ascending (d2, idx) order, -1 = missing): one point per lane.
 // Target-side record for the fused optimiser ticks: point and covariance of a target point in ONE 64-byte line
 // (a correspondence then costs one scattered cache line instead of two).
-struct __attribute__((aligned(64))) TargetRec { float4 p; double cov[6]; };
+// PLANE covariances are C = I - 0.999 n n^T: the record carries the normal (24 bytes) instead of six covariance entries.
+struct __attribute__((aligned(64))) TargetRec { float4 p; double n[3]; double pad[3]; };
 static_assert(sizeof(TargetRec) == 64, "TargetRec is one 64-byte line");
 // Threads walk the points in cell-sorted order (a block's points are spatial neighbours, so their k-NN gathers overlap in
 // L1/L2), blocks in XCD-aware order.
-static __global__ void __launch_bounds__(QN_BLOCK) k_cov_from_idx(const float4* __restrict__ raw, const float4* __restrict__ sorted, uint32_t n, int k, const int32_t* __restrict__ knn_idx, double* __restrict__ cov,
-                                                                  double* __restrict__ cov_sorted, TargetRec* __restrict__ rec) {
+static __global__ void __launch_bounds__(QN_BLOCK) k_cov_from_idx(const float4* __restrict__ raw, const float4* __restrict__ sorted, uint32_t n, int k, const int32_t* __restrict__ knn_idx, double* __restrict__ nrm,
+                                                                  double* __restrict__ nrm_sorted, TargetRec* __restrict__ rec) {
   const uint32_t spos = xcd_block(blockIdx.x, gridDim.x) * QN_BLOCK + threadIdx.x;
   if (spos >= n) return;
   const uint32_t i = __float_as_uint(sorted[spos].w);
@@ -86,19 +92,18 @@ static __global__ void __launch_bounds__(QN_BLOCK) k_cov_from_idx(const float4* 
   int found = 0;
   double mean[3] = {0, 0, 0};
   for (int j = 0; j < k; j++) { const int32_t u = nb[j]; if (u < 0) continue; const float4 p = raw[u]; mean[0] += (double)p.x; mean[1] += (double)p.y; mean[2] += (double)p.z; found++; }
-  double* cov_out = cov + (size_t)i * 6;
-  double co[6] = {0, 0, 0, 0, 0, 0};
-  // the layouts of the fused optimiser ticks are written here as well (cov_sorted: source, cell-sorted order; rec: target, 64-byte records)
+  double nv[3] = {0, 0, 0};                  // found == 0 cannot happen for a finite point (it is its own neighbour); a zero normal reads as C = I
+  // the layouts of the optimiser ticks are written here as well (nrm_sorted: source, cell-sorted order; rec: target, 64-byte records)
   auto store = [&]() __attribute__((always_inline)) {
 #pragma unroll
-    for (int u = 0; u < 6; u++) cov_out[u] = co[u];
-    if (cov_sorted) {
+    for (int u = 0; u < 3; u++) nrm[(size_t)i * 3 + u] = nv[u];
+    if (nrm_sorted) {
 #pragma unroll
-      for (int u = 0; u < 6; u++) cov_sorted[(size_t)spos * 6 + u] = co[u];
+      for (int u = 0; u < 3; u++) nrm_sorted[(size_t)spos * 3 + u] = nv[u];
     }
     if (rec) { TargetRec r; r.p = raw[i];
 #pragma unroll
-      for (int u = 0; u < 6; u++) r.cov[u] = co[u];
+      for (int u = 0; u < 3; u++) { r.n[u] = nv[u]; r.pad[u] = 0; }
       rec[i] = r; }
   };
   if (found == 0) { store(); return; }
@@ -114,18 +119,18 @@ static __global__ void __launch_bounds__(QN_BLOCK) k_cov_from_idx(const float4* 
   for (int t = 0; t < 6; t++) c[t] /= found;
   double w[3], V[3][3];
   sym_eig3(c, w, V);
-  const double vals[3] = {1.0, 1.0, 1e-3};
-  int t = 0;
-#pragma unroll
-  for (int a = 0; a < 3; a++)
-#pragma unroll
-    for (int b = a; b < 3; b++, t++) {
-      double s = 0;
-#pragma unroll
-      for (int e = 0; e < 3; e++) s += V[a][e] * vals[e] * V[b][e];
-      co[t] = s;
-    }
+  // C = V diag(1, 1, 1e-3) V^T = I - 0.999 v3 v3^T  (V orthonormal): keep v3, the eigenvector of the smallest eigenvalue
+  nv[0] = V[0][2]; nv[1] = V[1][2]; nv[2] = V[2][2];
   store();
+}
+
+// parity read-back: the 3x3 covariances the reference stores (A.1.3), rebuilt from the normals: xx xy xz yy yz zz
+static __global__ void k_cov_from_normals(const double* __restrict__ nrm, uint32_t n, double* __restrict__ cov6) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const double a = nrm[(size_t)i * 3], b = nrm[(size_t)i * 3 + 1], c = nrm[(size_t)i * 3 + 2];
+  double* o = cov6 + (size_t)i * 6;
+  o[0] = 1.0 - 0.999 * a * a; o[1] = -0.999 * a * b; o[2] = -0.999 * a * c; o[3] = 1.0 - 0.999 * b * b; o[4] = -0.999 * b * c; o[5] = 1.0 - 0.999 * c * c;
 }
 
 
@@ -290,44 +295,52 @@ __global__ void __launch_bounds__(BLOCK, 6) k_nn_search(GridView src, GridView t
 // phase 1: compute_error at the trial transform xi with the CACHED correspondences and the M of x0.
 // Fixed grid, fixed per-thread striding, fixed reduction tree => bitwise reproducible partials.
 // one correspondence's contribution: M = (C_B + R C_A R^T)^-1, e = mu_B - T mu_A, J = [skew(T mu_A) | -I];
-// acc[0..20] += upper J^T M J, acc[21..26] += J^T M e (both only when `lin`), acc[27] += e^T M e
-__device__ __forceinline__ void accumulate_point(const double R[3][3], const double T[3][4], const float4 pa, const float4 pb,
-                                                 const double* __restrict__ ca, const double* __restrict__ cb, const bool lin, double acc[QN_NPART]) {
-  const double CA[3][3] = {{ca[0], ca[1], ca[2]}, {ca[1], ca[3], ca[4]}, {ca[2], ca[4], ca[5]}};
-  double RC[3][3];
+// acc[0..20] += upper J^T M J, acc[21..26] += J^T M e (both only when `lin`), acc[27] += e^T M e.
+// PLANE-regularised covariances are exactly C = I - 0.999 n n^T, so the kernels carry the normals (3 f64 per point
+// instead of 6):  C_B + R C_A R^T = (I - 0.999 n_B n_B^T) + (I - 0.999 m m^T),  m = R n_A.
+// Rx: 3x4 pose whose rotation block transforms the source normal (x0); Tx: 3x4 pose the residual is evaluated at (x0 when linearising,
+// xi in an LM trial pass).  J = [skew(T mu_A) | -I] is mostly zeros and ones: the products are written out term by term, in the order
+// of the dense formula, so the sums are bit-identical to it (adding an exact 0 or multiplying by -1 does not round).
+__device__ __forceinline__ void accumulate_point_n(const double (*Rx)[4], const double (*Tx)[4], const float4 pa, const float4 pb,
+                                                   const double na[3], const double nb[3], const bool lin, double acc[QN_NPART]) {
+  double m[3];
 #pragma unroll
-  for (int a = 0; a < 3; a++)
-#pragma unroll
-    for (int b = 0; b < 3; b++) RC[a][b] = R[a][0] * CA[0][b] + R[a][1] * CA[1][b] + R[a][2] * CA[2][b];
+  for (int a = 0; a < 3; a++) m[a] = Rx[a][0] * na[0] + Rx[a][1] * na[1] + Rx[a][2] * na[2];
   M3 rcr;
-  const double CB[3][3] = {{cb[0], cb[1], cb[2]}, {cb[1], cb[3], cb[4]}, {cb[2], cb[4], cb[5]}};
 #pragma unroll
   for (int a = 0; a < 3; a++)
 #pragma unroll
-    for (int b = 0; b < 3; b++) rcr.m[a][b] = CB[a][b] + (RC[a][0] * R[b][0] + RC[a][1] * R[b][1] + RC[a][2] * R[b][2]);
+    for (int b = 0; b < 3; b++) rcr.m[a][b] = ((a == b ? 1.0 : 0.0) - 0.999 * nb[a] * nb[b]) + ((a == b ? 1.0 : 0.0) - 0.999 * m[a] * m[b]);
   const M3 M = m3_inverse(rcr);
   const double mA[3] = {(double)pa.x, (double)pa.y, (double)pa.z};
   double tA[3], e[3], Me[3];
 #pragma unroll
-  for (int r = 0; r < 3; r++) tA[r] = T[r][0] * mA[0] + T[r][1] * mA[1] + T[r][2] * mA[2] + T[r][3];
+  for (int r = 0; r < 3; r++) tA[r] = Tx[r][0] * mA[0] + Tx[r][1] * mA[1] + Tx[r][2] * mA[2] + Tx[r][3];
   e[0] = (double)pb.x - tA[0]; e[1] = (double)pb.y - tA[1]; e[2] = (double)pb.z - tA[2];
 #pragma unroll
   for (int r = 0; r < 3; r++) Me[r] = M.m[r][0] * e[0] + M.m[r][1] * e[1] + M.m[r][2] * e[2];
   acc[27] += e[0] * Me[0] + e[1] * Me[1] + e[2] * Me[2];
   if (lin) {
-    const double J[3][6] = {{0, -tA[2], tA[1], -1, 0, 0}, {tA[2], 0, -tA[0], 0, -1, 0}, {-tA[1], tA[0], 0, 0, 0, -1}};
-    double MJ[3][6];
+    const double x = tA[0], y = tA[1], z = tA[2];
+    // MS = M skew(tA): column 0 = M (0, z, -y), column 1 = M (-z, 0, x), column 2 = M (y, -x, 0);  M J = [MS | -M]
+    double MS[3][3];
 #pragma unroll
-    for (int r = 0; r < 3; r++)
-#pragma unroll
-      for (int c = 0; c < 6; c++) MJ[r][c] = M.m[r][0] * J[0][c] + M.m[r][1] * J[1][c] + M.m[r][2] * J[2][c];
-    int t = 0;
-#pragma unroll
-    for (int r = 0; r < 6; r++)
-#pragma unroll
-      for (int c = r; c < 6; c++, t++) acc[t] += J[0][r] * MJ[0][c] + J[1][r] * MJ[1][c] + J[2][r] * MJ[2][c];
-#pragma unroll
-    for (int r = 0; r < 6; r++) acc[21 + r] += J[0][r] * Me[0] + J[1][r] * Me[1] + J[2][r] * Me[2];
+    for (int r = 0; r < 3; r++) { MS[r][0] = M.m[r][1] * z + M.m[r][2] * (-y); MS[r][1] = M.m[r][0] * (-z) + M.m[r][2] * x; MS[r][2] = M.m[r][0] * y + M.m[r][1] * (-x); }
+    // upper J^T M J, row-major over (r, c >= r):  rows 0..2 = skew(tA)^T [MS | -M], rows 3..5 = M
+    // row 0: J[:,0] = (0, z, -y)
+    acc[0] += z * MS[1][0] + (-y) * MS[2][0]; acc[1] += z * MS[1][1] + (-y) * MS[2][1]; acc[2] += z * MS[1][2] + (-y) * MS[2][2];
+    acc[3] += z * (-M.m[1][0]) + (-y) * (-M.m[2][0]); acc[4] += z * (-M.m[1][1]) + (-y) * (-M.m[2][1]); acc[5] += z * (-M.m[1][2]) + (-y) * (-M.m[2][2]);
+    // row 1: J[:,1] = (-z, 0, x)
+    acc[6] += (-z) * MS[0][1] + x * MS[2][1]; acc[7] += (-z) * MS[0][2] + x * MS[2][2];
+    acc[8] += (-z) * (-M.m[0][0]) + x * (-M.m[2][0]); acc[9] += (-z) * (-M.m[0][1]) + x * (-M.m[2][1]); acc[10] += (-z) * (-M.m[0][2]) + x * (-M.m[2][2]);
+    // row 2: J[:,2] = (y, -x, 0)
+    acc[11] += y * MS[0][2] + (-x) * MS[1][2];
+    acc[12] += y * (-M.m[0][0]) + (-x) * (-M.m[1][0]); acc[13] += y * (-M.m[0][1]) + (-x) * (-M.m[1][1]); acc[14] += y * (-M.m[0][2]) + (-x) * (-M.m[1][2]);
+    // rows 3..5: (-I)^T (-M) = M
+    acc[15] += M.m[0][0]; acc[16] += M.m[0][1]; acc[17] += M.m[0][2]; acc[18] += M.m[1][1]; acc[19] += M.m[1][2]; acc[20] += M.m[2][2];
+    // J^T M e
+    acc[21] += z * Me[1] + (-y) * Me[2]; acc[22] += (-z) * Me[0] + x * Me[2]; acc[23] += y * Me[0] + (-x) * Me[1];
+    acc[24] += -Me[0]; acc[25] += -Me[1]; acc[26] += -Me[2];
   }
 }
 
@@ -350,25 +363,27 @@ __device__ __forceinline__ void reduce_block_partials(const double acc[QN_NPART]
   }
 }
 
-static __global__ void __launch_bounds__(QN_BLOCK) k_accumulate(const float4* __restrict__ src_raw, uint32_t ns, const float4* __restrict__ tgt_raw,
-                                                         const double* __restrict__ cov_s, const double* __restrict__ cov_t,
+static __global__ void __launch_bounds__(QN_BLOCK) k_accumulate(const float4* __restrict__ src_raw, uint32_t ns, const double* __restrict__ nrm_s, const TargetRec* __restrict__ tgt_rec,
                                                          const int32_t* __restrict__ corr, const GicpState* __restrict__ st,
                                                          double* __restrict__ partials) {
   __shared__ double red[QN_BLOCK / 64][QN_NPART];
   const int phase = st->phase;
   if (phase == 2) return;
-  double R[3][3], T[3][4];
+  double R[3][4], T[3][4];
 #pragma unroll
   for (int a = 0; a < 3; a++)
 #pragma unroll
-    for (int b = 0; b < 4; b++) { T[a][b] = phase == 0 ? st->x0[4 * a + b] : st->xi[4 * a + b]; if (b < 3) R[a][b] = st->x0[4 * a + b]; }
+    for (int b = 0; b < 4; b++) { T[a][b] = phase == 0 ? st->x0[4 * a + b] : st->xi[4 * a + b]; R[a][b] = st->x0[4 * a + b]; }
   double acc[QN_NPART];
 #pragma unroll
   for (int t = 0; t < QN_NPART; t++) acc[t] = 0;
   for (uint32_t i = blockIdx.x * QN_BLOCK + threadIdx.x; i < ns; i += gridDim.x * QN_BLOCK) {
     const int j = corr[i];
     if (j < 0) continue;
-    accumulate_point(R, T, src_raw[i], tgt_raw[j], cov_s + (size_t)i * 6, cov_t + (size_t)j * 6, phase == 0, acc);
+    const TargetRec* rec = tgt_rec + j;
+    const double na[3] = {nrm_s[(size_t)i * 3], nrm_s[(size_t)i * 3 + 1], nrm_s[(size_t)i * 3 + 2]};
+    const double nb[3] = {rec->n[0], rec->n[1], rec->n[2]};
+    accumulate_point_n(R, T, src_raw[i], rec->p, na, nb, phase == 0, acc);
   }
   reduce_block_partials(acc, phase == 0, partials, red, blockIdx.x);
 }
@@ -387,9 +402,8 @@ static __global__ void __launch_bounds__(QN_BLOCK) k_accumulate(const float4* __
 // j0 is still the unique nearest neighbour and the scan is skipped - bit-identical result, no search.
 // As the optimiser converges delta -> 0 and almost every query takes this path.
 //
-// FUSED (MODE 0, Gauss-Newton, converged regime): leftovers with a big ball are resolved inside the kernel, one at a
-// time by the whole wave (wave_search_single), and every lane adds its correspondence's contribution to the block's 28
-// partial sums - no list pass and no separate accumulate kernel in that tick.
+// The optimiser ticks of the tracked regime use the same logic inside k_tick (qn_tick.cuh); this kernel serves the fitness pass
+// (MODE 1) and the unfused / verification path (MODE 0).
 #define QN_TRACK_SEG 8
 // The pruning inequality  d(q, p_j0) + |q - q_ref| < d_other  evaluated in f32 with a margin that dominates every rounding
 // error involved.  Exact quantities: D0 = |q - p_j0|, DELTA = |q - q_ref|, B = the stored bound.  Computed: d0 (3 subtractions,
@@ -403,14 +417,11 @@ static __global__ void __launch_bounds__(QN_BLOCK) k_accumulate(const float4* __
 __device__ __forceinline__ bool track_bound_holds(float d0, float delta, float bound) {
   return (sqrtf(d0) + delta) * 1.000004f < bound;
 }
-template <int MODE, bool FUSED>
+template <int MODE>
 __global__ void __launch_bounds__(QN_BLOCK, 6) k_nn_track(GridView src, GridView tgt, const float4* __restrict__ tgt_raw, const GicpState* __restrict__ st,
                                                        double thr2, int32_t* __restrict__ corr, float* __restrict__ sqd, int32_t* __restrict__ nn_idx,
                                                        float4* __restrict__ nn_ref, uint2* __restrict__ fb_list, uint32_t* __restrict__ fb_count,
-                                                       uint2* __restrict__ big_list, uint32_t* __restrict__ big_count,
-                                                       const double* __restrict__ cov_s_sorted, const TargetRec* __restrict__ tgt_rec, double* __restrict__ partials) {
-  __shared__ WaveLds lds[FUSED ? QN_BLOCK / 64 : 1];
-  __shared__ double red[FUSED ? QN_BLOCK / 64 : 1][QN_NPART];
+                                                       uint2* __restrict__ big_list, uint32_t* __restrict__ big_count) {
   if (MODE == 0 && st->phase != 0) return;
   if (MODE == 1 && st->phase != 2) return;
   float Tf[12];
@@ -418,25 +429,20 @@ __global__ void __launch_bounds__(QN_BLOCK, 6) k_nn_track(GridView src, GridView
   for (int j = 0; j < 12; j++) Tf[j] = (float)st->x0[j];
   const uint32_t lblk = xcd_block(blockIdx.x, gridDim.x);          // XCD x tracks one contiguous eighth of the sorted queries
   const uint32_t t = lblk * QN_BLOCK + threadIdx.x;
-  const bool valid = t < src.n;
-  if (!FUSED && !valid) return;
+  if (t >= src.n) return;
   const float INF = __int_as_float(0x7f800000);
-  const float4 p = valid ? src.pts[t] : make_float4(0, 0, 0, 0);
+  const float4 p = src.pts[t];
   const uint32_t i = __float_as_uint(p.w);
   float qx, qy, qz; xform_query<MODE>(Tf, p.x, p.y, p.z, qx, qy, qz);
   unsigned long long best = QN_INF_KEY; float second = INF, d_unseen = INF;
-  bool rescanned = false, big = false;
+  bool rescanned = false, big = false, noseed = false;              // noseed: nn_idx = -1 after a non-finite pose, or an index from another target
   float r = 0.f, delta = 0.f;
-  bool noseed = false;                                              // no usable seed (nn_idx = -1 after a non-finite pose, or an index from another target): unseeded search
   const bool finite_q = (qx - qx == 0.f) && (qy - qy == 0.f) && (qz - qz == 0.f);   // a non-finite query has no neighbour: corr = -1, like the first search
-  if (valid && finite_q) {
-    const uint32_t j0 = (uint32_t)nn_idx[t];
-    if (j0 >= tgt.n) { noseed = true; big = true; r = tgt.cell; }
-  }
-  if (valid && finite_q && !noseed) {
-    const uint32_t j0 = (uint32_t)nn_idx[t];
+  const uint32_t j0 = (uint32_t)nn_idx[t];
+  if (finite_q && j0 >= tgt.n) { noseed = true; big = true; r = tgt.cell; }
+  if (finite_q && !noseed) {
     const float4 ref = nn_ref[t];
-    const float4 p0 = FUSED ? tgt_rec[j0].p : tgt_raw[j0];          // FUSED: point and covariance of a target point share one 64-byte line
+    const float4 p0 = tgt_raw[j0];
     const float d0 = sqdist(qx, qy, qz, p0.x, p0.y, p0.z);
     best = pack_key(d0, j0);
     delta = sqrtf(sqdist(qx, qy, qz, ref.x, ref.y, ref.z));
@@ -449,7 +455,7 @@ __global__ void __launch_bounds__(QN_BLOCK, 6) k_nn_track(GridView src, GridView
       const int bz0 = cell_coord(qz - r, tgt.oz, tgt.inv_cell, tgt.nz), bz1 = cell_coord(qz + r, tgt.oz, tgt.inv_cell, tgt.nz);
       const int tx0 = bx0 >> 3, ntr = (bx1 >> 3) - tx0 + 1, nyr = by1 - by0 + 1;
       const int nseg = ntr * nyr * (bz1 - bz0 + 1);
-      if (!(d0 == d0) || nseg > QN_TRACK_SEG) big = true;           // big ball (or non-finite query)
+      if (!(d0 == d0) || nseg > QN_TRACK_SEG) big = true;           // big ball
       else {
         uint32_t s[QN_TRACK_SEG], e[QN_TRACK_SEG];
 #pragma unroll
@@ -485,50 +491,13 @@ __global__ void __launch_bounds__(QN_BLOCK, 6) k_nn_track(GridView src, GridView
       }
     }
   }
-  if (!FUSED) {
-    // list passes, seeded with the bound.  tight seed (the query barely moved since it was scanned) AND far neighbour: one query per wave
-    const bool tight_far = r > 2.5f * tgt.cell && delta < 0.25f * r;
-    wave_append(big_list, big_count, big && tight_far, make_uint2(t, __float_as_uint(r)));
-    wave_append(fb_list, fb_count, big && !tight_far, make_uint2(t, __float_as_uint(noseed ? -r : r)));    // negative: unseeded, continue from |r|
-    if (big) return;
-  } else {       // resolve the wave's big-ball queries here, 16 at a time, cooperatively (neighbouring queries' balls overlap: one shared candidate stream)
-    const int lane = threadIdx.x & 63;
-    for (unsigned long long pending = __ballot(big); pending != 0;) {
-      unsigned long long grp = 0, tmp = pending; int srcl = -1;
-      for (int sl = 0; sl < 16 && tmp != 0; sl++) { const int L = __ffsll((long long)tmp) - 1; if (sl == (lane & 15)) srcl = L; grp |= 1ull << L; tmp &= tmp - 1; }
-      pending &= ~grp;
-      const bool act = srcl >= 0;
-      const int sl_ = act ? srcl : 0;
-      const float ax = __shfl(qx, sl_), ay = __shfl(qy, sl_), az = __shfl(qz, sl_), ar = __shfl(r, sl_), ad = __shfl(delta, sl_);
-      float rs = (ad < 0.25f * ar) ? ar * 1.1f + 0.5f * tgt.cell : ar;           // tight seed: scan a little wider (bound pruning next time)
-      Best1 sink; sink.init();
-      float du = INF;
-      wave_search<4>(tgt, ax, ay, az, act, rs, INF, 64, sink, &lds[threadIdx.x >> 6], du);
-      const int slot = __popcll(grp & ((1ull << lane) - 1ull));                   // my query's slot in the group (results sit in lanes 0..15)
-      const unsigned long long rk = __shfl(sink.key, slot); const float rsec = __shfl(sink.second, slot), rdu = __shfl(du, slot);
-      if ((grp >> lane) & 1ull) { best = rk; second = rsec; d_unseen = rdu; rescanned = true; }
-    }
-  }
-  if (valid) {
-    if (!FUSED) store_nn<MODE>(best, i, t, thr2, corr, sqd, nn_idx);          // FUSED ticks feed the accumulation directly: corr / sqd are not needed
-    else nn_idx[t] = best != QN_INF_KEY ? (int32_t)key_idx(best) : -1;
-    if (MODE == 0 && rescanned) nn_ref[t] = make_float4(qx, qy, qz, fminf(sqrtf(second), d_unseen));
-  }
-  if (FUSED) {
-    double R[3][3], T[3][4];
-#pragma unroll
-    for (int a = 0; a < 3; a++)
-#pragma unroll
-      for (int b = 0; b < 4; b++) { T[a][b] = st->x0[4 * a + b]; if (b < 3) R[a][b] = st->x0[4 * a + b]; }
-    double acc[QN_NPART];
-#pragma unroll
-    for (int u = 0; u < QN_NPART; u++) acc[u] = 0;
-    if (valid && best != QN_INF_KEY && (double)key_d2(best) < thr2) {
-      const TargetRec* rec = tgt_rec + key_idx(best);
-      accumulate_point(R, T, make_float4(p.x, p.y, p.z, 1.f), rec->p, cov_s_sorted + (size_t)t * 6, rec->cov, true, acc);
-    }
-    reduce_block_partials(acc, true, partials, red, lblk);
-  }
+  // list passes, seeded with the bound.  tight seed (the query barely moved since it was scanned) AND far neighbour: one query per wave
+  const bool tight_far = r > 2.5f * tgt.cell && delta < 0.25f * r;
+  wave_append(big_list, big_count, big && tight_far, make_uint2(t, __float_as_uint(r)));
+  wave_append(fb_list, fb_count, big && !tight_far, make_uint2(t, __float_as_uint(noseed ? -r : r)));    // negative: unseeded, continue from |r|
+  if (big) return;
+  store_nn<MODE>(best, i, t, thr2, corr, sqd, nn_idx);
+  if (MODE == 0 && rescanned) nn_ref[t] = make_float4(qx, qy, qz, fminf(sqrtf(second), d_unseen));
 }
 
 // ------------------------------------------------------------------ verification of the tracked passes (debug knob "verify_track")
@@ -690,7 +659,7 @@ __device__ inline void d_propose(GicpState* st, double lambda, double (*A)[6]) {
 __device__ inline void d_finish_outer(GicpState* st, const GicpConfig& cfg, qn_iter_trace* trace, qn_iter_trace tr) {
   bool conv = d_is_converged(st->delta, cfg, &tr.max_dR, &tr.max_dt);
   if (cfg.force_iterations > 0) conv = false;
-  if (st->trace_len < QN_MAX_TRACE) trace[st->trace_len++] = tr;
+  if (st->trace_len < QN_MAX_TRACE) { if (trace) trace[st->trace_len] = tr; st->trace_len++; }
   st->outer += 1;
   const int maxit = cfg.force_iterations > 0 ? cfg.force_iterations : cfg.max_iterations;
   if (conv) { st->converged = 1; st->phase = 2; }
@@ -740,7 +709,7 @@ __device__ inline void solve_controller(GicpState* st, const double* sums, const
     if (d_is_converged(st->delta, cfg, nullptr, nullptr)) { d_finish_outer(st, cfg, trace, tr); return; }   // `return true` without accepting
     st->lambda = st->nu * st->lambda; st->nu = 2 * st->nu;
     if (st->inner >= cfg.lm_max_iterations) {                            // "lm not converged!!"
-      if (st->trace_len < QN_MAX_TRACE) trace[st->trace_len++] = tr;
+      if (st->trace_len < QN_MAX_TRACE) { if (trace) trace[st->trace_len] = tr; st->trace_len++; }
       st->outer += 1; st->lm_failed = 1; st->phase = 2; return;
     }
     d_propose(st, st->lambda, Awork);                                    // stay in phase 1
@@ -755,34 +724,56 @@ __device__ inline void solve_controller(GicpState* st, const double* sums, const
 }
 
 
-#define QN_SOLVE_THREADS 1024
-static __global__ void __launch_bounds__(QN_SOLVE_THREADS) k_solve(GicpState* gst, const double* __restrict__ partials, int nblk, GicpConfig cfg, qn_iter_trace* trace, int mode) {
+// Deterministic sum of `rows` partial rows (28 f64 each) by a block of NT threads: SEGS = NT / 28 strided sub-sums per component
+// (thread (s, c) adds rows s, s + SEGS, ... in order; a wave reads whole rows: coalesced 224-byte runs), combined in a fixed order.
+// The loads of up to 32 rows per thread are issued back to back (ONE memory round trip for <= 32 SEGS rows - the rows sit in
+// L2 / MALL, ~1 us away - instead of one per small batch).  Every caller (the prologue of k_tick in every block, k_solve) runs the same
+// instantiation and gets the same bits.  Ends with a __syncthreads(); sums[] is valid for every thread afterwards.
+#define QN_ROWS_BATCH 32
+template <int NT>
+__device__ __forceinline__ void reduce_partial_rows(const double* __restrict__ part, const int rows, double (*part_s)[NT / QN_NPART + 1], double* sums) {
+  constexpr int SEGS = NT / QN_NPART;
+  const int tid = threadIdx.x;
+  if (tid < QN_NPART * SEGS) {
+    const int s = tid / QN_NPART, c = tid - s * QN_NPART;
+    double a = 0;
+    for (int r0 = s; r0 < rows; r0 += SEGS * QN_ROWS_BATCH) {
+      double v[QN_ROWS_BATCH];
+#pragma unroll
+      for (int u = 0; u < QN_ROWS_BATCH; u++) { const int r = r0 + SEGS * u; v[u] = r < rows ? part[(size_t)r * QN_NPART + c] : 0.0; }
+#pragma unroll
+      for (int u = 0; u < QN_ROWS_BATCH; u++) a += v[u];
+    }
+    part_s[c][s] = a;
+  }
+  __syncthreads();
+  if (tid < QN_NPART) { double v = 0;
+#pragma unroll
+    for (int s = 0; s < SEGS; s++) v += part_s[tid][s]; sums[tid] = v; }
+  __syncthreads();
+}
+
+// One controller step as its own launch (unseeded first ticks, the end of a chunk, the debug entry points): generation g -> g + 1.
+// mode 0: the LM / GN controller, if partial rows are pending under st_in.  mode 1 / 2: reduce a linearisation / an error pass only.
+// will_produce: a body that writes partial rows under the NEW state follows (so they are pending for the next controller step).
+template <int NT>      // NT = the thread count of the k_tick variant in use: both run the same row reduction, bit for bit
+static __global__ void __launch_bounds__(NT) k_solve(const GicpState* __restrict__ st_in, GicpState* __restrict__ st_out, const double* __restrict__ partials, int rows,
+                                                                   GicpConfig cfg, qn_iter_trace* trace, int mode, int will_produce) {
   __shared__ double sums[QN_NPART];
-  __shared__ double part32[QN_NPART][33];
+  __shared__ double part8[QN_NPART][NT / QN_NPART + 1];
   __shared__ GicpState sh;                       // the controller works on an LDS copy: one coalesced read, one coalesced write-back
   __shared__ double Awork[6][6];
   static_assert(sizeof(GicpState) % 8 == 0, "GicpState is copied as 8-byte words");
-  const int phase = gst->phase;
-  if (phase == 2 && mode == 0) { if (threadIdx.x == 0) { gst->fb_count = 0; gst->big_count = 0; } return; }
-  for (int i = threadIdx.x; i < (int)(sizeof(GicpState) / 8); i += QN_SOLVE_THREADS) ((unsigned long long*)&sh)[i] = ((const unsigned long long*)gst)[i];
-  // deterministic reduction of nblk x 28 partials: 32 strided sub-sums per component (all loads of a thread
-  // are independent and issued together), combined in a fixed order
-  if (threadIdx.x < QN_NPART * 32) {
-    const int c = threadIdx.x >> 5, s = threadIdx.x & 31;
-    double v[QN_ACC_MAX_BLOCKS / 32];
-#pragma unroll
-    for (int u = 0; u < QN_ACC_MAX_BLOCKS / 32; u++) { const int b = s + 32 * u; v[u] = b < nblk ? partials[(size_t)b * QN_NPART + c] : 0.0; }
-    double a = 0;
-#pragma unroll
-    for (int u = 0; u < QN_ACC_MAX_BLOCKS / 32; u++) a += v[u];
-    part32[c][s] = a;
+  for (int i = threadIdx.x; i < (int)(sizeof(GicpState) / 8); i += NT) ((unsigned long long*)&sh)[i] = ((const unsigned long long*)st_in)[i];
+  __syncthreads();
+  const int phase = sh.phase;
+  if (mode != 0 || (sh.pending && phase != 2)) {
+    reduce_partial_rows<NT>(partials, rows, part8, sums);
+    if (threadIdx.x == 0) solve_controller(&sh, sums, cfg, trace, mode, phase, Awork);
   }
+  if (threadIdx.x == 0) { sh.fb_count = 0; sh.big_count = 0; sh.pending = (will_produce && sh.phase != 2) ? 1 : 0; }
   __syncthreads();
-  if (threadIdx.x < QN_NPART) { double v = 0; for (int s = 0; s < 32; s++) v += part32[threadIdx.x][s]; sums[threadIdx.x] = v; }
-  __syncthreads();
-  if (threadIdx.x == 0) solve_controller(&sh, sums, cfg, trace, mode, phase, Awork);
-  __syncthreads();
-  for (int i = threadIdx.x; i < (int)(sizeof(GicpState) / 8); i += QN_SOLVE_THREADS) ((unsigned long long*)gst)[i] = ((const unsigned long long*)&sh)[i];
+  for (int i = threadIdx.x; i < (int)(sizeof(GicpState) / 8); i += NT) ((unsigned long long*)st_out)[i] = ((const unsigned long long*)&sh)[i];
 }
 
 static __global__ void k_init_state(GicpState* st, const float* __restrict__ guess /* 16 or null */, int has_guess, int phase) {
@@ -792,11 +783,12 @@ static __global__ void k_init_state(GicpState* st, const float* __restrict__ gue
   for (int i = 0; i < 6; i++) { st->b[i] = 0; st->d[i] = 0; }
   st->y0 = st->yi = st->den = 0; st->lambda = -1.0; st->nu = 2.0; st->fitness = 0;
   st->outer = st->inner = 0; st->phase = phase; st->converged = 0; st->lm_failed = 0; st->fb_count = 0; st->big_count = 0; st->trace_len = 0;
+  st->pending = phase != 2 ? 1 : 0; st->reserved = 0;      // the first tick's body writes partial rows under this state
 }
 static __global__ void k_set_pose(GicpState* st, const double* __restrict__ T, int which /*0 x0, 1 xi, 2 neither*/, int phase) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   for (int i = 0; i < 16; i++) { if (which == 0) st->x0[i] = T[i]; else if (which == 1) st->xi[i] = T[i]; }
-  st->phase = phase; st->fb_count = 0; st->big_count = 0;
+  st->phase = phase; st->fb_count = 0; st->big_count = 0; st->pending = phase != 2 ? 1 : 0;
 }
 
 // ------------------------------------------------------------------ K7 fitness reduce, K8 transform

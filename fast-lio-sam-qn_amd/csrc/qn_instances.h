@@ -2,10 +2,11 @@
 // explicitly instantiated in separate translation units so that hipcc compiles them in parallel: qn_inst.hip is
 // compiled once per group with -DQN_INST_GROUP=<g>; everywhere else (QN_INST_GROUP undefined / 0) the same list
 // is a set of explicit-instantiation DECLARATIONS, so the host TU launches the kernels without compiling them.
-// Group 1 (this file): histogram k-NN, 1-NN searches, tracking, fused tick.  Groups 2-9: qn_instances_knn.h.
+// Group 1 (this file): histogram k-NN, 1-NN searches, tracking, the optimiser tick (k_tick).  Groups 2-9: qn_instances_knn.h.
 #pragma once
 #include "qn_instances_knn.h"
 #include "qn_gicp_kernels.cuh"
+#include "qn_tick.cuh"
 
 #if QN_INST_GROUP == 1
 #define QN_G1 template
@@ -18,7 +19,7 @@ namespace qn {
 #define QN_NN_BLOCK 256        // threads per block of the grid-form 1-NN passes (16 queries per wave)
 #define QN_KNN_HIST_ARGS (GridView, int, float, int, int32_t*, float*, uint2*, uint32_t*, uint2*, uint32_t*)
 #define QN_NN_SEARCH_ARGS (GridView, GridView, const GicpState*, double, float, int, int32_t*, float*, int32_t*, float4*, uint2*, uint32_t*, uint2*, uint32_t*, int, float)
-#define QN_NN_TRACK_ARGS (GridView, GridView, const float4*, const GicpState*, double, int32_t*, float*, int32_t*, float4*, uint2*, uint32_t*, uint2*, uint32_t*, const double*, const TargetRec*, double*)
+#define QN_NN_TRACK_ARGS (GridView, GridView, const float4*, const GicpState*, double, int32_t*, float*, int32_t*, float4*, uint2*, uint32_t*, uint2*, uint32_t*)
 
 QN_G1 __global__ void k_knn_hist<false, 32> QN_KNN_HIST_ARGS;
 QN_G1 __global__ void k_knn_hist<true, 32> QN_KNN_HIST_ARGS;
@@ -28,8 +29,13 @@ QN_G1 __global__ void k_nn_search<0, false, QN_NN_BLOCK> QN_NN_SEARCH_ARGS;
 QN_G1 __global__ void k_nn_search<0, true, QN_BLOCK> QN_NN_SEARCH_ARGS;
 QN_G1 __global__ void k_nn_search<1, false, QN_NN_BLOCK> QN_NN_SEARCH_ARGS;
 QN_G1 __global__ void k_nn_search<1, true, QN_BLOCK> QN_NN_SEARCH_ARGS;
-QN_G1 __global__ void k_nn_track<0, false> QN_NN_TRACK_ARGS;
-QN_G1 __global__ void k_nn_track<1, false> QN_NN_TRACK_ARGS;
-QN_G1 __global__ void k_nn_track<0, true> QN_NN_TRACK_ARGS;
+QN_G1 __global__ void k_nn_track<0> QN_NN_TRACK_ARGS;
+QN_G1 __global__ void k_nn_track<1> QN_NN_TRACK_ARGS;
+QN_G1 __global__ void k_tick<256, 2>(TickArgs);
+QN_G1 __global__ void k_tick<256, 3>(TickArgs);
+QN_G1 __global__ void k_tick<256, 4>(TickArgs);
+QN_G1 __global__ void k_tick<512, 2>(TickArgs);
+QN_G1 __global__ void k_tick<512, 3>(TickArgs);
+QN_G1 __global__ void k_tick<512, 4>(TickArgs);
 
 }  // namespace qn

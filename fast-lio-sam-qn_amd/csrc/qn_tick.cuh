@@ -1,0 +1,284 @@
+// qn_tick.cuh - ONE kernel per optimiser tick in the tracked regime of NanoGICP::align() (call site
+// fast_lio_sam_qn/src/loop_closure.cpp:124; LsqRegistration loop restated in SURVEY.md A.1.4-A.1.5).
+//
+// Round 1 ran  [k_nn_track, k_solve]  per Gauss-Newton iteration and eight kernels per LM iteration; k_solve - one thread doing the
+// controller between two launches - was 20 % of the GPU time at 0.14 % of the roof.  k_tick removes that launch and
+// the serial hop from the chain:
+//
+//   prologue  every block reduces the previous tick's partial rows (rows x 28 f64, L2/MALL resident) in a fixed order and thread 0 runs the
+//             LM / GN controller on an LDS copy of the optimiser state - redundantly in every block, bit-identical by construction;
+//             block 0 publishes the new state.  The loads that do not depend on the pose (point, tracking seed, its target record,
+//             normal) are ISSUED BEFORE the prologue, so the gather latency hides behind the controller.
+//   body      phase 0 (linearise): tracked / bound-pruned exact 1-NN of every source point at the new pose + its contribution to the
+//             28 sums (J^T M J, J^T M e, e^T M e);  phase 1 (LM trial): the error at the trial pose with the cached correspondences;
+//   epilogue  the block's 28 sums through an LDS transpose (28 ds_write + 32 ds_read per thread instead of 28 x 6 shuffle steps),
+//             one row of the OTHER partial buffer (double buffered with the state: no block waits for another).
+//
+// PLANE-regularised covariances are exactly C = I - 0.999 n n^T, so a point carries its normal (3 f64) instead of six
+// covariance entries:  C_B + R C_A R^T = 2 I - 0.999 (n_B n_B^T + m m^T),  m = R n_A.
+#pragma once
+#include "qn_gicp_kernels.cuh"
+
+namespace qn {
+
+
+struct TickArgs {
+  GridView src, tgt;
+  const GicpState* st_in; GicpState* st_out;
+  const double* part_in; double* part_out;
+  int rows_in;                         // rows of part_in written by the previous producer (read only when st_in->pending)
+  GicpConfig cfg;
+  qn_iter_trace* trace;
+  double thr2;
+  int32_t* nn_idx; float4* nn_ref;
+  const double* nrm_s;                 // [n][3] source normals, cell-sorted order
+  const TargetRec* tgt_rec;
+  uint32_t ppt;                        // source points per thread (1 up to 131072 points)
+};
+
+// Block-level sum of the 28 per-thread accumulators.  Per wave: an LDS transpose in 4 rounds of 7 components through the wave's own
+// search scratch (7 x 64 f64 = 3.5 KB; DS operations of one wave execute in order, so no block barrier): lane (c, s) sums 8 of the 64
+// values of component c, three DPP steps fold the 8 sub-sums.  Then the 4 wave sums meet in a [4][28] LDS table.  ~150 wave
+// instructions instead of 28 x 6 shuffle steps (~600), and no LDS beyond what the search already owns, so 4+ blocks fit a CU.
+// Fixed order throughout: bitwise reproducible.
+__device__ __forceinline__ double dpp_xor_add(double v, const int which) {       // which: 0 -> lane ^ 1, 1 -> lane ^ 2 (quad_perm); 2 -> row_half_mirror (pairs l, 7 - l)
+  union { double d; int i[2]; } a, b; a.d = v;
+  if (which == 0) { b.i[0] = __builtin_amdgcn_mov_dpp(a.i[0], 0xB1, 0xF, 0xF, true); b.i[1] = __builtin_amdgcn_mov_dpp(a.i[1], 0xB1, 0xF, 0xF, true); }
+  else if (which == 1) { b.i[0] = __builtin_amdgcn_mov_dpp(a.i[0], 0x4E, 0xF, 0xF, true); b.i[1] = __builtin_amdgcn_mov_dpp(a.i[1], 0x4E, 0xF, 0xF, true); }
+  else { b.i[0] = __builtin_amdgcn_mov_dpp(a.i[0], 0x141, 0xF, 0xF, true); b.i[1] = __builtin_amdgcn_mov_dpp(a.i[1], 0x141, 0xF, 0xF, true); }
+  return v + b.d;
+}
+// fold 7 per-lane values across the wave (transpose through wbuf, 8 sub-sums per component, three DPP steps) into wsum[wid][7 G ..]
+__device__ __forceinline__ void fold7(const double g[7], const int G, const bool first, double* __restrict__ wbuf, double* __restrict__ wrow) {
+  const int lane = threadIdx.x & 63, c8 = lane >> 3, s8 = lane & 7;
+#pragma unroll
+  for (int c = 0; c < 7; c++) wbuf[c * 64 + lane] = g[c];
+  wave_lds_fence();
+  double v = 0;
+  if (c8 < 7) {
+#pragma unroll
+    for (int u = 0; u < 8; u++) v += wbuf[c8 * 64 + u * 8 + s8];
+  }
+  v = dpp_xor_add(v, 0); v = dpp_xor_add(v, 1); v = dpp_xor_add(v, 2);   // the 8 sub-sums of a component sit in one aligned group of 8 lanes
+  if (c8 < 7 && s8 == 0) wrow[7 * G + c8] = first ? v : wrow[7 * G + c8] + v;
+  wave_lds_fence();
+}
+
+// One correspondence's contribution to the 28 sums (accumulate_point_n's arithmetic, term for term), produced SEVEN values at a time
+// and folded across the wave at once: a lane never holds the 28 f64 accumulators (56 VGPRs) next to the matrices they are made of,
+// which is what pushed this kernel to 240 VGPRs.  have = false: the lane contributes zeros.
+__device__ __forceinline__ void emit_point(const bool have, const bool lin, const bool first, const double (*Rx)[4], const double (*Tx)[4], const float4 pa, const float4 pb,
+                                           const double na[3], const double nb[3], double* __restrict__ wbuf, double* __restrict__ wrow) {
+  double m[3];
+#pragma unroll
+  for (int a = 0; a < 3; a++) m[a] = Rx[a][0] * na[0] + Rx[a][1] * na[1] + Rx[a][2] * na[2];
+  M3 rcr;
+#pragma unroll
+  for (int a = 0; a < 3; a++)
+#pragma unroll
+    for (int b = 0; b < 3; b++) rcr.m[a][b] = ((a == b ? 1.0 : 0.0) - 0.999 * nb[a] * nb[b]) + ((a == b ? 1.0 : 0.0) - 0.999 * m[a] * m[b]);
+  const M3 M = m3_inverse(rcr);
+  const double mA[3] = {(double)pa.x, (double)pa.y, (double)pa.z};
+  double tA[3], e[3], Me[3];
+#pragma unroll
+  for (int r = 0; r < 3; r++) tA[r] = Tx[r][0] * mA[0] + Tx[r][1] * mA[1] + Tx[r][2] * mA[2] + Tx[r][3];
+  e[0] = (double)pb.x - tA[0]; e[1] = (double)pb.y - tA[1]; e[2] = (double)pb.z - tA[2];
+#pragma unroll
+  for (int r = 0; r < 3; r++) Me[r] = M.m[r][0] * e[0] + M.m[r][1] * e[1] + M.m[r][2] * e[2];
+  const double x = tA[0], y = tA[1], z = tA[2];
+  double g[7];
+  if (lin) {
+    double MS[3][3];
+#pragma unroll
+    for (int r = 0; r < 3; r++) { MS[r][0] = M.m[r][1] * z + M.m[r][2] * (-y); MS[r][1] = M.m[r][0] * (-z) + M.m[r][2] * x; MS[r][2] = M.m[r][0] * y + M.m[r][1] * (-x); }
+    g[0] = z * MS[1][0] + (-y) * MS[2][0]; g[1] = z * MS[1][1] + (-y) * MS[2][1]; g[2] = z * MS[1][2] + (-y) * MS[2][2];
+    g[3] = z * (-M.m[1][0]) + (-y) * (-M.m[2][0]); g[4] = z * (-M.m[1][1]) + (-y) * (-M.m[2][1]); g[5] = z * (-M.m[1][2]) + (-y) * (-M.m[2][2]);
+    g[6] = (-z) * MS[0][1] + x * MS[2][1];
+#pragma unroll
+    for (int u = 0; u < 7; u++) g[u] = have ? g[u] : 0.0;
+    fold7(g, 0, first, wbuf, wrow);
+    g[0] = (-z) * MS[0][2] + x * MS[2][2];
+    g[1] = (-z) * (-M.m[0][0]) + x * (-M.m[2][0]); g[2] = (-z) * (-M.m[0][1]) + x * (-M.m[2][1]); g[3] = (-z) * (-M.m[0][2]) + x * (-M.m[2][2]);
+    g[4] = y * MS[0][2] + (-x) * MS[1][2];
+    g[5] = y * (-M.m[0][0]) + (-x) * (-M.m[1][0]); g[6] = y * (-M.m[0][1]) + (-x) * (-M.m[1][1]);
+#pragma unroll
+    for (int u = 0; u < 7; u++) g[u] = have ? g[u] : 0.0;
+    fold7(g, 1, first, wbuf, wrow);
+    g[0] = y * (-M.m[0][2]) + (-x) * (-M.m[1][2]);
+    g[1] = M.m[0][0]; g[2] = M.m[0][1]; g[3] = M.m[0][2]; g[4] = M.m[1][1]; g[5] = M.m[1][2]; g[6] = M.m[2][2];
+#pragma unroll
+    for (int u = 0; u < 7; u++) g[u] = have ? g[u] : 0.0;
+    fold7(g, 2, first, wbuf, wrow);
+    g[0] = z * Me[1] + (-y) * Me[2]; g[1] = (-z) * Me[0] + x * Me[2]; g[2] = y * Me[0] + (-x) * Me[1];
+    g[3] = -Me[0]; g[4] = -Me[1]; g[5] = -Me[2];
+  } else {
+    if (first && (threadIdx.x & 63) < 21) wrow[threadIdx.x & 63] = 0.0;
+#pragma unroll
+    for (int u = 0; u < 6; u++) g[u] = 0.0;
+  }
+  g[6] = e[0] * Me[0] + e[1] * Me[1] + e[2] * Me[2];
+#pragma unroll
+  for (int u = 0; u < 7; u++) g[u] = have ? g[u] : 0.0;
+  fold7(g, 3, first, wbuf, wrow);
+}
+
+template <int TB, int OCC>
+__global__ void __launch_bounds__(TB, OCC) k_tick(TickArgs a) {
+  union WaveScratch { WaveLds w; double red[7 * 64]; };
+  static_assert(sizeof(WaveLds) >= 7 * 64 * sizeof(double), "the transpose buffer aliases the wave's search scratch");
+  __shared__ WaveScratch sc[TB / 64];
+  __shared__ double wsum[TB / 64][QN_NPART];
+  __shared__ GicpState sh;
+  __shared__ double part8[QN_NPART][TB / QN_NPART + 1];
+  __shared__ double sums[QN_NPART];
+  __shared__ double Awork[6][6];
+  static_assert(sizeof(GicpState) % 8 == 0, "GicpState is copied as 8-byte words");
+  const int tid = threadIdx.x, lane = tid & 63;
+  const float INF = __int_as_float(0x7f800000);
+  const uint32_t nblk = gridDim.x;
+  const uint32_t lblk = xcd_block(blockIdx.x, nblk);               // XCD x works on one contiguous eighth of the cell-sorted source
+  // ---- pose-independent loads of this thread's first point, in flight during the prologue
+  uint32_t t = (lblk * a.ppt) * TB + tid;
+  bool valid = t < a.src.n;
+  float4 p = valid ? a.src.pts[t] : make_float4(0, 0, 0, 0);
+  int32_t j0s = valid ? a.nn_idx[t] : -1;
+  float4 ref = valid ? a.nn_ref[t] : make_float4(0, 0, 0, 0);
+  double na[3] = {0, 0, 0};
+  if (valid) { na[0] = a.nrm_s[(size_t)t * 3]; na[1] = a.nrm_s[(size_t)t * 3 + 1]; na[2] = a.nrm_s[(size_t)t * 3 + 2]; }
+  TargetRec rec0; rec0.p = make_float4(0, 0, 0, 0); rec0.n[0] = rec0.n[1] = rec0.n[2] = 0;
+  if (valid && (uint32_t)j0s < a.tgt.n) { const TargetRec* r = a.tgt_rec + j0s; rec0.p = r->p; rec0.n[0] = r->n[0]; rec0.n[1] = r->n[1]; rec0.n[2] = r->n[2]; }
+
+  // ---- prologue: consume the pending partial rows, run the controller, publish the state.  The state words and the partial rows are
+  // requested back to back with the point loads above: one memory round trip in front of the controller.
+  for (int i = tid; i < (int)(sizeof(GicpState) / 8); i += TB) ((unsigned long long*)&sh)[i] = ((const unsigned long long*)a.st_in)[i];
+  reduce_partial_rows<TB>(a.part_in, a.rows_in, part8, sums);        // (rows of a state that is not pending are summed and ignored: rows_in is what matters)
+  const int pending = sh.pending, phase_in = sh.phase;
+  if (pending && phase_in != 2 && tid == 0) solve_controller(&sh, sums, a.cfg, blockIdx.x == 0 ? a.trace : nullptr, 0, phase_in, Awork);
+  if (tid == 0) { sh.fb_count = 0; sh.big_count = 0; sh.pending = sh.phase != 2 ? 1 : 0; }
+  __syncthreads();
+  if (blockIdx.x == 0) for (int i = tid; i < (int)(sizeof(GicpState) / 8); i += TB) ((unsigned long long*)a.st_out)[i] = ((const unsigned long long*)&sh)[i];
+  const int phase = sh.phase;
+  if (phase == 2) return;
+  const bool lin = phase == 0;
+  float Tf[12];
+#pragma unroll
+  for (int j = 0; j < 12; j++) Tf[j] = (float)sh.x0[j];
+  // the f64 poses are fetched from the LDS copy of the state only where the sums are formed (after the search: the search and the
+  // accumulation are the two register-hungry parts of this kernel, their live ranges are kept apart)
+  for (uint32_t it = 0; it < a.ppt; it++) {
+    if (it > 0) {                                                  // (only clouds beyond 131072 points)
+      t = (lblk * a.ppt + it) * TB + tid; valid = t < a.src.n;
+      p = valid ? a.src.pts[t] : make_float4(0, 0, 0, 0);
+      j0s = valid ? a.nn_idx[t] : -1;
+      ref = valid ? a.nn_ref[t] : make_float4(0, 0, 0, 0);
+      if (valid) { na[0] = a.nrm_s[(size_t)t * 3]; na[1] = a.nrm_s[(size_t)t * 3 + 1]; na[2] = a.nrm_s[(size_t)t * 3 + 2]; }
+      if (valid && (uint32_t)j0s < a.tgt.n) { const TargetRec* r = a.tgt_rec + j0s; rec0.p = r->p; rec0.n[0] = r->n[0]; rec0.n[1] = r->n[1]; rec0.n[2] = r->n[2]; }
+    }
+    float qx, qy, qz; xform_query<0>(Tf, p.x, p.y, p.z, qx, qy, qz);
+    const bool finite_q = (qx - qx == 0.f) && (qy - qy == 0.f) && (qz - qz == 0.f);
+    const uint32_t j0 = (uint32_t)j0s;
+    unsigned long long best = QN_INF_KEY;
+    if (!lin) {                                                    // LM trial error: cached correspondence, gate as at the linearisation
+      bool have = false;
+      if (valid && finite_q && j0 < a.tgt.n) have = (double)sqdist(qx, qy, qz, rec0.p.x, rec0.p.y, rec0.p.z) < a.thr2;
+      double X0[3][4], Xi[3][4];
+#pragma unroll
+      for (int r = 0; r < 3; r++)
+#pragma unroll
+        for (int c = 0; c < 4; c++) { X0[r][c] = sh.x0[4 * r + c]; Xi[r][c] = sh.xi[4 * r + c]; }
+      wave_lds_fence();
+      emit_point(have, false, it == 0, X0, Xi, make_float4(p.x, p.y, p.z, 1.f), rec0.p, na, rec0.n, sc[tid >> 6].red, wsum[tid >> 6]);
+      continue;
+    }
+    // ---- phase 0: tracked exact 1-NN (k_nn_track's logic: bound pruning, small in-lane rescan, cooperative big-ball search)
+    float second = INF, d_unseen = INF, r = 0.f, delta = 0.f;
+    bool rescanned = false, big = false;
+    const GridView& tg = a.tgt;
+    if (valid && finite_q && j0 >= tg.n) { big = true; r = tg.cell; }         // no usable seed: unseeded search
+    if (valid && finite_q && j0 < tg.n) {
+      const float d0 = sqdist(qx, qy, qz, rec0.p.x, rec0.p.y, rec0.p.z);
+      best = pack_key(d0, j0);
+      delta = sqrtf(sqdist(qx, qy, qz, ref.x, ref.y, ref.z));
+      if (!track_bound_holds(d0, delta, ref.w)) {
+        r = sqrtf(d0) * 1.000001f + tg.eps;
+        const int bx0 = cell_coord(qx - r, tg.ox, tg.inv_cell, tg.nx), bx1 = cell_coord(qx + r, tg.ox, tg.inv_cell, tg.nx);
+        const int by0 = cell_coord(qy - r, tg.oy, tg.inv_cell, tg.ny), by1 = cell_coord(qy + r, tg.oy, tg.inv_cell, tg.ny);
+        const int bz0 = cell_coord(qz - r, tg.oz, tg.inv_cell, tg.nz), bz1 = cell_coord(qz + r, tg.oz, tg.inv_cell, tg.nz);
+        const int tx0 = bx0 >> 3, ntr = (bx1 >> 3) - tx0 + 1, nyr = by1 - by0 + 1;
+        const int nseg = ntr * nyr * (bz1 - bz0 + 1);
+        if (!(d0 == d0) || nseg > QN_TRACK_SEG) big = true;
+        else {
+          uint32_t s[QN_TRACK_SEG], e[QN_TRACK_SEG];
+#pragma unroll
+          for (int sg = 0; sg < QN_TRACK_SEG; sg++) {
+            s[sg] = 0; e[sg] = 0;
+            if (sg < nseg) {
+              const int tt = sg % ntr, rr = sg / ntr;
+              const int ry = by0 + rr % nyr, rz = bz0 + rr / nyr, tx = tx0 + tt;
+              const int xa = max(bx0, tx << 3), xb = min(bx1, (tx << 3) + 7);
+              const uint32_t k0 = cell_key(tg, xa, ry, rz);
+              s[sg] = tg.cell_start[k0]; e[sg] = tg.cell_start[k0 + (xb - xa) + 1];
+            }
+          }
+#pragma unroll
+          for (int sg = 0; sg < QN_TRACK_SEG; sg++) {
+            for (uint32_t u = s[sg]; u < e[sg]; u++) {
+              const float4 c = tg.pts[u];
+              const float da = sqdist(qx, qy, qz, c.x, c.y, c.z);
+              const unsigned long long ka = pack_key(da, __float_as_uint(c.w));
+              if (ka < best) { second = key_d2(best); best = ka; }
+              else if (ka != best && da < second) second = da;
+            }
+          }
+          float d = INF;
+          if (bx0 > 0) d = fminf(d, qx - (tg.ox + bx0 * tg.cell));
+          if (bx1 < tg.nx - 1) d = fminf(d, (tg.ox + (bx1 + 1) * tg.cell) - qx);
+          if (by0 > 0) d = fminf(d, qy - (tg.oy + by0 * tg.cell));
+          if (by1 < tg.ny - 1) d = fminf(d, (tg.oy + (by1 + 1) * tg.cell) - qy);
+          if (bz0 > 0) d = fminf(d, qz - (tg.oz + bz0 * tg.cell));
+          if (bz1 < tg.nz - 1) d = fminf(d, (tg.oz + (bz1 + 1) * tg.cell) - qz);
+          d_unseen = d - tg.eps; rescanned = true;
+        }
+      }
+    }
+    // the wave's big-ball queries, 16 at a time, cooperatively (neighbouring queries' balls overlap: one shared candidate stream)
+    for (unsigned long long pend = __ballot(big); pend != 0;) {
+      unsigned long long grp = 0, tmp = pend; int srcl = -1;
+      for (int sl = 0; sl < 16 && tmp != 0; sl++) { const int L = __ffsll((long long)tmp) - 1; if (sl == (lane & 15)) srcl = L; grp |= 1ull << L; tmp &= tmp - 1; }
+      pend &= ~grp;
+      const bool act = srcl >= 0;
+      const int sl_ = act ? srcl : 0;
+      const float ax = __shfl(qx, sl_), ay = __shfl(qy, sl_), az = __shfl(qz, sl_), ar = __shfl(r, sl_), ad = __shfl(delta, sl_);
+      float rs = (ad < 0.25f * ar) ? ar * 1.1f + 0.5f * tg.cell : ar;           // tight seed: scan a little wider (bound pruning next time)
+      Best1 sink; sink.init();
+      float du = INF;
+      wave_search<4>(tg, ax, ay, az, act, rs, INF, 64, sink, &sc[tid >> 6].w, du);
+      const int slot = __popcll(grp & ((1ull << lane) - 1ull));
+      const unsigned long long rk = __shfl(sink.key, slot); const float rsec = __shfl(sink.second, slot), rdu = __shfl(du, slot);
+      if ((grp >> lane) & 1ull) { best = rk; second = rsec; d_unseen = rdu; rescanned = true; }
+    }
+    bool have = false;
+    if (valid) {
+      a.nn_idx[t] = best != QN_INF_KEY ? (int32_t)key_idx(best) : -1;
+      if (rescanned) a.nn_ref[t] = make_float4(qx, qy, qz, fminf(sqrtf(second), d_unseen));
+      if (best != QN_INF_KEY && (double)key_d2(best) < a.thr2) {
+        const uint32_t j = key_idx(best);
+        if (j != j0) { const TargetRec* rr = a.tgt_rec + j; rec0.p = rr->p; rec0.n[0] = rr->n[0]; rec0.n[1] = rr->n[1]; rec0.n[2] = rr->n[2]; }
+        have = true;
+      }
+    }
+    double X0[3][4];
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+#pragma unroll
+      for (int c = 0; c < 4; c++) X0[r][c] = sh.x0[4 * r + c];
+    wave_lds_fence();                                              // the wave's search scratch becomes its transpose buffer
+    emit_point(have, true, it == 0, X0, X0, make_float4(p.x, p.y, p.z, 1.f), rec0.p, na, rec0.n, sc[tid >> 6].red, wsum[tid >> 6]);
+  }
+  __syncthreads();
+  if (tid < QN_NPART) { double v = 0;
+#pragma unroll
+    for (int w = 0; w < TB / 64; w++) v += wsum[w][tid]; a.part_out[(size_t)lblk * QN_NPART + tid] = v; }
+}
+
+}  // namespace qn
