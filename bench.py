@@ -86,6 +86,7 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="only the headline measurement (profiling runs)")
     ap.add_argument("--pairs", type=int, default=8, help="distinct synthetic pairs (scenes) per rank, cycled over the steps (>= 2 x in-flight)")
     ap.add_argument("--in-flight", type=int, default=4, help="candidate pairs registered concurrently per GPU (one context = one hipStream each)")
+    ap.add_argument("--shift", type=float, default=None, help="developer: scene-window shift of the synthetic pairs in metres (default: the generator's 5 m = ~96 %% overlap; 24 = 80 %%)")
     ap.add_argument("--batch-pairs", type=int, default=64, help="BASELINE configs[3]: candidate pairs of one query, sharded over the ranks")
     args = ap.parse_args()
 
@@ -138,7 +139,7 @@ def main():
     npairs = max(args.pairs, 1)
     pairs = []
     for j in range(npairs):
-        src, tgt, T = synth.make_pair(rank + world * j, N_PTS)
+        src, tgt, T = synth.make_pair(rank + world * j, N_PTS, shift=args.shift)
         pairs.append((torch.from_numpy(src).cuda(), torch.from_numpy(tgt).cuda(), T))
     torch.cuda.synchronize()
 

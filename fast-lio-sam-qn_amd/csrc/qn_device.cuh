@@ -524,6 +524,37 @@ __device__ __forceinline__ bool wave_search(const GridView& g, float qx, float q
 
 // ------------------------------------------------------------------ k-NN by histogram selection
 // The k-NN stage is VALU-bound: keeping a sorted k-list per lane costs ~100 instructions per inserted candidate.
+// ------------------------------------------------------------------ a ball clipped to the grid's bounding box
+// Every point lies inside the grid box.  For a query OUTSIDE it (a source point beyond the target's extent) the part of the ball
+// (q, r) that can hold points is a spherical cap: along axis a it reaches only rho_a = sqrt(r^2 - sum_{b != a} o_b^2) from q, where o_b
+// is the query's distance to the box along axis b (0 when inside).  The search box shrinks from (2 r)^3 to the cap's bounding box -
+// for a neighbour 15 m away, a few hundred candidates instead of thousands - and the "unseen" distance behind a face at axis offset f
+// becomes sqrt(f^2 + sum_{b != a} o_b^2): whatever lies beyond that face AND inside the grid is at least that far away.
+struct CapBox {
+  float o2[3];                         // o_b^2 per axis
+  float S;                             // their sum
+};
+__device__ __forceinline__ CapBox cap_of(const GridView& g, float qx, float qy, float qz) {
+  CapBox c;
+  const float ox = fmaxf(fmaxf(g.ox - qx, qx - (g.ox + g.nx * g.cell)), 0.f);
+  const float oy = fmaxf(fmaxf(g.oy - qy, qy - (g.oy + g.ny * g.cell)), 0.f);
+  const float oz = fmaxf(fmaxf(g.oz - qz, qz - (g.oz + g.nz * g.cell)), 0.f);
+  c.o2[0] = ox * ox; c.o2[1] = oy * oy; c.o2[2] = oz * oz; c.S = (c.o2[0] + c.o2[1]) + c.o2[2];
+  return c;
+}
+// half extent of the cap along `axis` (>= the true one: rounded up, plus the grid's eps)
+__device__ __forceinline__ float cap_extent(const GridView& g, const CapBox& c, float r, int axis) {
+  const float rest = c.S - c.o2[axis];
+  if (rest <= 0.f) return r;                                         // inside the box along the other axes: the plain ball
+  const float v = r * r - rest * 0.999999f;
+  return v > 0.f ? sqrtf(v) * 1.000001f + g.eps : g.eps;
+}
+// lower bound on the distance from q to anything beyond a face at axis offset f (f = distance from q to the face plane along `axis`)
+__device__ __forceinline__ float cap_face_dist(const CapBox& c, float f, int axis) {
+  const float rest = (c.S - c.o2[axis]) * 0.999999f;
+  return rest > 0.f ? sqrtf(f * f + rest) * 0.999999f : f;
+}
+
 // ------------------------------------------------------------------ single-query search: one query per WAVE
 // For the few queries whose neighbour is far away (several cells): all 64 lanes share ONE query and each
 // scores its own candidate of the dense stream (no LDS tile needed), so a big ball is scanned 16x faster
@@ -534,10 +565,13 @@ __device__ __forceinline__ void wave_search_single(const GridView& g, float qx, 
                                                    unsigned long long& best_out, float& second_out, float& d_unseen, WaveLds* lds) {
   const int lane = threadIdx.x & 63;
   const float INF = __int_as_float(0x7f800000);
+  const CapBox cap = cap_of(g, qx, qy, qz);
+  if (cap.S > 0.f) r = fminf(fmaxf(r, sqrtf(cap.S) + g.cell), fmaxf(r_cap, r));   // nothing is closer than the grid box itself: do not spend rounds below that
   for (int round = 0;; round++) {
-    int x0 = rfl(cell_coord(qx - r, g.ox, g.inv_cell, g.nx)), x1 = rfl(cell_coord(qx + r, g.ox, g.inv_cell, g.nx));
-    int y0 = rfl(cell_coord(qy - r, g.oy, g.inv_cell, g.ny)), y1 = rfl(cell_coord(qy + r, g.oy, g.inv_cell, g.ny));
-    int z0 = rfl(cell_coord(qz - r, g.oz, g.inv_cell, g.nz)), z1 = rfl(cell_coord(qz + r, g.oz, g.inv_cell, g.nz));
+    const float rx = cap_extent(g, cap, r, 0), ry = cap_extent(g, cap, r, 1), rz = cap_extent(g, cap, r, 2);
+    int x0 = rfl(cell_coord(qx - rx, g.ox, g.inv_cell, g.nx)), x1 = rfl(cell_coord(qx + rx, g.ox, g.inv_cell, g.nx));
+    int y0 = rfl(cell_coord(qy - ry, g.oy, g.inv_cell, g.ny)), y1 = rfl(cell_coord(qy + ry, g.oy, g.inv_cell, g.ny));
+    int z0 = rfl(cell_coord(qz - rz, g.oz, g.inv_cell, g.nz)), z1 = rfl(cell_coord(qz + rz, g.oz, g.inv_cell, g.nz));
     const int tx0 = x0 >> 3, ntr = (x1 >> 3) - tx0 + 1;
     int nseg = ntr * (y1 - y0 + 1) * (z1 - z0 + 1);
     const bool tile_mode = nseg > 128;
@@ -592,17 +626,17 @@ __device__ __forceinline__ void wave_search_single(const GridView& g, float qx, 
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) c = fminf(c, __shfl_xor(c, o));
     float d = INF;
-    if (x0 > 0) d = fminf(d, qx - (g.ox + x0 * g.cell));
-    if (x1 < g.nx - 1) d = fminf(d, (g.ox + (x1 + 1) * g.cell) - qx);
-    if (y0 > 0) d = fminf(d, qy - (g.oy + y0 * g.cell));
-    if (y1 < g.ny - 1) d = fminf(d, (g.oy + (y1 + 1) * g.cell) - qy);
-    if (z0 > 0) d = fminf(d, qz - (g.oz + z0 * g.cell));
-    if (z1 < g.nz - 1) d = fminf(d, (g.oz + (z1 + 1) * g.cell) - qz);
+    if (x0 > 0) d = fminf(d, cap_face_dist(cap, qx - (g.ox + x0 * g.cell), 0));
+    if (x1 < g.nx - 1) d = fminf(d, cap_face_dist(cap, (g.ox + (x1 + 1) * g.cell) - qx, 0));
+    if (y0 > 0) d = fminf(d, cap_face_dist(cap, qy - (g.oy + y0 * g.cell), 1));
+    if (y1 < g.ny - 1) d = fminf(d, cap_face_dist(cap, (g.oy + (y1 + 1) * g.cell) - qy, 1));
+    if (z0 > 0) d = fminf(d, cap_face_dist(cap, qz - (g.oz + z0 * g.cell), 2));
+    if (z1 < g.nz - 1) d = fminf(d, cap_face_dist(cap, (g.oz + (z1 + 1) * g.cell) - qz, 2));
     bool cert;
     if (d == INF || !(r == r) || round > 160) { cert = true; d_unseen = INF; }
     else { d -= g.eps; d_unseen = d; cert = d > 0.f && b != QN_INF_KEY && key_d2(b) < d * d; }
     if (cert) { best_out = b; second_out = c; return; }
-    r = (b != QN_INF_KEY) ? fmaxf(sqrtf(key_d2(b)) * 1.000001f + g.eps, r) : 2.f * r + g.cell;
+    r = (b != QN_INF_KEY) ? fmaxf(sqrtf(key_d2(b)) * 1.000001f + g.eps, r) : (r > 6.f * g.cell ? r + (2.f + round) * g.cell : 2.f * r + g.cell);   // far away: grow by cells, not by factors (the cap's width grows with sqrt(r^2 - o^2))
     r = fminf(r, r_cap);
   }
 }

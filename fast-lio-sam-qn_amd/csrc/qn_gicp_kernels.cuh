@@ -229,7 +229,7 @@ template <int MODE, bool LIST, int BLOCK>
 __global__ void __launch_bounds__(BLOCK, 6) k_nn_search(GridView src, GridView tgt, const GicpState* __restrict__ st, double thr2, float r0, int max_rounds,
                                                         int32_t* __restrict__ corr, float* __restrict__ sqd, int32_t* __restrict__ nn_idx, float4* __restrict__ nn_ref,
                                                         uint2* __restrict__ fb_list, uint32_t* __restrict__ fb_count,
-                                                        uint2* __restrict__ big_list, uint32_t* __restrict__ big_count, int big_blocks, float big_ratio) {
+                                                        uint2* __restrict__ big_list, uint32_t* __restrict__ big_count, int big_blocks, float big_ratio, uint32_t* __restrict__ far_stats) {
   __shared__ WaveLds lds[BLOCK / 64];
   if (MODE == 0 && st->phase != 0) return;
   if (MODE == 1 && st->phase != 2) return;
@@ -239,6 +239,7 @@ __global__ void __launch_bounds__(BLOCK, 6) k_nn_search(GridView src, GridView t
   if (LIST && (int)blockIdx.x >= (int)gridDim.x - big_blocks) {            // ---- big entries: one query per wave
     const uint32_t nbig = *big_count;
     if (tgt.dbg && blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) atomicAdd(&tgt.dbg[7], nbig);
+    uint32_t nfar = 0;                                                     // far queries of this pass (the host hands far_stats only to the LAST unseeded pass, when the clouds are nearly aligned)
     const uint32_t bw0 = (blockIdx.x - (gridDim.x - big_blocks)) * (BLOCK / 64) + (threadIdx.x >> 6), nbw = big_blocks * (BLOCK / 64);
     for (uint32_t w = bw0; w < nbig; w += nbw) {
       const uint2 rec = big_list[w];
@@ -253,8 +254,10 @@ __global__ void __launch_bounds__(BLOCK, 6) k_nn_search(GridView src, GridView t
       if ((threadIdx.x & 63) == 0) {
         store_nn<MODE>(key, __float_as_uint(p.w), rec.x, thr2, corr, sqd, nn_idx);
         if (MODE == 0) nn_ref[rec.x] = make_float4(qx, qy, qz, fminf(sqrtf(second), d_unseen));
+        if (key != QN_INF_KEY && key_d2(key) > 36.f * tgt.cell * tgt.cell) nfar++;        // neighbour beyond 6 cells (QN_FAR_RMIN_CELLS)
       }
     }
+    if (far_stats && MODE == 0 && (threadIdx.x & 63) == 0 && nfar) atomicAdd(&far_stats[3], nfar);
     return;
   }
   const uint32_t nq = LIST ? *fb_count : src.n;
@@ -838,10 +841,13 @@ static __global__ void k_transform_cloud(const float4* __restrict__ in, uint32_t
   out[i] = make_float4(x, y, z, 1.0f);
 }
 
-struct ResultBlock { qn_gicp_result r; int32_t phase; uint32_t trace_len; };
+struct ResultBlock { qn_gicp_result r; int32_t phase; uint32_t trace_len; uint32_t far_requests, far_misses, far_queries, pad; };
 
-static __global__ void k_finalize(const GicpState* __restrict__ st, ResultBlock* out) {   // out lives in pinned host memory
+static __global__ void k_finalize(const GicpState* __restrict__ st, ResultBlock* out, uint32_t* __restrict__ far_stats) {   // out lives in pinned host memory
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  out->far_requests = far_stats ? far_stats[1] : 0u; out->far_misses = far_stats ? far_stats[0] : 0u; out->far_queries = far_stats ? far_stats[3] : 0u;
+  // [1]: requests of the last tick k_far served; [0]: misses counted since (mode 2); [3]: far queries of the chunk's last unseeded pass
+  if (far_stats) { far_stats[0] = 0u; far_stats[1] = 0u; far_stats[3] = 0u; }
   for (int i = 0; i < 16; i++) { out->r.T64[i] = st->x0[i]; out->r.T[i] = (float)st->x0[i]; }
   for (int i = 0; i < 36; i++) out->r.H[i] = st->final_H[i];
   out->r.fitness = st->fitness; out->r.iterations = st->outer; out->r.converged = st->converged; out->r.lm_failed = st->lm_failed; out->r.reserved = 0;

@@ -169,6 +169,8 @@ struct WaveLdsH1 {
   uint32_t hist[QN_HB];
   unsigned long long list[QN_HCAP1];
   uint32_t cnt, kth;
+  unsigned long long best;          // outputs of the last successful call: smallest key,
+  uint32_t second, pad;             // d2 bits of the runner-up (kth: d2 bits of the k-th)
 };
 
 __device__ __forceinline__ int wave_knn_single(const GridView& g, float qx, float qy, float qz, float r, int k, WaveLdsH1* L,
@@ -176,10 +178,14 @@ __device__ __forceinline__ int wave_knn_single(const GridView& g, float qx, floa
   const int lane = threadIdx.x & 63;
   const float INF = __int_as_float(0x7f800000);
   if (!(qx == qx) || !(qy == qy) || !(qz == qz) || !(r == r)) return 2;
+  const CapBox cap = cap_of(g, qx, qy, qz);                               // (all zeros for a query inside the grid box: the plain ball)
+  if (cap.S > 0.f) r = fmaxf(r, sqrtf(cap.S) + 0.5f * g.cell);
+  const float r_in = r;
   for (int round = 0; round < 64; round++) {
-    int x0 = rfl(cell_coord(qx - r, g.ox, g.inv_cell, g.nx)), x1 = rfl(cell_coord(qx + r, g.ox, g.inv_cell, g.nx));
-    int y0 = rfl(cell_coord(qy - r, g.oy, g.inv_cell, g.ny)), y1 = rfl(cell_coord(qy + r, g.oy, g.inv_cell, g.ny));
-    int z0 = rfl(cell_coord(qz - r, g.oz, g.inv_cell, g.nz)), z1 = rfl(cell_coord(qz + r, g.oz, g.inv_cell, g.nz));
+    const float rx = cap_extent(g, cap, r, 0), ry = cap_extent(g, cap, r, 1), rz = cap_extent(g, cap, r, 2);
+    int x0 = rfl(cell_coord(qx - rx, g.ox, g.inv_cell, g.nx)), x1 = rfl(cell_coord(qx + rx, g.ox, g.inv_cell, g.nx));
+    int y0 = rfl(cell_coord(qy - ry, g.oy, g.inv_cell, g.ny)), y1 = rfl(cell_coord(qy + ry, g.oy, g.inv_cell, g.ny));
+    int z0 = rfl(cell_coord(qz - rz, g.oz, g.inv_cell, g.nz)), z1 = rfl(cell_coord(qz + rz, g.oz, g.inv_cell, g.nz));
     const bool tile_mode = ((x1 >> 3) - (x0 >> 3) + 1) * (y1 - y0 + 1) * (z1 - z0 + 1) > 128;
     if (tile_mode) {                                                          // whole tiles: the certification below sees the larger scanned box
       x0 = (x0 >> 3) << 3; x1 = min(((x1 >> 3) << 3) + 7, g.nx - 1);
@@ -221,16 +227,17 @@ __device__ __forceinline__ int wave_knn_single(const GridView& g, float qx, floa
       tau_bits = (hi20 << 20) + ((uint32_t)(sub + 1) << 14);
     }
     float d = INF;                                                          // nearest face of the scanned box with unseen cells behind it
-    if (x0 > 0) d = fminf(d, qx - (g.ox + x0 * g.cell));
-    if (x1 < g.nx - 1) d = fminf(d, (g.ox + (x1 + 1) * g.cell) - qx);
-    if (y0 > 0) d = fminf(d, qy - (g.oy + y0 * g.cell));
-    if (y1 < g.ny - 1) d = fminf(d, (g.oy + (y1 + 1) * g.cell) - qy);
-    if (z0 > 0) d = fminf(d, qz - (g.oz + z0 * g.cell));
-    if (z1 < g.nz - 1) d = fminf(d, (g.oz + (z1 + 1) * g.cell) - qz);
+    if (x0 > 0) d = fminf(d, cap_face_dist(cap, qx - (g.ox + x0 * g.cell), 0));
+    if (x1 < g.nx - 1) d = fminf(d, cap_face_dist(cap, (g.ox + (x1 + 1) * g.cell) - qx, 0));
+    if (y0 > 0) d = fminf(d, cap_face_dist(cap, qy - (g.oy + y0 * g.cell), 1));
+    if (y1 < g.ny - 1) d = fminf(d, cap_face_dist(cap, (g.oy + (y1 + 1) * g.cell) - qy, 1));
+    if (z0 > 0) d = fminf(d, cap_face_dist(cap, qz - (g.oz + z0 * g.cell), 2));
+    if (z1 < g.nz - 1) d = fminf(d, cap_face_dist(cap, (g.oz + (z1 + 1) * g.cell) - qz, 2));
     const bool whole = d == INF;
     if (!enough) {
       if (whole) return 2;                                                   // fewer than k points within 2 r of the whole cloud: general path
-      r = total > 0 ? fmaxf(2.f * r * sqrtf((float)k / (float)total) * 1.1f, r + g.cell) : 2.f * r + g.cell;
+      if (r_in > 6.f * g.cell) r += (1.f + round) * g.cell;                  // a far query (its k nearest sit within centimetres to decimetres of each other): grow by cells
+      else r = total > 0 ? fmaxf(2.f * r * sqrtf((float)k / (float)total) * 1.1f, r + g.cell) : 2.f * r + g.cell;
       continue;
     }
     stream_box(g, x0, x1, y0, y1, z0, z1, tile_mode, &L->s, [&](const float4& p, bool valid, uint32_t) __attribute__((always_inline)) {
@@ -254,6 +261,13 @@ __device__ __forceinline__ int wave_knn_single(const GridView& g, float qx, floa
     if (whole || (df > 0.f && kth_d2 < df * df)) {
       if (own0 != QN_INF_KEY && rank0 < k) { idx_out[rank0] = (int32_t)key_idx(own0); if (d2_out) d2_out[rank0] = key_d2(own0); }
       if (own1 != QN_INF_KEY && rank1 < k) { idx_out[rank1] = (int32_t)key_idx(own1); if (d2_out) d2_out[rank1] = key_d2(own1); }
+      if (lane == 0) { L->second = 0x7f800000u; }
+      wave_lds_fence();
+      if (own0 != QN_INF_KEY && rank0 == 0) L->best = own0;
+      if (own1 != QN_INF_KEY && rank1 == 0) L->best = own1;
+      if (own0 != QN_INF_KEY && rank0 == 1) L->second = (uint32_t)(own0 >> 32);
+      if (own1 != QN_INF_KEY && rank1 == 1) L->second = (uint32_t)(own1 >> 32);
+      wave_lds_fence();
       return 0;
     }
     r = fmaxf(sqrtf(kth_d2) * 1.000001f + g.eps, r);                        // the k-th best is known: the next ball certifies

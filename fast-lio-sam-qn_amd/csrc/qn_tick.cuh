@@ -34,7 +34,29 @@ struct TickArgs {
   const double* nrm_s;                 // [n][3] source normals, cell-sorted order
   const TargetRec* tgt_rec;
   uint32_t ppt;                        // source points per thread (1 up to 131072 points)
+  // far queries (neighbour several cells away: no overlap there, occlusion): candidate cache + refresh requests (below)
+  int far_mode;                        // 0: resolve big balls in the kernel; 1: cache, misses go to k_far (request bits); 2: cache, misses resolved in the kernel
+  const float4* tgt_raw;
+  int32_t* cand; float4* cand_ref;     // [n][QN_FAR_M] candidate indices, [n] (q_ref, bound); cell-sorted source order
+  unsigned long long* far_req;         // [ceil(n / 64)] request bits, one word per 64 consecutive source positions
+  uint32_t* far_stats;                 // [0] refresh requests, [1] cache hits
 };
+
+// ------------------------------------------------------------------ far queries
+// A source point whose nearest target point is many cells away (the clouds do not overlap there, or the spot is occluded in the target)
+// defeats bound pruning: its runner-up is practically as close as its neighbour (for a neighbour at distance d on a surface of density
+// rho the m-th nearest lies only  m / (2 pi rho d)  further), so the inequality  d(q, p_j0) + delta < d_other  never holds and the ball
+// around the query - mostly empty space - is searched again at every iteration.  With 20 % of the source outside the target that
+// made one tick cost 145 us instead of 10 (profiles/r2_*).  Instead such a query keeps its QN_FAR_M nearest target points and the
+// radius B of the ball they were collected from (ONE pass over the ball around the query, wave_ball_collect): every point NOT in the
+// list is at least B away from where the list was made, so after a move by delta the true nearest neighbour is the best of the M candidates whenever
+// best_distance + delta < B - exact, and M gathers instead of a search.  The margin grows with M (0.1 m at d = 10 m for M = 64) and is sized to the step the query just made;
+// a miss (early iterations, big steps) requests a refresh, served chip-wide by k_far, one query per wave.
+#define QN_FAR_M 64
+#define QN_FAR_RMIN_CELLS 6.f           // a neighbour farther than this many cells makes a query "far"
+#define QN_FAR_BLOCKS 512            // x 8 waves: the refreshes are latency-bound (dependent LDS / global round trips), they need many waves in flight
+#define QN_FAR_THREADS 512
+
 
 // Block-level sum of the 28 per-thread accumulators.  Per wave: an LDS transpose in 4 rounds of 7 components through the wave's own
 // search scratch (7 x 64 f64 = 3.5 KB; DS operations of one wave execute in order, so no block barrier): lane (c, s) sums 8 of the 64
@@ -241,6 +263,47 @@ __global__ void __launch_bounds__(TB, OCC) k_tick(TickArgs a) {
         }
       }
     }
+    bool requested = false;
+    const bool far_lane = big && r > QN_FAR_RMIN_CELLS * tg.cell;       // only truly far neighbours: a ball of a few cells is cheaper to search with the wave (shared stream)
+    if (a.far_mode != 0) {
+      if (far_lane) {
+        const float4 cr = a.cand_ref[t];
+        if (cr.w > 0.f) {                                            // candidate list made at cr.xyz, everything else is >= cr.w away from there
+          const float dc = sqrtf(sqdist(qx, qy, qz, cr.x, cr.y, cr.z));
+          unsigned long long b1 = QN_INF_KEY; float s2 = INF;
+          const int4* cl = (const int4*)(a.cand + (size_t)t * QN_FAR_M);
+#pragma unroll 2
+          for (int u = 0; u < QN_FAR_M / 4; u++) {
+            const int4 c4 = cl[u];
+            const int cj[4] = {c4.x, c4.y, c4.z, c4.w};
+#pragma unroll
+            for (int v = 0; v < 4; v++) {
+              if ((uint32_t)cj[v] < tg.n) {
+                const float4 cp = a.tgt_raw[cj[v]];
+                const float dd = sqdist(qx, qy, qz, cp.x, cp.y, cp.z);
+                const unsigned long long kk = pack_key(dd, (uint32_t)cj[v]);
+                if (kk < b1) { s2 = b1 != QN_INF_KEY ? key_d2(b1) : s2; b1 = kk; } else if (dd < s2) s2 = dd;
+              }
+            }
+          }
+          if (b1 != QN_INF_KEY && track_bound_holds(key_d2(b1), dc, cr.w)) {      // the nearest neighbour is one of the candidates
+            best = b1; second = s2; d_unseen = cr.w - dc - tg.eps; rescanned = true; big = false;
+          }
+        }
+      }
+      if (a.far_mode == 1) {
+        requested = far_lane && big; big = big && !requested;        // misses: k_far searches them (and adds their share of the sums)
+        const unsigned long long word = __ballot(requested);
+        if (lane == 0) {
+          const uint32_t chunk = t >> 6;
+          if (chunk * 64u < a.src.n) a.far_req[chunk] = word;
+          if (word) atomicAdd(&a.far_stats[0], (uint32_t)__popcll(word));
+        }
+      } else {                                                       // mode 2: misses are searched right here; counted so that the host can bring k_far back
+        const unsigned long long word = __ballot(big && far_lane);
+        if (lane == 0 && word) atomicAdd(&a.far_stats[0], (uint32_t)__popcll(word));
+      }
+    }
     // the wave's big-ball queries, 16 at a time, cooperatively (neighbouring queries' balls overlap: one shared candidate stream)
     for (unsigned long long pend = __ballot(big); pend != 0;) {
       unsigned long long grp = 0, tmp = pend; int srcl = -1;
@@ -258,7 +321,7 @@ __global__ void __launch_bounds__(TB, OCC) k_tick(TickArgs a) {
       if ((grp >> lane) & 1ull) { best = rk; second = rsec; d_unseen = rdu; rescanned = true; }
     }
     bool have = false;
-    if (valid) {
+    if (valid && !requested) {
       a.nn_idx[t] = best != QN_INF_KEY ? (int32_t)key_idx(best) : -1;
       if (rescanned) a.nn_ref[t] = make_float4(qx, qy, qz, fminf(sqrtf(second), d_unseen));
       if (best != QN_INF_KEY && (double)key_d2(best) < a.thr2) {
@@ -279,6 +342,158 @@ __global__ void __launch_bounds__(TB, OCC) k_tick(TickArgs a) {
   if (tid < QN_NPART) { double v = 0;
 #pragma unroll
     for (int w = 0; w < TB / 64; w++) v += wsum[w][tid]; a.part_out[(size_t)lblk * QN_NPART + tid] = v; }
+}
+
+// All target points within R of q (one query per wave, ONE pass over the cap box of radius R - which covers ball(q, R) completely, so
+// every point that is NOT collected is farther than R): indices into list[], the smallest key and the runner-up's d2.  Returns the
+// number of points found (> cap: the list overflowed, the caller shrinks R).
+__device__ __forceinline__ uint32_t wave_ball_collect(const GridView& g, float qx, float qy, float qz, float R, int cap_n, WaveLdsH1* L,
+                                                      unsigned long long& best, float& second) {
+  const CapBox cb = cap_of(g, qx, qy, qz);
+  const float rx = cap_extent(g, cb, R, 0), ry = cap_extent(g, cb, R, 1), rz = cap_extent(g, cb, R, 2);
+  int x0 = rfl(cell_coord(qx - rx, g.ox, g.inv_cell, g.nx)), x1 = rfl(cell_coord(qx + rx, g.ox, g.inv_cell, g.nx));
+  int y0 = rfl(cell_coord(qy - ry, g.oy, g.inv_cell, g.ny)), y1 = rfl(cell_coord(qy + ry, g.oy, g.inv_cell, g.ny));
+  int z0 = rfl(cell_coord(qz - rz, g.oz, g.inv_cell, g.nz)), z1 = rfl(cell_coord(qz + rz, g.oz, g.inv_cell, g.nz));
+  const bool tile_mode = ((x1 >> 3) - (x0 >> 3) + 1) * (y1 - y0 + 1) * (z1 - z0 + 1) > 128;
+  if (tile_mode) {
+    x0 = (x0 >> 3) << 3; x1 = min(((x1 >> 3) << 3) + 7, g.nx - 1);
+    y0 = (y0 >> 2) << 2; y1 = min(((y1 >> 2) << 2) + 3, g.ny - 1);
+    z0 = (z0 >> 2) << 2; z1 = min(((z1 >> 2) << 2) + 3, g.nz - 1);
+  }
+  const int lane = threadIdx.x & 63;
+  wave_lds_fence();
+  if (lane == 0) L->cnt = 0;
+  wave_lds_fence();
+  const float R2 = R * R;
+  unsigned long long b = QN_INF_KEY; float s2 = __int_as_float(0x7f800000);
+  stream_box(g, x0, x1, y0, y1, z0, z1, tile_mode, &L->s, [&](const float4& p, bool valid, uint32_t) __attribute__((always_inline)) {
+    const float d2 = sqdist(qx, qy, qz, p.x, p.y, p.z);
+    if (valid && d2 <= R2) {
+      const unsigned long long k = pack_key(d2, __float_as_uint(p.w));
+      const uint32_t pos = atomicAdd(&L->cnt, 1u);
+      if (pos < QN_HCAP1) L->list[pos] = k;
+      if (k < b) { if (b != QN_INF_KEY) s2 = key_d2(b); b = k; } else if (d2 < s2) s2 = d2;
+    }
+  });
+  wave_lds_fence();
+  const unsigned long long wb = wave_min_u64(b);
+  float c = (b == wb) ? s2 : key_d2(b);
+  if (b == QN_INF_KEY) c = __int_as_float(0x7f800000);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) c = fminf(c, __shfl_xor(c, o));
+  best = wb; second = c;
+  (void)cap_n;
+  return L->cnt;
+}
+
+// k_far: the refresh requests of the tick that just ran (bits in far_req), one query per WAVE, chip-wide.  Chunks of 64 source positions
+// are dealt round-robin to the blocks (far points are spatially clustered = contiguous in the cell-sorted order; this spreads them) and
+// a block's requests go to its waves in position order - a fixed assignment, so the sums below are bitwise reproducible.  Per request:
+// exact QN_FAR_M-NN of the transformed point in the target grid (wave_knn_single), candidate list + bound for the following ticks,
+// nearest neighbour + tracking record, and the correspondence's contribution to the 28 sums (lane 0).  Each block writes one row of a
+// side table; k_far_reduce folds the table (fixed order) into ONE partial row behind the rows of k_tick.
+struct FarArgs {
+  GridView src, tgt;
+  const GicpState* st;                 // the state k_tick published (the pose its body used)
+  double thr2;
+  int32_t* nn_idx; float4* nn_ref;
+  const double* nrm_s; const TargetRec* tgt_rec; const float4* tgt_raw;
+  int32_t* cand; float4* cand_ref;
+  const unsigned long long* far_req;
+  double* far_rows;                    // [QN_FAR_BLOCKS][28] side table
+  uint32_t* far_stats;
+};
+static __global__ void __launch_bounds__(QN_FAR_THREADS) k_far(FarArgs a) {
+  __shared__ WaveLdsH1 lds[QN_FAR_THREADS / 64];
+  __shared__ double wsum[QN_FAR_THREADS / 64][QN_NPART];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  constexpr int NW = QN_FAR_THREADS / 64;
+  const int phase = a.st->phase;
+  double acc[QN_NPART];
+#pragma unroll
+  for (int u = 0; u < QN_NPART; u++) acc[u] = 0;
+  if (phase == 0 && a.st->pending) {
+    float Tf[12]; double X0[3][4];
+#pragma unroll
+    for (int j = 0; j < 12; j++) Tf[j] = (float)a.st->x0[j];
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+#pragma unroll
+      for (int c = 0; c < 4; c++) X0[r][c] = a.st->x0[4 * r + c];
+    const uint32_t nchunks = (a.src.n + 63u) >> 6;
+    uint32_t seen = 0;                                              // requests of this block so far (block-uniform)
+    for (uint32_t ch = blockIdx.x; ch < nchunks; ch += QN_FAR_BLOCKS) {
+      unsigned long long word = a.far_req[ch];
+      for (; word != 0; word &= word - 1, seen++) {
+        if ((int)(seen % NW) != wid) continue;                      // request e of the block goes to wave e mod NW
+        const uint32_t t = ch * 64u + (uint32_t)(__ffsll((long long)word) - 1);
+        const float4 p = a.src.pts[t];
+        float qx, qy, qz; xform_query<0>(Tf, p.x, p.y, p.z, qx, qy, qz);
+        const uint32_t j0 = (uint32_t)a.nn_idx[t];
+        float r = 2.f * a.tgt.cell;
+        if (j0 < a.tgt.n) { const float4 p0 = a.tgt_raw[j0]; r = sqrtf(sqdist(qx, qy, qz, p0.x, p0.y, p0.z)) * 1.002f + 0.4f * a.tgt.cell; }    // the M nearest of a far query lie within centimetres of the nearest
+        int32_t* cl = a.cand + (size_t)t * QN_FAR_M;
+        unsigned long long best = QN_INF_KEY; float second = __int_as_float(0x7f800000), bound = 0.f, other = __int_as_float(0x7f800000);
+        float dnn = -1.f;                                              // an upper bound on the nearest-neighbour distance
+        if (j0 < a.tgt.n) { const float4 p0 = a.tgt_raw[j0]; dnn = sqrtf(sqdist(qx, qy, qz, p0.x, p0.y, p0.z)); }
+        else { float du; wave_search_single(a.tgt, qx, qy, qz, r, __int_as_float(0x7f800000), best, second, du, &lds[wid].s); if (best != QN_INF_KEY) dnn = sqrtf(key_d2(best)); other = fminf(sqrtf(second), du); }
+        if (dnn >= 0.f) {
+          // Everything within R = dnn + m of q becomes the candidate list; everything else is farther than R.  On a surface of ~rho points/m^2 at
+          // distance d about 2 pi rho d m points qualify: m ~ 0.35 / d keeps the list at two dozen; a list that overflows halves m.
+          // 1 / rho ~ cell^2 / 4 (the grid is sized to ~4 points per surface cell): ~48 points expected at m0; and the list should survive the NEXT
+          // step, which is about as long as the one just made (the optimiser converges): at least 2.5 x the move since the last scan
+          const float4 lastq = a.nn_ref[t];
+          const float moved = sqrtf(sqdist(qx, qy, qz, lastq.x, lastq.y, lastq.z));
+          float m = fminf(fmaxf(fmaxf(2.f * a.tgt.cell * a.tgt.cell / fmaxf(dnn, a.tgt.cell), 2.5f * moved), 0.01f), 0.5f * a.tgt.cell);
+          for (int attempt = 0; attempt < 5; attempt++, m *= 0.5f) {
+            const float R = dnn * 1.000002f + a.tgt.eps + m;
+            const uint32_t cnt = wave_ball_collect(a.tgt, qx, qy, qz, R, QN_FAR_M, &lds[wid], best, second);
+            other = fminf(sqrtf(second), R * 0.9999995f);              // the runner-up inside the ball, or the ball's radius: nothing else is closer
+            if (cnt <= (uint32_t)QN_FAR_M && cnt > 0) {
+              if (lane < QN_FAR_M) cl[lane] = (uint32_t)lane < cnt ? (int32_t)key_idx(lds[wid].list[lane]) : -1;
+              bound = R * 0.9999995f;
+              break;
+            }
+          }
+        }
+        if (lane == 0) {
+          a.nn_idx[t] = best != QN_INF_KEY ? (int32_t)key_idx(best) : -1;
+          a.nn_ref[t] = make_float4(qx, qy, qz, other);
+          a.cand_ref[t] = make_float4(qx, qy, qz, bound);
+          if (best != QN_INF_KEY && (double)key_d2(best) < a.thr2) {
+            const TargetRec* rec = a.tgt_rec + key_idx(best);
+            const double na[3] = {a.nrm_s[(size_t)t * 3], a.nrm_s[(size_t)t * 3 + 1], a.nrm_s[(size_t)t * 3 + 2]};
+            const double nb[3] = {rec->n[0], rec->n[1], rec->n[2]};
+            accumulate_point_n(X0, X0, make_float4(p.x, p.y, p.z, 1.f), rec->p, na, nb, true, acc);
+          }
+        }
+      }
+    }
+  }
+  if (lane == 0) {
+#pragma unroll
+    for (int u = 0; u < QN_NPART; u++) wsum[wid][u] = acc[u];
+  }
+  __syncthreads();
+  if (tid < QN_NPART) { double v = 0;
+#pragma unroll
+    for (int w = 0; w < NW; w++) v += wsum[w][tid]; a.far_rows[(size_t)blockIdx.x * QN_NPART + tid] = v; }
+  if (blockIdx.x == 0 && tid == 0) { a.far_stats[1] = a.far_stats[0]; a.far_stats[0] = 0u; }      // [1] = requests of the tick just served
+}
+static __global__ void __launch_bounds__(QN_FAR_BLOCKS) k_far_reduce(const double* __restrict__ far_rows, double* __restrict__ part_row) {
+  __shared__ double sh[QN_FAR_BLOCKS / 32][QN_NPART];
+  const int tid = threadIdx.x, c = tid % 32, seg = tid / 32;          // 16 segments of 32 rows; threads c >= 28 idle
+  if (c < QN_NPART) {
+    double v[32];
+#pragma unroll
+    for (int u = 0; u < 32; u++) v[u] = far_rows[(size_t)(seg * 32 + u) * QN_NPART + c];       // 32 loads in flight
+    double a = 0;
+#pragma unroll
+    for (int u = 0; u < 32; u++) a += v[u];
+    sh[seg][c] = a;
+  }
+  __syncthreads();
+  if (tid < QN_NPART) { double v = 0; for (int s = 0; s < QN_FAR_BLOCKS / 32; s++) v += sh[s][tid]; part_row[tid] = v; }
 }
 
 }  // namespace qn

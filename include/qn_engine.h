@@ -86,6 +86,7 @@ enum {                     /* kernel families for qn_prof_get */
   QN_K_FPFH_NORMALS = 8, QN_K_FPFH_SPFH = 9, QN_K_FPFH_FPFH = 10, QN_K_FEAT_MATCH = 11,
   QN_K_GN_TICK_FUSED = 12,   /* fused Gauss-Newton tick: tracking NN + leftovers + accumulation in one kernel       */
   QN_K_KNN_SELECT = 13,      /* k-NN selection kernel alone (QN_K_KNN_COV then holds its list tail + covariances)  */
+  QN_K_FAR = 15,             /* refresh of far queries' candidate lists (k_far)                                     */
   QN_K_MATCH_TAIL = 14,      /* Matcher tail on the device: means, cross-check + gate, tuple test, hand-over        */
   QN_K_COUNT = 16
 };

@@ -95,3 +95,20 @@ def test_default_schedule_lm_reference_point(eng):
     bad, passes = int(ctx.debug_get("verify_mismatches")), int(ctx.debug_get("verify_passes"))
     ctx.debug_set("verify_track", 0)
     assert bad == 0 and passes >= 1, (bad, passes)
+
+
+@pytest.mark.parametrize("optimizer,force", [("gn", 20), ("lm", 0)])
+def test_partial_overlap_far_queries(eng, oracle, optimizer, force):
+    """80 % overlap: a fifth of the source has its nearest target point metres away (beyond the target's extent).  Those queries go through
+    the candidate cache / k_far refresh path (qn_tick.cuh); every tracked pass is compared with a fresh search, and the answer with the oracle."""
+    engine, ctx = eng
+    src, tgt, T = synth.make_pair(343, 40000, shift=24.0)
+    r, bad, passes, first, g = run_verified(engine, ctx, src, tgt, optimizer, force)
+    assert passes >= (15 if force else 2) and bad == 0, (passes, bad, first)
+    o = oracle.GicpOracle(k=20, max_iter=32, max_corr_dist=52.5, trans_eps=1e-5, rot_eps=1e-6, optimizer=optimizer, force_iterations=force)
+    o.set_source(src); o.compute_covariances(0); o.set_target(tgt); o.compute_covariances(1)
+    ro = o.align()
+    assert r.iterations == ro["iterations"] and bool(r.converged) == ro["converged"]
+    dt, dr = synth.pose_error(np.array(r.T64).reshape(4, 4), ro["T"])
+    assert dt <= 1e-4 and dr <= 1e-4, (dt, dr)
+    assert abs(r.fitness - ro["fitness"]) <= 1e-6 * ro["fitness"]
