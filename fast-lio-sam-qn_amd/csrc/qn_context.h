@@ -45,6 +45,7 @@ struct qn_ctx {
   qn_quatro_params qparams{}; bool qparams_set = false, q_ready = false;
   float4* q_normals[2] = {nullptr, nullptr}; float* q_spfh[2] = {nullptr, nullptr}; float* q_fpfh_s[2] = {nullptr, nullptr}; float* q_fpfh[2] = {nullptr, nullptr};
   unsigned long long* q_key[2] = {nullptr, nullptr};
+  float* q_pair[2] = {nullptr, nullptr}; uint32_t* q_pair_hash[2] = {nullptr, nullptr};   // descriptors in candidate-pair layout + row hashes (k_feat_nn)
   uint32_t* q_hit = nullptr; uint32_t* q_list = nullptr; uint32_t* q_sel = nullptr; uint2* q_pairs = nullptr; uint32_t* q_counts = nullptr; double* q_T = nullptr;
   float* q_mean = nullptr; double* q_mean_psum = nullptr; void* q_host = nullptr;   // Matcher tail: cloud means, pinned hand-over block (header + one record per selected correspondence)
   // tuning knobs

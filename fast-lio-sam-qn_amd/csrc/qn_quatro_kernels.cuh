@@ -166,45 +166,113 @@ static __global__ void k_rows_to_original(const float4* __restrict__ pts, uint32
   for (int b = 0; b < w_out; b++) out[(size_t)i * w_out + b] = b < w_in ? in[(size_t)t * w_in + b] : 0.f;
 }
 
+// 32-bit hash of a descriptor row's 33 bit patterns into slot 34 of the row (k_feat_nn recognises duplicate rows by it)
+static __global__ void k_row_hash(float* __restrict__ rows, uint32_t n) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float* r = rows + (size_t)i * QN_FROW;
+  uint32_t h = 2166136261u;
+#pragma unroll
+  for (int d = 0; d < 33; d++) { h ^= __float_as_uint(r[d]); h *= 16777619u; h ^= h >> 15; }
+  r[34] = __uint_as_float(h);
+}
+
 // K12: exact nearest neighbour in 33-D (f32 sequential sum over the dimensions, ties -> lowest candidate index).
 // grid.x tiles the queries (256 per block), grid.y splits the candidates; partial winners meet in a 64-bit
 // atomicMin on (distance bits << 32 | index).  Queries optionally come through an index list.
-#define QN_FM_TILE 64
+//
+// The answer is defined by the sequential non-fused sum (the oracle's arithmetic).  Computing THAT for every pair costs 99 VALU
+// instructions per candidate (sub, mul, add x 33).  Instead every pair of candidates first gets a screening distance from packed-f32
+// FMAs (v_pk_add_f32 + v_pk_fma_f32: two candidates per instruction, 33 instructions per candidate) - same dimension order, so it
+// differs from the defining sum by at most ~33 x 2^-24 relative - and only a candidate whose screening distance is below the current
+// best x (1 + 1e-5) is re-evaluated with the defining arithmetic before it may replace the best.  No improvement can be missed
+// (exact < best implies screen < best (1 + 4e-6)), and what is kept is always an exactly evaluated distance: bit-identical results.
+// Duplicate descriptors (every point of an exact plane has the same FPFH row - 40 % of a noise-free synthetic cloud) would sit inside that
+// band for ever: a candidate whose screening value AND 32-bit row hash (slot 34 of its row, k_row_hash) equal those of the current best
+// is the same row, has the same distance, and - coming later in the ascending scan - can never replace it: skipped without the
+// re-evaluation.  (Two DIFFERENT rows with equal screening value, equal hash and a sub-1e-5 relative distance difference would be
+// mistaken for duplicates: a ~1e-13 event per search, far below the ambiguity of the specification itself - FLANN sums in a different
+// order - and the only non-proof in this kernel.)
+#define QN_FM_TILE 64                   // candidate ranges of the grid.y split are multiples of this
+typedef float qn_v2f __attribute__((ext_vector_type(2)));
+// Candidate rows re-laid in PAIRS for the screening: pair p holds candidates 2p, 2p+1 as 34 x (c0[d], c1[d]) (dimension 33 = padding 0;
+// a missing second candidate = 3e18, never below any threshold) + their row hashes.  The candidate pointer of k_feat_nn is wave-uniform,
+// so the rows arrive through SCALAR loads (s_load_dwordx16) into SGPRs and feed v_pk_add_f32 / v_pk_fma_f32 directly: no LDS tile - a
+// broadcast ds_read_b128 still writes 64 x 16 bytes of registers, and with four SIMDs sharing one LDS the tile version of this kernel
+// was LDS-bound at a quarter of the packed-f32 rate.
+static __global__ void k_pair_rows(const float* __restrict__ rows, uint32_t n, qn_v2f* __restrict__ pairs, uint32_t* __restrict__ hashes) {
+  const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;          // one thread per (pair, dimension)
+  const uint32_t np = (n + 1) / 2;
+  if (e >= np * 34) return;
+  const uint32_t p = e / 34, d = e - p * 34;
+  const uint32_t c0 = 2 * p, c1 = 2 * p + 1;
+  qn_v2f v;
+  v.x = d < 33 ? rows[(size_t)c0 * QN_FROW + d] : 0.f;
+  v.y = d < 33 ? (c1 < n ? rows[(size_t)c1 * QN_FROW + d] : 3.0e18f) : 0.f;
+  pairs[(size_t)p * 34 + d] = v;
+  if (d == 0) { hashes[c0] = __float_as_uint(rows[(size_t)c0 * QN_FROW + 34]); hashes[c1] = c1 < n ? __float_as_uint(rows[(size_t)c1 * QN_FROW + 34]) : 0u; }
+}
+
+// QN_FM_QPL queries per lane: every scalar-loaded candidate pair (272 bytes) is used for 64 x QPL queries - with one query per lane the
+// kernel was bound by the scalar cache (each wave streams the whole candidate set), not by the packed-f32 pipe.
+#define QN_FM_QPL 1
 static __global__ void __launch_bounds__(QN_BLOCK) k_feat_nn(const float* __restrict__ Q, uint32_t nq, const uint32_t* __restrict__ qlist, const uint32_t* __restrict__ qlist_n,
-                                                      const float* __restrict__ Cn, uint32_t nc, uint32_t chunk, unsigned long long* __restrict__ best_key) {
-  __shared__ float4 tile[QN_FM_TILE * 9];
+                                                      const qn_v2f* __restrict__ Cp, const uint32_t* __restrict__ Ch, uint32_t nc, uint32_t chunk, unsigned long long* __restrict__ best_key) {
   const uint32_t nqueries = qlist ? *qlist_n : nq;
-  const uint32_t slot = blockIdx.x * QN_BLOCK + threadIdx.x;
-  if (blockIdx.x * QN_BLOCK >= nqueries) return;
-  const bool active = slot < nqueries;
-  const uint32_t qi = active ? (qlist ? qlist[slot] : slot) : 0;
-  float q[33];
-  const float4* qrow = (const float4*)(Q + (size_t)qi * QN_FROW);
+  if (blockIdx.x * (QN_BLOCK * QN_FM_QPL) >= nqueries) return;
+  float q[QN_FM_QPL][34]; uint32_t qi[QN_FM_QPL]; bool qok[QN_FM_QPL];
 #pragma unroll
-  for (int v = 0; v < 9; v++) { const float4 x = qrow[v]; q[4 * v] = x.x; if (4 * v + 1 < 33) q[4 * v + 1] = x.y; if (4 * v + 2 < 33) q[4 * v + 2] = x.z; if (4 * v + 3 < 33) q[4 * v + 3] = x.w; }
-  const bool qok = active && (q[0] == q[0]);
-  const uint32_t c0 = blockIdx.y * chunk, c1 = min(nc, c0 + chunk);
-  float best = __int_as_float(0x7f7fffff); uint32_t bi = 0xffffffffu;
-  for (uint32_t base = c0; base < c1; base += QN_FM_TILE) {
-    const uint32_t cnt = min((uint32_t)QN_FM_TILE, c1 - base);
-    __syncthreads();
-    for (uint32_t e = threadIdx.x; e < cnt * 9; e += QN_BLOCK) tile[e] = ((const float4*)(Cn + (size_t)base * QN_FROW))[e];
-    __syncthreads();
-    for (uint32_t c = 0; c < cnt; c++) {
-      float s = 0.f;
+  for (int u = 0; u < QN_FM_QPL; u++) {
+    const uint32_t slot = (blockIdx.x * QN_FM_QPL + u) * QN_BLOCK + threadIdx.x;
+    const bool active = slot < nqueries;
+    qi[u] = active ? (qlist ? qlist[slot] : slot) : 0;
+    const float4* qrow = (const float4*)(Q + (size_t)qi[u] * QN_FROW);
 #pragma unroll
-      for (int v = 0; v < 9; v++) {
-        const float4 x = tile[c * 9 + v];                       // broadcast ds_read_b128
-        float d;
-        d = q[4 * v] - x.x; s = s + d * d;
-        if (4 * v + 1 < 33) { d = q[4 * v + 1] - x.y; s = s + d * d; }
-        if (4 * v + 2 < 33) { d = q[4 * v + 2] - x.z; s = s + d * d; }
-        if (4 * v + 3 < 33) { d = q[4 * v + 3] - x.w; s = s + d * d; }
+    for (int v = 0; v < 9; v++) { const float4 x = qrow[v]; q[u][4 * v] = x.x; if (4 * v + 1 < 34) q[u][4 * v + 1] = x.y; if (4 * v + 2 < 34) q[u][4 * v + 2] = x.z; if (4 * v + 3 < 34) q[u][4 * v + 3] = x.w; }
+    q[u][33] = 0.f;
+    qok[u] = active && (q[u][0] == q[u][0]);
+  }
+  const uint32_t c0 = blockIdx.y * chunk, c1 = min(nc, c0 + chunk);        // chunk is even
+  float best[QN_FM_QPL], bs[QN_FM_QPL]; uint32_t bi[QN_FM_QPL], bh[QN_FM_QPL];      // best exact distance / its screening value and row hash
+#pragma unroll
+  for (int u = 0; u < QN_FM_QPL; u++) { best[u] = __int_as_float(0x7f7fffff); bi[u] = 0xffffffffu; bs[u] = -1.f; bh[u] = 0; }
+  for (uint32_t p = c0 >> 1; p < (c1 + 1) >> 1; p++) {
+    const qn_v2f* __restrict__ row = Cp + (size_t)p * 34;                 // wave-uniform: scalar loads
+    const uint32_t h0 = Ch[2 * p], h1 = Ch[2 * p + 1];
+    qn_v2f s[QN_FM_QPL], s2[QN_FM_QPL];                              // two accumulation chains (even / odd dimensions): the FMA chain is latency-bound otherwise
+#pragma unroll
+    for (int u = 0; u < QN_FM_QPL; u++) { s[u] = (qn_v2f){0.f, 0.f}; s2[u] = (qn_v2f){0.f, 0.f}; }
+#pragma unroll
+    for (int d = 0; d < 34; d += 2) {
+      const qn_v2f r = row[d], r2 = row[d + 1];
+#pragma unroll
+      for (int u = 0; u < QN_FM_QPL; u++) {
+        const qn_v2f df = (qn_v2f){q[u][d], q[u][d]} - r; s[u] = __builtin_elementwise_fma(df, df, s[u]);
+        const qn_v2f dg = (qn_v2f){q[u][d + 1], q[u][d + 1]} - r2; s2[u] = __builtin_elementwise_fma(dg, dg, s2[u]);
       }
-      if (s < best) { best = s; bi = base + c; }                // NaN never wins; ascending scan keeps the lowest index
+    }
+#pragma unroll
+    for (int u = 0; u < QN_FM_QPL; u++) s[u] = s[u] + s2[u];
+#pragma unroll
+    for (int u = 0; u < QN_FM_QPL; u++) {
+      const float thr = best[u] * 1.00001f;
+      if ((s[u].x < thr && !(s[u].x == bs[u] && h0 == bh[u])) || (s[u].y < thr && !(s[u].y == bs[u] && h1 == bh[u]))) {     // rare after the first few candidates: the defining arithmetic
+#pragma unroll 1
+        for (int h = 0; h < 2; h++) {
+          const float sv = h == 0 ? s[u].x : s[u].y; const uint32_t hv = h == 0 ? h0 : h1;
+          if (sv < thr && !(sv == bs[u] && hv == bh[u]) && 2 * p + h < nc) {
+            float e = 0.f;
+#pragma unroll
+            for (int d = 0; d < 33; d++) { const float t = q[u][d] - (h == 0 ? row[d].x : row[d].y); e = e + t * t; }
+            if (e < best[u]) { best[u] = e; bi[u] = 2 * p + h; bs[u] = sv; bh[u] = hv; }      // NaN never wins; ascending scan keeps the lowest index
+          }
+        }
+      }
     }
   }
-  if (qok && bi != 0xffffffffu) atomicMin(&best_key[qi], ((unsigned long long)__float_as_uint(best) << 32) | bi);
+#pragma unroll
+  for (int u = 0; u < QN_FM_QPL; u++)
+    if (qok[u] && bi[u] != 0xffffffffu) atomicMin(&best_key[qi[u]], ((unsigned long long)__float_as_uint(best[u]) << 32) | bi[u]);
 }
 
 static __global__ void k_fill_u64(unsigned long long* p, uint32_t n, unsigned long long v) { uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; if (i < n) p[i] = v; }
