@@ -55,6 +55,7 @@ struct qn_ctx {
   int nn_rounds = 1;                    // rounds of an unseeded NN search before a query goes to the list pass
   int track_from_tick = 3;              // NN passes before this tick search unseeded (ball around the query) instead of tracking the previous neighbour
   int fused_from_tick = 3;
+  bool fused_final = true;              // closing pass (last controller step + fitness sweep + output cloud) in one launch
   int knn_rounds = 2;                   // rounds of the first k-NN pass before a query goes to the list pass
   int knn_hist = 1;                     // 1: k-NN by histogram selection (wave_knn_hist), 0: sorted-list sink (wave_search + BestK)
   float margin_nn = 1.f, margin_knn = 2.f;   // first search radius in cells (1-NN of the first tick / k-NN of the covariances)

@@ -104,8 +104,8 @@ extern "C" int qn_ctx_create(int device, uint32_t max_points, qn_ctx** out) {
   CA(hipMalloc(&c->nn_ref, sizeof(float4) * max_points));
   CA(hipMalloc(&c->nrm_s_sorted, sizeof(double) * 3 * max_points));
   CA(hipMalloc(&c->tgt_rec, sizeof(TargetRec) * max_points));
-  CA(hipMalloc(&c->fit_psum, sizeof(double) * QN_FIT_BLOCKS));
-  CA(hipMalloc(&c->fit_pcnt, sizeof(uint32_t) * QN_FIT_BLOCKS));
+  CA(hipMalloc(&c->fit_psum, sizeof(double) * (QN_ACC_MAX_BLOCKS + 8)));
+  CA(hipMalloc(&c->fit_pcnt, sizeof(uint32_t) * (QN_ACC_MAX_BLOCKS + 8)));
   CA(hipMalloc(&c->trace, sizeof(qn_iter_trace) * QN_MAX_TRACE));
   CA(hipMalloc(&c->corr, sizeof(int32_t) * max_points));
   CA(hipMalloc(&c->sqd, sizeof(float) * max_points));
@@ -377,16 +377,22 @@ static void enqueue_solve(qn_ctx* c, int mode, int will_produce) {
 }
 // One "tick" of the device-side state machine = [controller step on the previous tick's partial rows] + [body under the new state].
 // Tracked regime: ONE kernel (k_tick: controller in the prologue of every block, tracked NN + accumulation, LM trial passes included).
-static void enqueue_tick_fused(qn_ctx* c) {
+static TickArgs tick_args(qn_ctx* c) {
   CloudBuf &S = c->cloud[0], &T = c->cloud[1];
   TickArgs a;
   a.src = S.grid; a.tgt = T.grid; a.st_in = st_cur(c); a.st_out = st_nxt(c); a.part_in = part_cur(c); a.part_out = part_nxt(c); a.rows_in = c->part_rows;
   a.cfg = make_cfg(c); a.trace = c->trace; a.thr2 = c->params.max_corr_dist * c->params.max_corr_dist;
   a.nn_idx = c->nn_idx; a.nn_ref = c->nn_ref; a.nrm_s = c->nrm_s_sorted; a.tgt_rec = c->tgt_rec; a.ppt = tick_ppt(c);
   a.far_mode = c->far_enabled ? c->far_mode : 0; a.tgt_raw = T.raw; a.cand = c->far_cand; a.cand_ref = c->far_cand_ref; a.far_req = c->far_req; a.far_stats = c->far_stats;
+  a.aligned = c->aligned; a.fit_psum = c->fit_psum; a.fit_pcnt = c->fit_pcnt;
+  return a;
+}
+static void enqueue_tick_fused(qn_ctx* c) {
+  CloudBuf &S = c->cloud[0], &T = c->cloud[1];
+  TickArgs a = tick_args(c);
   { ProfScope ps(c, QN_K_GN_TICK_FUSED);
     const dim3 gr(tick_blocks(c)), bl(c->tick_tb);
-#define QN_TICK_LAUNCH(TB, OCC) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_tick<TB, OCC>), gr, bl, 0, c->stream, a)
+#define QN_TICK_LAUNCH(TB, OCC) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_tick<TB, OCC, 0>), gr, bl, 0, c->stream, a)
     if (c->tick_tb == 256) { if (c->tick_occ >= 4) QN_TICK_LAUNCH(256, 4); else if (c->tick_occ == 3) QN_TICK_LAUNCH(256, 3); else QN_TICK_LAUNCH(256, 2); }
     else { if (c->tick_occ >= 4) QN_TICK_LAUNCH(512, 4); else if (c->tick_occ == 3) QN_TICK_LAUNCH(512, 3); else QN_TICK_LAUNCH(512, 2); }
 #undef QN_TICK_LAUNCH
@@ -413,9 +419,23 @@ static void enqueue_tick(qn_ctx* c, bool seeded, int tick, bool first) {
   if (c->verify_track && seeded) enqueue_verify(c, false);
   enqueue_accumulate(c);
 }
-static void enqueue_epilogue(qn_ctx* c, double max_range, bool seeded) {       // fitness + output cloud; each kernel is a no-op until phase == done
+// The closing pass of align(): the last controller step + (once the state machine is done) fitness sweep + output cloud in ONE launch
+// (k_tick<.., 1>) and the result block (k_finalize_fit).  `tracked`: the neighbours of the last tick seed the sweep; without them
+// (no iteration ran, or the fused path is switched off) the unfused sequence runs: controller, search + list pass, two reductions, transform.
+static void enqueue_epilogue(qn_ctx* c, double max_range, bool tracked) {
+  if (tracked && c->fused_ticks && c->fused_final) {
+    TickArgs a = tick_args(c);
+    { ProfScope ps(c, QN_K_FITNESS);
+      const dim3 gr(tick_blocks(c)), bl(c->tick_tb);
+      if (c->tick_tb == 256) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_tick<256, 4, 1>), gr, bl, 0, c->stream, a);
+      else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_tick<512, 4, 1>), gr, bl, 0, c->stream, a); }
+    c->gen++; c->part_rows = 0;
+    hipLaunchKernelGGL(k_finalize_fit, dim3(1), dim3(64), 0, c->stream, st_cur(c), c->result_host, c->far_stats, c->fit_psum, c->fit_pcnt, (int)tick_blocks(c));
+    return;
+  }
+  enqueue_solve(c, 0, 0);                                       // the controller step that consumes the chunk's last partial rows
   GicpState* st = st_cur(c);
-  enqueue_nn(c, 1, c->sqd_fit, seeded, 1);
+  enqueue_nn(c, 1, c->sqd_fit, tracked, 1);
   { ProfScope ps(c, QN_K_FITNESS);
     hipLaunchKernelGGL(k_fitness_partial, dim3(QN_FIT_BLOCKS), dim3(QN_BLOCK), 0, c->stream, c->sqd_fit, c->cloud[0].n, max_range, st, c->fit_psum, c->fit_pcnt, 1);
     hipLaunchKernelGGL(k_fitness_final, dim3(1), dim3(QN_FIT_BLOCKS), 0, c->stream, c->fit_psum, c->fit_pcnt, st, 1); }
@@ -463,8 +483,7 @@ extern "C" int qn_gicp_align(qn_ctx* c, const float guess[16], qn_gicp_result* o
     if (p.force_iterations > 0 && ticks_left > chunk) {           // forced iterations cannot be done yet: only the statistics block is needed at this chunk end
       hipLaunchKernelGGL(k_finalize, dim3(1), dim3(64), 0, s, st_cur(c), c->result_host, c->far_stats);
     } else {
-      enqueue_solve(c, 0, 0);                                   // the controller step that consumes the chunk's last partial rows
-      enqueue_epilogue(c, DBL_MAX, maxit > 0);
+      enqueue_epilogue(c, DBL_MAX, maxit > 0 && tick_no > 0);
     }
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipStreamSynchronize(s));
@@ -678,6 +697,7 @@ extern "C" int qn_debug_set(qn_ctx* c, const char* key, double v) {
   else if (k == "ticks_per_chunk") c->ticks_per_chunk = std::max(1, (int)v);
   else if (k == "tick_occ") c->tick_occ = (int)v;
   else if (k == "far") c->far_enabled = v != 0;
+  else if (k == "fused_final") c->fused_final = v != 0;
   else if (k == "tick_tb") c->tick_tb = v >= 512 ? 512 : 256;
   else if (k == "verify_track") {
     if (v != 0 && !c->v_counters) {

@@ -31,11 +31,13 @@ QN_G1 __global__ void k_nn_search<1, false, QN_NN_BLOCK> QN_NN_SEARCH_ARGS;
 QN_G1 __global__ void k_nn_search<1, true, QN_BLOCK> QN_NN_SEARCH_ARGS;
 QN_G1 __global__ void k_nn_track<0> QN_NN_TRACK_ARGS;
 QN_G1 __global__ void k_nn_track<1> QN_NN_TRACK_ARGS;
-QN_G1 __global__ void k_tick<256, 2>(TickArgs);
-QN_G1 __global__ void k_tick<256, 3>(TickArgs);
-QN_G1 __global__ void k_tick<256, 4>(TickArgs);
-QN_G1 __global__ void k_tick<512, 2>(TickArgs);
-QN_G1 __global__ void k_tick<512, 3>(TickArgs);
-QN_G1 __global__ void k_tick<512, 4>(TickArgs);
+QN_G1 __global__ void k_tick<256, 2, 0>(TickArgs);
+QN_G1 __global__ void k_tick<256, 3, 0>(TickArgs);
+QN_G1 __global__ void k_tick<256, 4, 0>(TickArgs);
+QN_G1 __global__ void k_tick<512, 2, 0>(TickArgs);
+QN_G1 __global__ void k_tick<512, 3, 0>(TickArgs);
+QN_G1 __global__ void k_tick<512, 4, 0>(TickArgs);
+QN_G1 __global__ void k_tick<256, 4, 1>(TickArgs);
+QN_G1 __global__ void k_tick<512, 4, 1>(TickArgs);
 
 }  // namespace qn

@@ -40,6 +40,8 @@ struct TickArgs {
   int32_t* cand; float4* cand_ref;     // [n][QN_FAR_M] candidate indices, [n] (q_ref, bound); cell-sorted source order
   unsigned long long* far_req;         // [ceil(n / 64)] request bits, one word per 64 consecutive source positions
   uint32_t* far_stats;                 // [0] refresh requests, [1] cache hits
+  // MODE 1 (closing pass)
+  float4* aligned; double* fit_psum; uint32_t* fit_pcnt;
 };
 
 // ------------------------------------------------------------------ far queries
@@ -144,7 +146,12 @@ __device__ __forceinline__ void emit_point(const bool have, const bool lin, cons
   fold7(g, 3, first, wbuf, wrow);
 }
 
-template <int TB, int OCC>
+// MODE 0: an optimiser tick.  MODE 1: the closing pass of align() in ONE kernel - the last controller step in the prologue, then (only
+// when the state machine is done) pcl::Registration::getFitnessScore's nearest-neighbour sweep at the FINAL pose (f32 transform in PCL's
+// SSE order, tracked from the last tick's neighbours; per-block f64 sums of the f32 squared distances) and the output cloud
+// pcl::transformPointCloud(*input_, output, final_transformation_) (loop_closure.cpp:124, 127).  It replaces six launches
+// (controller, tracked NN, its list pass, two fitness reductions, the transform); k_finalize_fit folds the block sums and fills the result.
+template <int TB, int OCC, int MODE>
 __global__ void __launch_bounds__(TB, OCC) k_tick(TickArgs a) {
   union WaveScratch { WaveLds w; double red[7 * 64]; };
   static_assert(sizeof(WaveLds) >= 7 * 64 * sizeof(double), "the transpose buffer aliases the wave's search scratch");
@@ -176,12 +183,12 @@ __global__ void __launch_bounds__(TB, OCC) k_tick(TickArgs a) {
   reduce_partial_rows<TB>(a.part_in, a.rows_in, part8, sums);        // (rows of a state that is not pending are summed and ignored: rows_in is what matters)
   const int pending = sh.pending, phase_in = sh.phase;
   if (pending && phase_in != 2 && tid == 0) solve_controller(&sh, sums, a.cfg, blockIdx.x == 0 ? a.trace : nullptr, 0, phase_in, Awork);
-  if (tid == 0) { sh.fb_count = 0; sh.big_count = 0; sh.pending = sh.phase != 2 ? 1 : 0; }
+  if (tid == 0) { sh.fb_count = 0; sh.big_count = 0; sh.pending = (MODE == 0 && sh.phase != 2) ? 1 : 0; }
   __syncthreads();
   if (blockIdx.x == 0) for (int i = tid; i < (int)(sizeof(GicpState) / 8); i += TB) ((unsigned long long*)a.st_out)[i] = ((const unsigned long long*)&sh)[i];
   const int phase = sh.phase;
-  if (phase == 2) return;
-  const bool lin = phase == 0;
+  if (MODE == 0 ? phase == 2 : phase != 2) return;
+  const bool lin = MODE == 1 || phase == 0;
   float Tf[12];
 #pragma unroll
   for (int j = 0; j < 12; j++) Tf[j] = (float)sh.x0[j];
@@ -196,7 +203,7 @@ __global__ void __launch_bounds__(TB, OCC) k_tick(TickArgs a) {
       if (valid) { na[0] = a.nrm_s[(size_t)t * 3]; na[1] = a.nrm_s[(size_t)t * 3 + 1]; na[2] = a.nrm_s[(size_t)t * 3 + 2]; }
       if (valid && (uint32_t)j0s < a.tgt.n) { const TargetRec* r = a.tgt_rec + j0s; rec0.p = r->p; rec0.n[0] = r->n[0]; rec0.n[1] = r->n[1]; rec0.n[2] = r->n[2]; }
     }
-    float qx, qy, qz; xform_query<0>(Tf, p.x, p.y, p.z, qx, qy, qz);
+    float qx, qy, qz; xform_query<MODE>(Tf, p.x, p.y, p.z, qx, qy, qz);
     const bool finite_q = (qx - qx == 0.f) && (qy - qy == 0.f) && (qz - qz == 0.f);
     const uint32_t j0 = (uint32_t)j0s;
     unsigned long long best = QN_INF_KEY;
@@ -264,8 +271,9 @@ __global__ void __launch_bounds__(TB, OCC) k_tick(TickArgs a) {
       }
     }
     bool requested = false;
+    const int far_mode = MODE == 0 ? a.far_mode : (a.far_mode != 0 ? 2 : 0);      // the closing pass has no refresh kernel behind it
     const bool far_lane = big && r > QN_FAR_RMIN_CELLS * tg.cell;       // only truly far neighbours: a ball of a few cells is cheaper to search with the wave (shared stream)
-    if (a.far_mode != 0) {
+    if (far_mode != 0) {
       if (far_lane) {
         const float4 cr = a.cand_ref[t];
         if (cr.w > 0.f) {                                            // candidate list made at cr.xyz, everything else is >= cr.w away from there
@@ -291,7 +299,7 @@ __global__ void __launch_bounds__(TB, OCC) k_tick(TickArgs a) {
           }
         }
       }
-      if (a.far_mode == 1) {
+      if (far_mode == 1) {
         requested = far_lane && big; big = big && !requested;        // misses: k_far searches them (and adds their share of the sums)
         const unsigned long long word = __ballot(requested);
         if (lane == 0) {
@@ -299,7 +307,7 @@ __global__ void __launch_bounds__(TB, OCC) k_tick(TickArgs a) {
           if (chunk * 64u < a.src.n) a.far_req[chunk] = word;
           if (word) atomicAdd(&a.far_stats[0], (uint32_t)__popcll(word));
         }
-      } else {                                                       // mode 2: misses are searched right here; counted so that the host can bring k_far back
+      } else if (MODE == 0) {                                        // mode 2: misses are searched right here; counted so that the host can bring k_far back
         const unsigned long long word = __ballot(big && far_lane);
         if (lane == 0 && word) atomicAdd(&a.far_stats[0], (uint32_t)__popcll(word));
       }
@@ -320,6 +328,18 @@ __global__ void __launch_bounds__(TB, OCC) k_tick(TickArgs a) {
       const unsigned long long rk = __shfl(sink.key, slot); const float rsec = __shfl(sink.second, slot), rdu = __shfl(du, slot);
       if ((grp >> lane) & 1ull) { best = rk; second = rsec; d_unseen = rdu; rescanned = true; }
     }
+    if (MODE == 1) {                                               // fitness + output cloud (original point order)
+      double d2 = 0.0; uint32_t cnt = 0;
+      if (valid) {
+        a.aligned[__float_as_uint(p.w)] = make_float4(qx, qy, qz, 1.0f);
+        if (best != QN_INF_KEY) { d2 = (double)key_d2(best); cnt = 1; }      // max_range = DBL_MAX: every source point with a neighbour counts
+      }
+      d2 = wave_sum_f64_dpp(d2);
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
+      if (lane == 0) { if (it == 0) { wsum[tid >> 6][0] = d2; wsum[tid >> 6][1] = (double)cnt; } else { wsum[tid >> 6][0] += d2; wsum[tid >> 6][1] += (double)cnt; } }
+      continue;
+    }
     bool have = false;
     if (valid && !requested) {
       a.nn_idx[t] = best != QN_INF_KEY ? (int32_t)key_idx(best) : -1;
@@ -339,9 +359,34 @@ __global__ void __launch_bounds__(TB, OCC) k_tick(TickArgs a) {
     emit_point(have, true, it == 0, X0, X0, make_float4(p.x, p.y, p.z, 1.f), rec0.p, na, rec0.n, sc[tid >> 6].red, wsum[tid >> 6]);
   }
   __syncthreads();
+  if (MODE == 1) {
+    if (tid == 0) { double sv = 0, cv = 0; for (int w = 0; w < TB / 64; w++) { sv += wsum[w][0]; cv += wsum[w][1]; } a.fit_psum[lblk] = sv; a.fit_pcnt[lblk] = (uint32_t)cv; }
+    return;
+  }
   if (tid < QN_NPART) { double v = 0;
 #pragma unroll
     for (int w = 0; w < TB / 64; w++) v += wsum[w][tid]; a.part_out[(size_t)lblk * QN_NPART + tid] = v; }
+}
+
+// result block of an align(): state + fitness = (sum of the block sums, fixed order) / (points with a neighbour), written to pinned host memory
+static __global__ void k_finalize_fit(const GicpState* __restrict__ st, ResultBlock* out, uint32_t* __restrict__ far_stats,
+                                      const double* __restrict__ fit_psum, const uint32_t* __restrict__ fit_pcnt, int nblk) {
+  const int lane = threadIdx.x;                                     // one wave
+  double s = 0; uint32_t c = 0;
+  if (st->phase == 2) {
+    for (int b = lane * 8; b < min(lane * 8 + 8, nblk); b++) { s += fit_psum[b]; c += fit_pcnt[b]; }      // nblk <= 512 = 64 lanes x 8
+    s = wave_sum_f64_dpp(s);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
+  }
+  if (lane != 0) return;
+  for (int i = 0; i < 16; i++) { out->r.T64[i] = st->x0[i]; out->r.T[i] = (float)st->x0[i]; }
+  for (int i = 0; i < 36; i++) out->r.H[i] = st->final_H[i];
+  out->r.fitness = c > 0 ? s / c : 1.7976931348623157e308;
+  out->r.iterations = st->outer; out->r.converged = st->converged; out->r.lm_failed = st->lm_failed; out->r.reserved = 0;
+  out->phase = st->phase; out->trace_len = st->trace_len;
+  out->far_requests = far_stats ? far_stats[1] : 0u; out->far_misses = far_stats ? far_stats[0] : 0u; out->far_queries = far_stats ? far_stats[3] : 0u;
+  if (far_stats) { far_stats[0] = 0u; far_stats[1] = 0u; far_stats[3] = 0u; }
 }
 
 // All target points within R of q (one query per wave, ONE pass over the cap box of radius R - which covers ball(q, R) completely, so

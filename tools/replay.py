@@ -12,8 +12,12 @@ What is reproduced from the reference (fast_lio_sam_qn/src/fast_lio_sam_qn.cpp):
 What is NOT the reference: GTSAM/iSAM2 is not installed here, so the pose graph is a small batch SE(3) Gauss-Newton in numpy
 (same factors, same noise models) - the optimiser stays on the host either way, as the north-star prescribes.
 The registration engine is the product under test: keyframe clouds resident in HBM (qn_kf_store), cloud assembly + voxel grid
-on the device, Nano-GICP on the device; with --quatro the assembled clouds are read back once for the Quatro entry point, which
-takes host clouds like the reference's quatro::align.
+on the device, Nano-GICP and (--quatro) Quatro + Nano-GICP on the device through the `_device` entry points: a loop attempt moves no
+point cloud across PCIe.  `backend="oracle"` runs the same loop with the CPU oracle's assembly and registrations instead (test
+infrastructure: tests/test_replay.py compares the two); `save_dir` writes the corrected trajectory the way saveFlagCallback does
+(FQ:344-373): poses_kitti.txt (3x4 row-major, default stream precision) and poses_tum.txt ("#timestamp x y z qx qy qz qw", 8 decimals).
+The reference's extra iSAM2::update() calls after a loop (FQ:160-165) are iSAM2 relinearisation sweeps; the batch Gauss-Newton stand-in
+iterates to convergence instead.
 """
 import argparse
 import os
@@ -140,23 +144,55 @@ def make_stream(n_kf, seed, scan_range=28.0, drift_yaw=0.004, drift_xy=0.03, pts
     return scans, gt, odom, np.arange(n_kf) * 1.0
 
 
+def rot_to_quat(R):
+    """(qx, qy, qz, qw) of a rotation matrix (what tf::Matrix3x3::getRotation yields in poseEigToPoseStamped, utilities.hpp)"""
+    t = np.trace(R)
+    if t > 0:
+        s = np.sqrt(t + 1.0) * 2; q = [(R[2, 1] - R[1, 2]) / s, (R[0, 2] - R[2, 0]) / s, (R[1, 0] - R[0, 1]) / s, 0.25 * s]
+    elif R[0, 0] > R[1, 1] and R[0, 0] > R[2, 2]:
+        s = np.sqrt(1.0 + R[0, 0] - R[1, 1] - R[2, 2]) * 2; q = [0.25 * s, (R[0, 1] + R[1, 0]) / s, (R[0, 2] + R[2, 0]) / s, (R[2, 1] - R[1, 2]) / s]
+    elif R[1, 1] > R[2, 2]:
+        s = np.sqrt(1.0 + R[1, 1] - R[0, 0] - R[2, 2]) * 2; q = [(R[0, 1] + R[1, 0]) / s, 0.25 * s, (R[1, 2] + R[2, 1]) / s, (R[0, 2] - R[2, 0]) / s]
+    else:
+        s = np.sqrt(1.0 + R[2, 2] - R[0, 0] - R[1, 1]) * 2; q = [(R[0, 2] + R[2, 0]) / s, (R[1, 2] + R[2, 1]) / s, 0.25 * s, (R[1, 0] - R[0, 1]) / s]
+    return np.array(q)
+
+
+def write_kitti_tum(save_dir, poses, stamps):
+    """saveFlagCallback's pose files (fast_lio_sam_qn.cpp:344-373): KITTI = the 3x4 [R|t] row by row with the stream's default
+    formatting (6 significant digits), TUM = header line + `stamp x y z qx qy qz qw`, fixed, 8 decimals."""
+    os.makedirs(save_dir, exist_ok=True)
+    with open(os.path.join(save_dir, "poses_kitti.txt"), "w") as fk, open(os.path.join(save_dir, "poses_tum.txt"), "w") as ft:
+        ft.write("#timestamp x y z qx qy qz qw\n")
+        for T, st in zip(poses, stamps):
+            fk.write(" ".join("%g" % T[r, c] for r in range(3) for c in range(4)) + "\n")
+            q = rot_to_quat(T[:3, :3])
+            ft.write("%.8f %.8f %.8f %.8f %.8f %.8f %.8f %.8f\n" % (st, T[0, 3], T[1, 3], T[2, 3], q[0], q[1], q[2], q[3]))
+
+
 def ate(poses, gt):
     return float(np.sqrt(np.mean([np.sum((a[:3, 3] - b[:3, 3]) ** 2) for a, b in zip(poses, gt)])))
 
 
-def run(n_kf=70, seed=7, use_quatro=False, radius=12.0, tdiff=15.0, voxel=0.3, submap_range=5, score_thr=1.5, verbose=True):
-    from qn_amd import engine
+def run(n_kf=70, seed=7, use_quatro=False, radius=12.0, tdiff=15.0, voxel=0.3, submap_range=5, score_thr=1.5, verbose=True, backend="gpu", save_dir=None):
     scans, gt, odom, stamps = make_stream(n_kf, seed)
-    store = engine.KeyframeStore()
-    ctx = engine.Context(400000)
-    g = engine.NanoGICP(ctx)                                        # LoopClosure ctor, loop_closure.cpp:9-16, SURVEY App. C values
-    g.setCorrespondenceRandomness(15); g.setMaximumIterations(32); g.setMaxCorrespondenceDistance(1.5 * radius); g.setTransformationEpsilon(0.01)
-    quatro = engine.Quatro(ctx) if use_quatro else None
+    if backend == "gpu":
+        from qn_amd import engine
+        store = engine.KeyframeStore()
+        ctx = engine.Context(400000)
+        g = engine.NanoGICP(ctx)                                    # LoopClosure ctor, loop_closure.cpp:9-16, SURVEY App. C values
+        g.setCorrespondenceRandomness(15); g.setMaximumIterations(32); g.setMaxCorrespondenceDistance(1.5 * radius); g.setTransformationEpsilon(0.01)
+        quatro = engine.Quatro(ctx) if use_quatro else None
+        loop_candidates = engine.loop_candidates
+    else:
+        from oracle import oracle as orc                           # the checker's side of the comparison (tests only)
+        loop_candidates = orc.loop_candidates
     pg = PoseGraph(); ids = []; corrected = []
     prior_var = np.array([1e-4, 1e-4, 1e-4, 1e-2, 1e-2, 1e-2]); odom_var = prior_var.copy()   # FQ:112-114, 132-133 (rot, then trans)
     loops = []; t_reg = []
     for k in range(n_kf):
-        ids.append(store.add(scans[k]))
+        if backend == "gpu":
+            ids.append(store.add(scans[k]))
         pose = odom[k] if k == 0 else corrected[-1] @ (inv(odom[k - 1]) @ odom[k])           # realtime pose = last corrected * delta odom (FQ:93-103)
         pg.add_pose(pose); corrected.append(pose)
         if k == 0:
@@ -165,25 +201,34 @@ def run(n_kf=70, seed=7, use_quatro=False, radius=12.0, tdiff=15.0, voxel=0.3, s
             pg.add_between(k - 1, k, inv(odom[k - 1]) @ odom[k], odom_var)
         # ---- loopTimerFunc
         pos = np.array([c[:3, 3] for c in corrected])
-        cand = engine.loop_candidates(pos, stamps[:k + 1], k, radius, tdiff, max_k=1)
+        cand = loop_candidates(pos, stamps[:k + 1], k, radius, tdiff, max_k=1)
         if len(cand) == 0:
             continue
         c = int(cand[0])
         t0 = time.perf_counter()
-        ps, ns = store.assemble([ids[k]], [corrected[k]], voxel, 0)                          # LC:89
         if use_quatro:
-            pd, nd = store.assemble([ids[c]], [corrected[c]], voxel, 1)                      # LC:92
-            src = store.download(0, ns); dst = store.download(1, nd)
-            r = engine.coarse_to_fine_alignment(ctx, src, dst, quatro=quatro, max_corr_dist=1.5 * radius, score_thr=score_thr)
-            valid, score, Treg = r["valid"], r["score"], r["T"]
+            sub = [c]                                                                        # LC:89-92: scan to scan
         else:
-            lo, hi = max(0, c - submap_range), min(k - 1, c + submap_range)                  # LC:98-104 (scan-to-submap)
+            lo, hi = max(0, c - submap_range), min(k - 1, c + submap_range)                  # LC:98-104: scan to submap
             sub = list(range(lo, hi + 1))
+        if backend == "gpu":
+            ps, ns = store.assemble([ids[k]], [corrected[k]], voxel, 0)
             pd, nd = store.assemble([ids[i] for i in sub], [corrected[i] for i in sub], voxel, 1)
-            res = engine.GicpResult(); v = C.c_int()
-            ctx.check(ctx._l.qn_icp_alignment_device(ctx.h, C.c_void_p(ps), C.c_uint32(ns), C.c_void_p(pd), C.c_uint32(nd), C.c_uint32(16),
-                                                     C.c_double(score_thr), C.byref(res), C.byref(v)))
-            valid, score, Treg = bool(v.value), res.fitness, np.array(res.T, dtype=np.float64).reshape(4, 4)
+            if use_quatro:                                                                   # both clouds stay on the device (qn_coarse_to_fine_alignment_device)
+                r = engine.coarse_to_fine_alignment_device(ctx, ps, ns, pd, nd, 16, quatro=quatro, max_corr_dist=1.5 * radius, score_thr=score_thr)
+                valid, score, Treg = r["valid"], r["score"], r["T"]
+            else:
+                res = engine.GicpResult(); v = C.c_int()
+                ctx.check(ctx._l.qn_icp_alignment_device(ctx.h, C.c_void_p(ps), C.c_uint32(ns), C.c_void_p(pd), C.c_uint32(nd), C.c_uint32(16),
+                                                         C.c_double(score_thr), C.byref(res), C.byref(v)))
+                valid, score, Treg = bool(v.value), res.fitness, np.array(res.T, dtype=np.float64).reshape(4, 4)
+        else:
+            src = orc.assemble_submap(scans, corrected, [k], voxel); dst = orc.assemble_submap(scans, corrected, sub, voxel)
+            if use_quatro:
+                r = orc.coarse_to_fine_alignment(src, dst, max_corr_dist=1.5 * radius, score_thr=score_thr)
+            else:
+                r = orc.icp_alignment(src, dst, max_corr_dist=1.5 * radius, score_thr=score_thr)
+            valid, score, Treg = r["valid"], r["score"], r["T"]
         t_reg.append(time.perf_counter() - t0)
         if not valid:
             continue
@@ -193,10 +238,13 @@ def run(n_kf=70, seed=7, use_quatro=False, radius=12.0, tdiff=15.0, voxel=0.3, s
         pg.optimize()
         corrected = [p.copy() for p in pg.poses]                                             # FQ:180-188
     out = dict(n_keyframes=n_kf, loops=len(loops), attempts=len(t_reg), ate_odometry=ate(odom, gt), ate_corrected=ate(corrected, gt),
-               ms_per_attempt=1e3 * float(np.mean(t_reg)) if t_reg else None, quatro=use_quatro)
+               ms_per_attempt=1e3 * float(np.mean(t_reg)) if t_reg else None, quatro=use_quatro, loop_list=loops, poses=corrected)
+    if save_dir:
+        write_kitti_tum(save_dir, corrected, stamps)
     if verbose:
-        print(out)
-    ctx.close(); store.close()
+        print({k: v for k, v in out.items() if k not in ("poses", "loop_list")})
+    if backend == "gpu":
+        ctx.close(); store.close()
     return out
 
 
@@ -205,5 +253,6 @@ if __name__ == "__main__":
     ap.add_argument("--keyframes", type=int, default=70)
     ap.add_argument("--quatro", action="store_true")
     ap.add_argument("--seed", type=int, default=7)
+    ap.add_argument("--save-dir", default=None, help="write poses_kitti.txt / poses_tum.txt (FQ:344-373) here")
     a = ap.parse_args()
-    run(a.keyframes, a.seed, a.quatro)
+    run(a.keyframes, a.seed, a.quatro, save_dir=a.save_dir)
