@@ -63,6 +63,7 @@ struct qn_ctx {
   uint32_t tick_tb = 512;               // threads per block of k_tick (and of k_solve: both run the same row reduction)
   int tick_occ = 4;                     // k_tick variant: waves per SIMD the register budget allows (4 = 128 VGPRs: other streams' kernels keep half of the register file)
   uint32_t* dbg_counters = nullptr;
+  unsigned long long* clk_probe = nullptr; uint32_t clk_n = 0;   // developer probe: device-clock stamps of k_tick
   // verify_track (debug): scratch of the fresh search every tracked pass is compared with
   bool verify_track = false; int32_t* v_corr = nullptr; int32_t* v_nn_idx = nullptr; float* v_sqd = nullptr; float4* v_nn_ref = nullptr; uint32_t* v_counters = nullptr;
   // profiling

@@ -385,6 +385,7 @@ static TickArgs tick_args(qn_ctx* c) {
   a.nn_idx = c->nn_idx; a.nn_ref = c->nn_ref; a.nrm_s = c->nrm_s_sorted; a.tgt_rec = c->tgt_rec; a.ppt = tick_ppt(c);
   a.far_mode = c->far_enabled ? c->far_mode : 0; a.tgt_raw = T.raw; a.cand = c->far_cand; a.cand_ref = c->far_cand_ref; a.far_req = c->far_req; a.far_stats = c->far_stats;
   a.aligned = c->aligned; a.fit_psum = c->fit_psum; a.fit_pcnt = c->fit_pcnt;
+  a.clk = c->clk_probe ? c->clk_probe + 8 * (c->clk_n++ % 256) : nullptr; a.clk_blk = c->clk_probe ? c->clk_probe + 8 * 256 : nullptr;
   return a;
 }
 static void enqueue_tick_fused(qn_ctx* c) {
@@ -698,6 +699,11 @@ extern "C" int qn_debug_set(qn_ctx* c, const char* key, double v) {
   else if (k == "tick_occ") c->tick_occ = (int)v;
   else if (k == "far") c->far_enabled = v != 0;
   else if (k == "fused_final") c->fused_final = v != 0;
+  else if (k == "clk_probe") {                                  // developer probe: device-clock stamps inside k_tick (qn_debug_get_clk)
+    if (v != 0 && !c->clk_probe) { if (hipMalloc(&c->clk_probe, 8 * 8 * 256 + 8 * 12 * 1024) != hipSuccess) return QN_ERR_HIP; }
+    if (c->clk_probe) (void)hipMemset(c->clk_probe, 0, 8 * 8 * 256 + 8 * 12 * 1024);
+    c->clk_n = 0; if (v == 0) { (void)hipFree(c->clk_probe); c->clk_probe = nullptr; }
+  }
   else if (k == "tick_tb") c->tick_tb = v >= 512 ? 512 : 256;
   else if (k == "verify_track") {
     if (v != 0 && !c->v_counters) {
@@ -728,6 +734,11 @@ extern "C" int qn_debug_get(qn_ctx* c, const char* key, double* value) {
     return QN_OK;
   }
   return QN_ERR_INVALID_ARG;
+}
+extern "C" int qn_debug_get_clk(qn_ctx* c, unsigned long long* out /* 256 x 8, then 1024 x 4 per-block stamps of the latest tick */, uint32_t* n) {
+  if (!c || !out || !n || !c->clk_probe) return QN_ERR_INVALID_ARG;
+  if (hipStreamSynchronize(c->stream) != hipSuccess || hipMemcpy(out, c->clk_probe, 8 * 8 * 256 + 8 * 12 * 1024, hipMemcpyDeviceToHost) != hipSuccess) return QN_ERR_HIP;
+  *n = c->clk_n; return QN_OK;
 }
 extern "C" int qn_debug_get_grid(qn_ctx* c, int which, double out[8]) {
   if (!c || (which != 0 && which != 1) || !c->cloud[which].has_grid) return QN_ERR_INVALID_ARG;

@@ -579,9 +579,11 @@ __device__ __forceinline__ bool d_ldlt_solve6_fast(const double Ain[36], double 
   return ok;
 }
 
-// LDL^T with diagonal pivoting (what Eigen::LDLT does), 6x6, f64
-__device__ inline void d_ldlt_solve6(const double Ain[36], double diag_add, const double rhs[6], double x[6], double (*A)[6]) {
-  int perm[6];
+// LDL^T with diagonal pivoting (what Eigen::LDLT does), 6x6, f64.  The rarely taken general path: all its dynamically indexed work
+// arrays live in LDS (SolveWork) - a kernel whose private arrays go to scratch pays ~5 us more per dispatch on gfx950.
+struct SolveWork { double A[6][6]; double l[6], y[6], z[6], rhs[6]; int perm[6]; int pad[2]; };
+__device__ inline void d_ldlt_solve6(const double Ain[36], double diag_add, double x[6] /* LDS */, SolveWork* w /* LDS; w->rhs set by the caller */) {
+  double (*A)[6] = w->A; int* perm = w->perm; double* l = w->l; double* y = w->y; double* z = w->z;
   for (int i = 0; i < 6; i++) { perm[i] = i; for (int j = 0; j < 6; j++) A[i][j] = Ain[6 * i + j] + (i == j ? diag_add : 0.0); }
   for (int k = 0; k < 6; k++) {
     int piv = k; double best = fabs(A[k][k]);
@@ -593,13 +595,11 @@ __device__ inline void d_ldlt_solve6(const double Ain[36], double diag_add, cons
     }
     double d = A[k][k];
     if (d == 0.0) continue;
-    double l[6];
     for (int i = k + 1; i < 6; i++) l[i] = A[i][k] / d;
     for (int i = k + 1; i < 6; i++) for (int j = k + 1; j <= i; j++) { A[i][j] -= l[i] * d * l[j]; A[j][i] = A[i][j]; }
     for (int i = k + 1; i < 6; i++) A[i][k] = l[i];
   }
-  double y[6], z[6];
-  for (int i = 0; i < 6; i++) { double s = rhs[perm[i]]; for (int j = 0; j < i; j++) s -= A[i][j] * y[j]; y[i] = s; }
+  for (int i = 0; i < 6; i++) { double s = w->rhs[perm[i]]; for (int j = 0; j < i; j++) s -= A[i][j] * y[j]; y[i] = s; }
   for (int i = 0; i < 6; i++) y[i] = (A[i][i] != 0.0) ? y[i] / A[i][i] : 0.0;
   for (int i = 5; i >= 0; i--) { double s = y[i]; for (int j = i + 1; j < 6; j++) s -= A[j][i] * z[j]; z[i] = s; }
   for (int i = 0; i < 6; i++) x[perm[i]] = z[i];
@@ -627,7 +627,7 @@ __device__ inline bool d_is_converged(const double delta[16], const GicpConfig& 
   return fmax(mr / cfg.rotation_epsilon, mt / cfg.transformation_epsilon) < 1.0;
 }
 
-__device__ inline void d_propose(GicpState* st, double lambda, double (*A)[6]) {      // d = LDLT(H + lambda I).solve(-b); delta; xi = delta * x0
+__device__ __forceinline__ void d_propose(GicpState* st, double lambda, SolveWork* A) {      // d = LDLT(H + lambda I).solve(-b); delta; xi = delta * x0
   double Hl[36], rhs[6], dl[6], x0l[16];
 #pragma unroll
   for (int i = 0; i < 36; i++) Hl[i] = st->H[i];
@@ -636,7 +636,9 @@ __device__ inline void d_propose(GicpState* st, double lambda, double (*A)[6]) {
 #pragma unroll
   for (int i = 0; i < 16; i++) x0l[i] = st->x0[i];
   if (!d_ldlt_solve6_fast(Hl, lambda, rhs, dl)) {
-    d_ldlt_solve6(st->H, lambda, rhs, st->d, A);
+#pragma unroll
+    for (int i = 0; i < 6; i++) A->rhs[i] = rhs[i];
+    d_ldlt_solve6(st->H, lambda, st->d, A);
 #pragma unroll
     for (int i = 0; i < 6; i++) dl[i] = st->d[i];
   }
@@ -671,7 +673,7 @@ __device__ inline void d_finish_outer(GicpState* st, const GicpConfig& cfg, qn_i
 }
 
 // mode 0: full controller.  mode 1: reduce a linearisation only (H, b, y0).  mode 2: reduce an error pass only (yi).
-__device__ inline void solve_controller(GicpState* st, const double* sums, const GicpConfig& cfg, qn_iter_trace* trace, int mode, int phase, double (*Awork)[6]) {
+__device__ inline void solve_controller(GicpState* st, const double* sums, const GicpConfig& cfg, qn_iter_trace* trace, int mode, int phase, SolveWork* Awork) {
   st->fb_count = 0; st->big_count = 0;
   const bool lin = (mode == 1) || (mode == 0 && phase == 0);
   if (lin) {
@@ -684,46 +686,56 @@ __device__ inline void solve_controller(GicpState* st, const double* sums, const
   }
   if (mode != 0) return;
 
+  // One d_propose call site, inlined (a real call would give the kernel a stack = scratch: ~5 us more per dispatch on gfx950).
+  bool propose = false, gn_finish = false;
   if (phase == 0) {
     if (cfg.optimizer == QN_OPT_GN) {                                   // step_gn
-      d_propose(st, 0.0, Awork);
+      propose = true; gn_finish = true;
+    } else {                                                            // step_lm, first try of this outer iteration
+      if (st->lambda < 0.0) {
+        double mx = 0;
+#pragma unroll
+        for (int i = 0; i < 6; i++) mx = fmax(mx, fabs(st->H[7 * i]));
+        st->lambda = cfg.lm_init_lambda_factor * mx;
+      }
+      st->nu = 2.0; st->inner = 0; st->phase = 1; propose = true;
+    }
+  } else {                                                              // phase 1: an error pass at xi just finished
+    double den = 0;
+#pragma unroll
+    for (int i = 0; i < 6; i++) den += st->d[i] * (st->lambda * st->d[i] - st->b[i]);
+    const double rho = (st->y0 - st->yi) / den;
+    st->inner += 1;
+    qn_iter_trace tr; tr.y0 = st->y0; tr.lambda = st->lambda; tr.rho = rho; tr.inner = st->inner; tr.accepted = 0; tr.max_dR = tr.max_dt = 0;
+    if (rho < 0) {
+      if (d_is_converged(st->delta, cfg, nullptr, nullptr)) d_finish_outer(st, cfg, trace, tr);               // `return true` without accepting
+      else {
+        st->lambda = st->nu * st->lambda; st->nu = 2 * st->nu;
+        if (st->inner >= cfg.lm_max_iterations) {                        // "lm not converged!!"
+          if (st->trace_len < QN_MAX_TRACE) { if (trace) trace[st->trace_len] = tr; st->trace_len++; }
+          st->outer += 1; st->lm_failed = 1; st->phase = 2;
+        } else propose = true;                                           // stay in phase 1
+      }
+    } else {
+#pragma unroll
       for (int i = 0; i < 16; i++) st->x0[i] = st->xi[i];
+      const double c3 = (2 * rho - 1) * (2 * rho - 1) * (2 * rho - 1);
+      st->lambda = st->lambda * fmax(1.0 / 3.0, 1 - c3);
+#pragma unroll
       for (int i = 0; i < 36; i++) st->final_H[i] = st->H[i];
-      qn_iter_trace tr; tr.y0 = st->y0; tr.lambda = 0; tr.rho = 0; tr.inner = 1; tr.accepted = 1; tr.max_dR = tr.max_dt = 0;
+      tr.accepted = 1;
       d_finish_outer(st, cfg, trace, tr);
-      return;
     }
-    // step_lm, first try of this outer iteration
-    if (st->lambda < 0.0) {
-      double mx = 0; for (int i = 0; i < 6; i++) mx = fmax(mx, fabs(st->H[7 * i]));
-      st->lambda = cfg.lm_init_lambda_factor * mx;
-    }
-    st->nu = 2.0; st->inner = 0;
-    d_propose(st, st->lambda, Awork);
-    st->phase = 1;
-    return;
   }
-  // phase 1: an error pass at xi just finished
-  double den = 0; for (int i = 0; i < 6; i++) den += st->d[i] * (st->lambda * st->d[i] - st->b[i]);
-  const double rho = (st->y0 - st->yi) / den;
-  st->inner += 1;
-  qn_iter_trace tr; tr.y0 = st->y0; tr.lambda = st->lambda; tr.rho = rho; tr.inner = st->inner; tr.accepted = 0; tr.max_dR = tr.max_dt = 0;
-  if (rho < 0) {
-    if (d_is_converged(st->delta, cfg, nullptr, nullptr)) { d_finish_outer(st, cfg, trace, tr); return; }   // `return true` without accepting
-    st->lambda = st->nu * st->lambda; st->nu = 2 * st->nu;
-    if (st->inner >= cfg.lm_max_iterations) {                            // "lm not converged!!"
-      if (st->trace_len < QN_MAX_TRACE) { if (trace) trace[st->trace_len] = tr; st->trace_len++; }
-      st->outer += 1; st->lm_failed = 1; st->phase = 2; return;
-    }
-    d_propose(st, st->lambda, Awork);                                    // stay in phase 1
-    return;
+  if (propose) d_propose(st, gn_finish ? 0.0 : st->lambda, Awork);
+  if (gn_finish) {
+#pragma unroll
+    for (int i = 0; i < 16; i++) st->x0[i] = st->xi[i];
+#pragma unroll
+    for (int i = 0; i < 36; i++) st->final_H[i] = st->H[i];
+    qn_iter_trace tr; tr.y0 = st->y0; tr.lambda = 0; tr.rho = 0; tr.inner = 1; tr.accepted = 1; tr.max_dR = tr.max_dt = 0;
+    d_finish_outer(st, cfg, trace, tr);
   }
-  for (int i = 0; i < 16; i++) st->x0[i] = st->xi[i];
-  const double c3 = (2 * rho - 1) * (2 * rho - 1) * (2 * rho - 1);
-  st->lambda = st->lambda * fmax(1.0 / 3.0, 1 - c3);
-  for (int i = 0; i < 36; i++) st->final_H[i] = st->H[i];
-  tr.accepted = 1;
-  d_finish_outer(st, cfg, trace, tr);
 }
 
 
@@ -765,7 +777,7 @@ static __global__ void __launch_bounds__(NT) k_solve(const GicpState* __restrict
   __shared__ double sums[QN_NPART];
   __shared__ double part8[QN_NPART][NT / QN_NPART + 1];
   __shared__ GicpState sh;                       // the controller works on an LDS copy: one coalesced read, one coalesced write-back
-  __shared__ double Awork[6][6];
+  __shared__ SolveWork Awork_s; SolveWork* Awork = &Awork_s;
   static_assert(sizeof(GicpState) % 8 == 0, "GicpState is copied as 8-byte words");
   for (int i = threadIdx.x; i < (int)(sizeof(GicpState) / 8); i += NT) ((unsigned long long*)&sh)[i] = ((const unsigned long long*)st_in)[i];
   __syncthreads();

@@ -42,6 +42,8 @@ struct TickArgs {
   uint32_t* far_stats;                 // [0] refresh requests, [1] cache hits
   // MODE 1 (closing pass)
   float4* aligned; double* fit_psum; uint32_t* fit_pcnt;
+  unsigned long long* clk;              // developer probe (null in production): wall_clock64() stamps of block 0, 8 per launch
+  unsigned long long* clk_blk;          // ... and [start, +prologue, +nn, end] of every block of the latest tick launch
 };
 
 // ------------------------------------------------------------------ far queries
@@ -160,11 +162,15 @@ __global__ void __launch_bounds__(TB, OCC) k_tick(TickArgs a) {
   __shared__ GicpState sh;
   __shared__ double part8[QN_NPART][TB / QN_NPART + 1];
   __shared__ double sums[QN_NPART];
-  __shared__ double Awork[6][6];
+  __shared__ SolveWork Awork_s; SolveWork* Awork = &Awork_s;
   static_assert(sizeof(GicpState) % 8 == 0, "GicpState is copied as 8-byte words");
   const int tid = threadIdx.x, lane = tid & 63;
   const float INF = __int_as_float(0x7f800000);
   const uint32_t nblk = gridDim.x;
+  const bool probe = a.clk != nullptr && blockIdx.x == 0 && threadIdx.x == 0;
+  if (probe) a.clk[0] = wall_clock64();
+  if (a.clk != nullptr && threadIdx.x == 0) atomicMax(&a.clk[7], ~wall_clock64());       // earliest block start (as a max of the complement)
+  if (MODE == 0 && a.clk != nullptr && threadIdx.x == 0) { a.clk_blk[8 * blockIdx.x] = wall_clock64(); a.clk_blk[8 * blockIdx.x + 4] = 0; a.clk_blk[8 * blockIdx.x + 5] = 0; a.clk_blk[8 * blockIdx.x + 6] = 0; }
   const uint32_t lblk = xcd_block(blockIdx.x, nblk);               // XCD x works on one contiguous eighth of the cell-sorted source
   // ---- pose-independent loads of this thread's first point, in flight during the prologue
   uint32_t t = (lblk * a.ppt) * TB + tid;
@@ -181,8 +187,11 @@ __global__ void __launch_bounds__(TB, OCC) k_tick(TickArgs a) {
   // requested back to back with the point loads above: one memory round trip in front of the controller.
   for (int i = tid; i < (int)(sizeof(GicpState) / 8); i += TB) ((unsigned long long*)&sh)[i] = ((const unsigned long long*)a.st_in)[i];
   reduce_partial_rows<TB>(a.part_in, a.rows_in, part8, sums);        // (rows of a state that is not pending are summed and ignored: rows_in is what matters)
+  if (probe) a.clk[1] = wall_clock64();
   const int pending = sh.pending, phase_in = sh.phase;
   if (pending && phase_in != 2 && tid == 0) solve_controller(&sh, sums, a.cfg, blockIdx.x == 0 ? a.trace : nullptr, 0, phase_in, Awork);
+  if (probe) a.clk[2] = wall_clock64();
+  if (MODE == 0 && a.clk != nullptr && threadIdx.x == 0) a.clk_blk[8 * blockIdx.x + 1] = wall_clock64();
   if (tid == 0) { sh.fb_count = 0; sh.big_count = 0; sh.pending = (MODE == 0 && sh.phase != 2) ? 1 : 0; }
   __syncthreads();
   if (blockIdx.x == 0) for (int i = tid; i < (int)(sizeof(GicpState) / 8); i += TB) ((unsigned long long*)a.st_out)[i] = ((const unsigned long long*)&sh)[i];
@@ -312,6 +321,10 @@ __global__ void __launch_bounds__(TB, OCC) k_tick(TickArgs a) {
         if (lane == 0 && word) atomicAdd(&a.far_stats[0], (uint32_t)__popcll(word));
       }
     }
+    if (probe) a.clk[3] = wall_clock64();
+    if (MODE == 0 && a.clk != nullptr) { const unsigned long long wb = __ballot(big), wr = __ballot(rescanned), wf = __ballot(big && far_lane);
+      if (big || rescanned) { a.clk_blk[8 * blockIdx.x + 7] = ((unsigned long long)t << 32) | (unsigned long long)(uint32_t)j0s; a.clk_blk[8 * 1024 + 4 * blockIdx.x] = __float_as_uint(key_d2(best)); a.clk_blk[8 * 1024 + 4 * blockIdx.x + 1] = __float_as_uint(ref.w); a.clk_blk[8 * 1024 + 4 * blockIdx.x + 2] = __float_as_uint(delta); a.clk_blk[8 * 1024 + 4 * blockIdx.x + 3] = __float_as_uint(r); }
+      if (lane == 0) { atomicAdd(&a.clk_blk[8 * blockIdx.x + 4], (unsigned long long)__popcll(wb)); atomicAdd(&a.clk_blk[8 * blockIdx.x + 5], (unsigned long long)__popcll(wr)); atomicAdd(&a.clk_blk[8 * blockIdx.x + 6], (unsigned long long)__popcll(wf)); } }
     // the wave's big-ball queries, 16 at a time, cooperatively (neighbouring queries' balls overlap: one shared candidate stream)
     for (unsigned long long pend = __ballot(big); pend != 0;) {
       unsigned long long grp = 0, tmp = pend; int srcl = -1;
@@ -350,6 +363,8 @@ __global__ void __launch_bounds__(TB, OCC) k_tick(TickArgs a) {
         have = true;
       }
     }
+    if (probe) a.clk[4] = wall_clock64();
+    if (MODE == 0 && a.clk != nullptr && threadIdx.x == 0) a.clk_blk[8 * blockIdx.x + 2] = wall_clock64();
     double X0[3][4];
 #pragma unroll
     for (int r = 0; r < 3; r++)
@@ -366,6 +381,9 @@ __global__ void __launch_bounds__(TB, OCC) k_tick(TickArgs a) {
   if (tid < QN_NPART) { double v = 0;
 #pragma unroll
     for (int w = 0; w < TB / 64; w++) v += wsum[w][tid]; a.part_out[(size_t)lblk * QN_NPART + tid] = v; }
+  if (probe) a.clk[5] = wall_clock64();
+  if (a.clk != nullptr && threadIdx.x == 0) atomicMax(&a.clk[6], wall_clock64());        // latest block end
+  if (MODE == 0 && a.clk != nullptr && threadIdx.x == 0) a.clk_blk[8 * blockIdx.x + 3] = wall_clock64();
 }
 
 // result block of an align(): state + fitness = (sum of the block sums, fixed order) / (points with a neighbour), written to pinned host memory
