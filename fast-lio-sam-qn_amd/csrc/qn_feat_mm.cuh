@@ -1,0 +1,256 @@
+// qn_feat_mm.cuh - K12 on the matrix cores: exact nearest neighbour in FPFH space (33-D, f32 sequential sum, ties -> lowest index;
+// Matcher::searchKDTree) by SCREENING with v_mfma_f32_32x32x16_f16 and re-evaluating the survivors with the defining arithmetic.
+//
+//   d(q, c) = |q - c|^2 = |q'|^2 - 2 S(q, c),   S = q'.c' - |c'|^2 / 2,   x' = x - P  (P = the FPFH row of an exact plane: 100 in bins 5, 16, 27 -
+//   the mode of every structured scene; any P is CORRECT, it only decides how tight the bound below is where the rows are dense)
+//
+// For a fixed query the nearest candidate maximises S.  Rows are split x' = h + l + e (h, l in f16, |e| <= 2^-24 |x'|) and laid out along K = 112:
+//        candidate row  [ h(33) n1 n2 n3 | l(33) b|c'|^2 |c'| 0 | h(33) 0 0 0 | 0 0 0 0 ]      n1 + n2 + n3 = -|c'|^2 / 2 (three f16 pieces)
+//        query row      [ h(33) 1  1  1  | h(33) s  s a|q'| 0   | l(33) 0 0 0 | 0 0 0 0 ]      s = -1 (pass 1) / +1 (pass 2)
+// so one chain of 7 MFMAs per 32 x 32 tile yields  S~ -/+ delta  with  delta(q, c) = a |q'||c'| + b |c'|^2  an upper bound of |S~ - S|:
+//        split:       |q'.c' - (hh + hl + lh)| <= 3.1 x 2^-24 |q'||c'|
+//        matrix core: each instruction returns C + (16 products) rounded ONCE (measured: tools/micro/mfma_probe.hip - f16 subnormals kept, the
+//                     sum carried wider than f32); assumed with an 8 x margin: 2^-21 (|C| + sum |products|) per instruction, 7 instructions
+//        =>  a = 3.6e-6, b = 1.7e-6  (the f16 images of a|q'|, |c'|, b|c'|^2 are rounded UP)
+// Pass 1:  L(q) = max_c (S~ - delta)   <= S of the best candidate.
+// Pass 2:  every c with  S~ + delta >= L(q) - X(q)  is a SURVIVOR;  X = 2.3e-6 (|q'|^2 - 2 L) covers the rounding of the defining f32 sum itself
+//          (36 x 2^-24 relative on both candidates compared).  The defining nearest neighbour is always a survivor ("feature matching").
+// Exact:   survivors are evaluated with the defining arithmetic; 64-bit atomicMin on (distance bits, index).  Bit-identical results.
+// Duplicate rows (every point of an exact plane has the same FPFH row) are removed from the CANDIDATE side first: a hash table keeps the lowest
+// index of each distinct row, the others become dead rows (S~ = -196512, below every live value) - their distance is the representative's and
+// their index is higher, so they can never win.  Dead rows also stand for NaN rows and tile padding.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace qn {
+
+#define QN_MM_KS 7                      // K = 112 = 7 x 16
+#define QN_MM_QT 4                      // query tiles (32 queries each) per wave
+#define QN_MM_WAVES 4                   // waves per block: 512 queries per block
+#define QN_MM_ALPHA 3.6e-6
+#define QN_MM_BETA 1.7e-6
+#define QN_MM_DEAD (-65504.0f)          // x 3 pieces
+#define QN_MM_EMPTY 0xFFFFFFFFFFFFFFFFull
+typedef _Float16 qn_h8 __attribute__((ext_vector_type(8)));
+typedef float qn_f16v __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ uint32_t mm_enc(float f) { const uint32_t b = __float_as_uint(f); return (b & 0x80000000u) ? ~b : (b | 0x80000000u); }
+__device__ __forceinline__ float mm_dec(uint32_t u) { return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u); }
+__device__ __forceinline__ float mm_plane(int d) { return (d == 5 || d == 16 || d == 27) ? 100.f : 0.f; }
+
+// ---- candidate de-duplication: open addressing, entry = (row hash << 32 | lowest index of that row); rows compared bit for bit
+static __global__ void k_feat_dedupe(const float* __restrict__ rows, uint32_t n, unsigned long long* __restrict__ table, uint32_t mask) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t* r = (const uint32_t*)(rows + (size_t)i * QN_FROW);
+  if ((r[0] & 0x7fffffffu) > 0x7f800000u) return;                      // NaN row (k_fpfh marks a dead point by NaN in bin 0)
+  const uint32_t h = r[34];
+  const unsigned long long mine = ((unsigned long long)h << 32) | i;
+  for (uint32_t slot = h & mask;; slot = (slot + 1) & mask) {
+    unsigned long long e = table[slot];
+    if (e == QN_MM_EMPTY) { e = atomicCAS(&table[slot], QN_MM_EMPTY, mine); if (e == QN_MM_EMPTY) return; }
+    if ((uint32_t)(e >> 32) == h) {
+      const uint32_t* o = (const uint32_t*)(rows + (size_t)(uint32_t)e * QN_FROW);
+      bool same = true;
+#pragma unroll
+      for (int d = 0; d < 33; d++) same = same && (o[d] == r[d]);
+      if (same) { atomicMin(&table[slot], mine); return; }
+    }
+  }
+}
+__device__ __forceinline__ bool feat_is_rep(const float* __restrict__ rows, uint32_t i, const unsigned long long* __restrict__ table, uint32_t mask) {
+  const uint32_t* r = (const uint32_t*)(rows + (size_t)i * QN_FROW);
+  const uint32_t h = r[34];
+  for (uint32_t slot = h & mask;; slot = (slot + 1) & mask) {
+    const unsigned long long e = table[slot];
+    if (e == QN_MM_EMPTY) return true;                                  // (not reached for an inserted row)
+    if ((uint32_t)(e >> 32) == h) {
+      if ((uint32_t)e == i) return true;
+      const uint32_t* o = (const uint32_t*)(rows + (size_t)(uint32_t)e * QN_FROW);
+      bool same = true;
+#pragma unroll
+      for (int d = 0; d < 33; d++) same = same && (o[d] == r[d]);
+      if (same) return false;
+    }
+  }
+}
+
+// ---- operand images.  Tile-major: element (row r, k) of a set sits at  (((r / 32) * 7 + k / 16) * 64 + (r % 32) + 32 * ((k % 16) / 8)) * 8 + k % 8,
+// i.e. the 16 bytes lane l of a wave needs for k-step ks of tile t are at  ((t * 7 + ks) * 64 + l) * 16: every fragment load is one coalesced KB.
+// One thread per row (padding rows of the last tile included).  side 0: candidate rows (index = row), side 1: query slots (row = qlist[slot]).
+__device__ __forceinline__ _Float16 mm_up(double v) { return (_Float16)(float)(v * (1.0 + 1.0 / 1024.0) + 1e-7); }      // f16 image >= v (v >= 0)
+static __global__ void k_feat_prep(const float* __restrict__ rows, uint32_t n, const uint32_t* __restrict__ qlist, const uint32_t* __restrict__ qlist_n, int side,
+                                   const unsigned long long* __restrict__ table, uint32_t mask, _Float16* __restrict__ out, float* __restrict__ qn_up, uint32_t n_pad) {
+  const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= n_pad) return;
+  const uint32_t count = (side == 1 && qlist) ? *qlist_n : n;
+  bool live = s < count;
+  uint32_t row = s;
+  if (live && side == 1 && qlist) row = qlist[s];
+  double xp[33]; double nn = 0;
+  if (live) {
+    const float* r = rows + (size_t)row * QN_FROW;
+    live = r[0] == r[0];
+    if (live && side == 0 && table) live = feat_is_rep(rows, row, table, mask);
+#pragma unroll
+    for (int d = 0; d < 33; d++) { xp[d] = live ? (double)r[d] - (double)mm_plane(d) : 0.0; nn += xp[d] * xp[d]; }
+  } else {
+#pragma unroll
+    for (int d = 0; d < 33; d++) xp[d] = 0.0;
+  }
+  _Float16 v[112];
+#pragma unroll
+  for (int k = 0; k < 112; k++) v[k] = (_Float16)0.f;
+#pragma unroll
+  for (int d = 0; d < 33; d++) {
+    const _Float16 h = (_Float16)(float)xp[d];
+    const _Float16 l = (_Float16)(float)(xp[d] - (double)(float)h);
+    v[d] = h;
+    if (side == 0) { v[36 + d] = l; v[72 + d] = h; } else { v[36 + d] = h; v[72 + d] = l; }
+  }
+  if (side == 0) {
+    if (live) {
+      const double half = -0.5 * nn;
+      const _Float16 n1 = (_Float16)(float)half; const double r1 = half - (double)(float)n1;
+      const _Float16 n2 = (_Float16)(float)r1; const double r2 = r1 - (double)(float)n2;
+      v[33] = n1; v[34] = n2; v[35] = (_Float16)(float)r2;
+      v[69] = mm_up(QN_MM_BETA * nn); v[70] = mm_up(sqrt(nn));
+    } else { v[33] = (_Float16)QN_MM_DEAD; v[34] = (_Float16)QN_MM_DEAD; v[35] = (_Float16)QN_MM_DEAD; }
+  } else {
+    v[33] = (_Float16)1.f; v[34] = (_Float16)1.f; v[35] = (_Float16)1.f;
+    v[69] = (_Float16)1.f; v[70] = mm_up(QN_MM_ALPHA * sqrt(nn));
+    qn_up[s] = live ? (float)(nn * (1.0 + 1e-6)) : __int_as_float(0x7fc00000);       // NaN: this slot admits nothing
+  }
+  const uint32_t tile = s >> 5, rr = s & 31;
+  qn_h8* o = (qn_h8*)out;
+#pragma unroll
+  for (int ks = 0; ks < QN_MM_KS; ks++)
+#pragma unroll
+    for (int half = 0; half < 2; half++) {
+      qn_h8 w;
+#pragma unroll
+      for (int j = 0; j < 8; j++) w[j] = v[ks * 16 + half * 8 + j];
+      o[((size_t)tile * QN_MM_KS + ks) * 64 + rr + 32 * half] = w;
+    }
+}
+
+// ---- the screening passes.  Candidates are the A operand (rows), queries the B operand (columns): in the 32 x 32 result a lane holds ONE query
+// (column lane & 31) and 16 candidates (rows (r & 3) + 8 (r >> 2) + 4 (lane >> 5)), so the running maximum / the threshold is a per-lane scalar.
+// A wave keeps the fragments of QN_MM_QT query tiles in registers (112 VGPRs) and streams the candidate tiles of its grid.y segment; each
+// candidate fragment (one coalesced KB per k-step) feeds QN_MM_QT x 7 MFMAs.
+template <int PASS>
+static __global__ void __launch_bounds__(64 * QN_MM_WAVES, 2) k_feat_mm(const qn_h8* __restrict__ Qm, uint32_t nq_max, const uint32_t* __restrict__ qcount_p,
+                                                                       const qn_h8* __restrict__ Cm, uint32_t nc_tiles, uint32_t tiles_per_seg,
+                                                                       uint32_t* __restrict__ Lq, const float* __restrict__ qn_up, uint2* __restrict__ pairs,
+                                                                       uint32_t* __restrict__ pair_count, uint32_t cap) {
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const uint32_t nqueries = qcount_p ? *qcount_p : nq_max;
+  const uint32_t nq_tiles = (nqueries + 31) >> 5;
+  const uint32_t qt0 = (blockIdx.x * QN_MM_WAVES + wid) * QN_MM_QT;
+  if (qt0 >= nq_tiles) return;
+  qn_h8 bq[QN_MM_QT][QN_MM_KS];
+#pragma unroll
+  for (int u = 0; u < QN_MM_QT; u++)
+#pragma unroll
+    for (int ks = 0; ks < QN_MM_KS; ks++) {
+      const uint32_t t = min(qt0 + u, nq_tiles - 1);                        // a tile past the end repeats the last one (its results are dropped)
+      bq[u][ks] = Qm[((size_t)t * QN_MM_KS + ks) * 64 + lane];
+    }
+  if (PASS == 1 && lane < 32) {                                           // k = 69, 70: the delta terms enter with a minus sign
+#pragma unroll
+    for (int u = 0; u < QN_MM_QT; u++) { bq[u][4][5] = -bq[u][4][5]; bq[u][4][6] = -bq[u][4][6]; }
+  }
+  float m[QN_MM_QT];                                                     // pass 1: running max; pass 2: the admission threshold
+#pragma unroll
+  for (int u = 0; u < QN_MM_QT; u++) {
+    m[u] = __int_as_float(0xff800000);
+    if (PASS == 2) {
+      const uint32_t slot = (qt0 + u) * 32 + (lane & 31);
+      float thr = __int_as_float(0x7f800000);
+      if (qt0 + u < nq_tiles && slot < nqueries) {
+        const float L = mm_dec(Lq[slot]); const float qn = qn_up[slot];
+        if (qn == qn && L > -150000.f) thr = L - 2.3e-6f * fmaxf(qn - 2.f * L, 0.f) * 1.01f - 2.4e-7f * fabsf(L) - 1e-30f;
+      }
+      m[u] = thr;
+    }
+  }
+  const uint32_t t0 = blockIdx.y * tiles_per_seg, t1 = min(nc_tiles, t0 + tiles_per_seg);
+  qn_h8 a[QN_MM_KS], an[QN_MM_KS];
+  if (t0 < t1) {
+#pragma unroll
+    for (int ks = 0; ks < QN_MM_KS; ks++) an[ks] = Cm[((size_t)t0 * QN_MM_KS + ks) * 64 + lane];
+  }
+  for (uint32_t t = t0; t < t1; t++) {
+#pragma unroll
+    for (int ks = 0; ks < QN_MM_KS; ks++) a[ks] = an[ks];
+    if (t + 1 < t1) {
+#pragma unroll
+      for (int ks = 0; ks < QN_MM_KS; ks++) an[ks] = Cm[((size_t)(t + 1) * QN_MM_KS + ks) * 64 + lane];
+    }
+#pragma unroll
+    for (int u = 0; u < QN_MM_QT; u++) {
+      qn_f16v acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < QN_MM_KS; ks++) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[ks], bq[u][ks], acc, 0, 0, 0);
+      if (PASS == 1) {
+        float x = fmaxf(fmaxf(acc[0], acc[1]), fmaxf(acc[2], acc[3]));
+        x = fmaxf(x, fmaxf(fmaxf(acc[4], acc[5]), fmaxf(acc[6], acc[7])));
+        x = fmaxf(x, fmaxf(fmaxf(acc[8], acc[9]), fmaxf(acc[10], acc[11])));
+        x = fmaxf(x, fmaxf(fmaxf(acc[12], acc[13]), fmaxf(acc[14], acc[15])));
+        m[u] = fmaxf(m[u], x);
+      } else {
+        float x = fmaxf(fmaxf(acc[0], acc[1]), fmaxf(acc[2], acc[3]));
+        x = fmaxf(x, fmaxf(fmaxf(acc[4], acc[5]), fmaxf(acc[6], acc[7])));
+        x = fmaxf(x, fmaxf(fmaxf(acc[8], acc[9]), fmaxf(acc[10], acc[11])));
+        x = fmaxf(x, fmaxf(fmaxf(acc[12], acc[13]), fmaxf(acc[14], acc[15])));
+        if (__ballot(x >= m[u]) != 0ull) {                                // rare: some lane of the wave has a survivor in this tile
+          const uint32_t slot = (qt0 + u) * 32 + (lane & 31);
+#pragma unroll
+          for (int r = 0; r < 16; r++) {
+            if (acc[r] >= m[u]) {
+              const uint32_t cand = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+              const uint32_t pos = atomicAdd(pair_count, 1u);
+              if (pos < cap) pairs[pos] = make_uint2(slot, cand);
+            }
+          }
+        }
+      }
+    }
+  }
+  if (PASS == 1) {
+#pragma unroll
+    for (int u = 0; u < QN_MM_QT; u++) {
+      const float x = fmaxf(m[u], __shfl_xor(m[u], 32));
+      const uint32_t slot = (qt0 + u) * 32 + (lane & 31);
+      if (lane < 32 && qt0 + u < nq_tiles && slot < nqueries && x == x) atomicMax(&Lq[slot], mm_enc(x));
+    }
+  }
+}
+
+// ---- survivors: the defining arithmetic (f32, bins in order, no contraction), winner by 64-bit atomicMin on (distance bits << 32 | candidate index)
+static __global__ void k_feat_exact(const uint2* __restrict__ pairs, const uint32_t* __restrict__ pair_count, uint32_t cap, const float* __restrict__ Q,
+                                    const uint32_t* __restrict__ qlist, const float* __restrict__ C, uint32_t nc, unsigned long long* __restrict__ best_key,
+                                    uint32_t* __restrict__ overflow) {
+  const uint32_t n = *pair_count;
+  if (n > cap) { if (blockIdx.x == 0 && threadIdx.x == 0) *overflow = 1u; }
+  const uint32_t m = min(n, cap);
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < m; i += gridDim.x * blockDim.x) {
+    const uint2 pr = pairs[i];
+    if (pr.y >= nc) continue;
+    const uint32_t qi = qlist ? qlist[pr.x] : pr.x;
+    const float4* q = (const float4*)(Q + (size_t)qi * QN_FROW); const float4* c = (const float4*)(C + (size_t)pr.y * QN_FROW);
+    float e = 0.f;
+#pragma unroll
+    for (int v = 0; v < 9; v++) {
+      const float4 a = q[v], b = c[v];
+      { const float t = a.x - b.x; e = e + t * t; }
+      if (4 * v + 1 < 33) { const float t = a.y - b.y; e = e + t * t; }
+      if (4 * v + 2 < 33) { const float t = a.z - b.z; e = e + t * t; }
+      if (4 * v + 3 < 33) { const float t = a.w - b.w; e = e + t * t; }
+    }
+    if (e == e) atomicMin(&best_key[qi], ((unsigned long long)__float_as_uint(e) << 32) | pr.y);
+  }
+}
+
+}  // namespace qn

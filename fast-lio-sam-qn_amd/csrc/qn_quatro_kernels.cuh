@@ -166,6 +166,9 @@ static __global__ void k_rows_to_original(const float4* __restrict__ pts, uint32
   for (int b = 0; b < w_out; b++) out[(size_t)i * w_out + b] = b < w_in ? in[(size_t)t * w_in + b] : 0.f;
 }
 
+}  // namespace qn
+#include "qn_feat_mm.cuh"
+namespace qn {
 // 32-bit hash of a descriptor row's 33 bit patterns into slot 34 of the row (k_feat_nn recognises duplicate rows by it)
 static __global__ void k_row_hash(float* __restrict__ rows, uint32_t n) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -396,7 +399,8 @@ static __global__ void __launch_bounds__(QN_TUPLE_THREADS) k_tuple_test(const ui
 
 // one 32-byte record per selected correspondence, written straight to pinned host memory in candidate (ascending j) order
 struct QuatroCorr { uint32_t i, j; float pi[3], pj[3]; };
-struct QuatroTailOut { uint32_t n_cand, n_sel, overflow, pad; };
+struct QuatroTailOut { uint32_t n_cand, n_sel, overflow, pad /* survivor-list overflow of the matrix-core search */, survivors, r0, r1, r2; };
+static __global__ void k_feat_survivors(const uint32_t* __restrict__ cnt, uint32_t* __restrict__ out) { *out = *cnt; }
 static __global__ void __launch_bounds__(QN_TUPLE_THREADS) k_collect_corres(const uint2* __restrict__ cand, const uint32_t* __restrict__ ncand_p, const uint32_t* __restrict__ sel,
                                                                             const float4* __restrict__ Pi, const float4* __restrict__ Pj, uint32_t cap, QuatroTailOut* __restrict__ head, QuatroCorr* __restrict__ out) {
   __shared__ uint32_t wcnt[QN_TUPLE_THREADS / 64];
