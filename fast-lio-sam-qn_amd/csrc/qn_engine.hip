@@ -140,7 +140,7 @@ extern "C" void qn_ctx_destroy(qn_ctx* c) {
   for (int w = 0; w < 2; w++) { CloudBuf& b = c->cloud[w]; hipFree(b.raw); hipFree(b.sorted); hipFree(b.cell_of_pt); hipFree(b.cell_start); hipFree(b.counts); hipFree(b.nrm); }
   hipFree(c->staging); hipFree(c->scan_sums); hipFree(c->bbox); hipFree(c->state); hipFree(c->partials); hipFree(c->trace);
   hipFree(c->nn_idx); hipFree(c->knn_idx); hipFree(c->nn_ref); hipFree(c->nrm_s_sorted); hipFree(c->tgt_rec); hipFree(c->fit_psum); hipFree(c->fit_pcnt); hipFree(c->corr); hipFree(c->sqd); hipFree(c->sqd_fit); hipFree(c->far_cand); hipFree(c->far_cand_ref); hipFree(c->far_req); hipFree(c->far_stats); hipFree(c->far_rows); hipFree(c->fb_list); hipFree(c->big_list); hipFree(c->fb_count2); hipFree(c->aligned);
-  hipFree(c->q_mm_c); hipFree(c->q_mm_q); hipFree(c->q_mm_qn); hipFree(c->q_mm_L); hipFree(c->q_mm_table); hipFree(c->q_mm_pairs); hipFree(c->q_mm_cnt);
+  hipFree(c->q_mm_c); hipFree(c->q_mm_q); hipFree(c->q_mm_qn); hipFree(c->q_mm_L); hipFree(c->q_mm_table); hipFree(c->q_mm_pairs); hipFree(c->q_mm_cnt); hipFree(c->q_mm_vkeys); hipFree(c->q_mm_vcnt);
   for (int w = 0; w < 2; w++) { hipFree(c->q_normals[w]); hipFree(c->q_spfh[w]); hipFree(c->q_fpfh_s[w]); hipFree(c->q_fpfh[w]); hipFree(c->q_key[w]); hipFree(c->q_pair[w]); hipFree(c->q_pair_hash[w]); }
   hipFree(c->q_hit); hipFree(c->q_list); hipFree(c->q_sel); hipFree(c->q_pairs); hipFree(c->q_counts); hipFree(c->q_T); hipFree(c->q_mean); hipFree(c->q_mean_psum);
   if (c->q_host) hipHostFree(c->q_host);
@@ -701,6 +701,8 @@ extern "C" int qn_debug_set(qn_ctx* c, const char* key, double v) {
   else if (k == "far") c->far_enabled = v != 0;
   else if (k == "fused_final") c->fused_final = v != 0;
   else if (k == "feat_mfma") c->feat_mfma = v != 0;
+  else if (k == "feat_sample") c->feat_sample = (int)v;
+  else if (k == "feat_verify") { c->feat_verify = v != 0; if (c->q_mm_vcnt) (void)hipMemset(c->q_mm_vcnt, 0, 16); }
   else if (k == "clk_probe") {                                  // developer probe: device-clock stamps inside k_tick (qn_debug_get_clk)
     if (v != 0 && !c->clk_probe) { if (hipMalloc(&c->clk_probe, 8 * 8 * 256 + 8 * 12 * 1024) != hipSuccess) return QN_ERR_HIP; }
     if (c->clk_probe) (void)hipMemset(c->clk_probe, 0, 8 * 8 * 256 + 8 * 12 * 1024);
@@ -733,6 +735,13 @@ extern "C" int qn_debug_get(qn_ctx* c, const char* key, double* value) {
     uint32_t h[4];
     if (hipStreamSynchronize(c->stream) != hipSuccess || hipMemcpy(h, c->v_counters, 16, hipMemcpyDeviceToHost) != hipSuccess) return QN_ERR_HIP;
     *value = k == "verify_mismatches" ? h[0] : (k == "verify_passes" ? h[1] : h[2]);
+    return QN_OK;
+  }
+  if (k == "feat_mismatches" || k == "feat_verified" || k == "feat_first_mismatch") {
+    if (!c->q_mm_vcnt) return QN_ERR_NOT_READY;
+    uint32_t h[4];
+    if (hipStreamSynchronize(c->stream) != hipSuccess || hipMemcpy(h, c->q_mm_vcnt, 16, hipMemcpyDeviceToHost) != hipSuccess) return QN_ERR_HIP;
+    *value = k == "feat_mismatches" ? h[0] : (k == "feat_verified" ? h[2] : h[1]);
     return QN_OK;
   }
   if (k == "feat_fallbacks") { *value = c->feat_fallbacks; return QN_OK; }      // matrix-core feature searches repeated with the VALU kernel (survivor overflow)

@@ -12,9 +12,11 @@
 //        matrix core: each instruction returns C + (16 products) rounded ONCE (measured: tools/micro/mfma_probe.hip - f16 subnormals kept, the
 //                     sum carried wider than f32); assumed with an 8 x margin: 2^-21 (|C| + sum |products|) per instruction, 7 instructions
 //        =>  a = 3.6e-6, b = 1.7e-6  (the f16 images of a|q'|, |c'|, b|c'|^2 are rounded UP)
-// Pass 1:  L(q) = max_c (S~ - delta)   <= S of the best candidate.
+// Pass 1:  L(q) = max (S~ - delta) over a SAMPLE of the candidates (every QN_MM_SAMPLE-th tile)  <= S of the best candidate.
 // Pass 2:  every c with  S~ + delta >= L(q) - X(q)  is a SURVIVOR;  X = 2.3e-6 (|q'|^2 - 2 L) covers the rounding of the defining f32 sum itself
 //          (36 x 2^-24 relative on both candidates compared).  The defining nearest neighbour is always a survivor ("feature matching").
+//          (Sampling makes pass 1 cost 1 / QN_MM_SAMPLE of pass 2; the price is ~QN_MM_SAMPLE survivors per query - the candidates that beat the best of
+//          the sample - instead of ~1.)
 // Exact:   survivors are evaluated with the defining arithmetic; 64-bit atomicMin on (distance bits, index).  Bit-identical results.
 // Duplicate rows (every point of an exact plane has the same FPFH row) are removed from the CANDIDATE side first: a hash table keeps the lowest
 // index of each distinct row, the others become dead rows (S~ = -196512, below every live value) - their distance is the representative's and
@@ -28,6 +30,7 @@ namespace qn {
 #define QN_MM_KS 7                      // K = 112 = 7 x 16
 #define QN_MM_QT 4                      // query tiles (32 queries each) per wave
 #define QN_MM_WAVES 4                   // waves per block: 512 queries per block
+#define QN_MM_SAMPLE 8                  // pass 1 visits every 8th candidate tile
 #define QN_MM_ALPHA 3.6e-6
 #define QN_MM_BETA 1.7e-6
 #define QN_MM_DEAD (-65504.0f)          // x 3 pieces
@@ -37,13 +40,29 @@ typedef float qn_f16v __attribute__((ext_vector_type(16)));
 
 __device__ __forceinline__ uint32_t mm_enc(float f) { const uint32_t b = __float_as_uint(f); return (b & 0x80000000u) ? ~b : (b | 0x80000000u); }
 __device__ __forceinline__ float mm_dec(uint32_t u) { return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u); }
+// max of the 16 results of a tile and a seed (plain fmaxf: an inline-asm v_max3_f32 here reads the MFMA result registers without the wait
+// states the compiler's hazard recognizer inserts for its own instructions - measured: wrong maxima)
+__device__ __forceinline__ float mm_max16(const float __attribute__((ext_vector_type(16)))& v, float seed) {
+  float x = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
+  x = fmaxf(x, fmaxf(fmaxf(v[4], v[5]), fmaxf(v[6], v[7])));
+  x = fmaxf(x, fmaxf(fmaxf(v[8], v[9]), fmaxf(v[10], v[11])));
+  x = fmaxf(x, fmaxf(fmaxf(v[12], v[13]), fmaxf(v[14], v[15])));
+  return fmaxf(seed, x);
+}
 __device__ __forceinline__ float mm_plane(int d) { return (d == 5 || d == 16 || d == 27) ? 100.f : 0.f; }
 
 // ---- candidate de-duplication: open addressing, entry = (row hash << 32 | lowest index of that row); rows compared bit for bit
-static __global__ void k_feat_dedupe(const float* __restrict__ rows, uint32_t n, unsigned long long* __restrict__ table, uint32_t mask) {
+static __global__ void k_feat_dedupe(const float* __restrict__ rows, uint32_t n, unsigned long long* __restrict__ table, uint32_t mask, uint32_t* __restrict__ plane_min /* zeroed */) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const uint32_t* r = (const uint32_t*)(rows + (size_t)i * QN_FROW);
+  const uint32_t* r = (const uint32_t*)(rows + (size_t)min(i, n - 1) * QN_FROW);
+  // the exact-plane row (half of a synthetic cloud, every flat patch of a real one) does not go through the table - tens of thousands of
+  // atomics on one slot took 0.3 ms: the lowest lane of each wave that holds one reports its index (plane_min keeps ~min as a max)
+  bool plane = i < n;
+#pragma unroll
+  for (int d = 0; d < 33; d++) plane = plane && (__uint_as_float(r[d]) == mm_plane(d));
+  const unsigned long long pw = __ballot(plane);
+  if (pw != 0ull && (int)(threadIdx.x & 63) == __ffsll((long long)pw) - 1 && ~*plane_min > i) atomicMax(plane_min, ~i);
+  if (i >= n || plane) return;
   if ((r[0] & 0x7fffffffu) > 0x7f800000u) return;                      // NaN row (k_fpfh marks a dead point by NaN in bin 0)
   const uint32_t h = r[34];
   const unsigned long long mine = ((unsigned long long)h << 32) | i;
@@ -55,12 +74,16 @@ static __global__ void k_feat_dedupe(const float* __restrict__ rows, uint32_t n,
       bool same = true;
 #pragma unroll
       for (int d = 0; d < 33; d++) same = same && (o[d] == r[d]);
-      if (same) { atomicMin(&table[slot], mine); return; }
+      if (same) { if ((uint32_t)e > i) atomicMin(&table[slot], mine); return; }      // (most duplicates find a lower index already there: no atomic on the hot slot)
     }
   }
 }
-__device__ __forceinline__ bool feat_is_rep(const float* __restrict__ rows, uint32_t i, const unsigned long long* __restrict__ table, uint32_t mask) {
+__device__ __forceinline__ bool feat_is_rep(const float* __restrict__ rows, uint32_t i, const unsigned long long* __restrict__ table, uint32_t mask, const uint32_t* __restrict__ plane_min) {
   const uint32_t* r = (const uint32_t*)(rows + (size_t)i * QN_FROW);
+  bool plane = true;
+#pragma unroll
+  for (int d = 0; d < 33; d++) plane = plane && (__uint_as_float(r[d]) == mm_plane(d));
+  if (plane) return ~*plane_min == i;
   const uint32_t h = r[34];
   for (uint32_t slot = h & mask;; slot = (slot + 1) & mask) {
     const unsigned long long e = table[slot];
@@ -81,7 +104,7 @@ __device__ __forceinline__ bool feat_is_rep(const float* __restrict__ rows, uint
 // One thread per row (padding rows of the last tile included).  side 0: candidate rows (index = row), side 1: query slots (row = qlist[slot]).
 __device__ __forceinline__ _Float16 mm_up(double v) { return (_Float16)(float)(v * (1.0 + 1.0 / 1024.0) + 1e-7); }      // f16 image >= v (v >= 0)
 static __global__ void k_feat_prep(const float* __restrict__ rows, uint32_t n, const uint32_t* __restrict__ qlist, const uint32_t* __restrict__ qlist_n, int side,
-                                   const unsigned long long* __restrict__ table, uint32_t mask, _Float16* __restrict__ out, float* __restrict__ qn_up, uint32_t n_pad) {
+                                   const unsigned long long* __restrict__ table, uint32_t mask, const uint32_t* __restrict__ plane_min, _Float16* __restrict__ out, float* __restrict__ qn_up, uint32_t n_pad) {
   const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= n_pad) return;
   const uint32_t count = (side == 1 && qlist) ? *qlist_n : n;
@@ -92,7 +115,7 @@ static __global__ void k_feat_prep(const float* __restrict__ rows, uint32_t n, c
   if (live) {
     const float* r = rows + (size_t)row * QN_FROW;
     live = r[0] == r[0];
-    if (live && side == 0 && table) live = feat_is_rep(rows, row, table, mask);
+    if (live && side == 0 && table) live = feat_is_rep(rows, row, table, mask, plane_min);
 #pragma unroll
     for (int d = 0; d < 33; d++) { xp[d] = live ? (double)r[d] - (double)mm_plane(d) : 0.0; nn += xp[d] * xp[d]; }
   } else {
@@ -141,14 +164,22 @@ static __global__ void k_feat_prep(const float* __restrict__ rows, uint32_t n, c
 // candidate fragment (one coalesced KB per k-step) feeds QN_MM_QT x 7 MFMAs.
 template <int PASS>
 static __global__ void __launch_bounds__(64 * QN_MM_WAVES, 2) k_feat_mm(const qn_h8* __restrict__ Qm, uint32_t nq_max, const uint32_t* __restrict__ qcount_p,
-                                                                       const qn_h8* __restrict__ Cm, uint32_t nc_tiles, uint32_t tiles_per_seg,
+                                                                       const qn_h8* __restrict__ Cm, uint32_t nc_tiles, uint32_t tiles_per_seg, uint32_t tile_step,
                                                                        uint32_t* __restrict__ Lq, const float* __restrict__ qn_up, uint2* __restrict__ pairs,
-                                                                       uint32_t* __restrict__ pair_count, uint32_t cap) {
+                                                                       uint32_t* __restrict__ counts, uint32_t cap_block, uint2* __restrict__ spill, uint32_t cap_spill) {
+  // survivors of this block go to its own region pairs[block * cap_block ..] through a counter in LDS (one global counter for the whole grid
+  // serialises a million atomics on one address: measured 3 ms); what does not fit there goes to the shared spill list (global counter counts[3]).
+  // counts[0] = all survivors, counts[1] = lost survivors (the caller repeats the search with the VALU kernel), counts[4 + block] = the block's count
+  __shared__ uint32_t bcnt;
+  const uint32_t blk = blockIdx.y * gridDim.x + blockIdx.x;
+  if (PASS == 2) { if (threadIdx.x == 0) bcnt = 0; __syncthreads(); }
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const uint32_t nqueries = qcount_p ? *qcount_p : nq_max;
   const uint32_t nq_tiles = (nqueries + 31) >> 5;
   const uint32_t qt0 = (blockIdx.x * QN_MM_WAVES + wid) * QN_MM_QT;
-  if (qt0 >= nq_tiles) return;
+  const bool idle = qt0 >= nq_tiles;                                      // (no early return in pass 2: the block meets again at the end)
+  if (idle && PASS == 1) return;
+  if (!idle) {
   qn_h8 bq[QN_MM_QT][QN_MM_KS];
 #pragma unroll
   for (int u = 0; u < QN_MM_QT; u++)
@@ -170,23 +201,25 @@ static __global__ void __launch_bounds__(64 * QN_MM_WAVES, 2) k_feat_mm(const qn
       float thr = __int_as_float(0x7f800000);
       if (qt0 + u < nq_tiles && slot < nqueries) {
         const float L = mm_dec(Lq[slot]); const float qn = qn_up[slot];
-        if (qn == qn && L > -150000.f) thr = L - 2.3e-6f * fmaxf(qn - 2.f * L, 0.f) * 1.01f - 2.4e-7f * fabsf(L) - 1e-30f;
+        if (qn == qn) thr = L > -150000.f ? L - 2.3e-6f * fmaxf(qn - 2.f * L, 0.f) * 1.01f - 2.4e-7f * fabsf(L) - 1e-30f
+                                          : -150000.f;                      // no live candidate in the sample: every live candidate survives
       }
       m[u] = thr;
     }
   }
-  const uint32_t t0 = blockIdx.y * tiles_per_seg, t1 = min(nc_tiles, t0 + tiles_per_seg);
+  // the segment's tiles, every tile_step-th one (pass 1 looks at a SAMPLE of the candidates: any lower bound L is a valid one)
+  const uint32_t t0 = blockIdx.y * tiles_per_seg * tile_step, t1 = min(nc_tiles, t0 + tiles_per_seg * tile_step);
   qn_h8 a[QN_MM_KS], an[QN_MM_KS];
   if (t0 < t1) {
 #pragma unroll
     for (int ks = 0; ks < QN_MM_KS; ks++) an[ks] = Cm[((size_t)t0 * QN_MM_KS + ks) * 64 + lane];
   }
-  for (uint32_t t = t0; t < t1; t++) {
+  for (uint32_t t = t0; t < t1; t += tile_step) {
 #pragma unroll
     for (int ks = 0; ks < QN_MM_KS; ks++) a[ks] = an[ks];
-    if (t + 1 < t1) {
+    if (t + tile_step < t1) {
 #pragma unroll
-      for (int ks = 0; ks < QN_MM_KS; ks++) an[ks] = Cm[((size_t)(t + 1) * QN_MM_KS + ks) * 64 + lane];
+      for (int ks = 0; ks < QN_MM_KS; ks++) an[ks] = Cm[((size_t)(t + tile_step) * QN_MM_KS + ks) * 64 + lane];
     }
 #pragma unroll
     for (int u = 0; u < QN_MM_QT; u++) {
@@ -194,24 +227,18 @@ static __global__ void __launch_bounds__(64 * QN_MM_WAVES, 2) k_feat_mm(const qn
 #pragma unroll
       for (int ks = 0; ks < QN_MM_KS; ks++) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[ks], bq[u][ks], acc, 0, 0, 0);
       if (PASS == 1) {
-        float x = fmaxf(fmaxf(acc[0], acc[1]), fmaxf(acc[2], acc[3]));
-        x = fmaxf(x, fmaxf(fmaxf(acc[4], acc[5]), fmaxf(acc[6], acc[7])));
-        x = fmaxf(x, fmaxf(fmaxf(acc[8], acc[9]), fmaxf(acc[10], acc[11])));
-        x = fmaxf(x, fmaxf(fmaxf(acc[12], acc[13]), fmaxf(acc[14], acc[15])));
-        m[u] = fmaxf(m[u], x);
+        m[u] = mm_max16(acc, m[u]);
       } else {
-        float x = fmaxf(fmaxf(acc[0], acc[1]), fmaxf(acc[2], acc[3]));
-        x = fmaxf(x, fmaxf(fmaxf(acc[4], acc[5]), fmaxf(acc[6], acc[7])));
-        x = fmaxf(x, fmaxf(fmaxf(acc[8], acc[9]), fmaxf(acc[10], acc[11])));
-        x = fmaxf(x, fmaxf(fmaxf(acc[12], acc[13]), fmaxf(acc[14], acc[15])));
+        const float x = mm_max16(acc, __int_as_float(0xff800000));
         if (__ballot(x >= m[u]) != 0ull) {                                // rare: some lane of the wave has a survivor in this tile
           const uint32_t slot = (qt0 + u) * 32 + (lane & 31);
 #pragma unroll
           for (int r = 0; r < 16; r++) {
             if (acc[r] >= m[u]) {
               const uint32_t cand = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-              const uint32_t pos = atomicAdd(pair_count, 1u);
-              if (pos < cap) pairs[pos] = make_uint2(slot, cand);
+              const uint32_t pos = atomicAdd(&bcnt, 1u);
+              if (pos < cap_block) pairs[(size_t)blk * cap_block + pos] = make_uint2(slot, cand);
+              else { const uint32_t g = atomicAdd(&counts[3], 1u); if (g < cap_spill) spill[g] = make_uint2(slot, cand); else counts[1] = 1u; }
             }
           }
         }
@@ -226,17 +253,24 @@ static __global__ void __launch_bounds__(64 * QN_MM_WAVES, 2) k_feat_mm(const qn
       if (lane < 32 && qt0 + u < nq_tiles && slot < nqueries && x == x) atomicMax(&Lq[slot], mm_enc(x));
     }
   }
+  }
+  if (PASS == 2) {
+    __syncthreads();
+    if (threadIdx.x == 0) { const uint32_t n = bcnt; counts[4 + blk] = min(n, cap_block); if (n) atomicAdd(&counts[0], n); }
+  }
 }
 
 // ---- survivors: the defining arithmetic (f32, bins in order, no contraction), winner by 64-bit atomicMin on (distance bits << 32 | candidate index)
-static __global__ void k_feat_exact(const uint2* __restrict__ pairs, const uint32_t* __restrict__ pair_count, uint32_t cap, const float* __restrict__ Q,
-                                    const uint32_t* __restrict__ qlist, const float* __restrict__ C, uint32_t nc, unsigned long long* __restrict__ best_key,
-                                    uint32_t* __restrict__ overflow) {
-  const uint32_t n = *pair_count;
-  if (n > cap) { if (blockIdx.x == 0 && threadIdx.x == 0) *overflow = 1u; }
-  const uint32_t m = min(n, cap);
-  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < m; i += gridDim.x * blockDim.x) {
-    const uint2 pr = pairs[i];
+static __global__ void k_feat_exact(const uint2* __restrict__ pairs, const uint32_t* __restrict__ counts, uint32_t cap_block, uint32_t nregions, const uint2* __restrict__ spill,
+                                    uint32_t cap_spill, const float* __restrict__ Q, const uint32_t* __restrict__ qlist, const float* __restrict__ C, uint32_t nc,
+                                    unsigned long long* __restrict__ best_key, uint32_t* __restrict__ overflow) {
+  if (counts[1] && blockIdx.x == 0 && threadIdx.x == 0) *overflow = 1u;
+  // blocks [0, nregions): one region each; the blocks behind them share the spill list
+  const bool reg = blockIdx.x < nregions;
+  const uint32_t m = reg ? counts[4 + blockIdx.x] : min(counts[3], cap_spill);
+  const uint32_t i0 = reg ? threadIdx.x : (blockIdx.x - nregions) * blockDim.x + threadIdx.x, di = reg ? blockDim.x : (gridDim.x - nregions) * blockDim.x;
+  for (uint32_t i = i0; i < m; i += di) {
+    const uint2 pr = reg ? pairs[(size_t)blockIdx.x * cap_block + i] : spill[i];
     if (pr.y >= nc) continue;
     const uint32_t qi = qlist ? qlist[pr.x] : pr.x;
     const float4* q = (const float4*)(Q + (size_t)qi * QN_FROW); const float4* c = (const float4*)(C + (size_t)pr.y * QN_FROW);
@@ -251,6 +285,17 @@ static __global__ void k_feat_exact(const uint2* __restrict__ pairs, const uint3
     }
     if (e == e) atomicMin(&best_key[qi], ((unsigned long long)__float_as_uint(e) << 32) | pr.y);
   }
+}
+
+// developer check ("feat_verify"): the matrix-core search against the VALU search, every query
+static __global__ void k_feat_compare(const unsigned long long* __restrict__ a, const unsigned long long* __restrict__ b, uint32_t n, const uint32_t* __restrict__ qlist,
+                                      const uint32_t* __restrict__ qlist_n, uint32_t* __restrict__ out /* mismatches, first + 1, queries */) {
+  const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t cnt = qlist ? *qlist_n : n;
+  if (s >= cnt) return;
+  const uint32_t i = qlist ? qlist[s] : s;
+  atomicAdd(&out[2], 1u);
+  if (a[i] != b[i]) { atomicAdd(&out[0], 1u); atomicMax(&out[1], i + 1); }
 }
 
 }  // namespace qn

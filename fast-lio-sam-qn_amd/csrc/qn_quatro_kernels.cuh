@@ -424,7 +424,7 @@ static __global__ void __launch_bounds__(QN_TUPLE_THREADS) k_collect_corres(cons
     total += tot;
     __syncthreads();
   }
-  if (threadIdx.x == 0) { head->n_cand = n; head->n_sel = total < cap ? total : cap; head->overflow = total > cap ? 1u : 0u; head->pad = 0; }
+  if (threadIdx.x == 0) { head->n_cand = n; head->n_sel = total < cap ? total : cap; head->overflow = total > cap ? 1u : 0u; }
 }
 
 // transformPcd(src, T_q): pcl::transformPointCloud with a Matrix4d on f32 points (utilities.hpp:164-175,
