@@ -744,6 +744,9 @@ extern "C" int qn_debug_get(qn_ctx* c, const char* key, double* value) {
     *value = k == "feat_mismatches" ? h[0] : (k == "feat_verified" ? h[2] : h[1]);
     return QN_OK;
   }
+  if (k == "quatro_wall_features_ms") { *value = c->q_wall_ms[0]; return QN_OK; }   // host wall clock of the latest Quatro align, by section
+  if (k == "quatro_wall_match_ms") { *value = c->q_wall_ms[1]; return QN_OK; }
+  if (k == "quatro_wall_solve_ms") { *value = c->q_wall_ms[2]; return QN_OK; }
   if (k == "feat_fallbacks") { *value = c->feat_fallbacks; return QN_OK; }      // matrix-core feature searches repeated with the VALU kernel (survivor overflow)
   if (k == "feat_survivors") { *value = c->feat_survivors; return QN_OK; }      // survivors of the latest forward search (exactly re-evaluated pairs)
   return QN_ERR_INVALID_ARG;

@@ -30,7 +30,7 @@ namespace qn {
 #define QN_MM_KS 7                      // K = 112 = 7 x 16
 #define QN_MM_QT 4                      // query tiles (32 queries each) per wave
 #define QN_MM_WAVES 4                   // waves per block: 512 queries per block
-#define QN_MM_SAMPLE 8                  // pass 1 visits every 8th candidate tile
+#define QN_MM_SAMPLE 4                  // pass 1 visits every 4th candidate tile (measured: 2 -> 3.00, 4 -> 2.79, 8 -> 3.03, 16 -> 5.2 ms at 100k)
 #define QN_MM_ALPHA 3.6e-6
 #define QN_MM_BETA 1.7e-6
 #define QN_MM_DEAD (-65504.0f)          // x 3 pieces
@@ -221,20 +221,28 @@ static __global__ void __launch_bounds__(64 * QN_MM_WAVES, 2) k_feat_mm(const qn
 #pragma unroll
       for (int ks = 0; ks < QN_MM_KS; ks++) an[ks] = Cm[((size_t)(t + tile_step) * QN_MM_KS + ks) * 64 + lane];
     }
+    // the four query tiles' MFMA chains are independent (the compiler interleaves them: a dependent chain alone runs the matrix pipe at half
+    // rate); in pass 2 ONE branch per candidate tile decides whether any survivor exists - a branch per chain serialises the chains
+    qn_f16v acc[QN_MM_QT];
 #pragma unroll
     for (int u = 0; u < QN_MM_QT; u++) {
-      qn_f16v acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      acc[u] = (qn_f16v){0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int ks = 0; ks < QN_MM_KS; ks++) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[ks], bq[u][ks], acc, 0, 0, 0);
-      if (PASS == 1) {
-        m[u] = mm_max16(acc, m[u]);
-      } else {
-        const float x = mm_max16(acc, __int_as_float(0xff800000));
-        if (__ballot(x >= m[u]) != 0ull) {                                // rare: some lane of the wave has a survivor in this tile
+      for (int ks = 0; ks < QN_MM_KS; ks++) acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[ks], bq[u][ks], acc[u], 0, 0, 0);
+      if (PASS == 1) m[u] = mm_max16(acc[u], m[u]);
+    }
+    if (PASS == 2) {
+      bool hu[QN_MM_QT], hit = false;
+#pragma unroll
+      for (int u = 0; u < QN_MM_QT; u++) { hu[u] = mm_max16(acc[u], __int_as_float(0xff800000)) >= m[u]; hit = hit || hu[u]; }
+      if (__ballot(hit) != 0ull) {                                        // rare: some lane of the wave has a survivor in this tile
+#pragma unroll
+        for (int u = 0; u < QN_MM_QT; u++) {
+          if (__ballot(hu[u]) == 0ull) continue;
           const uint32_t slot = (qt0 + u) * 32 + (lane & 31);
 #pragma unroll
           for (int r = 0; r < 16; r++) {
-            if (acc[r] >= m[u]) {
+            if (acc[u][r] >= m[u]) {
               const uint32_t cand = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
               const uint32_t pos = atomicAdd(&bcnt, 1u);
               if (pos < cap_block) pairs[(size_t)blk * cap_block + pos] = make_uint2(slot, cand);

@@ -8,6 +8,8 @@ from qn_amd import engine, synth
 for npts in (30000, 100000):
     qs, qt, _ = synth.make_pair(400 + npts // 1000, npts, mode="quatro")
     ctx = engine.Context(npts + 1024)
+    for kk, vv in json.loads(os.environ.get("QN_DEBUG_KNOBS", "{}")).items():
+        ctx.debug_set(kk, float(vv))
     res = {}
     for mm in (1, 0):
         ctx.debug_set("feat_mfma", mm)
@@ -20,6 +22,7 @@ for npts in (30000, 100000):
         st = ctx.prof_stats()
         stage = {k: round(st[k][0], 3) for k in ("grid_build", "fpfh_normals", "fpfh_spfh", "fpfh_fpfh", "feat_match", "match_tail") if st[k][1] > 0}
         res[mm] = np.array(T)
-        print(npts, "mfma" if mm else "valu", "align ms median %.3f" % np.median(lat), stage, "survivors", ctx.debug_get("feat_survivors"), "fallbacks", ctx.debug_get("feat_fallbacks"), "valid", valid)
+        print(npts, "mfma" if mm else "valu", "align ms median %.3f" % np.median(lat), stage, "survivors", ctx.debug_get("feat_survivors"), "fallbacks", ctx.debug_get("feat_fallbacks"), "valid", valid,
+              "wall ms: features %.3f match %.3f solve %.3f" % (ctx.debug_get("quatro_wall_features_ms"), ctx.debug_get("quatro_wall_match_ms"), ctx.debug_get("quatro_wall_solve_ms")))
     print("  same T:", np.array_equal(res[0], res[1]))
     ctx.close()
