@@ -32,6 +32,7 @@ import torch
 N_PTS, K_COV, GN_ITERS = 100000, 20, 20
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec (MI355X_MICROARCH.md); 6290 GB/s measured-achievable
 FP32_VALU_PEAK_TF = 157.3    # f32 vector peak with FMA (MI355X_MICROARCH.md); 78.6 without FMA contraction
+MFMA_F16_PEAK_TF = 2500.0    # dense f16 / bf16 matrix-core peak (MI355X_MICROARCH.md)
 
 
 def algorithmic_bytes(n=N_PTS, k=K_COV, it=GN_ITERS):
@@ -268,10 +269,10 @@ def main():
         ab = algorithmic_bytes()
         # kernel families timed as ONE kernel per span, with the rocprofv3 name of that kernel and its algorithmic bytes per launch
         single_k = {"knn_select": ("k_knn_hist<false, 32>", N_PTS * (16 + 16 * K_COV)),          # k-NN selection of one cloud: point + k neighbour points
-                    "gn_tick_fused": ("k_nn_track<0, true>", ab["gn_iteration"]),              # one whole GN iteration (NN + accumulate + solve)
+                    "gn_tick_fused": ("k_tick<512, 4, 0>", ab["gn_iteration"]),                # one whole GN / LM tick (controller + tracked NN + accumulate)
                     "nn_search": ("k_nn_search<0, false, 256>", ab["gn_iteration"]),                # first (unseeded) NN passes of an align
                     "nn_fallback": ("k_nn_search<0, true, 256>", ab["gn_iteration"]),
-                    "accumulate": ("k_accumulate", ab["gn_iteration"]), "solve": ("k_solve", 28 * 8 * 512)}
+                    "accumulate": ("k_accumulate", ab["gn_iteration"]), "solve": ("k_solve<512>", 28 * 8 * 512)}
         dom = max((k for k in fam_ms if k in single_k), key=fam_ms.get)
         dom_kernel, per_launch_bytes = single_k[dom]
         dom_ms = fam_avg[dom]
@@ -342,6 +343,9 @@ def main():
                 lat = []
                 for _ in range(5):
                     tq = time.perf_counter(); Tq, qvalid = q.align(qs, qt); lat.append(1e3 * (time.perf_counter() - tq))
+                host_wall = {"uploads_grids_enqueue": round(ctx.debug_get("quatro_wall_features_ms"), 3), "fpfh_wait_matching_tail": round(ctx.debug_get("quatro_wall_match_ms"), 3),
+                             "clique_gnc_solve": round(ctx.debug_get("quatro_wall_solve_ms"), 3)}          # of the last timed align (before the profiled one)
+                n_surv, n_fb = int(ctx.debug_get("feat_survivors")), int(ctx.debug_get("feat_fallbacks"))
                 ctx.prof_reset(); ctx.prof_enable(True); q.align(qs, qt); ctx.synchronize(); ctx.prof_enable(False)
                 st = ctx.prof_stats()
                 stage = {k: round(st[k][0], 4) for k in ("grid_build", "fpfh_normals", "fpfh_spfh", "fpfh_fpfh", "feat_match", "match_tail") if st[k][1] > 0}
@@ -351,12 +355,17 @@ def main():
                 ab_q = {"normals": npts * (16 + 16 * m_n + 12), "spfh": npts * (28 + 28 * m_f + 132), "fpfh": npts * (136 * m_f + 132)}     # per cloud, SURVEY 8d
                 fm_ms = stage.get("feat_match", 0.0)
                 flops = 2.0 * 33 * npts * npts                                   # forward direction; the lazy reverse search adds the hit fraction
+                mm_flops = 2.0 * 112 * npts * npts * 1.25                        # what the matrix cores execute for it (K = 112, full pass + 1/4 sample)
                 e = {"ms_per_align": pct(lat), "valid": bool(qvalid), "stage_ms": stage, "m_n": round(m_n, 1), "m_f": round(m_f, 1),
                      "algorithmic_bytes_per_cloud": {k: int(v) for k, v in ab_q.items()},
                      "frac_hbm": {k: round(ab_q[k] * 2 / (stage[s] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) for k, s in (("normals", "fpfh_normals"), ("spfh", "fpfh_spfh"), ("fpfh", "fpfh_fpfh")) if s in stage},
-                     "feat_match": {"flops_forward": flops, "achieved_TF_lower_bound": round(flops / (fm_ms * 1e-3) / 1e12, 2) if fm_ms else None,
-                                    "frac_of_f32_valu_peak": round(flops / (fm_ms * 1e-3) / 1e12 / FP32_VALU_PEAK_TF, 4) if fm_ms else None,
-                                    "peak_TF": FP32_VALU_PEAK_TF, "note": "2*33*Ns*Nt flop (sub+fma counted as 2) over BOTH searches' time: a lower bound"}}
+                     "feat_match": {"bound": "mfma", "kernel": "k_feat_mm<2>", "flops_f16_mfma": mm_flops, "achieved_TF_lower_bound": round(mm_flops / (fm_ms * 1e-3) / 1e12, 1) if fm_ms else None,
+                                    "peak_TF": MFMA_F16_PEAK_TF, "frac_of_mfma_f16_peak": round(mm_flops / (fm_ms * 1e-3) / 1e12 / MFMA_F16_PEAK_TF, 4) if fm_ms else None,
+                                    "effective_f32_TF": round(flops / (fm_ms * 1e-3) / 1e12, 2) if fm_ms else None,
+                                    "survivors_exactly_re_evaluated": n_surv, "fallbacks_to_valu_search": n_fb,
+                                    "note": "screening GEMM on v_mfma_f32_32x32x16_f16: K = 112 (f16 hi/lo split of 33 bins + bound terms), full pass + 1/4 sampled pass, forward search only "
+                                            "(Ns x Nt); time = BOTH searches + de-duplication + operand images + exact stage, so the fraction is a lower bound. effective_f32_TF = 2*33*Ns*Nt / time"},
+                     "host_wall_ms": host_wall}
                 quatro["%dk" % (npts // 1000)] = e
 
         cpu = None

@@ -9,9 +9,9 @@ bench.py reads the committed copy (profiles/pmc_latest.json) for the `roofline.t
 import csv, json, os, sys
 from collections import defaultdict
 
-FAMILY = [("k_knn_hist<false, 32>", "knn_select"), ("k_nn_track<0, true>", "gn_tick_fused"), ("k_nn_track<0, false>", "nn_track"),
+FAMILY = [("k_knn_hist<false, 32>", "knn_select"), ("k_tick<512, 4, 0>", "gn_tick_fused"), ("k_tick<512, 4, 1>", "closing_pass"), ("k_far(", "far_refresh"),
           ("k_nn_search<0, false,", "nn_search"), ("k_nn_search<0, true,", "nn_fallback"), ("k_accumulate", "accumulate"),
-          ("k_solve", "solve"), ("k_cov_from_idx", "cov_from_idx"), ("k_scatter", "grid_scatter"), ("k_fitness_partial", "fitness")]
+          ("k_solve<512>", "solve"), ("k_cov_from_idx", "cov_from_idx"), ("k_scatter", "grid_scatter"), ("k_fitness_partial", "fitness")]
 
 
 def per_kernel(path):
@@ -36,6 +36,7 @@ def main(d):
                     "WRITE_SIZE_KB_per_launch": round(w, 1), "hbm_bytes_per_launch": int((2.0 * f + w) * 1024),
                     "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, KB; FETCH_SIZE x2 (gfx950 under-count, "
                             "MI355X_MICROARCH.md HBM section); WRITE_SIZE uncalibrated; working set is L2/MALL resident"}
+    out["_meta"] = {"tag": os.path.basename(os.path.normpath(d))}
     print(json.dumps(out, indent=1))
 
 
