@@ -269,7 +269,11 @@ extern "C" int qn_gicp_set_target_device(qn_ctx* c, const float* xyz, uint32_t n
 template <int KMAX>
 static void launch_knn_cov(qn_ctx* c, CloudBuf& b, int k, int32_t* kidx, float* kd2) {
   hipStream_t s = c->stream;
-  const float r0 = c->margin_knn * b.grid.cell;
+  // first radius in cells.  A cloud of <= 65536 points is ONE round of waves (16 queries each, 4096 resident): the kernel then lasts as long as
+  // its slowest wave, and a wave that has to retry with a doubled radius is 3-4x slower - a wider first radius (fewer retries) wins there
+  // (30k points: 174 -> 116 us); beyond that the retries hide behind the next round of waves and the smaller radius wins (100k: 100 vs 131 us);
+  // at 10k points the wider radius measured slower again (few waves, each with more candidates): 2.5 only between 16k and 64k.
+  const float r0 = (c->margin_knn > 0.f ? c->margin_knn : (b.n > 16384u && b.n <= 65536u ? 2.5f : 2.0f)) * b.grid.cell;
   if (c->knn_hist) {                        // histogram selection (default); its leftovers -> hist list pass -> general sorted-list pass
     const uint32_t nb = (b.n + QN_KNN_BLOCK / 4 - 1) / (QN_KNN_BLOCK / 4);     // 16 queries per wave
     uint32_t* genc = c->fb_count2 + 1;

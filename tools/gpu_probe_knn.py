@@ -37,5 +37,5 @@ if os.environ.get("SWEEP"):
 else:
     run("default", knn_hist=1)
     for m in (2.0, 2.5, 3.0):
-        for rd in (2, 3):
+        for rd in (1, 2, 3):
             run("margin %.2f rounds %d" % (m, rd), knn_hist=1, margin_knn=m, knn_rounds=rd)
