@@ -91,7 +91,17 @@ static __global__ void __launch_bounds__(QN_BLOCK) k_cov_from_idx(const float4* 
   const int32_t* nb = knn_idx + (size_t)i * k;
   int found = 0;
   double mean[3] = {0, 0, 0};
-  for (int j = 0; j < k; j++) { const int32_t u = nb[j]; if (u < 0) continue; const float4 p = raw[u]; mean[0] += (double)p.x; mean[1] += (double)p.y; mean[2] += (double)p.z; found++; }
+  // neighbours four at a time: the four index loads, then the four point gathers are issued together (a loop of dependent idx -> point
+  // round trips with 1.5 waves per SIMD was the whole cost of this kernel); the sums are still formed in neighbour order
+  for (int j = 0; j < k; j += 4) {
+    int32_t u[4]; float4 q[4];
+#pragma unroll
+    for (int e = 0; e < 4; e++) u[e] = j + e < k ? nb[j + e] : -1;
+#pragma unroll
+    for (int e = 0; e < 4; e++) q[e] = raw[u[e] < 0 ? 0 : u[e]];
+#pragma unroll
+    for (int e = 0; e < 4; e++) if (u[e] >= 0) { mean[0] += (double)q[e].x; mean[1] += (double)q[e].y; mean[2] += (double)q[e].z; found++; }
+  }
   double nv[3] = {0, 0, 0};                  // found == 0 cannot happen for a finite point (it is its own neighbour); a zero normal reads as C = I
   // the layouts of the optimiser ticks are written here as well (nrm_sorted: source, cell-sorted order; rec: target, 64-byte records)
   auto store = [&]() __attribute__((always_inline)) {
@@ -109,11 +119,17 @@ static __global__ void __launch_bounds__(QN_BLOCK) k_cov_from_idx(const float4* 
   if (found == 0) { store(); return; }
   mean[0] /= found; mean[1] /= found; mean[2] /= found;
   double c[6] = {0, 0, 0, 0, 0, 0};
-  for (int j = 0; j < k; j++) {
-    const int32_t u = nb[j]; if (u < 0) continue;
-    const float4 p = raw[u];
-    const double dx = (double)p.x - mean[0], dy = (double)p.y - mean[1], dz = (double)p.z - mean[2];
-    c[0] += dx * dx; c[1] += dx * dy; c[2] += dx * dz; c[3] += dy * dy; c[4] += dy * dz; c[5] += dz * dz;
+  for (int j = 0; j < k; j += 4) {
+    int32_t u[4]; float4 q[4];
+#pragma unroll
+    for (int e = 0; e < 4; e++) u[e] = j + e < k ? nb[j + e] : -1;
+#pragma unroll
+    for (int e = 0; e < 4; e++) q[e] = raw[u[e] < 0 ? 0 : u[e]];
+#pragma unroll
+    for (int e = 0; e < 4; e++) if (u[e] >= 0) {
+      const double dx = (double)q[e].x - mean[0], dy = (double)q[e].y - mean[1], dz = (double)q[e].z - mean[2];
+      c[0] += dx * dx; c[1] += dx * dy; c[2] += dx * dz; c[3] += dy * dy; c[4] += dy * dz; c[5] += dz * dz;
+    }
   }
 #pragma unroll
   for (int t = 0; t < 6; t++) c[t] /= found;
