@@ -109,6 +109,7 @@ def main():
     if backend == "nccl" and torch.cuda.device_count() <= local:
         raise SystemExit("bench.py: rank %d has no GPU of its own (%d visible)" % (rank, torch.cuda.device_count()))
     local = local % torch.cuda.device_count() if backend != "nccl" else local
+    torch.cuda.init()                       # torch's bundled HIP runtime first, then libqn_engine.so
     torch.cuda.set_device(local)
     cdev = "cuda" if backend == "nccl" else "cpu"
     dist = None
@@ -225,7 +226,7 @@ def main():
             tmax = torch.tensor([bwall], dtype=torch.float64, device=cdev); dist.all_reduce(tmax, op=dist.ReduceOp.MAX); bwall = float(tmax.item())
         assert all(r.status == 0 for r in recs), [r.status for r in recs]
         batch64 = {"pairs": nb, "distinct_pairs": nb, "wall_ms": round(1e3 * bwall, 3), "pairs_per_s": round(nb / bwall, 2), "ms_per_pair": round(1e3 * bwall / nb, 4),
-                   "winner_pair": int(bwin[0]), "winner_score": bwin[2], "sharding": "pair i -> rank i mod %d; qn_multi_align_best per rank (RCCL all-gather of the 96-byte records inside), all_gather of the rank winners" % world,
+                   "winner_pair": int(bwin[0]), "winner_score": bwin[2], "sharding": "pair i -> rank i mod %d; qn_multi_align_best per rank on its GPU (a process that owns several GPUs gathers its 96-byte records with RCCL inside the C-ABI), all_gather of the rank winners" % world,
                    "valid_pairs_this_rank": int(sum(r.valid for r in recs))}
         mg.close()
 

@@ -193,7 +193,7 @@ static int build_grid(qn_ctx* c, CloudBuf& b) {
   *c->bbox_host = init;
   HIPCHK(c, hipMemcpyAsync(c->bbox, c->bbox_host, sizeof(BBoxOut), hipMemcpyHostToDevice, s));
   { ProfScope ps(c, QN_K_GRID_BUILD);
-    hipLaunchKernelGGL(k_bbox, dim3(std::min<uint32_t>((n + QN_BLOCK - 1) / QN_BLOCK, 128)), dim3(QN_BLOCK), 0, s, b.raw, n, c->bbox); }
+    hipLaunchKernelGGL(k_bbox, dim3(std::min<uint32_t>((n + QN_BLOCK - 1) / QN_BLOCK, (uint32_t)c->bbox_blocks)), dim3(QN_BLOCK), 0, s, b.raw, n, c->bbox); }
   HIPCHK(c, hipMemcpyAsync(c->bbox_host, c->bbox, sizeof(BBoxOut), hipMemcpyDeviceToHost, s));
   HIPCHK(c, hipStreamSynchronize(s));
   if (c->bbox_host->nonfinite) { c->last_error = "cloud contains non-finite coordinates (is_dense == false clouds are not supported)"; return QN_ERR_INVALID_ARG; }
@@ -279,7 +279,7 @@ static void launch_knn_cov(qn_ctx* c, CloudBuf& b, int k, int32_t* kidx, float* 
     uint32_t* genc = c->fb_count2 + 1;
     constexpr int HCAP = KMAX <= 24 ? 32 : 48;      // pass-2 list capacity: 32 keeps the selection kernel at 4 waves/SIMD
     { ProfScope sel(c, QN_K_KNN_SELECT);
-      hipLaunchKernelGGL(HIP_KERNEL_NAME(k_knn_hist<false, HCAP>), dim3(nb), dim3(QN_KNN_BLOCK), 0, s, b.grid, k, r0, c->knn_rounds, kidx, kd2, c->fb_list, c->fb_count2, c->big_list, genc); }
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(k_knn_hist<false, HCAP>), dim3(nb), dim3(QN_KNN_BLOCK), 0, s, b.grid, k, r0, c->knn_single_all ? -1 : c->knn_rounds, kidx, kd2, c->fb_list, c->fb_count2, c->big_list, genc); }
     ProfScope ps(c, QN_K_KNN_COV);
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_knn_hist<true, HCAP>), dim3(std::min<uint32_t>((b.n + 63) / 64, 512) * (QN_BLOCK / QN_KNN_BLOCK)), dim3(QN_KNN_BLOCK), 0, s, b.grid, k, r0, 64, kidx, kd2, c->fb_list, c->fb_count2, c->big_list, genc);
     // far / overflowing queries (isolated points, sparse far field): one per wave; its leftovers -> the sorted-list kernel (fb_list is free again)
@@ -685,6 +685,8 @@ extern "C" int qn_debug_set(qn_ctx* c, const char* key, double v) {
   if (k == "cell") { c->cell_override = v; c->cloud[0].has_grid = c->cloud[1].has_grid = false; }
   else if (k == "margin_nn") c->margin_nn = (float)v;
   else if (k == "margin_knn") c->margin_knn = (float)v;
+  else if (k == "knn_single_all") c->knn_single_all = v != 0;
+  else if (k == "bbox_blocks") c->bbox_blocks = std::max(1, (int)v);
   else if (k == "knn_hist") c->knn_hist = v != 0;
   else if (k == "nn_rounds") c->nn_rounds = v < 1 ? 1 : (int)v;
   else if (k == "track_from_tick") c->track_from_tick = v < 1 ? 1 : (int)v;

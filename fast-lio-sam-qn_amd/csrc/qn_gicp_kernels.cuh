@@ -178,12 +178,12 @@ __global__ void __launch_bounds__(QN_KNN_BLOCK, HCAP <= 32 ? 4 : 3) k_knn_hist(G
     const uint32_t i = __float_as_uint(q.w);
     int status = 2;
     {
-      const int st = wave_knn_hist<HCAP>(g, q.x, q.y, q.z, active && !general, r, k, max_rounds, my, knn_idx + (size_t)i * k, knn_d2 ? knn_d2 + (size_t)i * k : nullptr);
+      const int st = wave_knn_hist<HCAP>(g, q.x, q.y, q.z, active && !general, r, k, max_rounds < 0 ? -max_rounds : max_rounds, my, knn_idx + (size_t)i * k, knn_d2 ? knn_d2 + (size_t)i * k : nullptr);
       if (!general) status = st;
     }
     if (!active || (threadIdx.x & 63) >= 16 || status == 0) continue;
     if (LIST) { const uint32_t fs = atomicAdd(gen_count, 1u); gen_list[fs] = make_uint2(t, __float_as_uint(r)); }
-    else if (status == 2 || r > 2.5f * r0) { const uint32_t fs = atomicAdd(gen_count, 1u); gen_list[fs] = make_uint2(t, __float_as_uint(r)); }   // far or overflowing: one query per wave (k_knn_single)
+    else if (status == 2 || r > 2.5f * r0 || max_rounds < 0 /* every leftover: launch_knn_cov */) { const uint32_t fs = atomicAdd(gen_count, 1u); gen_list[fs] = make_uint2(t, __float_as_uint(r)); }   // far or overflowing: one query per wave (k_knn_single)
     else { const uint32_t fs = atomicAdd(fb_count, 1u); fb_list[fs] = make_uint2(t, __float_as_uint(r)); }
   }
 }

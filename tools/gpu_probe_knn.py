@@ -36,6 +36,9 @@ if os.environ.get("SWEEP"):
             run("cell x%.2f margin %.2f" % (cf, m), cell=cell0 * cf, knn_hist=1, margin_knn=m * 1.0, knn_rounds=2)
 else:
     run("default", knn_hist=1)
+    for m in (0, 2.0, 2.5):
+        run("single_all margin %.1f" % m, knn_hist=1, knn_single_all=1, margin_knn=m)
+    ctx.debug_set("knn_single_all", 0); ctx.debug_set("margin_knn", 0)
     for m in (2.0, 2.5, 3.0):
         for rd in (1, 2, 3):
             run("margin %.2f rounds %d" % (m, rd), knn_hist=1, margin_knn=m, knn_rounds=rd)
