@@ -228,6 +228,26 @@ def main():
         batch64 = {"pairs": nb, "distinct_pairs": nb, "wall_ms": round(1e3 * bwall, 3), "pairs_per_s": round(nb / bwall, 2), "ms_per_pair": round(1e3 * bwall / nb, 4),
                    "winner_pair": int(bwin[0]), "winner_score": bwin[2], "sharding": "pair i -> rank i mod %d; qn_multi_align_best per rank on its GPU (a process that owns several GPUs gathers its 96-byte records with RCCL inside the C-ABI), all_gather of the rank winners" % world,
                    "valid_pairs_this_rank": int(sum(r.valid for r in recs))}
+        # ---- the same 64 candidates as ONE loop-closure query sees them: every pair shares the query's source cloud, which each context
+        # prepares once (qn_icp_alignment_same_source inside qn_multi_align_best); the reference's single-candidate code path rebuilds it per call
+        s0, t0_ = pairs[0][0], pairs[0][1]
+        stg = []
+        for v in range(len(my_ids)):                                   # this rank's candidates: rigid re-poses of the query scene's target
+            a = 0.004 * (v + 1); ca, sa = float(np.cos(a)), float(np.sin(a))
+            R = torch.tensor([[ca, -sa, 0.0], [sa, ca, 0.0], [0.0, 0.0, 1.0]], dtype=torch.float32, device=t0_.device)
+            stg.append((t0_ @ R.T + torch.tensor([0.02 * v, -0.01 * v, 0.0], dtype=torch.float32, device=t0_.device)).contiguous())
+        sdescs = [(s0.data_ptr(), N_PTS, t.data_ptr(), N_PTS, 12, 1) for t in stg]
+        mg.align_best(sdescs[:min(len(sdescs), 4)])
+        barrier()
+        tb = time.perf_counter()
+        srecs, _ = mg.align_best(sdescs)
+        barrier()
+        swall = time.perf_counter() - tb
+        if dist is not None:
+            tmax = torch.tensor([swall], dtype=torch.float64, device=cdev); dist.all_reduce(tmax, op=dist.ReduceOp.MAX); swall = float(tmax.item())
+        assert all(r.status == 0 for r in srecs), [r.status for r in srecs]
+        batch64["shared_query"] = {"pairs": nb, "wall_ms": round(1e3 * swall, 3), "pairs_per_s": round(nb / swall, 2),
+                                   "note": "64 candidate targets against ONE query cloud per rank: source grid + covariances prepared once per context"}
         mg.close()
 
     out = None

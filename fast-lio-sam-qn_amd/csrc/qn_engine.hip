@@ -552,19 +552,29 @@ extern "C" int qn_gicp_get_trace(qn_ctx* c, qn_iter_trace* out, uint32_t cap, ui
 // 2 = source on the device as packed float4 (the coarse-aligned cloud of coarseToFineAlignment), target on the host,
 // 3 = like 2 with the target on the device too.
 static int icp_alignment(qn_ctx* c, const float* src, uint32_t ns, const float* dst, uint32_t nt, uint32_t stride, double thr,
-                         qn_gicp_result* out, int* valid, int where) {
+                         qn_gicp_result* out, int* valid, int where, bool reuse_source = false) {
   if (!c || !out || !valid) return QN_ERR_INVALID_ARG;
   *valid = 0;
   memset(out, 0, sizeof(*out)); out->fitness = DBL_MAX;
   for (int i = 0; i < 4; i++) { out->T[5 * i] = 1.f; out->T64[5 * i] = 1.0; }
   int rc;
-  if ((rc = set_cloud(c, QN_SOURCE, src, ns, where >= 2 ? 16 : stride, where != 0)) != QN_OK) return rc;   // :120
-  if ((rc = qn_gicp_compute_covariances(c, QN_SOURCE)) != QN_OK) return rc;         // :121
+  // reuse_source: the context still holds this source cloud's grid and covariances (the candidates of ONE loop-closure query share their
+  // source; loop_closure.cpp:116-123 rebuilds it for every call because the reference only ever tries one candidate)
+  if (!(reuse_source && c->cloud[0].has_grid && c->cloud[0].has_cov && c->cloud[0].n == ns)) {
+    if ((rc = set_cloud(c, QN_SOURCE, src, ns, where >= 2 ? 16 : stride, where != 0)) != QN_OK) return rc;   // :120
+    if ((rc = qn_gicp_compute_covariances(c, QN_SOURCE)) != QN_OK) return rc;         // :121
+  }
   if ((rc = set_cloud(c, QN_TARGET, dst, nt, stride, where == 1 || where == 3)) != QN_OK) return rc;     // :122
   if ((rc = qn_gicp_compute_covariances(c, QN_TARGET)) != QN_OK) return rc;         // :123
   if ((rc = qn_gicp_align(c, nullptr, out)) != QN_OK) return rc;                    // :124, :127
   *valid = (out->converged && out->fitness < thr) ? 1 : 0;                          // :129
   return QN_OK;
+}
+// the same registration against the source cloud the context already holds (set + covariances done by the previous call with THIS source)
+extern "C" int qn_icp_alignment_same_source(qn_ctx* c, const float* dst, uint32_t nt, uint32_t stride, int dst_on_device, double thr, qn_gicp_result* out, int* valid) {
+  if (!c) return QN_ERR_INVALID_ARG;
+  if (!c->cloud[0].has_grid || !c->cloud[0].has_cov) return QN_ERR_NOT_READY;
+  return icp_alignment(c, nullptr, c->cloud[0].n, dst, nt, stride, thr, out, valid, dst_on_device ? 1 : 0, true);
 }
 extern "C" int qn_icp_alignment(qn_ctx* c, const float* src, uint32_t ns, const float* dst, uint32_t nt, uint32_t stride, double thr, qn_gicp_result* out, int* valid) {
   return icp_alignment(c, src, ns, dst, nt, stride, thr, out, valid, 0);

@@ -145,14 +145,20 @@ extern "C" int qn_multi_align_best(qn_multi* m, const qn_pair_desc* pairs, uint3
   std::vector<std::atomic<uint32_t>> next(N);
   for (auto& a : next) a.store(0);
   auto worker = [&](int g, qn_ctx* c) {
+    const float* last_src = nullptr; uint32_t last_ns = 0, last_stride = 0; int last_dev = -1;      // the source this context holds (within THIS call: same pointer = same cloud)
     for (;;) {
       const uint32_t l = next[g].fetch_add(1);
       const uint64_t i = (uint64_t)g + (uint64_t)l * N;
       if (l >= per || i >= n_pairs) break;
       const qn_pair_desc& p = pairs[i];
       qn_gicp_result res; int valid = 0;
-      const int st = p.on_device ? qn_icp_alignment_device(c, p.src, p.ns, p.dst, p.nt, p.stride_bytes, score_thr, &res, &valid)
-                                 : qn_icp_alignment(c, p.src, p.ns, p.dst, p.nt, p.stride_bytes, score_thr, &res, &valid);
+      int st;
+      if (last_src == p.src && last_ns == p.ns && last_stride == p.stride_bytes && last_dev == p.on_device)      // candidates of one query: the source is prepared once per context
+        st = qn_icp_alignment_same_source(c, p.dst, p.nt, p.stride_bytes, p.on_device, score_thr, &res, &valid);
+      else
+        st = p.on_device ? qn_icp_alignment_device(c, p.src, p.ns, p.dst, p.nt, p.stride_bytes, score_thr, &res, &valid)
+                         : qn_icp_alignment(c, p.src, p.ns, p.dst, p.nt, p.stride_bytes, score_thr, &res, &valid);
+      if (st == QN_OK) { last_src = p.src; last_ns = p.ns; last_stride = p.stride_bytes; last_dev = p.on_device; } else last_src = nullptr;
       qn_pair_record& r = mine[g][l];
       r.pair_id = (int32_t)i; r.status = st; r.valid = (st == QN_OK && valid) ? 1 : 0; r.converged = st == QN_OK ? res.converged : 0;
       r.iterations = st == QN_OK ? res.iterations : 0; r.fitness = st == QN_OK ? res.fitness : DBL_MAX;

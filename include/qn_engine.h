@@ -118,6 +118,10 @@ int  qn_icp_alignment(qn_ctx*, const float* src, uint32_t ns, const float* dst, 
                       uint32_t stride_bytes, double score_thr, qn_gicp_result* out, int* valid);
 int  qn_icp_alignment_device(qn_ctx*, const float* d_src, uint32_t ns, const float* d_dst, uint32_t nt,
                              uint32_t stride_bytes, double score_thr, qn_gicp_result* out, int* valid);
+/* The candidates of ONE loop-closure query share their source cloud: after a qn_icp_alignment[_device] call the context still holds the
+   source's grid and covariances; this registers another target against it (the reference rebuilds the source per call,
+   loop_closure.cpp:116-123, because it only ever tries one candidate).  QN_ERR_NOT_READY without a prepared source. */
+int  qn_icp_alignment_same_source(qn_ctx*, const float* dst, uint32_t nt, uint32_t stride_bytes, int dst_on_device, double score_thr, qn_gicp_result* out, int* valid);
 
 /* ---- batch of independent candidate pairs (BASELINE config "batch of 64 candidate keyframe pairs") ----
  * Every candidate pair of a loop-closure query is an independent icpAlignment (loop_closure.cpp:116-123 rebuilds

@@ -133,3 +133,40 @@ def test_qn_multi_align_best_matches_single_context(oracle):
         engine.MultiGpu(ngpu + 1, 1024)
     assert ei.value.status == engine.QN_ERR_NO_DEVICE
     mg.close(); ctx.close()
+
+
+@pytest.mark.gpu
+def test_candidates_of_one_query_share_the_prepared_source():
+    """64-candidate style batch: every pair has the SAME source buffer - qn_multi prepares it once per context (grid + covariances) and
+    registers the other targets against it (qn_icp_alignment_same_source); records must equal independent full registrations bit for bit,
+    also when a different source is interleaved."""
+    from qn_amd import engine, synth
+    import ctypes as C
+    mg = engine.MultiGpu(1, 8192, in_flight=2)
+    gg = engine.GicpParams(); engine.lib().qn_gicp_default_params(C.byref(gg))
+    gg.k_correspondences = 15; gg.max_iterations = 32; gg.max_corr_dist = 52.5; gg.transformation_epsilon = 0.01
+    mg.set_params(gg)
+    src, tgt0, _ = synth.make_pair(240, 4000, extent=36.0)
+    other_src, other_tgt, _ = synth.make_pair(241, 3500, extent=36.0)
+    tgts = []
+    for v in range(6):
+        a = 0.004 * v; c, s = np.cos(a), np.sin(a)
+        R = np.array([[c, -s, 0], [s, c, 0], [0, 0, 1]])
+        tgts.append((tgt0.astype(np.float64) @ R.T + np.array([0.05 * v, -0.02 * v, 0.0])).astype(np.float32))
+    pairs = [(src, len(src), t, len(t), 12, 0) for t in tgts[:3]] + [(other_src, len(other_src), other_tgt, len(other_tgt), 12, 0)] + [(src, len(src), t, len(t), 12, 0) for t in tgts[3:]]
+    recs, best = mg.align_best(pairs)
+    ctx = engine.Context(8192)
+    for r, p in zip(recs, pairs):
+        e = engine.icp_alignment(ctx, p[0], p[2])
+        assert r.status == 0 and r.iterations == e["iterations"] and bool(r.converged) == e["converged"]
+        assert r.fitness == e["score"] and np.array_equal(np.array(r.T, dtype=np.float32).reshape(4, 4).astype(np.float64), e["T"])
+    # and the entry point itself: NOT_READY without a prepared source, same answer with one
+    c2 = engine.Context(8192)
+    res = engine.GicpResult(); valid = C.c_int()
+    st = c2._l.qn_icp_alignment_same_source(c2.h, engine._p(tgts[0]), C.c_uint32(len(tgts[0])), C.c_uint32(12), C.c_int(0), C.c_double(1.5), C.byref(res), C.byref(valid))
+    assert st == engine.QN_ERR_NOT_READY
+    e0 = engine.icp_alignment(c2, src, tgts[0])
+    c2.check(c2._l.qn_icp_alignment_same_source(c2.h, engine._p(tgts[1]), C.c_uint32(len(tgts[1])), C.c_uint32(12), C.c_int(0), C.c_double(1.5), C.byref(res), C.byref(valid)))
+    e1 = engine.icp_alignment(ctx, src, tgts[1])
+    assert res.fitness == e1["score"] and res.iterations == e1["iterations"]
+    mg.close(); ctx.close(); c2.close()
