@@ -718,6 +718,7 @@ extern "C" int qn_debug_set(qn_ctx* c, const char* key, double v) {
   else if (k == "fused_final") c->fused_final = v != 0;
   else if (k == "feat_mfma") c->feat_mfma = v != 0;
   else if (k == "feat_sample") c->feat_sample = (int)v;
+  else if (k == "feat_min_blocks") c->feat_min_blocks = (int)v;
   else if (k == "feat_verify") { c->feat_verify = v != 0; if (c->q_mm_vcnt) (void)hipMemset(c->q_mm_vcnt, 0, 16); }
   else if (k == "clk_probe") {                                  // developer probe: device-clock stamps inside k_tick (qn_debug_get_clk)
     if (v != 0 && !c->clk_probe) { if (hipMalloc(&c->clk_probe, 8 * 8 * 256 + 8 * 12 * 1024) != hipSuccess) return QN_ERR_HIP; }

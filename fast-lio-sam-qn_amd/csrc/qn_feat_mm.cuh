@@ -36,6 +36,7 @@ namespace qn {
 #define QN_MM_DEAD (-65504.0f)          // x 3 pieces
 #define QN_MM_EMPTY 0xFFFFFFFFFFFFFFFFull
 typedef _Float16 qn_h8 __attribute__((ext_vector_type(8)));
+typedef uint32_t qn_u4 __attribute__((ext_vector_type(4)));      // a fragment as the kernels hold it: raw 128 bits (copies of f16 VECTORS were compiled to per-element shifts and v_perm)
 typedef float qn_f16v __attribute__((ext_vector_type(16)));
 
 __device__ __forceinline__ uint32_t mm_enc(float f) { const uint32_t b = __float_as_uint(f); return (b & 0x80000000u) ? ~b : (b | 0x80000000u); }
@@ -163,8 +164,8 @@ static __global__ void k_feat_prep(const float* __restrict__ rows, uint32_t n, c
 // A wave keeps the fragments of QN_MM_QT query tiles in registers (112 VGPRs) and streams the candidate tiles of its grid.y segment; each
 // candidate fragment (one coalesced KB per k-step) feeds QN_MM_QT x 7 MFMAs.
 template <int PASS>
-static __global__ void __launch_bounds__(64 * QN_MM_WAVES, 2) k_feat_mm(const qn_h8* __restrict__ Qm, uint32_t nq_max, const uint32_t* __restrict__ qcount_p,
-                                                                       const qn_h8* __restrict__ Cm, uint32_t nc_tiles, uint32_t tiles_per_seg, uint32_t tile_step,
+static __global__ void __launch_bounds__(64 * QN_MM_WAVES, 2) k_feat_mm(const qn_u4* __restrict__ Qm, uint32_t nq_max, const uint32_t* __restrict__ qcount_p,
+                                                                       const qn_u4* __restrict__ Cm, uint32_t nc_tiles, uint32_t tiles_per_seg, uint32_t tile_step,
                                                                        uint32_t* __restrict__ Lq, const float* __restrict__ qn_up, uint2* __restrict__ pairs,
                                                                        uint32_t* __restrict__ counts, uint32_t cap_block, uint2* __restrict__ spill, uint32_t cap_spill) {
   // survivors of this block go to its own region pairs[block * cap_block ..] through a counter in LDS (one global counter for the whole grid
@@ -180,7 +181,7 @@ static __global__ void __launch_bounds__(64 * QN_MM_WAVES, 2) k_feat_mm(const qn
   const bool idle = qt0 >= nq_tiles;                                      // (no early return in pass 2: the block meets again at the end)
   if (idle && PASS == 1) return;
   if (!idle) {
-  qn_h8 bq[QN_MM_QT][QN_MM_KS];
+  qn_u4 bq[QN_MM_QT][QN_MM_KS];
 #pragma unroll
   for (int u = 0; u < QN_MM_QT; u++)
 #pragma unroll
@@ -190,7 +191,7 @@ static __global__ void __launch_bounds__(64 * QN_MM_WAVES, 2) k_feat_mm(const qn
     }
   if (PASS == 1 && lane < 32) {                                           // k = 69, 70: the delta terms enter with a minus sign
 #pragma unroll
-    for (int u = 0; u < QN_MM_QT; u++) { bq[u][4][5] = -bq[u][4][5]; bq[u][4][6] = -bq[u][4][6]; }
+    for (int u = 0; u < QN_MM_QT; u++) { bq[u][4][2] ^= 0x80000000u; bq[u][4][3] ^= 0x00008000u; }      // f16 elements 5 and 6 of the fragment
   }
   float m[QN_MM_QT];                                                     // pass 1: running max; pass 2: the admission threshold
 #pragma unroll
@@ -209,7 +210,7 @@ static __global__ void __launch_bounds__(64 * QN_MM_WAVES, 2) k_feat_mm(const qn
   }
   // the segment's tiles, every tile_step-th one (pass 1 looks at a SAMPLE of the candidates: any lower bound L is a valid one)
   const uint32_t t0 = blockIdx.y * tiles_per_seg * tile_step, t1 = min(nc_tiles, t0 + tiles_per_seg * tile_step);
-  qn_h8 a[QN_MM_KS], an[QN_MM_KS];
+  qn_u4 a[QN_MM_KS], an[QN_MM_KS];
   if (t0 < t1) {
 #pragma unroll
     for (int ks = 0; ks < QN_MM_KS; ks++) an[ks] = Cm[((size_t)t0 * QN_MM_KS + ks) * 64 + lane];
@@ -228,7 +229,7 @@ static __global__ void __launch_bounds__(64 * QN_MM_WAVES, 2) k_feat_mm(const qn
     for (int u = 0; u < QN_MM_QT; u++) {
       acc[u] = (qn_f16v){0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int ks = 0; ks < QN_MM_KS; ks++) acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[ks], bq[u][ks], acc[u], 0, 0, 0);
+      for (int ks = 0; ks < QN_MM_KS; ks++) acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(qn_h8, a[ks]), __builtin_bit_cast(qn_h8, bq[u][ks]), acc[u], 0, 0, 0);
       if (PASS == 1) m[u] = mm_max16(acc[u], m[u]);
     }
     if (PASS == 2) {
@@ -240,14 +241,15 @@ static __global__ void __launch_bounds__(64 * QN_MM_WAVES, 2) k_feat_mm(const qn
         for (int u = 0; u < QN_MM_QT; u++) {
           if (__ballot(hu[u]) == 0ull) continue;
           const uint32_t slot = (qt0 + u) * 32 + (lane & 31);
-#pragma unroll
-          for (int r = 0; r < 16; r++) {
-            if (acc[u][r] >= m[u]) {
-              const uint32_t cand = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-              const uint32_t pos = atomicAdd(&bcnt, 1u);
-              if (pos < cap_block) pairs[(size_t)blk * cap_block + pos] = make_uint2(slot, cand);
-              else { const uint32_t g = atomicAdd(&counts[3], 1u); if (g < cap_spill) spill[g] = make_uint2(slot, cand); else counts[1] = 1u; }
-            }
+          uint32_t bits = 0;                                              // this lane's survivors of the tile as a 16-bit mask, then one loop
+#pragma unroll                                                            // iteration per survivor (a compare-and-branch per result cost as much
+          for (int r = 0; r < 16; r++) bits |= (acc[u][r] >= m[u] ? 1u : 0u) << r;      // as two tiles of MFMAs every time the path was entered)
+          while (bits != 0u) {
+            const int r = __ffs((int)bits) - 1; bits &= bits - 1u;
+            const uint32_t cand = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            const uint32_t pos = atomicAdd(&bcnt, 1u);
+            if (pos < cap_block) pairs[(size_t)blk * cap_block + pos] = make_uint2(slot, cand);
+            else { const uint32_t g = atomicAdd(&counts[3], 1u); if (g < cap_spill) spill[g] = make_uint2(slot, cand); else counts[1] = 1u; }
           }
         }
       }
