@@ -389,6 +389,20 @@ def main():
                      "host_wall_ms": host_wall}
                 quatro["%dk" % (npts // 1000)] = e
 
+        # ---- BASELINE configs[4]: loopTimerFunc replay on a synthetic keyframe stream (tools/replay.py): candidate search, submaps assembled on the
+        # device, registration (Nano-GICP scan-to-submap, and Quatro + Nano-GICP scan-to-scan), loop factors into a host pose graph (iSAM2 stand-in)
+        if world == 1 and not args.no_extras:
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import replay
+            rp = {}
+            for name, uq in (("nano_gicp", False), ("quatro_nano_gicp", True)):
+                replay.run(n_kf=20, seed=7, use_quatro=uq, verbose=False)            # warm-up (allocations)
+                o = replay.run(n_kf=60, seed=7, use_quatro=uq, verbose=False)
+                rp[name] = {"keyframes": o["n_keyframes"], "loop_attempts": o["attempts"], "loops_accepted": o["loops"],
+                            "ms_per_attempt": round(o["ms_per_attempt"], 3) if o["ms_per_attempt"] else None,
+                            "ate_odometry_m": round(o["ate_odometry"], 3), "ate_corrected_m": round(o["ate_corrected"], 3)}
+            extras["replay"] = {"note": "assembly of both clouds on the device + registration per loop attempt; pose graph on the host", **rp}
+
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             from oracle import oracle as orc                      # CPU baseline leg only
