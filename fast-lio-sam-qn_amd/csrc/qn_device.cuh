@@ -271,11 +271,24 @@ struct BestK {
   __device__ __forceinline__ int wanted() const { return k; }
 };
 
+// Lower bound (squared, rounded down) of the distance from q to any point stored in tile (tx, ty, tz): the tile's cell box, shrunk by the
+// grid's eps on every side (the slack of cell_coord's f32 rounding).  Big-ball scans skip the tiles this proves to be outside the ball:
+// the bounding box of a 24 m ball around a query beside the target covers thousands of square metres of ground that no neighbour can be on.
+__device__ __forceinline__ float tile_box_d2(const GridView& g, int tx, int ty, int tz, float qx, float qy, float qz) {
+  const float xl = g.ox + (float)(tx << 3) * g.cell, xh = g.ox + (float)min((tx << 3) + 8, g.nx) * g.cell;
+  const float yl = g.oy + (float)(ty << 2) * g.cell, yh = g.oy + (float)min((ty << 2) + 4, g.ny) * g.cell;
+  const float zl = g.oz + (float)(tz << 2) * g.cell, zh = g.oz + (float)min((tz << 2) + 4, g.nz) * g.cell;
+  const float dx = fmaxf(fmaxf(xl - qx, qx - xh) - g.eps, 0.f), dy = fmaxf(fmaxf(yl - qy, qy - yh) - g.eps, 0.f), dz = fmaxf(fmaxf(zl - qz, qz - zh) - g.eps, 0.f);
+  return ((dx * dx + dy * dy) + dz * dz) * 0.999998f;
+}
+
 // ------------------------------------------------------------------ dense candidate stream over a cell box
 // Calls body(p, valid, cnt) once per 64-candidate chunk with one candidate per lane (`valid` = lane
 // holds a real one, `cnt` = candidates in this chunk, wave-uniform).  All 64 lanes must call.
 template <class Body>
-__device__ __forceinline__ uint32_t stream_box(const GridView& g, int x0, int x1, int y0, int y1, int z0, int z1, const bool tile_mode, WaveLds* lds, Body&& body) {
+__device__ __forceinline__ uint32_t stream_box(const GridView& g, int x0, int x1, int y0, int y1, int z0, int z1, const bool tile_mode, WaveLds* lds, Body&& body,
+                                               const float bqx = 0.f, const float bqy = 0.f, const float bqz = 0.f, const float ball_r2 = -1.f) {
+  // ball_r2 >= 0 (tile mode only): tiles proven farther than sqrt(ball_r2) from (bqx, bqy, bqz) are skipped - the caller only wants points inside that ball
   // tile_mode: the box has been widened to whole 8x4x4-cell tiles by the caller and is enumerated tile by tile (a tile's 128
   // cells are one contiguous run of pts[]) - a big ball is mostly empty space, row-wise enumeration would spend its time on
   // cell_start look-ups of empty rows.
@@ -290,8 +303,9 @@ __device__ __forceinline__ uint32_t stream_box(const GridView& g, int x0, int x1
     if (sidx < nseg) {
       const int t = sidx % ntr, r = sidx / ntr;
       if (tile_mode) {
-        const uint32_t tile = ((uint32_t)((z0 >> 2) + r / ntyr) * g.nty + (ty0 + r % ntyr)) * g.ntx + (tx0 + t);
-        s = g.cell_start[tile << 7]; len = g.cell_start[(tile + 1) << 7] - s;
+        const int tzz = (z0 >> 2) + r / ntyr, tyy = ty0 + r % ntyr, txx = tx0 + t;
+        const uint32_t tile = ((uint32_t)tzz * g.nty + tyy) * g.ntx + txx;
+        if (!(ball_r2 >= 0.f && tile_box_d2(g, txx, tyy, tzz, bqx, bqy, bqz) > ball_r2)) { s = g.cell_start[tile << 7]; len = g.cell_start[(tile + 1) << 7] - s; }
       } else {
         const int ry = y0 + r % nyr, rz = z0 + r / nyr, tx = tx0 + t;
         const int xa = max(x0, tx << 3), xb = min(x1, (tx << 3) + 7);
@@ -590,9 +604,10 @@ __device__ __forceinline__ void wave_search_single(const GridView& g, float qx, 
       uint32_t s = 0, len = 0;
       if (sidx < nseg) {
         const int t = sidx % ntr, rr = sidx / ntr;
-        if (tile_mode) {
-          const uint32_t tile = ((uint32_t)((z0 >> 2) + rr / ntyr) * g.nty + (ty0 + rr % ntyr)) * g.ntx + (tx0 + t);
-          s = g.cell_start[tile << 7]; len = g.cell_start[(tile + 1) << 7] - s;
+        if (tile_mode) {                                               // only the tiles that reach into the ball of radius r
+          const int tzz = (z0 >> 2) + rr / ntyr, tyy = ty0 + rr % ntyr, txx = tx0 + t;
+          const uint32_t tile = ((uint32_t)tzz * g.nty + tyy) * g.ntx + txx;
+          if (!(tile_box_d2(g, txx, tyy, tzz, qx, qy, qz) > r * r * 1.000002f)) { s = g.cell_start[tile << 7]; len = g.cell_start[(tile + 1) << 7] - s; }
         } else {
           const int ry = y0 + rr % nyr, rz = z0 + rr / nyr, tx = tx0 + t;
           const int xa = max(x0, tx << 3), xb = min(x1, (tx << 3) + 7);
@@ -633,6 +648,7 @@ __device__ __forceinline__ void wave_search_single(const GridView& g, float qx, 
     if (z0 > 0) d = fminf(d, cap_face_dist(cap, qz - (g.oz + z0 * g.cell), 2));
     if (z1 < g.nz - 1) d = fminf(d, cap_face_dist(cap, (g.oz + (z1 + 1) * g.cell) - qz, 2));
     bool cert;
+    if (tile_mode && r == r && round <= 160) d = fminf(d, r * 0.999998f + g.eps);   // skipped tiles: everything in them is farther than r (the eps is taken off below)
     if (d == INF || !(r == r) || round > 160) { cert = true; d_unseen = INF; }
     else { d -= g.eps; d_unseen = d; cert = d > 0.f && b != QN_INF_KEY && key_d2(b) < d * d; }
     if (cert) { best_out = b; second_out = c; return; }

@@ -437,7 +437,7 @@ __device__ __forceinline__ uint32_t wave_ball_collect(const GridView& g, float q
       if (pos < QN_HCAP1) L->list[pos] = k;
       if (k < b) { if (b != QN_INF_KEY) s2 = key_d2(b); b = k; } else if (d2 < s2) s2 = d2;
     }
-  });
+  }, qx, qy, qz, tile_mode ? R2 * 1.000002f : -1.f);                    // (tiles outside the ball are not streamed: only points with d2 <= R2 are used)
   wave_lds_fence();
   const unsigned long long wb = wave_min_u64(b);
   float c = (b == wb) ? s2 : key_d2(b);
