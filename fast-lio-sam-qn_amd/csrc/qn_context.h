@@ -62,7 +62,10 @@ struct qn_ctx {
   int knn_rounds = 2;                   // rounds of the first k-NN pass before a query goes to the list pass
   int knn_hist = 1;                     // 1: k-NN by histogram selection (wave_knn_hist), 0: sorted-list sink (wave_search + BestK)
   float margin_nn = 1.f, margin_knn = 0.f;   // first search radius in cells (1-NN of the first tick / k-NN of the covariances; 0 = by cloud size, launch_knn_cov)
-  int margin_nn_cap = 3, margin_knn_cap = 5, ticks_per_chunk = 8; bool knn_single_all = false; int bbox_blocks = 32;   // 128 blocks = 768 atomics on six words: 10.6 us per cloud; 32: 5 us   // experiment: one selection round, every leftover to the one-query-per-wave pass
+  int margin_nn_cap = 3, margin_knn_cap = 5, ticks_per_chunk = 8; bool knn_single_all = false; int bbox_blocks = 32;
+  // pair pipeline of icpAlignment: the target cloud is prepared on a second stream with its own scratch while the source's k-NN runs
+  hipStream_t stream2 = nullptr; hipEvent_t ev_pair = nullptr; bool pair_pipeline = true, pair_failed = false, tgt_on_stream2 = false, tgt_pending = false, no_pipe = false;
+  uint32_t* scan_sums2 = nullptr; uint2* fb_list2 = nullptr; uint2* big_list2 = nullptr; uint32_t* fb_count2b = nullptr; int32_t* knn_idx2 = nullptr; qn::BBoxOut* bbox2 = nullptr; qn::BBoxOut* bbox_host2 = nullptr;   // 128 blocks = 768 atomics on six words: 10.6 us per cloud; 32: 5 us   // experiment: one selection round, every leftover to the one-query-per-wave pass
   uint32_t tick_tb = 512;               // threads per block of k_tick (and of k_solve: both run the same row reduction)
   int tick_occ = 4;                     // k_tick variant: waves per SIMD the register budget allows (4 = 128 VGPRs: other streams' kernels keep half of the register file)
   uint32_t* dbg_counters = nullptr;
