@@ -83,3 +83,24 @@ def test_oracle_coarse_to_fine_recovers_large_yaw(oracle):
     assert dt < 3.0 and dr < 0.2                                   # coarse stage: loose
     dt, dr = synth.pose_error(r["T"], T)
     assert r["converged"] and dt < 0.05 and dr < 0.005             # after Nano-GICP refinement
+
+
+@pytest.mark.parametrize("n,inlier_frac,noise,seed", [(177, 0.5, 0.05, 1), (200, 1.0, 0.02, 2), (120, 0.0, 0.0, 3), (300, 0.4, 0.08, 4),
+                                                       (600, 0.2, 0.05, 5), (1100, 0.1, 0.05, 6), (2, 1.0, 0.0, 7), (1, 1.0, 0.0, 8), (260, 0.7, 0.15, 9)])
+def test_product_clique_search_matches_oracle_on_hard_graphs(oracle, n, inlier_frac, noise, seed):
+    """The product's maximum-clique search (stack bit sets, degree relabelling, k-core peeling, witness clique - qn_quatro_host.inc) against
+    the oracle's independent implementation: dense consistency graphs (many inliers, loose noise: lots of near-maximum cliques), all
+    inliers, none, sizes across the bit-set widths (<= 256, <= 1024, <= 4096).  Same lexicographically smallest maximum clique, same T."""
+    from qn_amd import engine
+    rng = np.random.default_rng(500 + seed)
+    src = rng.uniform(-30, 30, size=(n, 3)).astype(np.float32); src[:, 2] = rng.uniform(0, 5, n)
+    T = yaw_T(rng.uniform(-3, 3), [rng.uniform(-6, 6), rng.uniform(-6, 6), 0.1])
+    dst = (src.astype(np.float64) @ T[:3, :3].T + T[:3, 3] + rng.normal(0, noise, (n, 3))).astype(np.float32)
+    n_bad = int(round(n * (1.0 - inlier_frac)))
+    if n_bad:
+        bad = rng.choice(n, n_bad, replace=False); dst[bad] = rng.uniform(-30, 30, size=(n_bad, 3))
+    corres = np.c_[np.arange(n), np.arange(n)]
+    a = engine.quatro_solve(src, dst, corres)
+    b = oracle.quatro_solve(src, dst, corres)
+    assert a["valid"] == b["valid"] and a["clique"].tolist() == b["clique"].tolist()
+    assert np.abs(a["T"] - b["T"]).max() < 1e-9
