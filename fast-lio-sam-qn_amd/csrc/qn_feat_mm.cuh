@@ -5,13 +5,14 @@
 //   the mode of every structured scene; any P is CORRECT, it only decides how tight the bound below is where the rows are dense)
 //
 // For a fixed query the nearest candidate maximises S.  Rows are split x' = h + l + e (h, l in f16, |e| <= 2^-24 |x'|) and laid out along K = 112:
-//        candidate row  [ h(33) n1 n2 n3 | l(33) b|c'|^2 |c'| 0 | h(33) 0 0 0 | 0 0 0 0 ]      n1 + n2 + n3 = -|c'|^2 / 2 (three f16 pieces)
-//        query row      [ h(33) 1  1  1  | h(33) s  s a|q'| 0   | l(33) 0 0 0 | 0 0 0 0 ]      s = -1 (pass 1) / +1 (pass 2)
-// so one chain of 7 MFMAs per 32 x 32 tile yields  S~ -/+ delta  with  delta(q, c) = a |q'||c'| + b |c'|^2  an upper bound of |S~ - S|:
+//        candidate row  [ h(33) n1 n2 n3 | l(33) b|c'|^2+g|c'|  |c'|     1      | h(33) 0 0 0 | 0 0 0 0 ]      n1 + n2 + n3 = -|c'|^2 / 2 (three f16 pieces)
+//        query row      [ h(33) 1  1  1  | h(33) s              s a|q'|  s g|q'| | l(33) 0 0 0 | 0 0 0 0 ]      s = -1 (pass 1) / +1 (pass 2)
+// so one chain of 7 MFMAs per 32 x 32 tile yields  S~ -/+ delta  with  delta(q, c) = a |q'||c'| + b |c'|^2 + g (|q'| + |c'|)  an upper bound of |S~ - S|:
 //        split:       |q'.c' - (hh + hl + lh)| <= 3.1 x 2^-24 |q'||c'|
 //        matrix core: each instruction returns C + (16 products) rounded ONCE (measured: tools/micro/mfma_probe.hip - f16 subnormals kept, the
 //                     sum carried wider than f32); assumed with an 8 x margin: 2^-21 (|C| + sum |products|) per instruction, 7 instructions
-//        =>  a = 3.6e-6, b = 1.7e-6  (the f16 images of a|q'|, |c'|, b|c'|^2 are rounded UP)
+//        subnormal low pieces (|x'| < 0.25): absolute error <= 2^-25 per element, <= 2^-25 sqrt(33) (|q'| + |c'|) on the product
+//        =>  a = 3.6e-6, b = 1.7e-6, g = 2e-7  (the f16 images of the bound terms are rounded UP)
 // Pass 1:  L(q) = max (S~ - delta) over a SAMPLE of the candidates (every QN_MM_SAMPLE-th tile)  <= S of the best candidate.
 // Pass 2:  every c with  S~ + delta >= L(q) - X(q)  is a SURVIVOR;  X = 2.3e-6 (|q'|^2 - 2 L) covers the rounding of the defining f32 sum itself
 //          (36 x 2^-24 relative on both candidates compared).  The defining nearest neighbour is always a survivor ("feature matching").
@@ -33,6 +34,7 @@ namespace qn {
 #define QN_MM_SAMPLE 4                  // pass 1 visits every 4th candidate tile (measured: 2 -> 3.00, 4 -> 2.79, 8 -> 3.03, 16 -> 5.2 ms at 100k)
 #define QN_MM_ALPHA 3.6e-6
 #define QN_MM_BETA 1.7e-6
+#define QN_MM_GAMMA 2.0e-7             // absolute part: an f16 low piece in the subnormal range is off by up to 2^-25 per element whatever the element's size
 #define QN_MM_DEAD (-65504.0f)          // x 3 pieces
 #define QN_MM_EMPTY 0xFFFFFFFFFFFFFFFFull
 typedef _Float16 qn_h8 __attribute__((ext_vector_type(8)));
@@ -139,11 +141,11 @@ static __global__ void k_feat_prep(const float* __restrict__ rows, uint32_t n, c
       const _Float16 n1 = (_Float16)(float)half; const double r1 = half - (double)(float)n1;
       const _Float16 n2 = (_Float16)(float)r1; const double r2 = r1 - (double)(float)n2;
       v[33] = n1; v[34] = n2; v[35] = (_Float16)(float)r2;
-      v[69] = mm_up(QN_MM_BETA * nn); v[70] = mm_up(sqrt(nn));
+      v[69] = mm_up(QN_MM_BETA * nn + QN_MM_GAMMA * sqrt(nn)); v[70] = mm_up(sqrt(nn)); v[71] = (_Float16)1.f;
     } else { v[33] = (_Float16)QN_MM_DEAD; v[34] = (_Float16)QN_MM_DEAD; v[35] = (_Float16)QN_MM_DEAD; }
   } else {
     v[33] = (_Float16)1.f; v[34] = (_Float16)1.f; v[35] = (_Float16)1.f;
-    v[69] = (_Float16)1.f; v[70] = mm_up(QN_MM_ALPHA * sqrt(nn));
+    v[69] = (_Float16)1.f; v[70] = mm_up(QN_MM_ALPHA * sqrt(nn)); v[71] = mm_up(QN_MM_GAMMA * sqrt(nn));
     qn_up[s] = live ? (float)(nn * (1.0 + 1e-6)) : __int_as_float(0x7fc00000);       // NaN: this slot admits nothing
   }
   const uint32_t tile = s >> 5, rr = s & 31;
@@ -189,9 +191,9 @@ static __global__ void __launch_bounds__(64 * QN_MM_WAVES, 2) k_feat_mm(const qn
       const uint32_t t = min(qt0 + u, nq_tiles - 1);                        // a tile past the end repeats the last one (its results are dropped)
       bq[u][ks] = Qm[((size_t)t * QN_MM_KS + ks) * 64 + lane];
     }
-  if (PASS == 1 && lane < 32) {                                           // k = 69, 70: the delta terms enter with a minus sign
+  if (PASS == 1 && lane < 32) {                                           // k = 69, 70, 71: the delta terms enter with a minus sign
 #pragma unroll
-    for (int u = 0; u < QN_MM_QT; u++) { bq[u][4][2] ^= 0x80000000u; bq[u][4][3] ^= 0x00008000u; }      // f16 elements 5 and 6 of the fragment
+    for (int u = 0; u < QN_MM_QT; u++) { bq[u][4][2] ^= 0x80000000u; bq[u][4][3] ^= 0x80008000u; }      // f16 elements 5, 6 and 7 of the fragment
   }
   float m[QN_MM_QT];                                                     // pass 1: running max; pass 2: the admission threshold
 #pragma unroll
