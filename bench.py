@@ -325,83 +325,92 @@ def main():
 
         extras = {}
         if not args.no_extras:
-            # ---- a less favourable pair: 80 % overlap (target window shifted 24 m; the default pairs overlap ~96 %), same workload
-            s80, t80, _ = synth.make_pair(9000, N_PTS, shift=24.0)
-            p80 = [(torch.from_numpy(s80).cuda(), torch.from_numpy(t80).cuda(), None)]
-            batch(8, p80); torch.cuda.synchronize()
-            t8 = time.perf_counter(); batch(40, p80); torch.cuda.synchronize()
-            extras["overlap80"] = {"registrations_per_s": round(40 / (time.perf_counter() - t8), 2), "note": "one pair with 80 % overlap cycled, same in-flight setting"}
-            # ---- BASELINE configs[0]: the reference's operating point: k = 15, LM, <= 32 iterations, real stopping rule,
-            # clouds handed over as HOST buffers through qn_icp_alignment (PCIe inclusive), 30k and 100k points; CPU oracle beside it
-            rop = {}
-            for npts in (30000, N_PTS):
-                sr, tr_, _ = synth.make_pair(700 + npts // 1000, npts)
-                engine.icp_alignment(ctx, sr, tr_)
-                lat = []
-                for _ in range(15):
-                    tq = time.perf_counter(); rr = engine.icp_alignment(ctx, sr, tr_); lat.append(1e3 * (time.perf_counter() - tq))
-                e = {"gpu_ms_from_host_buffers": pct(lat), "iterations": rr["iterations"], "converged": rr["converged"], "score": rr["score"]}
-                if not args.no_cpu_baseline:
-                    from oracle import oracle as orc
-                    tc = time.perf_counter(); ro = orc.icp_alignment(sr, tr_); c1 = time.perf_counter() - tc
-                    reps = max(1, min(5, int(4.0 / max(c1, 1e-3)))); tc = time.perf_counter()
-                    for _ in range(reps):
-                        orc.icp_alignment(sr, tr_)
-                    e["cpu_oracle_ms"] = round(1e3 * (time.perf_counter() - tc) / reps, 2); e["cpu_threads"] = orc.num_threads()
-                    e["same_iterations_as_oracle"] = bool(ro["iterations"] == rr["iterations"])
-                rop["%dk" % (npts // 1000)] = e
-            extras["reference_operating_point"] = {"config": "k=15, LM, max 32 iterations, eps_t 0.01, eps_r 2e-3, max_corr_dist 52.5 m, score thr 1.5 (SURVEY App. C)", **rop}
+            try:
+                # ---- a less favourable pair: 80 % overlap (target window shifted 24 m; the default pairs overlap ~96 %), same workload
+                s80, t80, _ = synth.make_pair(9000, N_PTS, shift=24.0)
+                p80 = [(torch.from_numpy(s80).cuda(), torch.from_numpy(t80).cuda(), None)]
+                batch(8, p80); torch.cuda.synchronize()
+                t8 = time.perf_counter(); batch(40, p80); torch.cuda.synchronize()
+                extras["overlap80"] = {"registrations_per_s": round(40 / (time.perf_counter() - t8), 2), "note": "one pair with 80 % overlap cycled, same in-flight setting"}
+                # ---- BASELINE configs[0]: the reference's operating point: k = 15, LM, <= 32 iterations, real stopping rule,
+                # clouds handed over as HOST buffers through qn_icp_alignment (PCIe inclusive), 30k and 100k points; CPU oracle beside it
+                rop = {}
+                for npts in (30000, N_PTS):
+                    sr, tr_, _ = synth.make_pair(700 + npts // 1000, npts)
+                    engine.icp_alignment(ctx, sr, tr_)
+                    lat = []
+                    for _ in range(15):
+                        tq = time.perf_counter(); rr = engine.icp_alignment(ctx, sr, tr_); lat.append(1e3 * (time.perf_counter() - tq))
+                    e = {"gpu_ms_from_host_buffers": pct(lat), "iterations": rr["iterations"], "converged": rr["converged"], "score": rr["score"]}
+                    if not args.no_cpu_baseline:
+                        from oracle import oracle as orc
+                        tc = time.perf_counter(); ro = orc.icp_alignment(sr, tr_); c1 = time.perf_counter() - tc
+                        reps = max(1, min(5, int(4.0 / max(c1, 1e-3)))); tc = time.perf_counter()
+                        for _ in range(reps):
+                            orc.icp_alignment(sr, tr_)
+                        e["cpu_oracle_ms"] = round(1e3 * (time.perf_counter() - tc) / reps, 2); e["cpu_threads"] = orc.num_threads()
+                        e["same_iterations_as_oracle"] = bool(ro["iterations"] == rr["iterations"])
+                    rop["%dk" % (npts // 1000)] = e
+                extras["reference_operating_point"] = {"config": "k=15, LM, max 32 iterations, eps_t 0.01, eps_r 2e-3, max_corr_dist 52.5 m, score thr 1.5 (SURVEY App. C)", **rop}
+            except Exception as ex:                                      # an extra must never cost the headline line
+                extras["extras_error"] = repr(ex)
 
         # ---- Quatro coarse stage (BASELINE configs[2]): FPFH + optimizedMatching (cap 200) + GNC solve, 30k and 100k pairs from the host
         quatro = None
         if world == 1 and not args.no_quatro and not args.no_extras:
-            from scipy.spatial import cKDTree
-            quatro = {}
-            for npts in (30000, N_PTS):
-                qs, qt, _ = synth.make_pair(400 + npts // 1000, npts, mode="quatro")
-                q = engine.Quatro(ctx)
-                q.align(qs, qt)
-                lat = []
-                for _ in range(5):
-                    tq = time.perf_counter(); Tq, qvalid = q.align(qs, qt); lat.append(1e3 * (time.perf_counter() - tq))
-                host_wall = {"uploads_grids_enqueue": round(ctx.debug_get("quatro_wall_features_ms"), 3), "fpfh_wait_matching_tail": round(ctx.debug_get("quatro_wall_match_ms"), 3),
-                             "clique_gnc_solve": round(ctx.debug_get("quatro_wall_solve_ms"), 3)}          # of the last timed align (before the profiled one)
-                n_surv, n_fb = int(ctx.debug_get("feat_survivors")), int(ctx.debug_get("feat_fallbacks"))
-                ctx.prof_reset(); ctx.prof_enable(True); q.align(qs, qt); ctx.synchronize(); ctx.prof_enable(False)
-                st = ctx.prof_stats()
-                stage = {k: round(st[k][0], 4) for k in ("grid_build", "fpfh_normals", "fpfh_spfh", "fpfh_fpfh", "feat_match", "match_tail") if st[k][1] > 0}
-                tree = cKDTree(qs.astype(np.float64)); sel = np.random.default_rng(0).choice(len(qs), 4000, replace=False)
-                m_n = float(np.mean(tree.query_ball_point(qs[sel].astype(np.float64), 0.9, return_length=True)))
-                m_f = float(np.mean(tree.query_ball_point(qs[sel].astype(np.float64), 1.5, return_length=True)))
-                ab_q = {"normals": npts * (16 + 16 * m_n + 12), "spfh": npts * (28 + 28 * m_f + 132), "fpfh": npts * (136 * m_f + 132)}     # per cloud, SURVEY 8d
-                fm_ms = stage.get("feat_match", 0.0)
-                flops = 2.0 * 33 * npts * npts                                   # forward direction; the lazy reverse search adds the hit fraction
-                mm_flops = 2.0 * 112 * npts * npts * 1.25                        # what the matrix cores execute for it (K = 112, full pass + 1/4 sample)
-                e = {"ms_per_align": pct(lat), "valid": bool(qvalid), "stage_ms": stage, "m_n": round(m_n, 1), "m_f": round(m_f, 1),
-                     "algorithmic_bytes_per_cloud": {k: int(v) for k, v in ab_q.items()},
-                     "frac_hbm": {k: round(ab_q[k] * 2 / (stage[s] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) for k, s in (("normals", "fpfh_normals"), ("spfh", "fpfh_spfh"), ("fpfh", "fpfh_fpfh")) if s in stage},
-                     "feat_match": {"bound": "mfma", "kernel": "k_feat_mm<2>", "flops_f16_mfma": mm_flops, "achieved_TF_lower_bound": round(mm_flops / (fm_ms * 1e-3) / 1e12, 1) if fm_ms else None,
-                                    "peak_TF": MFMA_F16_PEAK_TF, "frac_of_mfma_f16_peak": round(mm_flops / (fm_ms * 1e-3) / 1e12 / MFMA_F16_PEAK_TF, 4) if fm_ms else None,
-                                    "effective_f32_TF": round(flops / (fm_ms * 1e-3) / 1e12, 2) if fm_ms else None,
-                                    "survivors_exactly_re_evaluated": n_surv, "fallbacks_to_valu_search": n_fb,
-                                    "note": "screening GEMM on v_mfma_f32_32x32x16_f16: K = 112 (f16 hi/lo split of 33 bins + bound terms), full pass + 1/4 sampled pass, forward search only "
-                                            "(Ns x Nt); time = BOTH searches + de-duplication + operand images + exact stage, so the fraction is a lower bound. effective_f32_TF = 2*33*Ns*Nt / time"},
-                     "host_wall_ms": host_wall}
-                quatro["%dk" % (npts // 1000)] = e
+            try:
+                from scipy.spatial import cKDTree
+                quatro = {}
+                for npts in (30000, N_PTS):
+                    qs, qt, _ = synth.make_pair(400 + npts // 1000, npts, mode="quatro")
+                    q = engine.Quatro(ctx)
+                    q.align(qs, qt)
+                    lat = []
+                    for _ in range(5):
+                        tq = time.perf_counter(); Tq, qvalid = q.align(qs, qt); lat.append(1e3 * (time.perf_counter() - tq))
+                    host_wall = {"uploads_grids_enqueue": round(ctx.debug_get("quatro_wall_features_ms"), 3), "fpfh_wait_matching_tail": round(ctx.debug_get("quatro_wall_match_ms"), 3),
+                                 "clique_gnc_solve": round(ctx.debug_get("quatro_wall_solve_ms"), 3)}          # of the last timed align (before the profiled one)
+                    n_surv, n_fb = int(ctx.debug_get("feat_survivors")), int(ctx.debug_get("feat_fallbacks"))
+                    ctx.prof_reset(); ctx.prof_enable(True); q.align(qs, qt); ctx.synchronize(); ctx.prof_enable(False)
+                    st = ctx.prof_stats()
+                    stage = {k: round(st[k][0], 4) for k in ("grid_build", "fpfh_normals", "fpfh_spfh", "fpfh_fpfh", "feat_match", "match_tail") if st[k][1] > 0}
+                    tree = cKDTree(qs.astype(np.float64)); sel = np.random.default_rng(0).choice(len(qs), 4000, replace=False)
+                    m_n = float(np.mean(tree.query_ball_point(qs[sel].astype(np.float64), 0.9, return_length=True)))
+                    m_f = float(np.mean(tree.query_ball_point(qs[sel].astype(np.float64), 1.5, return_length=True)))
+                    ab_q = {"normals": npts * (16 + 16 * m_n + 12), "spfh": npts * (28 + 28 * m_f + 132), "fpfh": npts * (136 * m_f + 132)}     # per cloud, SURVEY 8d
+                    fm_ms = stage.get("feat_match", 0.0)
+                    flops = 2.0 * 33 * npts * npts                                   # forward direction; the lazy reverse search adds the hit fraction
+                    mm_flops = 2.0 * 112 * npts * npts * 1.25                        # what the matrix cores execute for it (K = 112, full pass + 1/4 sample)
+                    e = {"ms_per_align": pct(lat), "valid": bool(qvalid), "stage_ms": stage, "m_n": round(m_n, 1), "m_f": round(m_f, 1),
+                         "algorithmic_bytes_per_cloud": {k: int(v) for k, v in ab_q.items()},
+                         "frac_hbm": {k: round(ab_q[k] * 2 / (stage[s] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) for k, s in (("normals", "fpfh_normals"), ("spfh", "fpfh_spfh"), ("fpfh", "fpfh_fpfh")) if s in stage},
+                         "feat_match": {"bound": "mfma", "kernel": "k_feat_mm<2>", "flops_f16_mfma": mm_flops, "achieved_TF_lower_bound": round(mm_flops / (fm_ms * 1e-3) / 1e12, 1) if fm_ms else None,
+                                        "peak_TF": MFMA_F16_PEAK_TF, "frac_of_mfma_f16_peak": round(mm_flops / (fm_ms * 1e-3) / 1e12 / MFMA_F16_PEAK_TF, 4) if fm_ms else None,
+                                        "effective_f32_TF": round(flops / (fm_ms * 1e-3) / 1e12, 2) if fm_ms else None,
+                                        "survivors_exactly_re_evaluated": n_surv, "fallbacks_to_valu_search": n_fb,
+                                        "note": "screening GEMM on v_mfma_f32_32x32x16_f16: K = 112 (f16 hi/lo split of 33 bins + bound terms), full pass + 1/4 sampled pass, forward search only "
+                                                "(Ns x Nt); time = BOTH searches + de-duplication + operand images + exact stage, so the fraction is a lower bound. effective_f32_TF = 2*33*Ns*Nt / time"},
+                         "host_wall_ms": host_wall}
+                    quatro["%dk" % (npts // 1000)] = e
+            except Exception as ex:
+                quatro = {"error": repr(ex)}
 
         # ---- BASELINE configs[4]: loopTimerFunc replay on a synthetic keyframe stream (tools/replay.py): candidate search, submaps assembled on the
         # device, registration (Nano-GICP scan-to-submap, and Quatro + Nano-GICP scan-to-scan), loop factors into a host pose graph (iSAM2 stand-in)
         if world == 1 and not args.no_extras:
-            sys.path.insert(0, os.path.join(ROOT, "tools"))
-            import replay
-            rp = {}
-            for name, uq in (("nano_gicp", False), ("quatro_nano_gicp", True)):
-                replay.run(n_kf=20, seed=7, use_quatro=uq, verbose=False)            # warm-up (allocations)
-                o = replay.run(n_kf=60, seed=7, use_quatro=uq, verbose=False)
-                rp[name] = {"keyframes": o["n_keyframes"], "loop_attempts": o["attempts"], "loops_accepted": o["loops"],
-                            "ms_per_attempt": round(o["ms_per_attempt"], 3) if o["ms_per_attempt"] else None,
-                            "ate_odometry_m": round(o["ate_odometry"], 3), "ate_corrected_m": round(o["ate_corrected"], 3)}
-            extras["replay"] = {"note": "assembly of both clouds on the device + registration per loop attempt; pose graph on the host", **rp}
+            try:
+                sys.path.insert(0, os.path.join(ROOT, "tools"))
+                import replay
+                rp = {}
+                for name, uq in (("nano_gicp", False), ("quatro_nano_gicp", True)):
+                    replay.run(n_kf=20, seed=7, use_quatro=uq, verbose=False)            # warm-up (allocations)
+                    o = replay.run(n_kf=60, seed=7, use_quatro=uq, verbose=False)
+                    rp[name] = {"keyframes": o["n_keyframes"], "loop_attempts": o["attempts"], "loops_accepted": o["loops"],
+                                "ms_per_attempt": round(o["ms_per_attempt"], 3) if o["ms_per_attempt"] else None,
+                                "ate_odometry_m": round(o["ate_odometry"], 3), "ate_corrected_m": round(o["ate_corrected"], 3)}
+                extras["replay"] = {"note": "assembly of both clouds on the device + registration per loop attempt; pose graph on the host", **rp}
+            except Exception as ex:
+                extras["replay"] = {"error": repr(ex)}
 
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
