@@ -10,6 +10,7 @@ struct CloudBuf {                       // one point cloud, resident in HBM
   bool has_grid = false, has_cov = false;
   float4* raw = nullptr;                // [max_points] original order, (x, y, z, 1)
   float4* sorted = nullptr;             // [max_points] cell-sorted, .w = original index bits
+  float4* sorted_tmp = nullptr;         // [max_points] the scatter's output before the cells are put in a run-independent order (k_stable_cells)
   uint32_t* cell_of_pt = nullptr;       // [max_points]
   uint32_t* cell_start = nullptr;       // [max_cells + 1]
   uint32_t* counts = nullptr;           // [max_cells + 1] histogram / scatter cursors
@@ -62,7 +63,7 @@ struct qn_ctx {
   int knn_rounds = 2;                   // rounds of the first k-NN pass before a query goes to the list pass
   int knn_hist = 1;                     // 1: k-NN by histogram selection (wave_knn_hist), 0: sorted-list sink (wave_search + BestK)
   float margin_nn = 1.f, margin_knn = 0.f;   // first search radius in cells (1-NN of the first tick / k-NN of the covariances; 0 = by cloud size, launch_knn_cov)
-  int margin_nn_cap = 3, margin_knn_cap = 5, ticks_per_chunk = 8; bool knn_single_all = false; int bbox_blocks = 32;
+  int margin_nn_cap = 3, margin_knn_cap = 5, ticks_per_chunk = 8; bool knn_single_all = false, stable_cells = true; int bbox_blocks = 32;
   // pair pipeline of icpAlignment: the target cloud is prepared on a second stream with its own scratch while the source's k-NN runs
   hipStream_t stream2 = nullptr; hipEvent_t ev_pair = nullptr; bool pair_pipeline = true, pair_failed = false, tgt_on_stream2 = false, tgt_pending = false, no_pipe = false;
   uint32_t* scan_sums2 = nullptr; uint2* fb_list2 = nullptr; uint2* big_list2 = nullptr; uint32_t* fb_count2b = nullptr; int32_t* knn_idx2 = nullptr; qn::BBoxOut* bbox2 = nullptr; qn::BBoxOut* bbox_host2 = nullptr;   // 128 blocks = 768 atomics on six words: 10.6 us per cloud; 32: 5 us   // experiment: one selection round, every leftover to the one-query-per-wave pass

@@ -69,6 +69,7 @@ extern "C" void qn_gicp_default_params(qn_gicp_params* p) {
 static int alloc_cloud(qn_ctx* c, CloudBuf& b) {
   HIPCHK(c, hipMalloc(&b.raw, sizeof(float4) * c->max_points));
   HIPCHK(c, hipMalloc(&b.sorted, sizeof(float4) * c->max_points));
+  HIPCHK(c, hipMalloc(&b.sorted_tmp, sizeof(float4) * c->max_points));
   HIPCHK(c, hipMalloc(&b.cell_of_pt, sizeof(uint32_t) * c->max_points));
   HIPCHK(c, hipMalloc(&b.cell_start, sizeof(uint32_t) * ((size_t)c->max_cells + 1)));
   HIPCHK(c, hipMalloc(&b.counts, sizeof(uint32_t) * ((size_t)c->max_cells + 1)));
@@ -145,7 +146,7 @@ extern "C" void qn_ctx_destroy(qn_ctx* c) {
   hipSetDevice(c->device);
   if (c->stream) hipStreamSynchronize(c->stream);
   c->prof_collect();
-  for (int w = 0; w < 2; w++) { CloudBuf& b = c->cloud[w]; hipFree(b.raw); hipFree(b.sorted); hipFree(b.cell_of_pt); hipFree(b.cell_start); hipFree(b.counts); hipFree(b.nrm); }
+  for (int w = 0; w < 2; w++) { CloudBuf& b = c->cloud[w]; hipFree(b.raw); hipFree(b.sorted); hipFree(b.sorted_tmp); hipFree(b.cell_of_pt); hipFree(b.cell_start); hipFree(b.counts); hipFree(b.nrm); }
   hipFree(c->staging); hipFree(c->scan_sums); hipFree(c->bbox); hipFree(c->state); hipFree(c->partials); hipFree(c->trace);
   hipFree(c->nn_idx); hipFree(c->knn_idx); hipFree(c->nn_ref); hipFree(c->nrm_s_sorted); hipFree(c->tgt_rec); hipFree(c->fit_psum); hipFree(c->fit_pcnt); hipFree(c->corr); hipFree(c->sqd); hipFree(c->sqd_fit); hipFree(c->far_cand); hipFree(c->far_cand_ref); hipFree(c->far_req); hipFree(c->far_stats); hipFree(c->far_rows); hipFree(c->fb_list); hipFree(c->big_list); hipFree(c->fb_count2); hipFree(c->aligned);
   hipFree(c->q_mm_c); hipFree(c->q_mm_q); hipFree(c->q_mm_qn); hipFree(c->q_mm_L); hipFree(c->q_mm_table); hipFree(c->q_mm_pairs); hipFree(c->q_mm_cnt); hipFree(c->q_mm_vkeys); hipFree(c->q_mm_vcnt);
@@ -274,7 +275,8 @@ static int build_grid(qn_ctx* c, CloudBuf& b) {
     hipLaunchKernelGGL(k_scan_block, dim3(sb), dim3(QN_BLOCK), 0, s, b.counts, ncells, b.cell_start, c->scan_sums);
     hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(QN_BLOCK), 0, s, c->scan_sums, sb);
     hipLaunchKernelGGL(k_scan_add, dim3(sb), dim3(QN_BLOCK), 0, s, b.cell_start, ncells, c->scan_sums, n);
-    hipLaunchKernelGGL(k_scatter, dim3(nb), dim3(QN_BLOCK), 0, s, b.raw, n, b.cell_of_pt, b.cell_start, b.counts, b.sorted); }
+    hipLaunchKernelGGL(k_scatter, dim3(nb), dim3(QN_BLOCK), 0, s, b.raw, n, b.cell_of_pt, b.cell_start, b.counts, c->stable_cells ? b.sorted_tmp : b.sorted);
+    if (c->stable_cells) hipLaunchKernelGGL(k_stable_cells, dim3(nb), dim3(QN_BLOCK), 0, s, (const float4*)b.sorted_tmp, n, (const uint32_t*)b.cell_of_pt, (const uint32_t*)b.cell_start, b.sorted); }
   HIPCHK(c, hipGetLastError());
   b.has_grid = true; b.has_cov = false;
   return QN_OK;
@@ -760,6 +762,7 @@ extern "C" int qn_debug_set(qn_ctx* c, const char* key, double v) {
   else if (k == "knn_single_all") c->knn_single_all = v != 0;
   else if (k == "bbox_blocks") c->bbox_blocks = std::max(1, (int)v);
   else if (k == "pair_pipeline") c->pair_pipeline = v != 0;
+  else if (k == "stable_cells") c->stable_cells = v != 0;
   else if (k == "knn_hist") c->knn_hist = v != 0;
   else if (k == "nn_rounds") c->nn_rounds = v < 1 ? 1 : (int)v;
   else if (k == "track_from_tick") c->track_from_tick = v < 1 ? 1 : (int)v;
@@ -835,6 +838,13 @@ extern "C" int qn_debug_get_clk(qn_ctx* c, unsigned long long* out /* 256 x 8, t
   if (!c || !out || !n || !c->clk_probe) return QN_ERR_INVALID_ARG;
   if (hipStreamSynchronize(c->stream) != hipSuccess || hipMemcpy(out, c->clk_probe, 8 * 8 * 256 + 8 * 12 * 1024, hipMemcpyDeviceToHost) != hipSuccess) return QN_ERR_HIP;
   *n = c->clk_n; return QN_OK;
+}
+extern "C" int qn_debug_get_partials(qn_ctx* c, double* out /* 2 x (QN_ACC_MAX_BLOCKS + 8) x 28 */, uint32_t* rows_per_buffer, double* state /* 2 x sizeof(GicpState) / 8 */) {
+  if (!c || !out || !rows_per_buffer || !state) return QN_ERR_INVALID_ARG;
+  *rows_per_buffer = QN_ACC_MAX_BLOCKS + 8;
+  if (hipStreamSynchronize(c->stream) != hipSuccess || hipMemcpy(out, c->partials, 2 * sizeof(double) * (QN_ACC_MAX_BLOCKS + 8) * QN_NPART, hipMemcpyDeviceToHost) != hipSuccess
+      || hipMemcpy(state, c->state, 2 * sizeof(GicpState), hipMemcpyDeviceToHost) != hipSuccess) return QN_ERR_HIP;
+  return QN_OK;
 }
 extern "C" int qn_debug_get_grid(qn_ctx* c, int which, double out[8]) {
   if (!c || (which != 0 && which != 1) || !c->cloud[which].has_grid) return QN_ERR_INVALID_ARG;

@@ -60,8 +60,8 @@ static __global__ void k_cell_count(const float4* __restrict__ pts, uint32_t n, 
 }
 
 // counting-sort scatter: counts[] still holds the per-cell population; slots are handed out from the
-// back of each cell's run.  Order inside a cell is arbitrary - every consumer is order independent
-// (ties resolve on the original index carried in .w).
+// back of each cell's run.  Order inside a cell is the atomics' arrival order here; k_stable_cells (below) replaces it by ascending
+// original index (carried in .w) before any consumer reads the cloud.
 static __global__ void k_scatter(const float4* __restrict__ pts, uint32_t n, const uint32_t* __restrict__ cell_of_pt,
                           const uint32_t* __restrict__ cell_start, uint32_t* __restrict__ counts, float4* __restrict__ sorted) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -71,6 +71,24 @@ static __global__ void k_scatter(const float4* __restrict__ pts, uint32_t n, con
   float4 p = pts[i];
   p.w = __uint_as_float(i);
   sorted[slot] = p;
+}
+
+// The scatter's atomics hand out the slots of a cell in arrival order: the order INSIDE a cell differs from run to run.  Searches do not care
+// (ties resolve on the original index), but the optimiser ticks sum the correspondences in sorted order, block by block and lane by lane, and
+// the FPFH kernels sum neighbours in walk order: with an arbitrary order inside the cells those f64 sums - and so H, b and the pose - differed
+// in the last bits between two runs of the same registration.  This pass puts every cell's points in ascending original index (rank = number of
+// smaller indices in the cell: ~4 points per cell, one thread per point).  Cells above 256 points (degenerate clouds) keep the arrival order.
+static __global__ void k_stable_cells(const float4* __restrict__ in, uint32_t n, const uint32_t* __restrict__ cell_of_pt, const uint32_t* __restrict__ cell_start,
+                                      float4* __restrict__ out) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  const float4 p = in[t];
+  const uint32_t i = __float_as_uint(p.w), c = cell_of_pt[i];
+  const uint32_t s = cell_start[c], e = cell_start[c + 1];
+  if (e - s > 256u) { out[t] = p; return; }
+  uint32_t rank = 0;
+  for (uint32_t u = s; u < e; u++) rank += __float_as_uint(in[u].w) < i ? 1u : 0u;
+  out[s + rank] = p;
 }
 
 // ------------------------------------------------------------------ K2+K3 k-NN + covariance (k-NN selection: k_knn_hist below, k_knn_cov in qn_knn_kernels.cuh)
