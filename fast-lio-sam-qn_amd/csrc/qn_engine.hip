@@ -418,7 +418,7 @@ static void enqueue_verify(qn_ctx* c, bool fused) {
   hipLaunchKernelGGL(k_reset_lists, dim3(1), dim3(64), 0, s, st);
 }
 static uint32_t acc_blocks(const qn_ctx* c) { return std::min<uint32_t>((c->cloud[0].n + QN_BLOCK - 1) / QN_BLOCK, QN_ACC_MAX_BLOCKS); }
-static uint32_t tick_ppt(const qn_ctx* c) { return std::max<uint32_t>(1u, (c->cloud[0].n + c->tick_tb * QN_ACC_MAX_BLOCKS - 1) / (c->tick_tb * QN_ACC_MAX_BLOCKS)); }
+static uint32_t tick_ppt(const qn_ctx* c) { return std::max<uint32_t>(c->tick_ppt_min, (c->cloud[0].n + c->tick_tb * QN_ACC_MAX_BLOCKS - 1) / (c->tick_tb * QN_ACC_MAX_BLOCKS)); }
 static uint32_t tick_blocks(const qn_ctx* c) { const uint32_t per = c->tick_tb * tick_ppt(c); return (c->cloud[0].n + per - 1) / per; }
 static void enqueue_accumulate(qn_ctx* c) {          // partial rows of the CURRENT generation
   ProfScope ps(c, QN_K_ACCUMULATE);
@@ -792,6 +792,7 @@ extern "C" int qn_debug_set(qn_ctx* c, const char* key, double v) {
     c->clk_n = 0; if (v == 0) { (void)hipFree(c->clk_probe); c->clk_probe = nullptr; }
   }
   else if (k == "tick_tb") c->tick_tb = v >= 512 ? 512 : 256;
+  else if (k == "tick_ppt_min") c->tick_ppt_min = v < 1 ? 1u : (uint32_t)v;
   else if (k == "verify_track") {
     if (v != 0 && !c->v_counters) {
       const size_t n = c->max_points;
