@@ -387,7 +387,7 @@ static void enqueue_nn(qn_ctx* c, int mode /*0 align, 1 fitness*/, float* sqd_ou
   uint32_t* far_stats = (mode == 0 && !seeded && tick == std::max(1, std::min(c->track_from_tick, c->fused_from_tick)) - 1) ? c->far_stats : nullptr;
   const int big_blocks = tick <= 2 ? 4096 : 1024;                                           // waves with one far query each (idle blocks exit at once)
   const uint32_t fbb = std::min<uint32_t>(nb4, tick <= 2 ? 512 : 256);                     // list pass: wave-stride over the leftovers
-  const float r0 = c->margin_nn * T.grid.cell;
+  const float r0 = (tick == 0 && mode == 0 && c->margin_nn_t0 > 0.f ? c->margin_nn_t0 : c->margin_nn) * T.grid.cell;
   if (mode == 0) {
     { ProfScope ps(c, QN_K_NN_SEARCH);
       if (seeded) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_nn_track<0>), dim3(nbt), dim3(QN_BLOCK), 0, s, S.grid, T.grid, T.raw, st, thr2, c->corr, sqd_out, c->nn_idx, c->nn_ref, c->fb_list, fbc, c->big_list, bgc);
@@ -758,6 +758,7 @@ extern "C" int qn_debug_set(qn_ctx* c, const char* key, double v) {
   std::string k(key);
   if (k == "cell") { c->cell_override = v; c->cloud[0].has_grid = c->cloud[1].has_grid = false; }
   else if (k == "margin_nn") c->margin_nn = (float)v;
+  else if (k == "margin_nn_t0") c->margin_nn_t0 = (float)v;
   else if (k == "margin_knn") c->margin_knn = (float)v;
   else if (k == "knn_single_all") c->knn_single_all = v != 0;
   else if (k == "bbox_blocks") c->bbox_blocks = std::max(1, (int)v);
