@@ -1,5 +1,5 @@
 """Stress tool (GPU box): randomized GPU-vs-oracle parity over many seeded pairs, sizes, k, optimizers and stopping rules.
-Prints one line per mismatch and a summary; exit code 1 on any mismatch.  usage: python tools/gpu_parity_sweep.py [n_cases]"""
+Prints one line per mismatch and a summary; exit code 1 on any mismatch.  usage: python tools/gpu_parity_sweep.py [n_cases [seed]]   (seed != 0: other pairs and, for a third of the cases, 80 % overlap)"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "fast-lio-sam-qn_amd"))
@@ -7,7 +7,8 @@ import numpy as np
 from qn_amd import engine, synth
 from oracle import oracle as orc          # checker only
 ncases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
-rng = np.random.default_rng(2024)
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+rng = np.random.default_rng(2024 + seed)
 ctx = engine.Context(70000)
 bad = 0; t0 = time.time(); worst_t = worst_r = 0.0
 for case in range(ncases):
@@ -17,11 +18,12 @@ for case in range(ncases):
     max_iter = int(rng.choice([8, 32]))
     eps = float(rng.choice([0.01, 5e-4]))
     ext = float(rng.choice([25.0, 45.0, 70.0]))
-    pid = 5000 + case
+    pid = 5000 + 1000 * seed + case
+    shift = None if seed == 0 or rng.random() > 0.33 else 0.2 * (120.0 if n > 20000 else max(ext, 45.0) if n > 4000 else ext)
     if n > 20000: ext = 120.0
     elif n > 4000: ext = max(ext, 45.0)
     try:
-        src, tgt, T = synth.make_pair(pid, n, extent=ext)
+        src, tgt, T = synth.make_pair(pid, n, extent=ext, shift=shift)
     except RuntimeError:
         src, tgt, T = synth.make_pair(pid, n)
     if rng.random() < 0.25: tgt = tgt[: int(0.7 * n)]                      # ragged sizes
