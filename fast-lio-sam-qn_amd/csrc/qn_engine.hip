@@ -385,8 +385,8 @@ static void enqueue_nn(qn_ctx* c, int mode /*0 align, 1 fitness*/, float* sqd_ou
   GicpState* st = st_cur(c);
   uint32_t* fbc = &st->fb_count; uint32_t* bgc = &st->big_count;
   uint32_t* far_stats = (mode == 0 && !seeded && tick == std::max(1, std::min(c->track_from_tick, c->fused_from_tick)) - 1) ? c->far_stats : nullptr;
-  const int big_blocks = tick <= 2 ? 4096 : 1024;                                           // waves with one far query each (idle blocks exit at once)
-  const uint32_t fbb = std::min<uint32_t>(nb4, tick <= 2 ? 512 : 256);                     // list pass: wave-stride over the leftovers
+  const int big_blocks = tick <= 2 ? c->big_blocks0 : 1024;                                           // waves with one far query each (idle blocks exit at once)
+  const uint32_t fbb = std::min<uint32_t>(nb4, tick <= 2 ? (uint32_t)c->fb_blocks0 : 256u);                     // list pass: wave-stride over the leftovers
   const float r0 = (tick == 0 && mode == 0 && c->margin_nn_t0 > 0.f ? c->margin_nn_t0 : c->margin_nn) * T.grid.cell;
   if (mode == 0) {
     { ProfScope ps(c, QN_K_NN_SEARCH);
@@ -759,6 +759,8 @@ extern "C" int qn_debug_set(qn_ctx* c, const char* key, double v) {
   if (k == "cell") { c->cell_override = v; c->cloud[0].has_grid = c->cloud[1].has_grid = false; }
   else if (k == "margin_nn") c->margin_nn = (float)v;
   else if (k == "margin_nn_t0") c->margin_nn_t0 = (float)v;
+  else if (k == "big_blocks0") c->big_blocks0 = v < 64 ? 64 : (int)v;
+  else if (k == "fb_blocks0") c->fb_blocks0 = v < 64 ? 64 : (int)v;
   else if (k == "margin_knn") c->margin_knn = (float)v;
   else if (k == "knn_single_all") c->knn_single_all = v != 0;
   else if (k == "bbox_blocks") c->bbox_blocks = std::max(1, (int)v);

@@ -1,11 +1,11 @@
 #!/bin/bash
-# A/B of engine knobs on the GPU box: usage tools/gpu_ab.sh <tag> '<json knobs 1>' '<json knobs 2>' ...   (bench headline only)
+# A/B of engine knobs on the GPU box: usage [BENCH_ARGS='--shift 24'] [SKIP_TESTS=1] tools/gpu_ab.sh <tag> '<json knobs 1>' '<json knobs 2>' ...   (bench headline only)
 TAG=${1:-ab}; shift; OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG; mkdir -p $OUT; cd $GRAFT_REPO_ROOT
-timeout 600 python -m pytest tests/test_gpu_gicp.py tests/test_golden.py tests/test_gpu_adversarial.py -m gpu -q -x > $OUT/pytest_quick.log 2>&1; echo "pytest exit $?"; tail -3 $OUT/pytest_quick.log
+[ -n "$SKIP_TESTS" ] || timeout 600 python -m pytest tests/test_gpu_gicp.py tests/test_golden.py tests/test_gpu_adversarial.py -m gpu -q -x > $OUT/pytest_quick.log 2>&1; echo "pytest exit $?"; tail -3 $OUT/pytest_quick.log
 i=0
 for K in "$@"; do
   i=$((i+1))
-  QN_DEBUG_KNOBS="$K" timeout 300 python bench.py --no-cpu-baseline --no-quatro --no-extras --steps 200 > $OUT/ab_$i.json 2> $OUT/ab_$i.err
+  QN_DEBUG_KNOBS="$K" timeout 300 python bench.py --no-cpu-baseline --no-quatro --no-extras --steps 200 $BENCH_ARGS > $OUT/ab_$i.json 2> $OUT/ab_$i.err
   python - "$K" $OUT/ab_$i.json <<'PY'
 import json,sys
 try:
