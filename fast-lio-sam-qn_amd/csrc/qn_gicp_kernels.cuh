@@ -263,7 +263,8 @@ template <int MODE, bool LIST, int BLOCK>
 __global__ void __launch_bounds__(BLOCK, 6) k_nn_search(GridView src, GridView tgt, const GicpState* __restrict__ st, double thr2, float r0, int max_rounds,
                                                         int32_t* __restrict__ corr, float* __restrict__ sqd, int32_t* __restrict__ nn_idx, float4* __restrict__ nn_ref,
                                                         uint2* __restrict__ fb_list, uint32_t* __restrict__ fb_count,
-                                                        uint2* __restrict__ big_list, uint32_t* __restrict__ big_count, int big_blocks, float big_ratio, uint32_t* __restrict__ far_stats) {
+                                                        uint2* __restrict__ big_list, uint32_t* __restrict__ big_count, int big_blocks, float big_ratio, uint32_t* __restrict__ far_stats,
+                                                        const float4* __restrict__ seed_raw) {
   __shared__ WaveLds lds[BLOCK / 64];
   if (MODE == 0 && st->phase != 0) return;
   if (MODE == 1 && st->phase != 2) return;
@@ -319,9 +320,20 @@ __global__ void __launch_bounds__(BLOCK, 6) k_nn_search(GridView src, GridView t
       if (MODE == 0) nn_ref[t] = make_float4(qx, qy, qz, fminf(sqrtf(sink.second), d_unseen));
     }
     if (!LIST) {
-      const bool far = r > big_ratio * r0;
-      wave_append(big_list, big_count, mine && !done && far, make_uint2(t, __float_as_uint(-r)));     // far: one query per wave
-      wave_append(fb_list, fb_count, mine && !done && !far, make_uint2(t, __float_as_uint(-r)));      // continue from r
+      // seed_raw (the target in original order; knob seed_lists): the unseeded re-search of a later tick knows the PREVIOUS tick's neighbour j0 (nn_idx[t] is
+      // rewritten only when a query is settled).  |q - p_j0| bounds the neighbour distance from above, so a query the first radius does not settle goes to
+      // the list passes with THAT radius (widened like the tracked entries, so that the bound it leaves behind is worth something) instead of the
+      // doubled one: one tight scan instead of growth rounds that overshoot.
+      float r_seed = 0.f;
+      if (MODE == 0 && seed_raw && mine && !done) {
+        const int32_t j0 = nn_idx[t];
+        if ((uint32_t)j0 < tgt.n) { const float4 p0 = seed_raw[j0]; r_seed = sqrtf(sqdist(qx, qy, qz, p0.x, p0.y, p0.z)) * 1.1f + 0.5f * tgt.cell; }
+        if (!(r_seed == r_seed) || r_seed > 3.0e38f) r_seed = 0.f;
+      }
+      const float rn = r_seed > 0.f ? r_seed : r;
+      const bool far = rn > big_ratio * r0;
+      wave_append(big_list, big_count, mine && !done && far, make_uint2(t, __float_as_uint(-rn)));     // far: one query per wave
+      wave_append(fb_list, fb_count, mine && !done && !far, make_uint2(t, __float_as_uint(-rn)));      // continue from rn
     }
   }
 }

@@ -75,6 +75,11 @@ class Context:
             raise EngineError(st, self._l.qn_status_str(st).decode())
         self.h = h
         self.max_points = max_points
+        knobs = os.environ.get("QN_DEBUG_KNOBS")        # developer tuning (qn_debug_set) for every context of the process: a whole test file can run under a knob
+        if knobs:
+            import json
+            for k, v in json.loads(knobs).items():
+                self.debug_set(k, float(v))
 
     def close(self):
         if getattr(self, "h", None):
