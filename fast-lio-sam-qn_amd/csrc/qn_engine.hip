@@ -393,7 +393,7 @@ static void enqueue_nn(qn_ctx* c, int mode /*0 align, 1 fitness*/, float* sqd_ou
       if (seeded) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_nn_track<0>), dim3(nbt), dim3(QN_BLOCK), 0, s, S.grid, T.grid, T.raw, st, thr2, c->corr, sqd_out, c->nn_idx, c->nn_ref, c->fb_list, fbc, c->big_list, bgc);
       else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_nn_search<0, false, QN_NN_BLOCK>), dim3(nb), dim3(QN_NN_BLOCK), 0, s, S.grid, T.grid, st, thr2, r0, c->nn_rounds, c->corr, sqd_out, c->nn_idx, c->nn_ref, c->fb_list, fbc, c->big_list, bgc, 0, c->big_ratio, far_stats, (c->seed_lists && tick > 0) ? (const float4*)T.raw : (const float4*)nullptr); }
     { ProfScope ps(c, QN_K_NN_FALLBACK);
-      hipLaunchKernelGGL(HIP_KERNEL_NAME(k_nn_search<0, true, QN_BLOCK>), dim3(fbb + big_blocks), dim3(QN_BLOCK), 0, s, S.grid, T.grid, st, thr2, r0, 64, c->corr, sqd_out, c->nn_idx, c->nn_ref, c->fb_list, fbc, c->big_list, bgc, big_blocks, c->big_ratio, far_stats, (const float4*)nullptr); }
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(k_nn_search<0, true, QN_BLOCK>), dim3(fbb + big_blocks), dim3(QN_BLOCK), 0, s, S.grid, T.grid, st, thr2, r0, 64, c->corr, sqd_out, c->nn_idx, c->nn_ref, c->fb_list, fbc, c->big_list, bgc, big_blocks, c->big_ratio, far_stats, (c->chain_far && tick == 0) ? (const float4*)T.raw : (const float4*)nullptr); }
   } else {
     ProfScope ps(c, QN_K_FITNESS);
     if (seeded) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_nn_track<1>), dim3(nbt), dim3(QN_BLOCK), 0, s, S.grid, T.grid, T.raw, st, thr2, c->corr, sqd_out, c->nn_idx, c->nn_ref, c->fb_list, fbc, c->big_list, bgc);
@@ -760,6 +760,7 @@ extern "C" int qn_debug_set(qn_ctx* c, const char* key, double v) {
   else if (k == "margin_nn") c->margin_nn = (float)v;
   else if (k == "margin_nn_t0") c->margin_nn_t0 = (float)v;
   else if (k == "seed_lists") c->seed_lists = v != 0;
+  else if (k == "chain_far") c->chain_far = v != 0;
   else if (k == "big_blocks0") c->big_blocks0 = v < 64 ? 64 : (int)v;
   else if (k == "fb_blocks0") c->fb_blocks0 = v < 64 ? 64 : (int)v;
   else if (k == "margin_knn") c->margin_knn = (float)v;

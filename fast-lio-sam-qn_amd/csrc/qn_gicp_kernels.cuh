@@ -276,20 +276,34 @@ __global__ void __launch_bounds__(BLOCK, 6) k_nn_search(GridView src, GridView t
     if (tgt.dbg && blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) atomicAdd(&tgt.dbg[7], nbig);
     uint32_t nfar = 0;                                                     // far queries of this pass (the host hands far_stats only to the LAST unseeded pass, when the clouds are nearly aligned)
     const uint32_t bw0 = (blockIdx.x - (gridDim.x - big_blocks)) * (BLOCK / 64) + (threadIdx.x >> 6), nbw = big_blocks * (BLOCK / 64);
-    for (uint32_t w = bw0; w < nbig; w += nbw) {
-      const uint2 rec = big_list[w];
-      const float4 p = src.pts[rec.x];
-      float qx, qy, qz; xform_query<MODE>(Tf, p.x, p.y, p.z, qx, qy, qz);
-      const float v = __uint_as_float(rec.y);
-      // v > 0: tight seed (the query barely moved since its last scan): scan a little wider than the bound so that the
-      // following iterations can prove the neighbour unchanged; v < 0: unseeded, continue from |v|
-      const float r = v > 0.f ? v * 1.1f + 0.5f * tgt.cell : -v;
-      unsigned long long key; float second, d_unseen;
-      wave_search_single(tgt, qx, qy, qz, r, __int_as_float(0x7f800000), key, second, d_unseen, &lds[threadIdx.x >> 6]);
-      if ((threadIdx.x & 63) == 0) {
-        store_nn<MODE>(key, __float_as_uint(p.w), rec.x, thr2, corr, sqd, nn_idx);
-        if (MODE == 0) nn_ref[rec.x] = make_float4(qx, qy, qz, fminf(sqrtf(second), d_unseen));
-        if (key != QN_INF_KEY && key_d2(key) > 36.f * tgt.cell * tgt.cell) nfar++;        // neighbour beyond 6 cells (QN_FAR_RMIN_CELLS)
+    // seed_raw in a LIST launch (knob chain_far, first tick): a wave takes CH CONSECUTIVE entries - the list keeps the cell-sorted order of the queries, so they are
+    // neighbours in space - and the neighbour p* found for one entry bounds the next entry's neighbour distance from above by |q - p*| (p* is a target point):
+    // one scan of exactly that ball instead of growth rounds from the failed radius (3 -> 7 -> 10 cells ...) that rescan the inner region and overshoot.
+    const uint32_t CH = (MODE == 0 && seed_raw) ? 4u : 1u;
+    for (uint32_t w0 = bw0 * CH; w0 < nbig; w0 += nbw * CH) {
+      unsigned long long prev = QN_INF_KEY; float prev_d = 0.f;
+      const uint32_t w1 = min(w0 + CH, nbig);
+      for (uint32_t w = w0; w < w1; w++) {
+        const uint2 rec = big_list[w];
+        const float4 p = src.pts[rec.x];
+        float qx, qy, qz; xform_query<MODE>(Tf, p.x, p.y, p.z, qx, qy, qz);
+        const float v = __uint_as_float(rec.y);
+        // v > 0: tight seed (the query barely moved since its last scan): scan a little wider than the bound so that the
+        // following iterations can prove the neighbour unchanged; v < 0: unseeded, continue from |v|
+        float r = v > 0.f ? v * 1.1f + 0.5f * tgt.cell : -v;
+        if (CH > 1 && prev != QN_INF_KEY) {
+          const float4 ps = seed_raw[key_idx(prev)];
+          const float B = sqrtf(sqdist(qx, qy, qz, ps.x, ps.y, ps.z));
+          if (B <= prev_d + 3.f * tgt.cell) r = B * 1.000002f + 2.f * tgt.eps;           // (an entry from elsewhere in the cloud: the bound is worthless, keep the growth rounds)
+        }
+        unsigned long long key; float second, d_unseen;
+        wave_search_single(tgt, qx, qy, qz, r, __int_as_float(0x7f800000), key, second, d_unseen, &lds[threadIdx.x >> 6]);
+        prev = key; prev_d = key != QN_INF_KEY ? sqrtf(key_d2(key)) : 0.f;
+        if ((threadIdx.x & 63) == 0) {
+          store_nn<MODE>(key, __float_as_uint(p.w), rec.x, thr2, corr, sqd, nn_idx);
+          if (MODE == 0) nn_ref[rec.x] = make_float4(qx, qy, qz, fminf(sqrtf(second), d_unseen));
+          if (key != QN_INF_KEY && key_d2(key) > 36.f * tgt.cell * tgt.cell) nfar++;        // neighbour beyond 6 cells (QN_FAR_RMIN_CELLS)
+        }
       }
     }
     if (far_stats && MODE == 0 && (threadIdx.x & 63) == 0 && nfar) atomicAdd(&far_stats[3], nfar);
