@@ -54,6 +54,53 @@ def pct(xs):
     return {"median": round(float(np.median(xs)), 4), "p10": round(float(np.percentile(xs, 10)), 4), "p90": round(float(np.percentile(xs, 90)), 4), "n": int(len(xs))}
 
 
+def roofline_leg(ctx, register, ms_step, align_ms, nprof=4):
+    """per-kernel-family device time from hipEvents on the engine's own stream (qn_prof_*), the `roofline` object of the dominant single-kernel family"""
+    ctx.prof_reset(); ctx.prof_enable(True)
+    for j in range(nprof):
+        register(j)
+    ctx.synchronize(); ctx.prof_enable(False)
+    stats = ctx.prof_stats()
+    fam_ms = {k: v[0] / nprof for k, v in stats.items() if v[1] > 0}             # ms per registration
+    fam_avg = {k: v[0] / v[1] for k, v in stats.items() if v[1] > 0}             # ms per profiled span (= one launch for the single-kernel families)
+    ab = algorithmic_bytes()
+    # kernel families timed as ONE kernel per span, with the rocprofv3 name of that kernel and its algorithmic bytes per launch
+    single_k = {"knn_select": ("k_knn_hist<false, 32>", N_PTS * (16 + 16 * K_COV)),          # k-NN selection of one cloud: point + k neighbour points
+                "gn_tick_fused": ("k_tick<512, 4, 0>", ab["gn_iteration"]),                # one whole GN / LM tick (controller + tracked NN + accumulate)
+                "nn_search": ("k_nn_search<0, false, 256>", ab["gn_iteration"]),                # first (unseeded) NN passes of an align
+                "nn_fallback": ("k_nn_search<0, true, 256>", ab["gn_iteration"]),
+                "accumulate": ("k_accumulate", ab["gn_iteration"]), "solve": ("k_solve<512>", 28 * 8 * 512)}
+    dom = max((k for k in fam_ms if k in single_k), key=fam_ms.get)
+    dom_kernel, per_launch_bytes = single_k[dom]
+    dom_ms = fam_avg[dom]
+    achieved = per_launch_bytes / (dom_ms * 1e-3) / 1e9
+    pmc, pmc_all = None, None
+    pmc_path = os.path.join(ROOT, "profiles", "pmc_latest.json")
+    if os.path.exists(pmc_path):
+        try:
+            pmc_all = json.load(open(pmc_path)); pmc = pmc_all.get(dom)
+        except Exception:
+            pmc = None
+    traffic = pmc.get("hbm_bytes_per_launch") if isinstance(pmc, dict) else None
+    kernels = {k: {"kernel": single_k[k][0], "avg_launch_ms": round(fam_avg[k], 5), "launches_per_registration": round(stats[k][1] / nprof, 2),
+                   "algorithmic_bytes_per_launch": single_k[k][1], "achieved_GBs": round(single_k[k][1] / (fam_avg[k] * 1e-3) / 1e9, 2),
+                   "frac": round(single_k[k][1] / (fam_avg[k] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                   "traffic": (pmc_all or {}).get(k, {}).get("hbm_bytes_per_launch") if isinstance(pmc_all, dict) else None} for k in single_k if k in fam_avg}
+    roofline = {"bound": "hbm", "kernel": dom_kernel, "family": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                "traffic_source": "NOT measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the same workload (tools/gpu_round.sh <tag> pmc), stored in profiles/pmc_latest.json",
+                "stale_from": (pmc_all or {}).get("_meta", {}).get("tag", "profiles/pmc_latest.json") if isinstance(pmc_all, dict) else None,
+                "traffic_detail": pmc, "avg_launch_ms": round(dom_ms, 5), "algorithmic_bytes_per_launch": per_launch_bytes,
+                "whole_registration": {"algorithmic_bytes": ab["full"], "achieved": round(ab["full"] / (ms_step * 1e-3) / 1e9, 2),
+                                       "frac": round(ab["full"] / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                                       "note": "amortised over the registrations in flight"},
+                "align_only": {"algorithmic_bytes": ab["align"], "ms": round(align_ms, 4),
+                               "frac": round(ab["align"] / (align_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)},
+                "family_ms_per_registration": {k: round(v, 4) for k, v in fam_ms.items()}, "kernels": kernels,
+                "note": "working set (<=20 MB) is L2/MALL resident: nominal HBM yardstick (SURVEY 8d)"}
+    return roofline
+
+
 def spawn_ranks(args):
     """plain `python bench.py --gpus N`: start the N ranks (one process per GPU) and relay rank 0's JSON line."""
     n = args.gpus
@@ -77,6 +124,75 @@ def spawn_ranks(args):
         raise SystemExit("bench.py: rank exit codes %s" % rcs)
 
 
+def single_process(args, engine, synth, json_fd):
+    """`--gpus N --single-process`: ONE process drives all N GPUs through qn_multi_init(N) / qn_multi_align_best - pair i -> GPU i mod N on
+    `in_flight` streams each, ncclCommInitAll(N) and ONE grouped ncclAllGather of the 96-byte records inside the C-ABI.  This is what a C++ host
+    like the reference's single process (fast_lio_sam_qn.cpp:213-219) would call.  A step = one registration per GPU: K x N registrations timed."""
+    n = args.gpus
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if have < n:
+        raise SystemExit("bench.py --gpus %d --single-process needs %d GPUs, %d visible (no GPU sharing, no CPU fallback)" % (n, n, have))
+    torch.cuda.init()
+    host_pairs = [synth.make_pair(j, N_PTS, shift=args.shift) for j in range(max(args.pairs, 1))]
+    dev_pairs = []                                                   # clouds resident on EVERY GPU (distinct device buffers; clouds never move between GPUs)
+    for g in range(n):
+        dev_pairs.append([(torch.from_numpy(s).to("cuda:%d" % g), torch.from_numpy(t).to("cuda:%d" % g)) for s, t, _ in host_pairs])
+    for g in range(n):
+        torch.cuda.synchronize(g)
+    mg = engine.MultiGpu(n, N_PTS + 1024, in_flight=max(1, args.in_flight))
+    gg = engine.GicpParams(); engine.lib().qn_gicp_default_params(__import__("ctypes").byref(gg))
+    gg.k_correspondences, gg.max_iterations, gg.max_corr_dist, gg.optimizer, gg.force_iterations = K_COV, GN_ITERS, 52.5, 1, GN_ITERS
+    mg.set_params(gg)
+
+    def descs(k_per_gpu):
+        out = []
+        for i in range(k_per_gpu * n):                                # pair i -> GPU i mod N
+            g, j = i % n, (i // n) % len(host_pairs)
+            s, t = dev_pairs[g][j]
+            out.append((s.data_ptr(), N_PTS, t.data_ptr(), N_PTS, 12, 1))
+        return out
+
+    if args.warmup > 0:
+        mg.align_best(descs(args.warmup))
+    for g in range(n):
+        torch.cuda.synchronize(g)
+    t0 = time.perf_counter()
+    recs, best = mg.align_best(descs(args.steps))                    # EXACTLY `steps` registrations per GPU, the RCCL gather included
+    for g in range(n):
+        torch.cuda.synchronize(g)
+    elapsed = time.perf_counter() - t0
+    assert all(r.status == 0 for r in recs), [r.status for r in recs]
+    per_gpu_ms, gather_ms = mg.timing()
+    winner = best if best is not None else min(recs, key=lambda r: (r.fitness, r.pair_id))     # forced iterations never "converge": rank by score
+    # roofline leg on GPU 0 with a context of its own (the same kernels the qn_multi contexts run)
+    torch.cuda.set_device(0)
+    ctx = engine.Context(N_PTS + 1024, device=0)
+    g0 = engine.NanoGICP(ctx); g0.p = gg; g0.bind()
+    def register(j):
+        s, t = dev_pairs[0][j % len(host_pairs)]
+        g0.setInputSourceDevice(s.data_ptr(), N_PTS, 12); g0.calculateSourceCovariances()
+        g0.setInputTargetDevice(t.data_ptr(), N_PTS, 12); g0.calculateTargetCovariances()
+        return g0.align()
+    register(0); ctx.synchronize()
+    lat = []
+    for _ in range(30):
+        ta = time.perf_counter(); g0.align(); lat.append(1e3 * (time.perf_counter() - ta))
+    ms_step = 1e3 * elapsed / args.steps
+    roofline = roofline_leg(ctx, register, ms_step / n, pct(lat)["median"])
+    out = {"metric": "scan-pair registrations/sec on 100k-pt clouds", "value": round(n * args.steps / elapsed, 3), "unit": "registrations/s", "n_gpus": n,
+           "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": "f32 search / f64 accumulate", "data": "synthetic",
+           "config": {"workload": "Nano-GICP icpAlignment, synthetic 100k x 100k street-scene pairs, k=20 covariances, 20 forced GN iterations (BASELINE configs[1])",
+                      "mode": "single process: qn_multi_init(%d) -> ncclCommInitAll(%d), qn_multi_align_best with %d pairs (pair i -> GPU i mod N), one grouped ncclAllGather of the 96-byte records" % (n, n, n * args.steps),
+                      "points": N_PTS, "k": K_COV, "gn_iterations": GN_ITERS, "in_flight": max(1, args.in_flight), "distinct_pairs_per_gpu": len(host_pairs),
+                      "rccl_ranks": mg.gpu_count(), "per_gpu_pairs_per_s": [round(args.steps / (1e-3 * m), 2) if m > 0 else None for m in per_gpu_ms],
+                      "per_gpu_ms": [round(m, 3) for m in per_gpu_ms], "gather_ms": round(gather_ms, 4),
+                      "winner_pair": int(winner.pair_id), "winner_score": winner.fitness, "ms_per_align": pct(lat)["median"]},
+           "roofline": roofline, "cpu_baseline": None}
+    os.write(json_fd, (json.dumps(out) + "\n").encode())
+    ctx.close(); mg.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -89,9 +205,10 @@ def main():
     ap.add_argument("--in-flight", type=int, default=4, help="candidate pairs registered concurrently per GPU (one context = one hipStream each)")
     ap.add_argument("--shift", type=float, default=None, help="developer: scene-window shift of the synthetic pairs in metres (default: the generator's 5 m = ~96 %% overlap; 24 = 80 %%)")
     ap.add_argument("--batch-pairs", type=int, default=64, help="BASELINE configs[3]: candidate pairs of one query, sharded over the ranks")
+    ap.add_argument("--single-process", action="store_true", help="ONE process drives all --gpus N devices through qn_multi_init(N) / qn_multi_align_best (ncclCommInitAll + grouped ncclAllGather inside the C-ABI): the path a C++ host like the reference's single process would call")
     args = ap.parse_args()
 
-    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1 and not args.single_process:
         return spawn_ranks(args)
     # stdout carries ONE JSON line and nothing else: RCCL prints a version banner to fd 1 when a communicator comes up, so fd 1 is
     # pointed at stderr for the whole run and the line is written to the saved descriptor at the end
@@ -99,7 +216,9 @@ def main():
     json_fd = os.dup(1); os.dup2(2, 1)
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
+    if args.single_process and world != 1:
+        raise SystemExit("bench.py --single-process is ONE process for all GPUs: do not launch it under torchrun with WORLD_SIZE=%d" % world)
+    if world != args.gpus and not args.single_process:
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d: launch one rank per GPU (torchrun --nproc-per-node %d)" % (args.gpus, world, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the engine has no CPU fallback")
@@ -122,6 +241,9 @@ def main():
             dist.init_process_group(backend, rank=rank, world_size=world)
 
     from qn_amd import engine, synth
+    engine.DEBUG_KNOBS_FROM_ENV = True       # developer tuning only (QN_DEBUG_KNOBS -> qn_debug_set on every context); unset in every reported run
+    if args.single_process:
+        return single_process(args, engine, synth, json_fd)
     # `in_flight` contexts (= hipStreams) per GPU: the candidate pairs of a loop-closure query are independent
     # registrations (BASELINE "batch of candidate keyframe pairs"), several are kept in flight to fill the chip
     ctxs = [engine.Context(N_PTS + 1024, device=local) for _ in range(max(1, args.in_flight))]
@@ -132,10 +254,6 @@ def main():
         gg.setOptimizer("gn"); gg.setForceIterations(GN_ITERS)
         gs.append(gg)
     ctx, g = ctxs[0], gs[0]
-    knobs = json.loads(os.environ.get("QN_DEBUG_KNOBS", "{}"))     # developer tuning only (qn_debug_set); empty in every reported run
-    for cx in ctxs:
-        for kk, vv in knobs.items():
-            cx.debug_set(kk, float(vv))
 
     # candidate pairs of this rank: pair_id = rank + world * j   (pair i -> rank i mod N); distinct scenes, distinct device buffers
     npairs = max(args.pairs, 1)
@@ -228,6 +346,32 @@ def main():
         batch64 = {"pairs": nb, "distinct_pairs": nb, "wall_ms": round(1e3 * bwall, 3), "pairs_per_s": round(nb / bwall, 2), "ms_per_pair": round(1e3 * bwall / nb, 4),
                    "winner_pair": int(bwin[0]), "winner_score": bwin[2], "sharding": "pair i -> rank i mod %d; qn_multi_align_best per rank on its GPU (a process that owns several GPUs gathers its 96-byte records with RCCL inside the C-ABI), all_gather of the rank winners" % world,
                    "valid_pairs_this_rank": int(sum(r.valid for r in recs))}
+        # ---- the same 64 distinct pairs at the reference's operating point (k = 15, LM, <= 32 iterations, the real stopping rule):
+        # here the accept test `hasConverged() && score < thr` (loop_closure.cpp:129) is live, so `valid`, best_found and the arg-min of
+        # qn_multi_align_best are exercised in a measured run, and the winner is the C-ABI's, not this script's
+        import ctypes
+        pref = engine.GicpParams(); engine.lib().qn_gicp_default_params(ctypes.byref(pref))
+        pref.k_correspondences, pref.max_iterations, pref.max_corr_dist, pref.transformation_epsilon = 15, 32, 52.5, 0.01
+        mg.set_params(pref)
+        mg.align_best(descs[:min(len(descs), 4)])
+        barrier()
+        tb = time.perf_counter()
+        rrecs, rbest = mg.align_best(descs)
+        rmine = [float(my_ids[rbest.pair_id]), float(rbest.converged), rbest.fitness] + list(rbest.T) if rbest is not None else [-1.0, 0.0, 1.7e308] + [0.0] * 16
+        rwin = gather_best(rmine)
+        barrier()
+        rwall = time.perf_counter() - tb
+        if dist is not None:
+            tmax = torch.tensor([rwall], dtype=torch.float64, device=cdev); dist.all_reduce(tmax, op=dist.ReduceOp.MAX); rwall = float(tmax.item())
+        assert all(r.status == 0 for r in rrecs), [r.status for r in rrecs]
+        vrec = [r for r in rrecs if r.valid]
+        own = min(vrec, key=lambda r: (r.fitness, r.pair_id)) if vrec else None
+        batch64["reference_operating_point"] = {"config": "k=15, LM, max 32 iterations, eps_t 0.01, score thr 1.5", "pairs": nb, "wall_ms": round(1e3 * rwall, 3), "pairs_per_s": round(nb / rwall, 2),
+                                                "valid_pairs_this_rank": len(vrec), "converged_this_rank": int(sum(r.converged for r in rrecs)), "best_found": rbest is not None,
+                                                "winner_pair": int(rwin[0]), "winner_score": rwin[2],
+                                                "argmin_matches_records": bool((own is None and rbest is None) or (own is not None and rbest is not None and own.pair_id == rbest.pair_id)),
+                                                "iterations_min_max": [int(min(r.iterations for r in rrecs)), int(max(r.iterations for r in rrecs))]}
+        mg.set_params(g.p)
         # ---- the same 64 candidates as ONE loop-closure query sees them: every pair shares the query's source cloud, which each context
         # prepares once (qn_icp_alignment_same_source inside qn_multi_align_best); the reference's single-candidate code path rebuilds it per call
         s0, t0_ = pairs[0][0], pairs[0][1]
@@ -278,60 +422,68 @@ def main():
             ta = time.perf_counter(); g.align(); lat.append(1e3 * (time.perf_counter() - ta))
         align = pct(lat); align_ms = align["median"]
 
-        # ---- roofline leg: per-kernel-family device time from hipEvents on the engine's stream
-        ctx.prof_reset(); ctx.prof_enable(True)
-        nprof = 4
-        for j in range(nprof):
-            register(j)
-        ctx.synchronize(); ctx.prof_enable(False)
-        stats = ctx.prof_stats()
-        fam_ms = {k: v[0] / nprof for k, v in stats.items() if v[1] > 0}             # ms per registration
-        fam_avg = {k: v[0] / v[1] for k, v in stats.items() if v[1] > 0}             # ms per profiled span (= one launch for the single-kernel families)
-        ab = algorithmic_bytes()
-        # kernel families timed as ONE kernel per span, with the rocprofv3 name of that kernel and its algorithmic bytes per launch
-        single_k = {"knn_select": ("k_knn_hist<false, 32>", N_PTS * (16 + 16 * K_COV)),          # k-NN selection of one cloud: point + k neighbour points
-                    "gn_tick_fused": ("k_tick<512, 4, 0>", ab["gn_iteration"]),                # one whole GN / LM tick (controller + tracked NN + accumulate)
-                    "nn_search": ("k_nn_search<0, false, 256>", ab["gn_iteration"]),                # first (unseeded) NN passes of an align
-                    "nn_fallback": ("k_nn_search<0, true, 256>", ab["gn_iteration"]),
-                    "accumulate": ("k_accumulate", ab["gn_iteration"]), "solve": ("k_solve<512>", 28 * 8 * 512)}
-        dom = max((k for k in fam_ms if k in single_k), key=fam_ms.get)
-        dom_kernel, per_launch_bytes = single_k[dom]
-        dom_ms = fam_avg[dom]
-        achieved = per_launch_bytes / (dom_ms * 1e-3) / 1e9
-        pmc, pmc_all = None, None
-        pmc_path = os.path.join(ROOT, "profiles", "pmc_latest.json")
-        if os.path.exists(pmc_path):
-            try:
-                pmc_all = json.load(open(pmc_path)); pmc = pmc_all.get(dom)
-            except Exception:
-                pmc = None
-        traffic = pmc.get("hbm_bytes_per_launch") if isinstance(pmc, dict) else None
-        kernels = {k: {"kernel": single_k[k][0], "avg_launch_ms": round(fam_avg[k], 5), "launches_per_registration": round(stats[k][1] / nprof, 2),
-                       "algorithmic_bytes_per_launch": single_k[k][1], "achieved_GBs": round(single_k[k][1] / (fam_avg[k] * 1e-3) / 1e9, 2),
-                       "frac": round(single_k[k][1] / (fam_avg[k] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
-                       "traffic": (pmc_all or {}).get(k, {}).get("hbm_bytes_per_launch") if isinstance(pmc_all, dict) else None} for k in single_k if k in fam_avg}
-        roofline = {"bound": "hbm", "kernel": dom_kernel, "family": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                    "traffic_source": "NOT measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the same workload (tools/gpu_round.sh <tag> pmc), stored in profiles/pmc_latest.json",
-                    "stale_from": (pmc_all or {}).get("_meta", {}).get("tag", "profiles/pmc_latest.json") if isinstance(pmc_all, dict) else None,
-                    "traffic_detail": pmc, "avg_launch_ms": round(dom_ms, 5), "algorithmic_bytes_per_launch": per_launch_bytes,
-                    "whole_registration": {"algorithmic_bytes": ab["full"], "achieved": round(ab["full"] / (ms_step * 1e-3) / 1e9, 2),
-                                           "frac": round(ab["full"] / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
-                                           "note": "amortised over the registrations in flight"},
-                    "align_only": {"algorithmic_bytes": ab["align"], "ms": round(align_ms, 4),
-                                   "frac": round(ab["align"] / (align_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)},
-                    "family_ms_per_registration": {k: round(v, 4) for k, v in fam_ms.items()}, "kernels": kernels,
-                    "note": "working set (<=20 MB) is L2/MALL resident: nominal HBM yardstick (SURVEY 8d)"}
+        roofline = roofline_leg(ctx, register, ms_step, align_ms)
+
+        cpu = None
+        if world == 1 and not args.no_cpu_baseline:
+            from oracle import oracle as orc                      # CPU baseline leg only
+            s_np, t_np = pairs[0][0].cpu().numpy(), pairs[0][1].cpu().numpy()
+            nthreads = orc.num_threads()
+            def cpu_once():
+                o = orc.GicpOracle(k=K_COV, max_iter=GN_ITERS, max_corr_dist=52.5, optimizer="gn", force_iterations=GN_ITERS)
+                o.set_source(s_np); o.compute_covariances(0); o.set_target(t_np); o.compute_covariances(1)
+                return o.align()
+            tc = time.perf_counter(); ro = cpu_once(); first = time.perf_counter() - tc
+            nrep = max(1, min(8, int(15.0 / max(first, 1e-3))))
+            times = []
+            for _ in range(nrep):
+                tc = time.perf_counter(); cpu_once(); times.append(time.perf_counter() - tc)
+            cpu_s = float(np.median(times))
+            cpu = {"value": round(1.0 / cpu_s, 4), "unit": "registrations/s", "cores": nthreads, "kind": "port",
+                   "ms_per_registration": round(cpu_s * 1e3, 2), "ms_range": [round(1e3 * min(times), 2), round(1e3 * max(times), 2)],
+                   "sample": "%d full registrations of pair 0 (100k x 100k, k=20, 20 GN iterations) with the OpenMP C++ oracle; shared host, wall time varies run to run" % nrep}
+            # parity spot check of the benched workload against the oracle: pair 0, the bench's own parameters re-bound to the context
+            # (other NanoGICP objects may have used it), BEFORE any extra runs
+            g.bind(); r = register(0)
+            Tg = np.array(r.T64).reshape(4, 4)
+            dtp = float(np.abs(Tg - ro["T"]).max()); dt_m, dr_rad = synth.pose_error(Tg, ro["T"])
+            parity = {"pair": 0, "max_abs_T_diff": dtp, "dt_m": dt_m, "dr_rad": dr_rad, "iterations": [int(r.iterations), int(ro["iterations"])],
+                      "score_rel_diff": abs(r.fitness - ro["fitness"]) / max(ro["fitness"], 1e-300), "ok": bool(dtp <= 1e-9 and r.iterations == ro["iterations"])}
+        else:
+            dtp, parity = None, None
+
 
         extras = {}
         if not args.no_extras:
             try:
-                # ---- a less favourable pair: 80 % overlap (target window shifted 24 m; the default pairs overlap ~96 %), same workload
-                s80, t80, _ = synth.make_pair(9000, N_PTS, shift=24.0)
-                p80 = [(torch.from_numpy(s80).cuda(), torch.from_numpy(t80).cuda(), None)]
+                # ---- SURVEY 8d's generator case: 80 % overlap (target window shifted 24 m; the headline pairs overlap ~96 %).  Same workload, same
+                # in-flight setting, 8 DISTINCT pairs, `steps` timed registrations; single-stream percentiles and the kernel-family breakdown beside it
+                g.bind()
+                p80 = []
+                for j in range(8):
+                    s80, t80, _ = synth.make_pair(9000 + j, N_PTS, shift=24.0)
+                    p80.append((torch.from_numpy(s80).cuda(), torch.from_numpy(t80).cuda(), None))
                 batch(8, p80); torch.cuda.synchronize()
-                t8 = time.perf_counter(); batch(40, p80); torch.cuda.synchronize()
-                extras["overlap80"] = {"registrations_per_s": round(40 / (time.perf_counter() - t8), 2), "note": "one pair with 80 % overlap cycled, same in-flight setting"}
+                n80 = max(40, args.steps)
+                t8 = time.perf_counter(); _, _, st80 = batch(n80, p80); torch.cuda.synchronize(); w80 = time.perf_counter() - t8
+                assert all(x == 0 for x in st80), st80
+                def register80(j):
+                    s_, t_, _ = p80[j % len(p80)]
+                    g.setInputSourceDevice(s_.data_ptr(), N_PTS, 12); g.calculateSourceCovariances()
+                    g.setInputTargetDevice(t_.data_ptr(), N_PTS, 12); g.calculateTargetCovariances()
+                    return g.align()
+                register80(0); lat = []
+                for j in range(16):
+                    tl = time.perf_counter(); register80(j); lat.append(1e3 * (time.perf_counter() - tl))
+                ctx.prof_reset(); ctx.prof_enable(True)
+                for j in range(4):
+                    register80(j)
+                ctx.synchronize(); ctx.prof_enable(False)
+                st8 = ctx.prof_stats()
+                extras["overlap80"] = {"registrations_per_s": round(n80 / w80, 2), "ms_per_step": round(1e3 * w80 / n80, 4), "steps": n80, "distinct_pairs": len(p80), "in_flight": len(ctxs),
+                                       "ms_per_registration_single_stream_stats": pct(lat),
+                                       "family_ms_per_registration": {k: round(v[0] / 4, 4) for k, v in st8.items() if v[1] > 0},
+                                       "note": "SURVEY 8d generator: target scene window shifted so that the clouds overlap 80 % (20 % of the source has no counterpart)"}
                 # ---- BASELINE configs[0]: the reference's operating point: k = 15, LM, <= 32 iterations, real stopping rule,
                 # clouds handed over as HOST buffers through qn_icp_alignment (PCIe inclusive), 30k and 100k points; CPU oracle beside it
                 rop = {}
@@ -412,30 +564,6 @@ def main():
             except Exception as ex:
                 extras["replay"] = {"error": repr(ex)}
 
-        cpu = None
-        if world == 1 and not args.no_cpu_baseline:
-            from oracle import oracle as orc                      # CPU baseline leg only
-            s_np, t_np = pairs[0][0].cpu().numpy(), pairs[0][1].cpu().numpy()
-            nthreads = orc.num_threads()
-            def cpu_once():
-                o = orc.GicpOracle(k=K_COV, max_iter=GN_ITERS, max_corr_dist=52.5, optimizer="gn", force_iterations=GN_ITERS)
-                o.set_source(s_np); o.compute_covariances(0); o.set_target(t_np); o.compute_covariances(1)
-                return o.align()
-            tc = time.perf_counter(); ro = cpu_once(); first = time.perf_counter() - tc
-            nrep = max(1, min(8, int(15.0 / max(first, 1e-3))))
-            times = []
-            for _ in range(nrep):
-                tc = time.perf_counter(); cpu_once(); times.append(time.perf_counter() - tc)
-            cpu_s = float(np.median(times))
-            cpu = {"value": round(1.0 / cpu_s, 4), "unit": "registrations/s", "cores": nthreads, "kind": "port",
-                   "ms_per_registration": round(cpu_s * 1e3, 2), "ms_range": [round(1e3 * min(times), 2), round(1e3 * max(times), 2)],
-                   "sample": "%d full registrations of pair 0 (100k x 100k, k=20, 20 GN iterations) with the OpenMP C++ oracle; shared host, wall time varies run to run" % nrep}
-            # parity spot check of the benched workload against the oracle
-            r = register(0)
-            dtp = float(np.abs(np.array(r.T64).reshape(4, 4) - ro["T"]).max())
-        else:
-            dtp = None
-
         out = {"metric": "scan-pair registrations/sec on 100k-pt clouds", "value": round(world * args.steps / elapsed, 3),
                "unit": "registrations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(ms_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -446,9 +574,11 @@ def main():
                           "ms_per_registration_single_stream": single["median"], "ms_per_registration_single_stream_stats": single,
                           "ms_per_registration_from_host_buffers": host["median"], "ms_per_registration_from_host_buffers_stats": host,
                           "ms_per_align": align_ms, "ms_per_align_stats": align, "winner_pair": int(winner[0]), "winner_score": winner[2],
-                          "max_abs_T_diff_vs_oracle": dtp, "batch64": batch64, "quatro": quatro, **extras},
+                          "max_abs_T_diff_vs_oracle": dtp, "parity_vs_oracle": parity, "batch64": batch64, "quatro": quatro, **extras},
                "roofline": roofline, "cpu_baseline": cpu}
         os.write(json_fd, (json.dumps(out) + "\n").encode())
+        if parity is not None and not parity["ok"]:
+            raise SystemExit("bench.py: the benched workload does NOT match the oracle: %r" % (parity,))
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

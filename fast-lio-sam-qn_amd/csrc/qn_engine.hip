@@ -145,6 +145,7 @@ extern "C" void qn_ctx_destroy(qn_ctx* c) {
   if (!c) return;
   hipSetDevice(c->device);
   if (c->stream) hipStreamSynchronize(c->stream);
+  if (c->stream2) hipStreamSynchronize(c->stream2);                     // a target may still be in preparation there (TargetScope)
   c->prof_collect();
   for (int w = 0; w < 2; w++) { CloudBuf& b = c->cloud[w]; hipFree(b.raw); hipFree(b.sorted); hipFree(b.sorted_tmp); hipFree(b.cell_of_pt); hipFree(b.cell_start); hipFree(b.counts); hipFree(b.nrm); }
   hipFree(c->staging); hipFree(c->scan_sums); hipFree(c->bbox); hipFree(c->state); hipFree(c->partials); hipFree(c->trace);
@@ -182,6 +183,8 @@ extern "C" int qn_gicp_set_params(qn_ctx* c, const qn_gicp_params* p) {
   c->params = *p;
   return QN_OK;
 }
+
+extern "C" int qn_gicp_get_params(const qn_ctx* c, qn_gicp_params* p) { if (!c || !p) return QN_ERR_INVALID_ARG; *p = c->params; return QN_OK; }
 
 static GicpConfig make_cfg(const qn_ctx* c) {
   GicpConfig g; const qn_gicp_params& p = c->params;
@@ -532,22 +535,25 @@ extern "C" int qn_gicp_align(qn_ctx* c, const float guess[16], qn_gicp_result* o
   // chunk end from the refresh requests actually seen.  One more stream synchronisation per align (~15 us) buys a 4x faster
   // registration of partially overlapping clouds and keeps the extra launch out of the chain when nobody needs it.
   const int unseeded = std::max(1, std::min(c->track_from_tick, c->fused_from_tick)) * per_outer;
-  int ticks_left = p.force_iterations > 0 ? maxit * per_outer : 1 << 30;
-  int chunk = c->far_enabled ? std::min(unseeded, ticks_left) : (p.force_iterations > 0 ? ticks_left : c->ticks_per_chunk);
+  // The number of ticks is known in advance only for forced Gauss-Newton runs (one tick per iteration).  A forced LM run needs one more tick
+  // per rejected trial step, so it is driven like an unforced one: chunks until the device reports `done`, bounded by `budget`.
+  const bool exact_ticks = p.force_iterations > 0 && p.optimizer == QN_OPT_GN;
+  int ticks_left = exact_ticks ? maxit : 1 << 30;
+  int chunk = c->far_enabled ? std::min(unseeded, ticks_left) : (exact_ticks ? ticks_left : c->ticks_per_chunk);
   bool first_chunk = true;
   long budget = (long)maxit * (p.optimizer == QN_OPT_LM ? (p.lm_max_iterations + 1) : 1) + 2;
   c->result_host->phase = 0;
   bool seeded = false; int tick_no = 0;   // the first linearisation runs the full grid search; every later NN pass tracks from it
   for (;;) {
     for (int t = 0; t < chunk; t++) { enqueue_tick(c, seeded, tick_no / per_outer, tick_no == 0); tick_no++; seeded = true; }
-    if (p.force_iterations > 0 && ticks_left > chunk) {           // forced iterations cannot be done yet: only the statistics block is needed at this chunk end
+    if (exact_ticks && ticks_left > chunk) {                      // forced GN iterations cannot be done yet: only the statistics block is needed at this chunk end
       hipLaunchKernelGGL(k_finalize, dim3(1), dim3(64), 0, s, st_cur(c), c->result_host, c->far_stats);
     } else {
       enqueue_epilogue(c, DBL_MAX, maxit > 0 && tick_no > 0);
     }
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipStreamSynchronize(s));
-    budget -= chunk; ticks_left -= chunk;
+    budget -= std::max(chunk, 1); ticks_left -= chunk;
     if (c->result_host->phase == 2) break;
     // far queries: keep the refresh kernel in the chain only while ticks actually ask for refreshes (a launch costs ~4 us per tick)
     if (c->far_enabled) {
@@ -555,7 +561,7 @@ extern "C" int qn_gicp_align(qn_ctx* c, const float guess[16], qn_gicp_result* o
       if (first_chunk) c->far_mode = rb->far_queries * 16u > c->cloud[0].n ? 1 : 2;      // more than ~6 % of the source has a far neighbour
       else c->far_mode = (c->far_mode == 1 ? rb->far_requests : rb->far_misses / (uint32_t)std::max(1, chunk)) > 256u ? 1 : 2;   // stray misses are cheaper inside k_tick
     }
-    if (p.force_iterations <= 0) chunk = first_chunk ? c->ticks_per_chunk : std::max(2 * per_outer, c->ticks_per_chunk / 2);   // convergence is usually near after the first chunks: ticks past it are wasted launches
+    if (!exact_ticks) chunk = first_chunk ? c->ticks_per_chunk : std::max(2 * per_outer, c->ticks_per_chunk / 2);   // convergence is usually near after the first chunks: ticks past it are wasted launches
     else chunk = first_chunk && c->far_mode == 1 ? std::min(ticks_left, c->ticks_per_chunk) : ticks_left;
     first_chunk = false;
     if (budget <= 0) { c->last_error = "align: device state machine did not terminate"; return QN_ERR_HIP; }

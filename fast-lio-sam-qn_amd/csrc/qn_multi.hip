@@ -13,6 +13,7 @@
 #include <rccl/rccl.h>
 #include <dlfcn.h>
 #include <atomic>
+#include <chrono>
 #include <cfloat>
 #include <cstdio>
 #include <cstring>
@@ -40,6 +41,8 @@ struct qn_multi {
   decltype(&ncclGroupStart) p_group_start = nullptr;
   decltype(&ncclGroupEnd) p_group_end = nullptr;
   decltype(&ncclGetErrorString) p_err = nullptr;
+  std::vector<double> gpu_ms; double gather_ms = 0;   // timing of the latest qn_multi_align_best: per GPU (first pair start .. last pair end), the gather
+  bool poisoned = false;                          // a collective failed: the communicator state is undefined, every later call is refused
   std::string last_error;
 };
 
@@ -127,6 +130,13 @@ extern "C" int qn_multi_set_params(qn_multi* m, const qn_gicp_params* p) {
 }
 
 extern "C" int qn_multi_gpu_count(const qn_multi* m) { return m ? m->n_gpus : 0; }
+extern "C" int qn_multi_get_timing(const qn_multi* m, double* per_gpu_ms, double* gather_ms) {
+  if (!m || !per_gpu_ms || !gather_ms) return QN_ERR_INVALID_ARG;
+  if ((int)m->gpu_ms.size() != m->n_gpus) return QN_ERR_NOT_READY;
+  for (int g = 0; g < m->n_gpus; g++) per_gpu_ms[g] = m->gpu_ms[g];
+  *gather_ms = m->gather_ms;
+  return QN_OK;
+}
 
 // pair i -> GPU i mod N (clouds are read where the caller put them: host memory, or - on_device - memory of THAT GPU); every GPU
 // registers its pairs on `in_flight` streams; one ncclAllGather of the per-GPU record tables; the winner is the valid record
@@ -135,6 +145,7 @@ extern "C" int qn_multi_align_best(qn_multi* m, const qn_pair_desc* pairs, uint3
                                    qn_pair_record* records, qn_pair_record* best, int* best_found) {
   if (!m || (n_pairs && !pairs) || !best || !best_found) return QN_ERR_INVALID_ARG;
   *best_found = 0; memset(best, 0, sizeof(*best)); best->pair_id = -1; best->fitness = DBL_MAX;
+  if (m->poisoned) { m->last_error = "qn_multi handle poisoned by an earlier failed collective: destroy it and create a new one"; return QN_ERR_HIP; }
   if (n_pairs == 0) return QN_OK;
   const int N = m->n_gpus;
   const uint32_t per = (n_pairs + N - 1) / N;
@@ -166,20 +177,40 @@ extern "C" int qn_multi_align_best(qn_multi* m, const qn_pair_desc* pairs, uint3
       if (st == QN_OK) memcpy(r.T, res.T, sizeof(r.T)); else for (int k = 0; k < 16; k++) r.T[k] = (k % 5 == 0) ? 1.f : 0.f;
     }
   };
+  using clk = std::chrono::steady_clock;
+  const clk::time_point t_start = clk::now();
+  std::vector<std::atomic<long long>> t_end(N);
+  for (auto& a : t_end) a.store(0);
+  auto timed_worker = [&](int g, qn_ctx* c) {
+    worker(g, c);
+    const long long ns = std::chrono::duration_cast<std::chrono::nanoseconds>(clk::now() - t_start).count();
+    long long prev = t_end[g].load(); while (prev < ns && !t_end[g].compare_exchange_weak(prev, ns)) {}
+  };
   std::vector<std::thread> th;
-  for (int g = 0; g < N; g++) for (int s = 0; s < m->in_flight; s++) th.emplace_back(worker, g, m->ctx[g][s]);
+  for (int g = 0; g < N; g++) for (int s = 0; s < m->in_flight; s++) th.emplace_back(timed_worker, g, m->ctx[g][s]);
   for (auto& t : th) t.join();
+  m->gpu_ms.assign(N, 0.0);
+  for (int g = 0; g < N; g++) m->gpu_ms[g] = 1e-6 * (double)t_end[g].load();
+  const clk::time_point t_gather = clk::now();
   // ---- the one exchange step: gather the record tables (N x per x 96 bytes: latency-bound, ring or tree does not matter at this size)
+  // A failure after the first asynchronous operation must not return while copies out of `mine` (pageable host memory) may still be staging:
+  // every per-GPU stream is drained first.  A failed collective leaves the communicator in an undefined state: the handle is poisoned.
+  auto bail = [&](const std::string& why, bool poison) {
+    for (int g = 0; g < N; g++) { if (hipSetDevice(m->dev[g]) == hipSuccess) (void)hipStreamSynchronize(m->stream[g]); }
+    m->last_error = why; if (poison) m->poisoned = true;
+    return QN_ERR_HIP;
+  };
   for (int g = 0; g < N; g++) {
-    if (hipSetDevice(m->dev[g]) != hipSuccess || hipMemcpyAsync(m->d_send[g], mine[g].data(), sizeof(qn_pair_record) * per, hipMemcpyHostToDevice, m->stream[g]) != hipSuccess) { m->last_error = "upload of the record table failed"; return QN_ERR_HIP; }
+    if (hipSetDevice(m->dev[g]) != hipSuccess || hipMemcpyAsync(m->d_send[g], mine[g].data(), sizeof(qn_pair_record) * per, hipMemcpyHostToDevice, m->stream[g]) != hipSuccess) return bail("upload of the record table failed", false);
   }
   ncclResult_t nr = m->p_group_start();
   for (int g = 0; g < N && nr == ncclSuccess; g++) nr = m->p_all_gather(m->d_send[g], m->d_recv[g], sizeof(qn_pair_record) * per, ncclChar, m->comm[g], m->stream[g]);
   const ncclResult_t ne = m->p_group_end();
   if (nr == ncclSuccess) nr = ne;
-  if (nr != ncclSuccess) { m->last_error = std::string("ncclAllGather: ") + m->p_err(nr); return QN_ERR_HIP; }
-  if (hipSetDevice(m->dev[0]) != hipSuccess || hipMemcpyAsync(m->h_all, m->d_recv[0], sizeof(qn_pair_record) * per * N, hipMemcpyDeviceToHost, m->stream[0]) != hipSuccess) { m->last_error = "download of the gathered table failed"; return QN_ERR_HIP; }
-  for (int g = 0; g < N; g++) { if (hipSetDevice(m->dev[g]) != hipSuccess || hipStreamSynchronize(m->stream[g]) != hipSuccess) { m->last_error = "stream synchronisation after the gather failed"; return QN_ERR_HIP; } }
+  if (nr != ncclSuccess) return bail(std::string("ncclAllGather: ") + m->p_err(nr) + " (the communicator is unusable: destroy this qn_multi)", true);
+  if (hipSetDevice(m->dev[0]) != hipSuccess || hipMemcpyAsync(m->h_all, m->d_recv[0], sizeof(qn_pair_record) * per * N, hipMemcpyDeviceToHost, m->stream[0]) != hipSuccess) return bail("download of the gathered table failed", false);
+  for (int g = 0; g < N; g++) { if (hipSetDevice(m->dev[g]) != hipSuccess || hipStreamSynchronize(m->stream[g]) != hipSuccess) return bail("stream synchronisation after the gather failed", true); }
+  m->gather_ms = 1e-6 * (double)std::chrono::duration_cast<std::chrono::nanoseconds>(clk::now() - t_gather).count();
   // ---- the winner, from the GATHERED table (what rank 0 sees after the collective)
   int status = QN_OK;
   for (uint32_t e = 0; e < per * (uint32_t)N; e++) {

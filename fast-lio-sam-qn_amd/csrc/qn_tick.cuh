@@ -98,11 +98,17 @@ __device__ __forceinline__ void emit_point(const bool have, const bool lin, cons
   double m[3];
 #pragma unroll
   for (int a = 0; a < 3; a++) m[a] = Rx[a][0] * na[0] + Rx[a][1] * na[1] + Rx[a][2] * na[2];
+  // R C_A R^T = R R^T - 0.999 m m^T.  R R^T is I to rounding for every pose the optimiser builds from the identity guess of
+  // loop_closure.cpp:124, but NOT for a caller's f32 guess with a rotation (pcl::Registration::align(output, guess)): its rows are
+  // orthonormal to 6e-8 only, the reference multiplies with the matrix as it is, and the difference is 1e-7 of the cost.
   M3 rcr;
 #pragma unroll
   for (int a = 0; a < 3; a++)
 #pragma unroll
-    for (int b = 0; b < 3; b++) rcr.m[a][b] = ((a == b ? 1.0 : 0.0) - 0.999 * nb[a] * nb[b]) + ((a == b ? 1.0 : 0.0) - 0.999 * m[a] * m[b]);
+    for (int b = 0; b < 3; b++) {
+      const double g = Rx[a][0] * Rx[b][0] + Rx[a][1] * Rx[b][1] + Rx[a][2] * Rx[b][2];
+      rcr.m[a][b] = ((a == b ? 1.0 : 0.0) - 0.999 * nb[a] * nb[b]) + (g - 0.999 * m[a] * m[b]);
+    }
   const M3 M = m3_inverse(rcr);
   const double mA[3] = {(double)pa.x, (double)pa.y, (double)pa.z};
   double tA[3], e[3], Me[3];

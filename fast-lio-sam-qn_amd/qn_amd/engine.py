@@ -43,6 +43,7 @@ class EngineError(RuntimeError):
 
 
 _lib = None
+DEBUG_KNOBS_FROM_ENV = False     # harness opt-in for the QN_DEBUG_KNOBS environment variable (Context.__init__)
 
 
 def lib():
@@ -75,11 +76,18 @@ class Context:
             raise EngineError(st, self._l.qn_status_str(st).decode())
         self.h = h
         self.max_points = max_points
-        knobs = os.environ.get("QN_DEBUG_KNOBS")        # developer tuning (qn_debug_set) for every context of the process: a whole test file can run under a knob
+        # developer tuning (qn_debug_set) for every context of the process - a whole test file or bench run under a knob.  Opt-in only:
+        # a harness sets engine.DEBUG_KNOBS_FROM_ENV = True (tests/conftest.py, bench.py, tools/); a production host never reads the variable.
+        knobs = os.environ.get("QN_DEBUG_KNOBS") if DEBUG_KNOBS_FROM_ENV else None
         if knobs:
-            import json
-            for k, v in json.loads(knobs).items():
-                self.debug_set(k, float(v))
+            import json, sys
+            try:
+                for k, v in json.loads(knobs).items():
+                    self.debug_set(k, float(v))
+            except Exception:
+                self.close()
+                raise
+            print("qn_amd: QN_DEBUG_KNOBS applied to a context: %s" % knobs, file=sys.stderr)
 
     def close(self):
         if getattr(self, "h", None):
@@ -154,6 +162,10 @@ class NanoGICP:
 
     def _push(self):
         self.ctx.check(self._l.qn_gicp_set_params(self.ctx.h, C.byref(self.p)))
+
+    def bind(self):
+        """Make this object's parameters the context's again (several NanoGICP objects may share one context; the context holds ONE set)."""
+        self._push()
 
     # --- the 8 setters of loop_closure.cpp:9-16
     def setNumThreads(self, n):                      # CPU thread count: meaningless on the GPU, accepted
@@ -285,15 +297,36 @@ class NanoGICP:
         return e.value
 
 
+class _ParamsScope:
+    """The helpers below register at the reference's effective config on a context the caller handed in: the context's own NanoGICP
+    parameters are read first (qn_gicp_get_params) and put back afterwards, so a caller's configured object keeps working."""
+
+    def __init__(self, ctx):
+        self.ctx = ctx; self.saved = GicpParams()
+        ctx.check(ctx._l.qn_gicp_get_params(ctx.h, C.byref(self.saved)))
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.ctx.check(self.ctx._l.qn_gicp_set_params(self.ctx.h, C.byref(self.saved)))
+        return False
+
+
+def _reference_gicp(ctx, k, max_iter, max_corr_dist, trans_eps):
+    p = GicpParams(); ctx._l.qn_gicp_default_params(C.byref(p))
+    p.k_correspondences, p.max_iterations, p.max_corr_dist, p.transformation_epsilon = k, max_iter, max_corr_dist, trans_eps
+    ctx.check(ctx._l.qn_gicp_set_params(ctx.h, C.byref(p)))
+
+
 def icp_alignment(ctx, src, dst, *, k=15, max_iter=32, max_corr_dist=52.5, trans_eps=0.01, score_thr=1.5):
     """LoopClosure::icpAlignment (loop_closure.cpp:110-136) at the reference's effective config."""
-    g = NanoGICP(ctx)
-    g.setCorrespondenceRandomness(k); g.setMaximumIterations(max_iter)
-    g.setMaxCorrespondenceDistance(max_corr_dist); g.setTransformationEpsilon(trans_eps)
     a, ns, stride = _cloud_arg(src); b, nt, _ = _cloud_arg(dst)
     res = GicpResult(); valid = C.c_int()
-    st = ctx._l.qn_icp_alignment(ctx.h, _p(a), C.c_uint32(ns), _p(b), C.c_uint32(nt), C.c_uint32(stride),
-                                 C.c_double(score_thr), C.byref(res), C.byref(valid))
+    with _ParamsScope(ctx):
+        _reference_gicp(ctx, k, max_iter, max_corr_dist, trans_eps)
+        st = ctx._l.qn_icp_alignment(ctx.h, _p(a), C.c_uint32(ns), _p(b), C.c_uint32(nt), C.c_uint32(stride),
+                                     C.c_double(score_thr), C.byref(res), C.byref(valid))
     if st == QN_ERR_EMPTY_CLOUD:
         return dict(valid=False, converged=False, score=1.7976931348623157e308, T=np.eye(4), iterations=0)
     ctx.check(st)
@@ -393,13 +426,12 @@ def quatro_solve(src, dst, corres, params=None):
 def coarse_to_fine_alignment(ctx, src, dst, *, quatro=None, k=15, max_iter=32, max_corr_dist=52.5, trans_eps=0.01, score_thr=1.5):
     """LoopClosure::coarseToFineAlignment (loop_closure.cpp:138-159) at the reference's effective config."""
     quatro = quatro or Quatro(ctx)
-    g = NanoGICP(ctx)
-    g.setCorrespondenceRandomness(k); g.setMaximumIterations(max_iter)
-    g.setMaxCorrespondenceDistance(max_corr_dist); g.setTransformationEpsilon(trans_eps)
     a, ns, stride = _cloud_arg(src); b, nt, _ = _cloud_arg(dst)
     res = GicpResult(); valid = C.c_int(); T = np.zeros((4, 4)); Tq = np.zeros((4, 4))
-    st = ctx._l.qn_coarse_to_fine_alignment(ctx.h, _p(a), C.c_uint32(ns), _p(b), C.c_uint32(nt), C.c_uint32(stride), C.c_double(score_thr),
-                                            C.byref(res), _p(T), _p(Tq), C.byref(valid))
+    with _ParamsScope(ctx):
+        _reference_gicp(ctx, k, max_iter, max_corr_dist, trans_eps)
+        st = ctx._l.qn_coarse_to_fine_alignment(ctx.h, _p(a), C.c_uint32(ns), _p(b), C.c_uint32(nt), C.c_uint32(stride), C.c_double(score_thr),
+                                                C.byref(res), _p(T), _p(Tq), C.byref(valid))
     if st == QN_ERR_EMPTY_CLOUD:
         return dict(valid=False, converged=False, score=1.7976931348623157e308, T=np.eye(4), T_quatro=np.eye(4))
     ctx.check(st)
@@ -409,12 +441,11 @@ def coarse_to_fine_alignment(ctx, src, dst, *, quatro=None, k=15, max_iter=32, m
 def coarse_to_fine_alignment_device(ctx, src_ptr, ns, dst_ptr, nt, stride, *, quatro=None, k=15, max_iter=32, max_corr_dist=52.5, trans_eps=0.01, score_thr=1.5):
     """qn_coarse_to_fine_alignment_device: the same with both clouds resident on the GPU (e.g. KeyframeStore.assemble outputs)."""
     quatro = quatro or Quatro(ctx)
-    g = NanoGICP(ctx)
-    g.setCorrespondenceRandomness(k); g.setMaximumIterations(max_iter)
-    g.setMaxCorrespondenceDistance(max_corr_dist); g.setTransformationEpsilon(trans_eps)
     res = GicpResult(); valid = C.c_int(); T = np.zeros((4, 4)); Tq = np.zeros((4, 4))
-    ctx.check(ctx._l.qn_coarse_to_fine_alignment_device(ctx.h, C.c_void_p(src_ptr), C.c_uint32(ns), C.c_void_p(dst_ptr), C.c_uint32(nt), C.c_uint32(stride),
-                                                       C.c_double(score_thr), C.byref(res), _p(T), _p(Tq), C.byref(valid)))
+    with _ParamsScope(ctx):
+        _reference_gicp(ctx, k, max_iter, max_corr_dist, trans_eps)
+        ctx.check(ctx._l.qn_coarse_to_fine_alignment_device(ctx.h, C.c_void_p(src_ptr), C.c_uint32(ns), C.c_void_p(dst_ptr), C.c_uint32(nt), C.c_uint32(stride),
+                                                           C.c_double(score_thr), C.byref(res), _p(T), _p(Tq), C.byref(valid)))
     return dict(valid=bool(valid.value), converged=bool(res.converged), score=res.fitness, T=T, T_quatro=Tq, iterations=res.iterations)
 
 
@@ -477,6 +508,15 @@ class MultiGpu:
 
     def set_params(self, p):
         self._check(self._l.qn_multi_set_params(self.h, C.byref(p)))
+
+    def timing(self):
+        """(per-GPU ms [n_gpus], gather ms) of the latest align_best"""
+        per = (C.c_double * self.n_gpus)(); gms = C.c_double()
+        self._check(self._l.qn_multi_get_timing(self.h, per, C.byref(gms)))
+        return list(per), gms.value
+
+    def gpu_count(self):
+        return int(self._l.qn_multi_gpu_count(self.h))
 
     def align_best(self, pairs, score_thr=1.5):
         """pairs as for icp_alignment_batch.  -> (records[n], best or None)"""

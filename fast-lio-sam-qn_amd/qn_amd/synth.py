@@ -182,6 +182,26 @@ def make_pair(pair_id, n_src, n_tgt=None, *, extent=120.0, leaf=0.3, sigma=0.02,
     return src, tgt, T
 
 
+def lever_arm_pair(seed, n=3000, offset=300.0, rot_sigma=0.1, scene=True, noise=0.05):
+    """A small pair 300 m from the origin with a wrong initial rotation: the lever arm makes the cost strongly non-quadratic in the
+    rotation, so Levenberg-Marquardt REJECTS trial steps (inner tries 2..9) - pairs near the origin never do.  scene = True: a street-scene
+    pair (surface points: well-conditioned plane normals); False: uniform points in a cube (near-isotropic neighbourhoods: the plane normal
+    of A.1.3 is ill-conditioned there, see SURVEY App. B-4 - for probing, not for strict parity).  -> (src, tgt, guess[4,4] f64)"""
+    rng = np.random.Generator(np.random.PCG64(77000 + int(seed)))
+    if scene:
+        src, tgt, _ = make_pair(600 + int(seed), n, extent=30.0)
+        off = np.array([offset, 0.0, 0.0])
+        src = (src.astype(np.float64) + off).astype(np.float32); tgt = (tgt.astype(np.float64) + off).astype(np.float32)
+    w = rng.normal(0, rot_sigma, 3); th = np.linalg.norm(w)
+    K = np.array([[0, -w[2], w[1]], [w[2], 0, -w[0]], [-w[1], w[0], 0]])
+    R = np.eye(3) + np.sin(th) / th * K + (1 - np.cos(th)) / th ** 2 * K @ K
+    if not scene:
+        src = (rng.uniform(-3, 3, (n, 3)) + [offset, 0, 0]).astype(np.float32)
+        tgt = (src + rng.normal(0, noise, (n, 3))).astype(np.float32)
+    guess = np.eye(4); guess[:3, :3] = R; guess[:3, 3] = rng.uniform(-1, 1, 3)
+    return src, tgt, guess
+
+
 def pose_error(T_a, T_b):
     """(translation error [m], rotation error [rad]) between two 4x4 transforms."""
     D = np.linalg.inv(T_a) @ T_b

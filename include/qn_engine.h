@@ -96,12 +96,16 @@ int  qn_ctx_create(int device, uint32_t max_points, qn_ctx** out);
 void qn_ctx_destroy(qn_ctx* ctx);
 const char* qn_status_str(int status);
 const char* qn_last_error(const qn_ctx* ctx);
-void* qn_ctx_stream(qn_ctx* ctx);                   /* the hipStream_t every kernel of this ctx is launched on */
+/* The context's primary hipStream_t.  NOT an ordering guarantee for inputs: the engine also works on a private second stream (the target
+ * cloud of a pair is prepared there while the source's k-NN runs), so device buffers handed to a *_device entry point must be COMPLETE
+ * before the call (synchronise the producer, or make it wait on an event of yours); outputs are complete when the call returns.     */
+void* qn_ctx_stream(qn_ctx* ctx);
 int  qn_ctx_synchronize(qn_ctx* ctx);
 
 /* ---- Nano-GICP ------------------------------------------------------------------------ */
 void qn_gicp_default_params(qn_gicp_params* p);                       /* NanoGICP()/LsqRegistration() ctor defaults */
 int  qn_gicp_set_params(qn_ctx*, const qn_gicp_params*);              /* loop_closure.cpp:9-16  */
+int  qn_gicp_get_params(const qn_ctx*, qn_gicp_params* out);          /* what the setters above last stored (the getters of pcl::Registration / NanoGICP) */
 int  qn_gicp_set_source(qn_ctx*, const float* xyz, uint32_t n, uint32_t stride_bytes);          /* setInputSource, loop_closure.cpp:120 */
 int  qn_gicp_set_target(qn_ctx*, const float* xyz, uint32_t n, uint32_t stride_bytes);          /* setInputTarget, loop_closure.cpp:122 */
 int  qn_gicp_set_source_device(qn_ctx*, const float* d_xyz, uint32_t n, uint32_t stride_bytes);
@@ -159,6 +163,8 @@ void qn_multi_destroy(qn_multi*);
 const char* qn_multi_last_error(const qn_multi*);    /* NULL argument: why the last qn_multi_init on this thread failed */
 int  qn_multi_gpu_count(const qn_multi*);
 int  qn_multi_set_params(qn_multi*, const qn_gicp_params*);            /* loop_closure.cpp:9-16, on every context */
+/* host wall clock of the latest qn_multi_align_best: per GPU from the call's start to its last pair's end [n_gpus], and the gather step */
+int  qn_multi_get_timing(const qn_multi*, double* per_gpu_ms, double* gather_ms);
 /* pairs[i].src/dst: host buffers, or (on_device) buffers resident on GPU device_ids[i mod n_gpus].  records (optional, n_pairs
  * entries) receives every pair's record as rank 0 holds them after the gather; *best / *best_found the winning loop.             */
 int  qn_multi_align_best(qn_multi*, const qn_pair_desc* pairs, uint32_t n_pairs, double score_thr,

@@ -13,6 +13,11 @@ def pytest_configure(config):
     # serves the whole process, and torch only finds its GPUs on its own copy - so the tests that hand torch-allocated device
     # buffers to the engine need torch's runtime up BEFORE the engine library is opened.  (bench.py does the same by construction.)
     try:
+        from qn_amd import engine
+        engine.DEBUG_KNOBS_FROM_ENV = True       # harness opt-in: a whole test run under QN_DEBUG_KNOBS (tools/gpu_ab.sh)
+    except Exception:
+        pass
+    try:
         import torch
         if torch.cuda.is_available():
             torch.cuda.init()

@@ -162,6 +162,7 @@ def test_candidates_of_one_query_share_the_prepared_source():
         assert r.fitness == e["score"] and np.array_equal(np.array(r.T, dtype=np.float32).reshape(4, 4).astype(np.float64), e["T"])
     # and the entry point itself: NOT_READY without a prepared source, same answer with one
     c2 = engine.Context(8192)
+    g2 = engine.NanoGICP(c2); g2.p = gg; g2.bind()                # the context's own parameters = the reference's (the helper below restores what it finds)
     res = engine.GicpResult(); valid = C.c_int()
     st = c2._l.qn_icp_alignment_same_source(c2.h, engine._p(tgts[0]), C.c_uint32(len(tgts[0])), C.c_uint32(12), C.c_int(0), C.c_double(1.5), C.byref(res), C.byref(valid))
     assert st == engine.QN_ERR_NOT_READY
