@@ -134,6 +134,15 @@ extern "C" int qn_ctx_create(int device, uint32_t max_points, qn_ctx** out) {
   CA(hipMalloc(&c->knn_idx2, sizeof(int32_t) * (size_t)max_points * 32));
   CA(hipMalloc(&c->bbox2, sizeof(BBoxOut)));
   CA(hipHostMalloc(&c->bbox_host2, sizeof(BBoxOut), hipHostMallocDefault));
+  CA(hipMalloc(&c->pg_rows, sizeof(unsigned long long) * 3 * QN_PERSIST_ROWS * QN_PERSIST_RSTRIDE));
+  CA(hipMalloc(&c->pg_bc, sizeof(unsigned long long) * 64));
+  CA(hipMalloc(&c->pg_fit, sizeof(unsigned long long) * (QN_PERSIST_MAX_BLOCKS + 1) * 4));
+  CA(hipMalloc(&c->pg_status, 4 * sizeof(uint32_t)));
+  CA(hipHostMalloc(&c->pg_status_host, 4 * sizeof(uint32_t), hipHostMallocDefault));
+  CA(hipMemsetAsync(c->pg_rows, 0xFF, sizeof(unsigned long long) * 3 * QN_PERSIST_ROWS * QN_PERSIST_RSTRIDE, c->stream));      // every slot = QN_PERSIST_SENTINEL
+  CA(hipMemsetAsync(c->pg_bc, 0, sizeof(unsigned long long) * 64, c->stream));
+  CA(hipMemsetAsync(c->pg_fit, 0, sizeof(unsigned long long) * (QN_PERSIST_MAX_BLOCKS + 1) * 4, c->stream));
+  CA(hipMemsetAsync(c->pg_status, 0, 4 * sizeof(uint32_t), c->stream));
   CA(hipMemsetAsync(c->state, 0, 2 * sizeof(GicpState), c->stream));
   CA(hipStreamSynchronize(c->stream));
 #undef CA
@@ -159,6 +168,7 @@ extern "C" void qn_ctx_destroy(qn_ctx* c) {
   if (c->result_host) hipHostFree(c->result_host);
   if (c->bbox_host) hipHostFree(c->bbox_host);
   if (c->scalar_host) hipHostFree(c->scalar_host);
+  hipFree(c->pg_clk); hipFree(c->pg_rows); hipFree(c->pg_bc); hipFree(c->pg_fit); hipFree(c->pg_status); if (c->pg_status_host) hipHostFree(c->pg_status_host);
   hipFree(c->scan_sums2); hipFree(c->fb_list2); hipFree(c->big_list2); hipFree(c->fb_count2b); hipFree(c->knn_idx2); hipFree(c->bbox2); if (c->bbox_host2) hipHostFree(c->bbox_host2);
   if (c->ev_pair) hipEventDestroy(c->ev_pair);
   if (c->stream2) { hipStreamSynchronize(c->stream2); hipStreamDestroy(c->stream2); }
@@ -454,9 +464,10 @@ static void enqueue_tick_fused(qn_ctx* c) {
   TickArgs a = tick_args(c);
   { ProfScope ps(c, QN_K_GN_TICK_FUSED);
     const dim3 gr(tick_blocks(c)), bl(c->tick_tb);
-#define QN_TICK_LAUNCH(TB, OCC) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_tick<TB, OCC, 0>), gr, bl, 0, c->stream, a)
-    if (c->tick_tb == 256) { if (c->tick_occ >= 4) QN_TICK_LAUNCH(256, 4); else if (c->tick_occ == 3) QN_TICK_LAUNCH(256, 3); else QN_TICK_LAUNCH(256, 2); }
-    else { if (c->tick_occ >= 4) QN_TICK_LAUNCH(512, 4); else if (c->tick_occ == 3) QN_TICK_LAUNCH(512, 3); else QN_TICK_LAUNCH(512, 2); }
+#define QN_TICK_LAUNCH(TB, OCC, PR) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_tick<TB, OCC, 0, PR>), gr, bl, 0, c->stream, a)
+    if (a.clk) { if (c->tick_tb == 256) QN_TICK_LAUNCH(256, 4, true); else QN_TICK_LAUNCH(512, 4, true); }      // developer probe variant
+    else if (c->tick_tb == 256) { if (c->tick_occ >= 4) QN_TICK_LAUNCH(256, 4, false); else if (c->tick_occ == 3) QN_TICK_LAUNCH(256, 3, false); else QN_TICK_LAUNCH(256, 2, false); }
+    else { if (c->tick_occ >= 4) QN_TICK_LAUNCH(512, 4, false); else if (c->tick_occ == 3) QN_TICK_LAUNCH(512, 3, false); else QN_TICK_LAUNCH(512, 2, false); }
 #undef QN_TICK_LAUNCH
   }
   c->gen++; c->part_rows = (int)tick_blocks(c);
@@ -489,8 +500,8 @@ static void enqueue_epilogue(qn_ctx* c, double max_range, bool tracked) {
     TickArgs a = tick_args(c);
     { ProfScope ps(c, QN_K_FITNESS);
       const dim3 gr(tick_blocks(c)), bl(c->tick_tb);
-      if (c->tick_tb == 256) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_tick<256, 4, 1>), gr, bl, 0, c->stream, a);
-      else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_tick<512, 4, 1>), gr, bl, 0, c->stream, a); }
+      if (c->tick_tb == 256) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_tick<256, 4, 1, false>), gr, bl, 0, c->stream, a);
+      else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_tick<512, 4, 1, false>), gr, bl, 0, c->stream, a); }
     c->gen++; c->part_rows = 0;
     hipLaunchKernelGGL(k_finalize_fit, dim3(1), dim3(64), 0, c->stream, st_cur(c), c->result_host, c->far_stats, c->fit_psum, c->fit_pcnt, (int)tick_blocks(c));
     return;
@@ -506,13 +517,55 @@ static void enqueue_epilogue(qn_ctx* c, double max_range, bool tracked) {
   hipLaunchKernelGGL(k_finalize, dim3(1), dim3(64), 0, c->stream, st, c->result_host, c->far_stats);
 }
 
+// ---- the tracked regime as ONE persistent launch (qn_persist.cuh).  Only for the registration the reference runs - one pair at a time, nothing else on
+// the GPU: every block must be resident at once (nblk + 1 <= 241 blocks of 512 threads on 256 CUs), so contexts that work in a batch, concurrent aligns of
+// other contexts, the profiling / verification / probe modes and the far-query refresh regime (k_far between the ticks) keep the k_tick chain.
+static std::atomic<int> g_aligns_in_flight{0};
+static uint32_t persist_ppt(const qn_ctx* c) { const uint32_t cap = QN_PERSIST_TB * QN_PERSIST_MAX_BLOCKS; return (c->cloud[0].n + cap - 1) / cap; }
+static bool persist_usable(const qn_ctx* c, bool alone) {
+  return c->persist && !c->persist_batch_off && alone && c->fused_ticks && c->fused_final && !c->prof_on && !c->verify_track && !c->clk_probe && c->tick_tb == QN_PERSIST_TB &&
+         (!c->far_enabled || c->far_mode == 2) && c->pg_rows != nullptr;
+}
+static int launch_persist(qn_ctx* c, uint32_t max_ticks) {
+  PersistArgs A;
+  A.t = tick_args(c);
+  A.t.ppt = persist_ppt(c); A.t.clk = nullptr; A.t.clk_blk = nullptr;
+  A.t.far_mode = c->far_enabled ? 2 : 0;
+  const uint32_t per = QN_PERSIST_TB * A.t.ppt;
+  A.nblk = (c->cloud[0].n + per - 1) / per;
+  if (c->pg_epoch > 0xF0000000u) {                                   // epochs must never repeat within the life of the granule buffers
+    HIPCHK(c, hipMemsetAsync(c->pg_bc, 0, sizeof(unsigned long long) * 64, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->pg_fit, 0, sizeof(unsigned long long) * (QN_PERSIST_MAX_BLOCKS + 1) * 4, c->stream));
+    c->pg_epoch = 0;
+  }
+  A.rows_g = c->pg_rows; A.bc_g = c->pg_bc; A.fit_g = c->pg_fit; A.status = c->pg_status; A.result = c->result_host;
+  A.epoch0 = c->pg_epoch; A.max_ticks = max_ticks; c->pg_epoch += max_ticks + 8;
+  A.timeout = 25000000ull;                                           // 0.25 s of the 100 MHz wall clock: three orders of magnitude above any legitimate wait
+  HIPCHK(c, hipMemsetAsync(c->pg_status, 0, 4 * sizeof(uint32_t), c->stream));
+  { ProfScope ps(c, QN_K_GN_TICK_FUSED);
+    A.clk = c->pg_clk;
+    if (c->pg_clk) { (void)hipMemsetAsync(c->pg_clk, 0, 8 * (64 * 16 + 16), c->stream); for (int g = 0; g < 64; g++) (void)hipMemsetAsync(c->pg_clk + 16 * g + 12, 0xff, 8, c->stream); }
+    if (c->pg_clk) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_align_persist<QN_PERSIST_TB, true>), dim3(A.nblk + 1), dim3(QN_PERSIST_TB), 0, c->stream, A);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_align_persist<QN_PERSIST_TB, false>), dim3(A.nblk + 1), dim3(QN_PERSIST_TB), 0, c->stream, A); }
+  HIPCHK(c, hipMemcpyAsync(c->pg_status_host, c->pg_status, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+  c->gen++; c->part_rows = 0; c->persist_launches++;
+  return QN_OK;
+}
+
 static int ready(qn_ctx* c) {
   if (!c) return QN_ERR_INVALID_ARG;
   for (int w = 0; w < 2; w++) { if (c->cloud[w].n == 0) return QN_ERR_EMPTY_CLOUD; if (!c->cloud[w].has_grid || !c->cloud[w].has_cov) return QN_ERR_NOT_READY; }
   return QN_OK;
 }
 
+static int gicp_align(qn_ctx* c, const float guess[16], qn_gicp_result* out, bool alone);
 extern "C" int qn_gicp_align(qn_ctx* c, const float guess[16], qn_gicp_result* out) {
+  const bool alone = g_aligns_in_flight.fetch_add(1) == 0;           // (a heuristic for the persistent launch only: correctness never depends on it)
+  const int rc = gicp_align(c, guess, out, alone);
+  g_aligns_in_flight.fetch_sub(1);
+  return rc;
+}
+static int gicp_align(qn_ctx* c, const float guess[16], qn_gicp_result* out, bool alone) {
   if (c && join_target(c) != QN_OK) return QN_ERR_HIP;
   int rc = ready(c); if (rc != QN_OK) return rc;
   if (!out) return QN_ERR_INVALID_ARG;
@@ -563,8 +616,19 @@ extern "C" int qn_gicp_align(qn_ctx* c, const float guess[16], qn_gicp_result* o
     }
     if (!exact_ticks) chunk = first_chunk ? c->ticks_per_chunk : std::max(2 * per_outer, c->ticks_per_chunk / 2);   // convergence is usually near after the first chunks: ticks past it are wasted launches
     else chunk = first_chunk && c->far_mode == 1 ? std::min(ticks_left, c->ticks_per_chunk) : ticks_left;
-    first_chunk = false;
     if (budget <= 0) { c->last_error = "align: device state machine did not terminate"; return QN_ERR_HIP; }
+    if (first_chunk && tick_no > 0 && persist_usable(c, alone)) {          // everything that is left - ticks, closing pass, result - in ONE persistent launch
+      if ((rc = launch_persist(c, (uint32_t)budget + 2u)) != QN_OK) return rc;
+      HIPCHK(c, hipGetLastError());
+      HIPCHK(c, hipStreamSynchronize(s));
+      if (c->result_host->phase != 2) {
+        (void)hipMemsetAsync(c->pg_rows, 0xFF, sizeof(unsigned long long) * 3 * QN_PERSIST_ROWS * QN_PERSIST_RSTRIDE, s); (void)hipStreamSynchronize(s);      // a launch that gave up leaves its row buffers in an unknown state
+        char buf[160]; snprintf(buf, sizeof(buf), "align: the persistent kernel gave up (code %u after %u ticks: 1 rows, 2 tick budget, 3 closing sums, 4 pose)", c->pg_status_host[0], c->pg_status_host[1]);
+        c->last_error = buf; return QN_ERR_HIP;
+      }
+      break;
+    }
+    first_chunk = false;
   }
   c->prof_collect();
   *out = c->result_host->r;
@@ -653,7 +717,8 @@ extern "C" int qn_icp_alignment_batch(qn_ctx* const* ctxs, uint32_t n_ctx, const
   // several registrations in flight already fill the chip: the two-stream pair pipeline of a single registration (icp_alignment) would only
   // add streams to the hardware queues (measured: 2290 -> 1880 registrations/s with 4 contexts), so it is switched off for the batch
   std::vector<char> saved(n_ctx);
-  for (uint32_t i = 0; i < n_ctx; i++) { saved[i] = ctxs[i]->pair_pipeline; if (n_ctx > 1) ctxs[i]->pair_pipeline = false; }
+  std::vector<char> saved_p(n_ctx);
+  for (uint32_t i = 0; i < n_ctx; i++) { saved[i] = ctxs[i]->pair_pipeline; saved_p[i] = ctxs[i]->persist_batch_off; if (n_ctx > 1) { ctxs[i]->pair_pipeline = false; ctxs[i]->persist_batch_off = true; } }
   auto worker = [&](qn_ctx* c) {
     for (;;) {
       const uint32_t i = next.fetch_add(1);
@@ -666,7 +731,7 @@ extern "C" int qn_icp_alignment_batch(qn_ctx* const* ctxs, uint32_t n_ctx, const
   for (uint32_t i = 1; i < n_ctx; i++) th.emplace_back(worker, ctxs[i]);
   worker(ctxs[0]);
   for (auto& t : th) t.join();
-  for (uint32_t i = 0; i < n_ctx; i++) ctxs[i]->pair_pipeline = saved[i] != 0;
+  for (uint32_t i = 0; i < n_ctx; i++) { ctxs[i]->pair_pipeline = saved[i] != 0; ctxs[i]->persist_batch_off = saved_p[i] != 0; }
   return QN_OK;
 }
 
@@ -773,6 +838,13 @@ extern "C" int qn_debug_set(qn_ctx* c, const char* key, double v) {
   else if (k == "knn_single_all") c->knn_single_all = v != 0;
   else if (k == "bbox_blocks") c->bbox_blocks = std::max(1, (int)v);
   else if (k == "pair_pipeline") c->pair_pipeline = v != 0;
+  else if (k == "persist") c->persist = v != 0;
+  else if (k == "persist_probe") {                              // developer probe: wall-clock stamps inside k_align_persist (qn_debug_get_persist_clk)
+    if (v != 0 && !c->pg_clk) { if (hipMalloc(&c->pg_clk, 8 * (64 * 16 + 16)) != hipSuccess) return QN_ERR_HIP; }
+    if (c->pg_clk) (void)hipMemset(c->pg_clk, 0, 8 * (64 * 16 + 16));
+    if (v == 0) { (void)hipFree(c->pg_clk); c->pg_clk = nullptr; }
+  }
+  else if (k == "batch_member") c->persist_batch_off = v != 0;      // this context registers beside others (qn_multi with in_flight > 1): no persistent launches
   else if (k == "stable_cells") c->stable_cells = v != 0;
   else if (k == "knn_hist") c->knn_hist = v != 0;
   else if (k == "nn_rounds") c->nn_rounds = v < 1 ? 1 : (int)v;
@@ -842,6 +914,7 @@ extern "C" int qn_debug_get(qn_ctx* c, const char* key, double* value) {
   if (k == "quatro_wall_features_ms") { *value = c->q_wall_ms[0]; return QN_OK; }   // host wall clock of the latest Quatro align, by section
   if (k == "quatro_wall_match_ms") { *value = c->q_wall_ms[1]; return QN_OK; }
   if (k == "quatro_wall_solve_ms") { *value = c->q_wall_ms[2]; return QN_OK; }
+  if (k == "persist_launches") { *value = c->persist_launches; return QN_OK; }      // aligns of this context that ran the persistent kernel
   if (k == "feat_fallbacks") { *value = c->feat_fallbacks; return QN_OK; }      // matrix-core feature searches repeated with the VALU kernel (survivor overflow)
   if (k == "feat_survivors") { *value = c->feat_survivors; return QN_OK; }      // survivors of the latest forward search (exactly re-evaluated pairs)
   return QN_ERR_INVALID_ARG;
@@ -850,6 +923,11 @@ extern "C" int qn_debug_get_clk(qn_ctx* c, unsigned long long* out /* 256 x 8, t
   if (!c || !out || !n || !c->clk_probe) return QN_ERR_INVALID_ARG;
   if (hipStreamSynchronize(c->stream) != hipSuccess || hipMemcpy(out, c->clk_probe, 8 * 8 * 256 + 8 * 12 * 1024, hipMemcpyDeviceToHost) != hipSuccess) return QN_ERR_HIP;
   *n = c->clk_n; return QN_OK;
+}
+extern "C" int qn_debug_get_persist_clk(qn_ctx* c, unsigned long long* out /* 64 x 16 + 16 */) {
+  if (!c || !out || !c->pg_clk) return QN_ERR_INVALID_ARG;
+  if (hipStreamSynchronize(c->stream) != hipSuccess || hipMemcpy(out, c->pg_clk, 8 * (64 * 16 + 16), hipMemcpyDeviceToHost) != hipSuccess) return QN_ERR_HIP;
+  return QN_OK;
 }
 extern "C" int qn_debug_get_partials(qn_ctx* c, double* out /* 2 x (QN_ACC_MAX_BLOCKS + 8) x 28 */, uint32_t* rows_per_buffer, double* state /* 2 x sizeof(GicpState) / 8 */) {
   if (!c || !out || !rows_per_buffer || !state) return QN_ERR_INVALID_ARG;

@@ -2,16 +2,22 @@
 // explicitly instantiated in separate translation units so that hipcc compiles them in parallel: qn_inst.hip is
 // compiled once per group with -DQN_INST_GROUP=<g>; everywhere else (QN_INST_GROUP undefined / 0) the same list
 // is a set of explicit-instantiation DECLARATIONS, so the host TU launches the kernels without compiling them.
-// Group 1 (this file): histogram k-NN, 1-NN searches, tracking, the optimiser tick (k_tick).  Groups 2-9: qn_instances_knn.h.
+// Group 1 (this file): histogram k-NN, 1-NN searches, tracking, the optimiser tick (k_tick).  Groups 2-9: qn_instances_knn.h.  Group 10: k_align_persist.
 #pragma once
 #include "qn_instances_knn.h"
 #include "qn_gicp_kernels.cuh"
 #include "qn_tick.cuh"
+#include "qn_persist.cuh"
 
 #if QN_INST_GROUP == 1
 #define QN_G1 template
 #else
 #define QN_G1 extern template
+#endif
+#if QN_INST_GROUP == 10        // the persistent align kernel (qn_persist.cuh): a unit of its own
+#define QN_G10 template
+#else
+#define QN_G10 extern template
 #endif
 
 namespace qn {
@@ -31,13 +37,17 @@ QN_G1 __global__ void k_nn_search<1, false, QN_NN_BLOCK> QN_NN_SEARCH_ARGS;
 QN_G1 __global__ void k_nn_search<1, true, QN_BLOCK> QN_NN_SEARCH_ARGS;
 QN_G1 __global__ void k_nn_track<0> QN_NN_TRACK_ARGS;
 QN_G1 __global__ void k_nn_track<1> QN_NN_TRACK_ARGS;
-QN_G1 __global__ void k_tick<256, 2, 0>(TickArgs);
-QN_G1 __global__ void k_tick<256, 3, 0>(TickArgs);
-QN_G1 __global__ void k_tick<256, 4, 0>(TickArgs);
-QN_G1 __global__ void k_tick<512, 2, 0>(TickArgs);
-QN_G1 __global__ void k_tick<512, 3, 0>(TickArgs);
-QN_G1 __global__ void k_tick<512, 4, 0>(TickArgs);
-QN_G1 __global__ void k_tick<256, 4, 1>(TickArgs);
-QN_G1 __global__ void k_tick<512, 4, 1>(TickArgs);
+QN_G1 __global__ void k_tick<256, 2, 0, false>(TickArgs);
+QN_G1 __global__ void k_tick<256, 3, 0, false>(TickArgs);
+QN_G1 __global__ void k_tick<256, 4, 0, false>(TickArgs);
+QN_G1 __global__ void k_tick<512, 2, 0, false>(TickArgs);
+QN_G1 __global__ void k_tick<512, 3, 0, false>(TickArgs);
+QN_G1 __global__ void k_tick<512, 4, 0, false>(TickArgs);
+QN_G1 __global__ void k_tick<256, 4, 1, false>(TickArgs);
+QN_G1 __global__ void k_tick<512, 4, 1, false>(TickArgs);
+QN_G1 __global__ void k_tick<256, 4, 0, true>(TickArgs);      // developer variants with device-clock stamps (knob clk_probe)
+QN_G1 __global__ void k_tick<512, 4, 0, true>(TickArgs);
+QN_G10 __global__ void k_align_persist<QN_PERSIST_TB, false>(PersistArgs);
+QN_G10 __global__ void k_align_persist<QN_PERSIST_TB, true>(PersistArgs);      // developer variant with wall-clock stamps (knob persist_probe)
 
 }  // namespace qn

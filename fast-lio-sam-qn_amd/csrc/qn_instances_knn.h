@@ -6,7 +6,7 @@
 #ifndef QN_INST_GROUP
 #define QN_INST_GROUP 0
 #endif
-#define QN_NUM_INST_GROUPS 9
+#define QN_NUM_INST_GROUPS 10
 
 #if QN_INST_GROUP == 2
 #define QN_G2 template

@@ -110,7 +110,7 @@ extern "C" int qn_multi_init(int n_gpus, const int* device_ids, uint32_t max_poi
       qn_ctx* c = nullptr;
       const int rc = qn_ctx_create(m->dev[g], max_points, &c);
       if (rc != QN_OK) return fail(rc, std::string("qn_multi_init: qn_ctx_create: ") + qn_status_str(rc));
-      if (in_flight > 1) (void)qn_debug_set(c, "pair_pipeline", 0.0);      // the streams in flight fill the chip; a second stream per registration only crowds the queues
+      if (in_flight > 1) { (void)qn_debug_set(c, "pair_pipeline", 0.0); (void)qn_debug_set(c, "batch_member", 1.0); }      // the streams in flight fill the chip: no second stream per registration, no persistent launches
       m->ctx[g].push_back(c);
     }
   }

@@ -154,15 +154,301 @@ __device__ __forceinline__ void emit_point(const bool have, const bool lin, cons
   fold7(g, 3, first, wbuf, wrow);
 }
 
+// All target points within R of q (one query per wave, ONE pass over the cap box of radius R - which covers ball(q, R) completely, so
+// every point that is NOT collected is farther than R): indices into list[], the smallest key and the runner-up's d2.  Returns the
+// number of points found (> cap: the list overflowed, the caller shrinks R).
+__device__ __forceinline__ uint32_t wave_ball_collect(const GridView& g, float qx, float qy, float qz, float R, WaveLds* ws, unsigned long long* __restrict__ wlist /* [QN_HCAP1], LDS */,
+                                                      uint32_t* __restrict__ wcnt /* LDS */, unsigned long long& best, float& second) {
+  const CapBox cb = cap_of(g, qx, qy, qz);
+  const float rx = cap_extent(g, cb, R, 0), ry = cap_extent(g, cb, R, 1), rz = cap_extent(g, cb, R, 2);
+  int x0 = rfl(cell_coord(qx - rx, g.ox, g.inv_cell, g.nx)), x1 = rfl(cell_coord(qx + rx, g.ox, g.inv_cell, g.nx));
+  int y0 = rfl(cell_coord(qy - ry, g.oy, g.inv_cell, g.ny)), y1 = rfl(cell_coord(qy + ry, g.oy, g.inv_cell, g.ny));
+  int z0 = rfl(cell_coord(qz - rz, g.oz, g.inv_cell, g.nz)), z1 = rfl(cell_coord(qz + rz, g.oz, g.inv_cell, g.nz));
+  const bool tile_mode = ((x1 >> 3) - (x0 >> 3) + 1) * (y1 - y0 + 1) * (z1 - z0 + 1) > 128;
+  if (tile_mode) {
+    x0 = (x0 >> 3) << 3; x1 = min(((x1 >> 3) << 3) + 7, g.nx - 1);
+    y0 = (y0 >> 2) << 2; y1 = min(((y1 >> 2) << 2) + 3, g.ny - 1);
+    z0 = (z0 >> 2) << 2; z1 = min(((z1 >> 2) << 2) + 3, g.nz - 1);
+  }
+  const int lane = threadIdx.x & 63;
+  wave_lds_fence();
+  if (lane == 0) *wcnt = 0;
+  wave_lds_fence();
+  const float R2 = R * R;
+  unsigned long long b = QN_INF_KEY; float s2 = __int_as_float(0x7f800000);
+  stream_box(g, x0, x1, y0, y1, z0, z1, tile_mode, ws, [&](const float4& p, bool valid, uint32_t) __attribute__((always_inline)) {
+    const float d2 = sqdist(qx, qy, qz, p.x, p.y, p.z);
+    if (valid && d2 <= R2) {
+      const unsigned long long k = pack_key(d2, __float_as_uint(p.w));
+      const uint32_t pos = atomicAdd(wcnt, 1u);
+      if (pos < QN_HCAP1) wlist[pos] = k;
+      if (k < b) { if (b != QN_INF_KEY) s2 = key_d2(b); b = k; } else if (d2 < s2) s2 = d2;
+    }
+  }, qx, qy, qz, tile_mode ? R2 * 1.000002f : -1.f);                    // (tiles outside the ball are not streamed: only points with d2 <= R2 are used)
+  wave_lds_fence();
+  const unsigned long long wb = wave_min_u64(b);
+  float c = (b == wb) ? s2 : key_d2(b);
+  if (b == QN_INF_KEY) c = __int_as_float(0x7f800000);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) c = fminf(c, __shfl_xor(c, o));
+  best = wb; second = c;
+  return *wcnt;
+}
+
+// Tracking state of one query beyond (j0, q_ref, bound): the RUNNER-UP.  Used by the persistent kernel only (TOP2), where it lives in registers.
+// A query whose runner-up is as close as its neighbour - two target points equidistant to 1e-5 m: a source point metres off the target's surface sees many -
+// fails the pruning inequality  d(q, p_j0) + delta < d_other  at EVERY tick however little it moves, and its block then spends 2-6 us per tick in a rescan or
+// a wave-level search while the other 195 blocks finish in 3.6: the tick ends with its slowest block (device-clock timeline, profiles/r3_*).  With the
+// runner-up j1 kept beside j0, d_other bounds everything ELSE (the third-nearest point, the unscanned region): the nearer of the two is exact whenever
+// min(d0, d1) + delta < d_other, ties by index as everywhere.  The results are the same neighbours (exact both ways), so the sums and the pose are the
+// same bits as the k_tick chain's.
+struct Top2 { int32_t j1; float4 p1; };                                // j1 = -1: none
+
+// One source point of a tick (the body of k_tick's loop; also the body of the persistent align kernel, qn_persist.cuh).
+//   lin = false   LM trial error: the cached correspondence rec0 at the trial pose xi, gate as at the linearisation;
+//   lin = true    tracked exact 1-NN at the pose x0 (k_nn_track's logic: bound pruning, in-lane rescan of <= QN_TRACK_SEG segments, far-query cache,
+//                 cooperative big-ball search 16 queries at a time) and the correspondence's contribution to the 28 sums, or (MODE 1) its squared distance
+//                 and the transformed point of the output cloud.
+// sx0 / sxi: the f64 poses in LDS (fetched only where the sums are formed: the search and the accumulation are the two register-hungry parts, their live
+// ranges are kept apart).  wl / red: the wave's search scratch and the transpose buffer that aliases it; wrow: the wave's row of the block's 28 sums.
+// Must be called convergently by the whole wave.  PROBE: developer clock stamps (compiled out of the production kernels).
+template <int MODE, bool PROBE, bool TOP2>
+__device__ __forceinline__ void tick_point(const TickArgs& a, const float (&Tf)[12], const double* __restrict__ sx0, const double* __restrict__ sxi, const bool lin, const bool first,
+                                           const uint32_t t, const bool valid, const float4 p, int32_t& j0s, float4& ref, const double (&na)[3], TargetRec& rec0, Top2& t2,
+                                           WaveLds* __restrict__ wl, double* __restrict__ red, double* __restrict__ wrow, unsigned long long* __restrict__ wlist, uint32_t* __restrict__ wcnt, const bool probe) {
+  const int tid = threadIdx.x, lane = tid & 63;
+  const float INF = __int_as_float(0x7f800000);
+  float qx, qy, qz; xform_query<MODE>(Tf, p.x, p.y, p.z, qx, qy, qz);
+  const bool finite_q = (qx - qx == 0.f) && (qy - qy == 0.f) && (qz - qz == 0.f);
+  const uint32_t j0 = (uint32_t)j0s;
+  unsigned long long best = QN_INF_KEY;
+  if (!lin) {                                                    // LM trial error: cached correspondence, gate as at the linearisation
+    bool have = false;
+    if (valid && finite_q && j0 < a.tgt.n) have = (double)sqdist(qx, qy, qz, rec0.p.x, rec0.p.y, rec0.p.z) < a.thr2;
+    double X0[3][4], Xi[3][4];
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+#pragma unroll
+      for (int c = 0; c < 4; c++) { X0[r][c] = sx0[4 * r + c]; Xi[r][c] = sxi[4 * r + c]; }
+    wave_lds_fence();
+    emit_point(have, false, first, X0, Xi, make_float4(p.x, p.y, p.z, 1.f), rec0.p, na, rec0.n, red, wrow);
+    return;
+  }
+  // ---- phase 0: tracked exact 1-NN (k_nn_track's logic: bound pruning, small in-lane rescan, cooperative big-ball search)
+  float second = INF, d_unseen = INF, r = 0.f, delta = 0.f;
+  bool rescanned = false, big = false;
+  unsigned long long key2 = QN_INF_KEY; float third = INF;          // TOP2: the runner-up's key and the squared distance of the third-nearest, as far as this tick's scan knows them
+  const GridView& tg = a.tgt;
+  if (valid && finite_q && j0 >= tg.n) { big = true; r = tg.cell; }         // no usable seed: unseeded search
+  if (valid && finite_q && j0 < tg.n) {
+    float d0 = sqdist(qx, qy, qz, rec0.p.x, rec0.p.y, rec0.p.z);
+    best = pack_key(d0, j0);
+    if (TOP2 && (uint32_t)t2.j1 < tg.n) {                            // the nearer of the neighbour and its runner-up (ref.w bounds everything else)
+      const float d1 = sqdist(qx, qy, qz, t2.p1.x, t2.p1.y, t2.p1.z);
+      const unsigned long long k1 = pack_key(d1, (uint32_t)t2.j1);
+      if (k1 < best) { best = k1; d0 = d1; }
+    }
+    delta = sqrtf(sqdist(qx, qy, qz, ref.x, ref.y, ref.z));
+    if (!track_bound_holds(d0, delta, ref.w)) {
+      r = sqrtf(d0) * 1.000001f + tg.eps;
+      const int bx0 = cell_coord(qx - r, tg.ox, tg.inv_cell, tg.nx), bx1 = cell_coord(qx + r, tg.ox, tg.inv_cell, tg.nx);
+      const int by0 = cell_coord(qy - r, tg.oy, tg.inv_cell, tg.ny), by1 = cell_coord(qy + r, tg.oy, tg.inv_cell, tg.ny);
+      const int bz0 = cell_coord(qz - r, tg.oz, tg.inv_cell, tg.nz), bz1 = cell_coord(qz + r, tg.oz, tg.inv_cell, tg.nz);
+      const int tx0 = bx0 >> 3, ntr = (bx1 >> 3) - tx0 + 1, nyr = by1 - by0 + 1;
+      const int nseg = ntr * nyr * (bz1 - bz0 + 1);
+      if (!(d0 == d0) || nseg > QN_TRACK_SEG) big = true;
+      else {
+        uint32_t s[QN_TRACK_SEG], e[QN_TRACK_SEG];
+#pragma unroll
+        for (int sg = 0; sg < QN_TRACK_SEG; sg++) {
+          s[sg] = 0; e[sg] = 0;
+          if (sg < nseg) {
+            const int tt = sg % ntr, rr = sg / ntr;
+            const int ry = by0 + rr % nyr, rz = bz0 + rr / nyr, tx = tx0 + tt;
+            const int xa = max(bx0, tx << 3), xb = min(bx1, (tx << 3) + 7);
+            const uint32_t k0 = cell_key(tg, xa, ry, rz);
+            s[sg] = tg.cell_start[k0]; e[sg] = tg.cell_start[k0 + (xb - xa) + 1];
+          }
+        }
+#pragma unroll
+        for (int sg = 0; sg < QN_TRACK_SEG; sg++) {
+          for (uint32_t u = s[sg]; u < e[sg]; u++) {
+            const float4 c = tg.pts[u];
+            const float da = sqdist(qx, qy, qz, c.x, c.y, c.z);
+            const unsigned long long ka = pack_key(da, __float_as_uint(c.w));
+            if (TOP2) {                                            // best < key2 (keys), third = squared distance of the nearest point that is neither
+              if (ka < best) { third = key2 != QN_INF_KEY ? key_d2(key2) : third; key2 = best; best = ka; }
+              else if (ka != best) { if (ka < key2) { third = key2 != QN_INF_KEY ? key_d2(key2) : third; key2 = ka; } else if (ka != key2 && da < third) third = da; }
+            } else {
+              if (ka < best) { second = key_d2(best); best = ka; }
+              else if (ka != best && da < second) second = da;
+            }
+          }
+        }
+        if (TOP2) second = key2 != QN_INF_KEY ? key_d2(key2) : INF;
+        float d = INF;
+        if (bx0 > 0) d = fminf(d, qx - (tg.ox + bx0 * tg.cell));
+        if (bx1 < tg.nx - 1) d = fminf(d, (tg.ox + (bx1 + 1) * tg.cell) - qx);
+        if (by0 > 0) d = fminf(d, qy - (tg.oy + by0 * tg.cell));
+        if (by1 < tg.ny - 1) d = fminf(d, (tg.oy + (by1 + 1) * tg.cell) - qy);
+        if (bz0 > 0) d = fminf(d, qz - (tg.oz + bz0 * tg.cell));
+        if (bz1 < tg.nz - 1) d = fminf(d, (tg.oz + (bz1 + 1) * tg.cell) - qz);
+        d_unseen = d - tg.eps; rescanned = true;
+      }
+    }
+  }
+  bool requested = false;
+  const int far_mode = MODE == 0 ? a.far_mode : (a.far_mode != 0 ? 2 : 0);      // the closing pass has no refresh kernel behind it
+  const bool far_lane = big && r > QN_FAR_RMIN_CELLS * tg.cell;       // only truly far neighbours: a ball of a few cells is cheaper to search with the wave (shared stream)
+  if (far_mode != 0) {
+    if (far_lane) {
+      const float4 cr = a.cand_ref[t];
+      if (cr.w > 0.f) {                                            // candidate list made at cr.xyz, everything else is >= cr.w away from there
+        const float dc = sqrtf(sqdist(qx, qy, qz, cr.x, cr.y, cr.z));
+        unsigned long long b1 = QN_INF_KEY; float s2 = INF;
+        const int4* cl = (const int4*)(a.cand + (size_t)t * QN_FAR_M);
+#pragma unroll 2
+        for (int u = 0; u < QN_FAR_M / 4; u++) {
+          const int4 c4 = cl[u];
+          const int cj[4] = {c4.x, c4.y, c4.z, c4.w};
+#pragma unroll
+          for (int v = 0; v < 4; v++) {
+            if ((uint32_t)cj[v] < tg.n) {
+              const float4 cp = a.tgt_raw[cj[v]];
+              const float dd = sqdist(qx, qy, qz, cp.x, cp.y, cp.z);
+              const unsigned long long kk = pack_key(dd, (uint32_t)cj[v]);
+              if (kk < b1) { s2 = b1 != QN_INF_KEY ? key_d2(b1) : s2; b1 = kk; } else if (dd < s2) s2 = dd;
+            }
+          }
+        }
+        if (b1 != QN_INF_KEY && track_bound_holds(key_d2(b1), dc, cr.w)) {      // the nearest neighbour is one of the candidates
+          best = b1; second = s2; d_unseen = cr.w - dc - tg.eps; rescanned = true; big = false;
+        }
+      }
+    }
+    if (far_mode == 1) {
+      requested = far_lane && big; big = big && !requested;        // misses: k_far searches them (and adds their share of the sums)
+      const unsigned long long word = __ballot(requested);
+      if (lane == 0) {
+        const uint32_t chunk = t >> 6;
+        if (chunk * 64u < a.src.n) a.far_req[chunk] = word;
+        if (word) atomicAdd(&a.far_stats[0], (uint32_t)__popcll(word));
+      }
+    } else if (MODE == 0) {                                        // mode 2: misses are searched right here; counted so that the host can bring k_far back
+      const unsigned long long word = __ballot(big && far_lane);
+      if (lane == 0 && word) atomicAdd(&a.far_stats[0], (uint32_t)__popcll(word));
+    }
+  }
+  if (PROBE) {
+    if (probe) a.clk[3] = wall_clock64();
+    if (MODE == 0) { const unsigned long long wb = __ballot(big), wr = __ballot(rescanned), wf = __ballot(big && far_lane);
+      if (big || rescanned) { a.clk_blk[8 * blockIdx.x + 7] = ((unsigned long long)t << 32) | (unsigned long long)(uint32_t)j0s; a.clk_blk[8 * 1024 + 4 * blockIdx.x] = __float_as_uint(key_d2(best)); a.clk_blk[8 * 1024 + 4 * blockIdx.x + 1] = __float_as_uint(ref.w); a.clk_blk[8 * 1024 + 4 * blockIdx.x + 2] = __float_as_uint(delta); a.clk_blk[8 * 1024 + 4 * blockIdx.x + 3] = __float_as_uint(r); }
+      if (lane == 0) { atomicAdd(&a.clk_blk[8 * blockIdx.x + 4], (unsigned long long)__popcll(wb)); atomicAdd(&a.clk_blk[8 * blockIdx.x + 5], (unsigned long long)__popcll(wr)); atomicAdd(&a.clk_blk[8 * blockIdx.x + 6], (unsigned long long)__popcll(wf)); } }
+  }
+  // the wave's big-ball queries, 16 at a time, cooperatively (neighbouring queries' balls overlap: one shared candidate stream)
+  const bool was_big = big;
+  for (unsigned long long pend = __ballot(big); pend != 0;) {
+    unsigned long long grp = 0, tmp = pend; int srcl = -1;
+    for (int sl = 0; sl < 16 && tmp != 0; sl++) { const int L = __ffsll((long long)tmp) - 1; if (sl == (lane & 15)) srcl = L; grp |= 1ull << L; tmp &= tmp - 1; }
+    pend &= ~grp;
+    const bool act = srcl >= 0;
+    const int sl_ = act ? srcl : 0;
+    const float ax = __shfl(qx, sl_), ay = __shfl(qy, sl_), az = __shfl(qz, sl_), ar = __shfl(r, sl_), ad = __shfl(delta, sl_);
+    float rs = (ad < 0.25f * ar) ? ar * 1.1f + 0.5f * tg.cell : ar;           // tight seed: scan a little wider (bound pruning next time)
+    Best1 sink; sink.init();
+    float du = INF;
+    wave_search<4>(tg, ax, ay, az, act, rs, INF, 64, sink, wl, du);
+    const int slot = __popcll(grp & ((1ull << lane) - 1ull));
+    const unsigned long long rk = __shfl(sink.key, slot); const float rsec = __shfl(sink.second, slot), rdu = __shfl(du, slot);
+    if ((grp >> lane) & 1ull) { best = rk; second = rsec; d_unseen = rdu; rescanned = true; key2 = QN_INF_KEY; third = INF; }
+  }
+  // TOP2: a query that needed the wave although it barely moved, and whose fresh scan left no room either (a tie to 2e-4 cells), gets its runner-up from ONE
+  // pass over the ball of radius d_nn + m with all 64 lanes on that query: the three smallest keys inside it -> (j0, j1, bound on everything else).
+  if (TOP2 && MODE == 0) {
+    bool want = false;
+    if (valid && was_big && rescanned && best != QN_INF_KEY && !requested)
+      want = delta < 0.02f * tg.cell && fminf(sqrtf(second), d_unseen) - sqrtf(key_d2(best)) < fmaxf(1.5f * delta, 2e-4f * tg.cell);
+    for (unsigned long long pend = __ballot(want); pend != 0; pend &= pend - 1) {
+      const int L = __ffsll((long long)pend) - 1;
+      const float ax = __shfl(qx, L), ay = __shfl(qy, L), az = __shfl(qz, L), amoved = __shfl(delta, L);
+      const float dnn = sqrtf(key_d2(__shfl(best, L)));
+      float m = fminf(fmaxf(8.f * amoved, 0.05f * tg.cell), 0.5f * tg.cell);
+      unsigned long long lb = QN_INF_KEY; float lsec = INF;
+      for (int attempt = 0; attempt < 4; attempt++, m *= 0.25f) {
+        const float R = dnn * 1.000002f + tg.eps + m;
+        const uint32_t cnt = wave_ball_collect(tg, ax, ay, az, R, wl, wlist, wcnt, lb, lsec);
+        if (cnt <= (uint32_t)QN_HCAP1 && cnt > 0) {                  // every point of the ball is in the list: the three smallest keys
+          const unsigned long long o0 = (uint32_t)lane < cnt ? wlist[lane] : QN_INF_KEY, o1 = (uint32_t)lane + 64u < cnt ? wlist[lane + 64] : QN_INF_KEY;
+          const unsigned long long k1 = wave_min_u64(o0 < o1 ? o0 : o1);
+          const unsigned long long e0 = o0 == k1 ? QN_INF_KEY : o0, e1 = o1 == k1 ? QN_INF_KEY : o1;
+          const unsigned long long k2 = wave_min_u64(e0 < e1 ? e0 : e1);
+          const unsigned long long f0 = e0 == k2 ? QN_INF_KEY : e0, f1 = e1 == k2 ? QN_INF_KEY : e1;
+          const unsigned long long k3 = wave_min_u64(f0 < f1 ? f0 : f1);
+          if (lane == L) {
+            best = k1; key2 = k2; second = k2 != QN_INF_KEY ? key_d2(k2) : INF;
+            third = k3 != QN_INF_KEY ? key_d2(k3) : INF;
+            d_unseen = R * 0.9999995f;                               // nothing outside the ball is closer than its radius
+          }
+          break;
+        }
+      }
+    }
+  }
+  if (MODE == 1) {                                               // fitness + output cloud (original point order)
+    double d2 = 0.0; uint32_t cnt = 0;
+    if (valid) {
+      a.aligned[__float_as_uint(p.w)] = make_float4(qx, qy, qz, 1.0f);
+      if (best != QN_INF_KEY) { d2 = (double)key_d2(best); cnt = 1; }      // max_range = DBL_MAX: every source point with a neighbour counts
+    }
+    d2 = wave_sum_f64_dpp(d2);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
+    if (lane == 0) { if (first) { wrow[0] = d2; wrow[1] = (double)cnt; } else { wrow[0] += d2; wrow[1] += (double)cnt; } }
+    return;
+  }
+  bool have = false;
+  if (valid && !requested) {
+    const int32_t jn = best != QN_INF_KEY ? (int32_t)key_idx(best) : -1;
+    if (TOP2) {
+      if (rescanned) {                                             // a fresh scan: the runner-up it found (or none), its point fetched once
+        t2.j1 = key2 != QN_INF_KEY ? (int32_t)key_idx(key2) : -1;
+        if (t2.j1 >= 0) t2.p1 = a.tgt_raw[t2.j1];
+      } else if (jn != j0s) {                                      // proven, but the runner-up has become the nearer one: the two swap roles, ref still bounds everything else
+        t2.j1 = j0s; t2.p1 = rec0.p;
+      }
+    }
+    j0s = jn;                                                      // (the tracking record also stays in the caller's registers: the persistent kernel never re-reads it)
+    a.nn_idx[t] = j0s;
+    if (rescanned) { ref = make_float4(qx, qy, qz, fminf(sqrtf(TOP2 && key2 != QN_INF_KEY ? third : second), d_unseen)); a.nn_ref[t] = ref; }
+    if (best != QN_INF_KEY) {
+      const uint32_t j = key_idx(best);                              // rec0 always is the record of j0s (gated out or not)
+      if (j != j0) { const TargetRec* rr = a.tgt_rec + j; rec0.p = rr->p; rec0.n[0] = rr->n[0]; rec0.n[1] = rr->n[1]; rec0.n[2] = rr->n[2]; }
+      have = (double)key_d2(best) < a.thr2;
+    }
+  }
+  if (PROBE) {
+    if (probe) a.clk[4] = wall_clock64();
+    if (MODE == 0 && threadIdx.x == 0) a.clk_blk[8 * blockIdx.x + 2] = wall_clock64();
+  }
+  double X0[3][4];
+#pragma unroll
+  for (int r = 0; r < 3; r++)
+#pragma unroll
+    for (int c = 0; c < 4; c++) X0[r][c] = sx0[4 * r + c];
+  wave_lds_fence();                                              // the wave's search scratch becomes its transpose buffer
+  emit_point(have, true, first, X0, X0, make_float4(p.x, p.y, p.z, 1.f), rec0.p, na, rec0.n, red, wrow);
+}
+
 // MODE 0: an optimiser tick.  MODE 1: the closing pass of align() in ONE kernel - the last controller step in the prologue, then (only
 // when the state machine is done) pcl::Registration::getFitnessScore's nearest-neighbour sweep at the FINAL pose (f32 transform in PCL's
 // SSE order, tracked from the last tick's neighbours; per-block f64 sums of the f32 squared distances) and the output cloud
 // pcl::transformPointCloud(*input_, output, final_transformation_) (loop_closure.cpp:124, 127).  It replaces six launches
 // (controller, tracked NN, its list pass, two fitness reductions, the transform); k_finalize_fit folds the block sums and fills the result.
-template <int TB, int OCC, int MODE>
+// PROBE = true: the developer variant with device-clock stamps (knob clk_probe); the production instantiations carry none of it.
+union WaveScratch { WaveLds w; double red[7 * 64]; };
+static_assert(sizeof(WaveLds) >= 7 * 64 * sizeof(double), "the transpose buffer aliases the wave's search scratch");
+template <int TB, int OCC, int MODE, bool PROBE>
 __global__ void __launch_bounds__(TB, OCC) k_tick(TickArgs a) {
-  union WaveScratch { WaveLds w; double red[7 * 64]; };
-  static_assert(sizeof(WaveLds) >= 7 * 64 * sizeof(double), "the transpose buffer aliases the wave's search scratch");
   __shared__ WaveScratch sc[TB / 64];
   __shared__ double wsum[TB / 64][QN_NPART];
   __shared__ GicpState sh;
@@ -170,13 +456,14 @@ __global__ void __launch_bounds__(TB, OCC) k_tick(TickArgs a) {
   __shared__ double sums[QN_NPART];
   __shared__ SolveWork Awork_s; SolveWork* Awork = &Awork_s;
   static_assert(sizeof(GicpState) % 8 == 0, "GicpState is copied as 8-byte words");
-  const int tid = threadIdx.x, lane = tid & 63;
-  const float INF = __int_as_float(0x7f800000);
+  const int tid = threadIdx.x;
   const uint32_t nblk = gridDim.x;
-  const bool probe = a.clk != nullptr && blockIdx.x == 0 && threadIdx.x == 0;
-  if (probe) a.clk[0] = wall_clock64();
-  if (a.clk != nullptr && threadIdx.x == 0) atomicMax(&a.clk[7], ~wall_clock64());       // earliest block start (as a max of the complement)
-  if (MODE == 0 && a.clk != nullptr && threadIdx.x == 0) { a.clk_blk[8 * blockIdx.x] = wall_clock64(); a.clk_blk[8 * blockIdx.x + 4] = 0; a.clk_blk[8 * blockIdx.x + 5] = 0; a.clk_blk[8 * blockIdx.x + 6] = 0; }
+  const bool probe = PROBE && a.clk != nullptr && blockIdx.x == 0 && threadIdx.x == 0;
+  if (PROBE) {
+    if (probe) a.clk[0] = wall_clock64();
+    if (threadIdx.x == 0) atomicMax(&a.clk[7], ~wall_clock64());       // earliest block start (as a max of the complement)
+    if (MODE == 0 && threadIdx.x == 0) { a.clk_blk[8 * blockIdx.x] = wall_clock64(); a.clk_blk[8 * blockIdx.x + 4] = 0; a.clk_blk[8 * blockIdx.x + 5] = 0; a.clk_blk[8 * blockIdx.x + 6] = 0; }
+  }
   const uint32_t lblk = xcd_block(blockIdx.x, nblk);               // XCD x works on one contiguous eighth of the cell-sorted source
   // ---- pose-independent loads of this thread's first point, in flight during the prologue
   uint32_t t = (lblk * a.ppt) * TB + tid;
@@ -188,6 +475,7 @@ __global__ void __launch_bounds__(TB, OCC) k_tick(TickArgs a) {
   if (valid) { na[0] = a.nrm_s[(size_t)t * 3]; na[1] = a.nrm_s[(size_t)t * 3 + 1]; na[2] = a.nrm_s[(size_t)t * 3 + 2]; }
   TargetRec rec0; rec0.p = make_float4(0, 0, 0, 0); rec0.n[0] = rec0.n[1] = rec0.n[2] = 0;
   if (valid && (uint32_t)j0s < a.tgt.n) { const TargetRec* r = a.tgt_rec + j0s; rec0.p = r->p; rec0.n[0] = r->n[0]; rec0.n[1] = r->n[1]; rec0.n[2] = r->n[2]; }
+  Top2 no_t2; no_t2.j1 = -1; no_t2.p1 = make_float4(0, 0, 0, 0);     // (the chain keeps no runner-up: its tracking record is re-read from memory every tick)
 
   // ---- prologue: consume the pending partial rows, run the controller, publish the state.  The state words and the partial rows are
   // requested back to back with the point loads above: one memory round trip in front of the controller.
@@ -196,8 +484,10 @@ __global__ void __launch_bounds__(TB, OCC) k_tick(TickArgs a) {
   if (probe) a.clk[1] = wall_clock64();
   const int pending = sh.pending, phase_in = sh.phase;
   if (pending && phase_in != 2 && tid == 0) solve_controller(&sh, sums, a.cfg, blockIdx.x == 0 ? a.trace : nullptr, 0, phase_in, Awork);
-  if (probe) a.clk[2] = wall_clock64();
-  if (MODE == 0 && a.clk != nullptr && threadIdx.x == 0) a.clk_blk[8 * blockIdx.x + 1] = wall_clock64();
+  if (PROBE) {
+    if (probe) a.clk[2] = wall_clock64();
+    if (MODE == 0 && threadIdx.x == 0) a.clk_blk[8 * blockIdx.x + 1] = wall_clock64();
+  }
   if (tid == 0) { sh.fb_count = 0; sh.big_count = 0; sh.pending = (MODE == 0 && sh.phase != 2) ? 1 : 0; }
   __syncthreads();
   if (blockIdx.x == 0) for (int i = tid; i < (int)(sizeof(GicpState) / 8); i += TB) ((unsigned long long*)a.st_out)[i] = ((const unsigned long long*)&sh)[i];
@@ -207,8 +497,6 @@ __global__ void __launch_bounds__(TB, OCC) k_tick(TickArgs a) {
   float Tf[12];
 #pragma unroll
   for (int j = 0; j < 12; j++) Tf[j] = (float)sh.x0[j];
-  // the f64 poses are fetched from the LDS copy of the state only where the sums are formed (after the search: the search and the
-  // accumulation are the two register-hungry parts of this kernel, their live ranges are kept apart)
   for (uint32_t it = 0; it < a.ppt; it++) {
     if (it > 0) {                                                  // (only clouds beyond 131072 points)
       t = (lblk * a.ppt + it) * TB + tid; valid = t < a.src.n;
@@ -218,166 +506,7 @@ __global__ void __launch_bounds__(TB, OCC) k_tick(TickArgs a) {
       if (valid) { na[0] = a.nrm_s[(size_t)t * 3]; na[1] = a.nrm_s[(size_t)t * 3 + 1]; na[2] = a.nrm_s[(size_t)t * 3 + 2]; }
       if (valid && (uint32_t)j0s < a.tgt.n) { const TargetRec* r = a.tgt_rec + j0s; rec0.p = r->p; rec0.n[0] = r->n[0]; rec0.n[1] = r->n[1]; rec0.n[2] = r->n[2]; }
     }
-    float qx, qy, qz; xform_query<MODE>(Tf, p.x, p.y, p.z, qx, qy, qz);
-    const bool finite_q = (qx - qx == 0.f) && (qy - qy == 0.f) && (qz - qz == 0.f);
-    const uint32_t j0 = (uint32_t)j0s;
-    unsigned long long best = QN_INF_KEY;
-    if (!lin) {                                                    // LM trial error: cached correspondence, gate as at the linearisation
-      bool have = false;
-      if (valid && finite_q && j0 < a.tgt.n) have = (double)sqdist(qx, qy, qz, rec0.p.x, rec0.p.y, rec0.p.z) < a.thr2;
-      double X0[3][4], Xi[3][4];
-#pragma unroll
-      for (int r = 0; r < 3; r++)
-#pragma unroll
-        for (int c = 0; c < 4; c++) { X0[r][c] = sh.x0[4 * r + c]; Xi[r][c] = sh.xi[4 * r + c]; }
-      wave_lds_fence();
-      emit_point(have, false, it == 0, X0, Xi, make_float4(p.x, p.y, p.z, 1.f), rec0.p, na, rec0.n, sc[tid >> 6].red, wsum[tid >> 6]);
-      continue;
-    }
-    // ---- phase 0: tracked exact 1-NN (k_nn_track's logic: bound pruning, small in-lane rescan, cooperative big-ball search)
-    float second = INF, d_unseen = INF, r = 0.f, delta = 0.f;
-    bool rescanned = false, big = false;
-    const GridView& tg = a.tgt;
-    if (valid && finite_q && j0 >= tg.n) { big = true; r = tg.cell; }         // no usable seed: unseeded search
-    if (valid && finite_q && j0 < tg.n) {
-      const float d0 = sqdist(qx, qy, qz, rec0.p.x, rec0.p.y, rec0.p.z);
-      best = pack_key(d0, j0);
-      delta = sqrtf(sqdist(qx, qy, qz, ref.x, ref.y, ref.z));
-      if (!track_bound_holds(d0, delta, ref.w)) {
-        r = sqrtf(d0) * 1.000001f + tg.eps;
-        const int bx0 = cell_coord(qx - r, tg.ox, tg.inv_cell, tg.nx), bx1 = cell_coord(qx + r, tg.ox, tg.inv_cell, tg.nx);
-        const int by0 = cell_coord(qy - r, tg.oy, tg.inv_cell, tg.ny), by1 = cell_coord(qy + r, tg.oy, tg.inv_cell, tg.ny);
-        const int bz0 = cell_coord(qz - r, tg.oz, tg.inv_cell, tg.nz), bz1 = cell_coord(qz + r, tg.oz, tg.inv_cell, tg.nz);
-        const int tx0 = bx0 >> 3, ntr = (bx1 >> 3) - tx0 + 1, nyr = by1 - by0 + 1;
-        const int nseg = ntr * nyr * (bz1 - bz0 + 1);
-        if (!(d0 == d0) || nseg > QN_TRACK_SEG) big = true;
-        else {
-          uint32_t s[QN_TRACK_SEG], e[QN_TRACK_SEG];
-#pragma unroll
-          for (int sg = 0; sg < QN_TRACK_SEG; sg++) {
-            s[sg] = 0; e[sg] = 0;
-            if (sg < nseg) {
-              const int tt = sg % ntr, rr = sg / ntr;
-              const int ry = by0 + rr % nyr, rz = bz0 + rr / nyr, tx = tx0 + tt;
-              const int xa = max(bx0, tx << 3), xb = min(bx1, (tx << 3) + 7);
-              const uint32_t k0 = cell_key(tg, xa, ry, rz);
-              s[sg] = tg.cell_start[k0]; e[sg] = tg.cell_start[k0 + (xb - xa) + 1];
-            }
-          }
-#pragma unroll
-          for (int sg = 0; sg < QN_TRACK_SEG; sg++) {
-            for (uint32_t u = s[sg]; u < e[sg]; u++) {
-              const float4 c = tg.pts[u];
-              const float da = sqdist(qx, qy, qz, c.x, c.y, c.z);
-              const unsigned long long ka = pack_key(da, __float_as_uint(c.w));
-              if (ka < best) { second = key_d2(best); best = ka; }
-              else if (ka != best && da < second) second = da;
-            }
-          }
-          float d = INF;
-          if (bx0 > 0) d = fminf(d, qx - (tg.ox + bx0 * tg.cell));
-          if (bx1 < tg.nx - 1) d = fminf(d, (tg.ox + (bx1 + 1) * tg.cell) - qx);
-          if (by0 > 0) d = fminf(d, qy - (tg.oy + by0 * tg.cell));
-          if (by1 < tg.ny - 1) d = fminf(d, (tg.oy + (by1 + 1) * tg.cell) - qy);
-          if (bz0 > 0) d = fminf(d, qz - (tg.oz + bz0 * tg.cell));
-          if (bz1 < tg.nz - 1) d = fminf(d, (tg.oz + (bz1 + 1) * tg.cell) - qz);
-          d_unseen = d - tg.eps; rescanned = true;
-        }
-      }
-    }
-    bool requested = false;
-    const int far_mode = MODE == 0 ? a.far_mode : (a.far_mode != 0 ? 2 : 0);      // the closing pass has no refresh kernel behind it
-    const bool far_lane = big && r > QN_FAR_RMIN_CELLS * tg.cell;       // only truly far neighbours: a ball of a few cells is cheaper to search with the wave (shared stream)
-    if (far_mode != 0) {
-      if (far_lane) {
-        const float4 cr = a.cand_ref[t];
-        if (cr.w > 0.f) {                                            // candidate list made at cr.xyz, everything else is >= cr.w away from there
-          const float dc = sqrtf(sqdist(qx, qy, qz, cr.x, cr.y, cr.z));
-          unsigned long long b1 = QN_INF_KEY; float s2 = INF;
-          const int4* cl = (const int4*)(a.cand + (size_t)t * QN_FAR_M);
-#pragma unroll 2
-          for (int u = 0; u < QN_FAR_M / 4; u++) {
-            const int4 c4 = cl[u];
-            const int cj[4] = {c4.x, c4.y, c4.z, c4.w};
-#pragma unroll
-            for (int v = 0; v < 4; v++) {
-              if ((uint32_t)cj[v] < tg.n) {
-                const float4 cp = a.tgt_raw[cj[v]];
-                const float dd = sqdist(qx, qy, qz, cp.x, cp.y, cp.z);
-                const unsigned long long kk = pack_key(dd, (uint32_t)cj[v]);
-                if (kk < b1) { s2 = b1 != QN_INF_KEY ? key_d2(b1) : s2; b1 = kk; } else if (dd < s2) s2 = dd;
-              }
-            }
-          }
-          if (b1 != QN_INF_KEY && track_bound_holds(key_d2(b1), dc, cr.w)) {      // the nearest neighbour is one of the candidates
-            best = b1; second = s2; d_unseen = cr.w - dc - tg.eps; rescanned = true; big = false;
-          }
-        }
-      }
-      if (far_mode == 1) {
-        requested = far_lane && big; big = big && !requested;        // misses: k_far searches them (and adds their share of the sums)
-        const unsigned long long word = __ballot(requested);
-        if (lane == 0) {
-          const uint32_t chunk = t >> 6;
-          if (chunk * 64u < a.src.n) a.far_req[chunk] = word;
-          if (word) atomicAdd(&a.far_stats[0], (uint32_t)__popcll(word));
-        }
-      } else if (MODE == 0) {                                        // mode 2: misses are searched right here; counted so that the host can bring k_far back
-        const unsigned long long word = __ballot(big && far_lane);
-        if (lane == 0 && word) atomicAdd(&a.far_stats[0], (uint32_t)__popcll(word));
-      }
-    }
-    if (probe) a.clk[3] = wall_clock64();
-    if (MODE == 0 && a.clk != nullptr) { const unsigned long long wb = __ballot(big), wr = __ballot(rescanned), wf = __ballot(big && far_lane);
-      if (big || rescanned) { a.clk_blk[8 * blockIdx.x + 7] = ((unsigned long long)t << 32) | (unsigned long long)(uint32_t)j0s; a.clk_blk[8 * 1024 + 4 * blockIdx.x] = __float_as_uint(key_d2(best)); a.clk_blk[8 * 1024 + 4 * blockIdx.x + 1] = __float_as_uint(ref.w); a.clk_blk[8 * 1024 + 4 * blockIdx.x + 2] = __float_as_uint(delta); a.clk_blk[8 * 1024 + 4 * blockIdx.x + 3] = __float_as_uint(r); }
-      if (lane == 0) { atomicAdd(&a.clk_blk[8 * blockIdx.x + 4], (unsigned long long)__popcll(wb)); atomicAdd(&a.clk_blk[8 * blockIdx.x + 5], (unsigned long long)__popcll(wr)); atomicAdd(&a.clk_blk[8 * blockIdx.x + 6], (unsigned long long)__popcll(wf)); } }
-    // the wave's big-ball queries, 16 at a time, cooperatively (neighbouring queries' balls overlap: one shared candidate stream)
-    for (unsigned long long pend = __ballot(big); pend != 0;) {
-      unsigned long long grp = 0, tmp = pend; int srcl = -1;
-      for (int sl = 0; sl < 16 && tmp != 0; sl++) { const int L = __ffsll((long long)tmp) - 1; if (sl == (lane & 15)) srcl = L; grp |= 1ull << L; tmp &= tmp - 1; }
-      pend &= ~grp;
-      const bool act = srcl >= 0;
-      const int sl_ = act ? srcl : 0;
-      const float ax = __shfl(qx, sl_), ay = __shfl(qy, sl_), az = __shfl(qz, sl_), ar = __shfl(r, sl_), ad = __shfl(delta, sl_);
-      float rs = (ad < 0.25f * ar) ? ar * 1.1f + 0.5f * tg.cell : ar;           // tight seed: scan a little wider (bound pruning next time)
-      Best1 sink; sink.init();
-      float du = INF;
-      wave_search<4>(tg, ax, ay, az, act, rs, INF, 64, sink, &sc[tid >> 6].w, du);
-      const int slot = __popcll(grp & ((1ull << lane) - 1ull));
-      const unsigned long long rk = __shfl(sink.key, slot); const float rsec = __shfl(sink.second, slot), rdu = __shfl(du, slot);
-      if ((grp >> lane) & 1ull) { best = rk; second = rsec; d_unseen = rdu; rescanned = true; }
-    }
-    if (MODE == 1) {                                               // fitness + output cloud (original point order)
-      double d2 = 0.0; uint32_t cnt = 0;
-      if (valid) {
-        a.aligned[__float_as_uint(p.w)] = make_float4(qx, qy, qz, 1.0f);
-        if (best != QN_INF_KEY) { d2 = (double)key_d2(best); cnt = 1; }      // max_range = DBL_MAX: every source point with a neighbour counts
-      }
-      d2 = wave_sum_f64_dpp(d2);
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
-      if (lane == 0) { if (it == 0) { wsum[tid >> 6][0] = d2; wsum[tid >> 6][1] = (double)cnt; } else { wsum[tid >> 6][0] += d2; wsum[tid >> 6][1] += (double)cnt; } }
-      continue;
-    }
-    bool have = false;
-    if (valid && !requested) {
-      a.nn_idx[t] = best != QN_INF_KEY ? (int32_t)key_idx(best) : -1;
-      if (rescanned) a.nn_ref[t] = make_float4(qx, qy, qz, fminf(sqrtf(second), d_unseen));
-      if (best != QN_INF_KEY && (double)key_d2(best) < a.thr2) {
-        const uint32_t j = key_idx(best);
-        if (j != j0) { const TargetRec* rr = a.tgt_rec + j; rec0.p = rr->p; rec0.n[0] = rr->n[0]; rec0.n[1] = rr->n[1]; rec0.n[2] = rr->n[2]; }
-        have = true;
-      }
-    }
-    if (probe) a.clk[4] = wall_clock64();
-    if (MODE == 0 && a.clk != nullptr && threadIdx.x == 0) a.clk_blk[8 * blockIdx.x + 2] = wall_clock64();
-    double X0[3][4];
-#pragma unroll
-    for (int r = 0; r < 3; r++)
-#pragma unroll
-      for (int c = 0; c < 4; c++) X0[r][c] = sh.x0[4 * r + c];
-    wave_lds_fence();                                              // the wave's search scratch becomes its transpose buffer
-    emit_point(have, true, it == 0, X0, X0, make_float4(p.x, p.y, p.z, 1.f), rec0.p, na, rec0.n, sc[tid >> 6].red, wsum[tid >> 6]);
+    tick_point<MODE, PROBE, false>(a, Tf, sh.x0, sh.xi, lin, it == 0, t, valid, p, j0s, ref, na, rec0, no_t2, &sc[tid >> 6].w, sc[tid >> 6].red, wsum[tid >> 6], nullptr, nullptr, probe);
   }
   __syncthreads();
   if (MODE == 1) {
@@ -387,9 +516,11 @@ __global__ void __launch_bounds__(TB, OCC) k_tick(TickArgs a) {
   if (tid < QN_NPART) { double v = 0;
 #pragma unroll
     for (int w = 0; w < TB / 64; w++) v += wsum[w][tid]; a.part_out[(size_t)lblk * QN_NPART + tid] = v; }
-  if (probe) a.clk[5] = wall_clock64();
-  if (a.clk != nullptr && threadIdx.x == 0) atomicMax(&a.clk[6], wall_clock64());        // latest block end
-  if (MODE == 0 && a.clk != nullptr && threadIdx.x == 0) a.clk_blk[8 * blockIdx.x + 3] = wall_clock64();
+  if (PROBE) {
+    if (probe) a.clk[5] = wall_clock64();
+    if (threadIdx.x == 0) atomicMax(&a.clk[6], wall_clock64());        // latest block end
+    if (MODE == 0 && threadIdx.x == 0) a.clk_blk[8 * blockIdx.x + 3] = wall_clock64();
+  }
 }
 
 // result block of an align(): state + fitness = (sum of the block sums, fixed order) / (points with a neighbour), written to pinned host memory
@@ -411,48 +542,6 @@ static __global__ void k_finalize_fit(const GicpState* __restrict__ st, ResultBl
   out->phase = st->phase; out->trace_len = st->trace_len;
   out->far_requests = far_stats ? far_stats[1] : 0u; out->far_misses = far_stats ? far_stats[0] : 0u; out->far_queries = far_stats ? far_stats[3] : 0u;
   if (far_stats) { far_stats[0] = 0u; far_stats[1] = 0u; far_stats[3] = 0u; }
-}
-
-// All target points within R of q (one query per wave, ONE pass over the cap box of radius R - which covers ball(q, R) completely, so
-// every point that is NOT collected is farther than R): indices into list[], the smallest key and the runner-up's d2.  Returns the
-// number of points found (> cap: the list overflowed, the caller shrinks R).
-__device__ __forceinline__ uint32_t wave_ball_collect(const GridView& g, float qx, float qy, float qz, float R, int cap_n, WaveLdsH1* L,
-                                                      unsigned long long& best, float& second) {
-  const CapBox cb = cap_of(g, qx, qy, qz);
-  const float rx = cap_extent(g, cb, R, 0), ry = cap_extent(g, cb, R, 1), rz = cap_extent(g, cb, R, 2);
-  int x0 = rfl(cell_coord(qx - rx, g.ox, g.inv_cell, g.nx)), x1 = rfl(cell_coord(qx + rx, g.ox, g.inv_cell, g.nx));
-  int y0 = rfl(cell_coord(qy - ry, g.oy, g.inv_cell, g.ny)), y1 = rfl(cell_coord(qy + ry, g.oy, g.inv_cell, g.ny));
-  int z0 = rfl(cell_coord(qz - rz, g.oz, g.inv_cell, g.nz)), z1 = rfl(cell_coord(qz + rz, g.oz, g.inv_cell, g.nz));
-  const bool tile_mode = ((x1 >> 3) - (x0 >> 3) + 1) * (y1 - y0 + 1) * (z1 - z0 + 1) > 128;
-  if (tile_mode) {
-    x0 = (x0 >> 3) << 3; x1 = min(((x1 >> 3) << 3) + 7, g.nx - 1);
-    y0 = (y0 >> 2) << 2; y1 = min(((y1 >> 2) << 2) + 3, g.ny - 1);
-    z0 = (z0 >> 2) << 2; z1 = min(((z1 >> 2) << 2) + 3, g.nz - 1);
-  }
-  const int lane = threadIdx.x & 63;
-  wave_lds_fence();
-  if (lane == 0) L->cnt = 0;
-  wave_lds_fence();
-  const float R2 = R * R;
-  unsigned long long b = QN_INF_KEY; float s2 = __int_as_float(0x7f800000);
-  stream_box(g, x0, x1, y0, y1, z0, z1, tile_mode, &L->s, [&](const float4& p, bool valid, uint32_t) __attribute__((always_inline)) {
-    const float d2 = sqdist(qx, qy, qz, p.x, p.y, p.z);
-    if (valid && d2 <= R2) {
-      const unsigned long long k = pack_key(d2, __float_as_uint(p.w));
-      const uint32_t pos = atomicAdd(&L->cnt, 1u);
-      if (pos < QN_HCAP1) L->list[pos] = k;
-      if (k < b) { if (b != QN_INF_KEY) s2 = key_d2(b); b = k; } else if (d2 < s2) s2 = d2;
-    }
-  }, qx, qy, qz, tile_mode ? R2 * 1.000002f : -1.f);                    // (tiles outside the ball are not streamed: only points with d2 <= R2 are used)
-  wave_lds_fence();
-  const unsigned long long wb = wave_min_u64(b);
-  float c = (b == wb) ? s2 : key_d2(b);
-  if (b == QN_INF_KEY) c = __int_as_float(0x7f800000);
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) c = fminf(c, __shfl_xor(c, o));
-  best = wb; second = c;
-  (void)cap_n;
-  return L->cnt;
 }
 
 // k_far: the refresh requests of the tick that just ran (bits in far_req), one query per WAVE, chip-wide.  Chunks of 64 source positions
@@ -516,7 +605,7 @@ static __global__ void __launch_bounds__(QN_FAR_THREADS) k_far(FarArgs a) {
           float m = fminf(fmaxf(fmaxf(2.f * a.tgt.cell * a.tgt.cell / fmaxf(dnn, a.tgt.cell), 2.5f * moved), 0.01f), 0.5f * a.tgt.cell);
           for (int attempt = 0; attempt < 5; attempt++, m *= 0.5f) {
             const float R = dnn * 1.000002f + a.tgt.eps + m;
-            const uint32_t cnt = wave_ball_collect(a.tgt, qx, qy, qz, R, QN_FAR_M, &lds[wid], best, second);
+            const uint32_t cnt = wave_ball_collect(a.tgt, qx, qy, qz, R, &lds[wid].s, lds[wid].list, &lds[wid].cnt, best, second);
             other = fminf(sqrtf(second), R * 0.9999995f);              // the runner-up inside the ball, or the ball's radius: nothing else is closer
             if (cnt <= (uint32_t)QN_FAR_M && cnt > 0) {
               if (lane < QN_FAR_M) cl[lane] = (uint32_t)lane < cnt ? (int32_t)key_idx(lds[wid].list[lane]) : -1;
