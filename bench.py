@@ -54,6 +54,14 @@ def pct(xs):
     return {"median": round(float(np.median(xs)), 4), "p10": round(float(np.percentile(xs, 10)), 4), "p90": round(float(np.percentile(xs, 90)), 4), "n": int(len(xs))}
 
 
+def whole_registration(ms_step):
+    ab = algorithmic_bytes()
+    if not ms_step:
+        return None
+    return {"algorithmic_bytes": ab["full"], "achieved": round(ab["full"] / (ms_step * 1e-3) / 1e9, 2), "frac": round(ab["full"] / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+            "note": "amortised over the registrations in flight"}
+
+
 def roofline_leg(ctx, register, ms_step, align_ms, nprof=4):
     """per-kernel-family device time from hipEvents on the engine's own stream (qn_prof_*), the `roofline` object of the dominant single-kernel family"""
     ctx.prof_reset(); ctx.prof_enable(True)
@@ -91,9 +99,7 @@ def roofline_leg(ctx, register, ms_step, align_ms, nprof=4):
                 "traffic_source": "NOT measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the same workload (tools/gpu_round.sh <tag> pmc), stored in profiles/pmc_latest.json",
                 "stale_from": (pmc_all or {}).get("_meta", {}).get("tag", "profiles/pmc_latest.json") if isinstance(pmc_all, dict) else None,
                 "traffic_detail": pmc, "avg_launch_ms": round(dom_ms, 5), "algorithmic_bytes_per_launch": per_launch_bytes,
-                "whole_registration": {"algorithmic_bytes": ab["full"], "achieved": round(ab["full"] / (ms_step * 1e-3) / 1e9, 2),
-                                       "frac": round(ab["full"] / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
-                                       "note": "amortised over the registrations in flight"},
+                "whole_registration": whole_registration(ms_step),
                 "align_only": {"algorithmic_bytes": ab["align"], "ms": round(align_ms, 4),
                                "frac": round(ab["align"] / (align_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)},
                 "family_ms_per_registration": {k: round(v, 4) for k, v in fam_ms.items()}, "kernels": kernels,
@@ -122,6 +128,172 @@ def spawn_ranks(args):
     sys.stdout.write(out.decode()); sys.stdout.flush()
     if any(rcs):
         raise SystemExit("bench.py: rank exit codes %s" % rcs)
+
+
+def latency_legs(engine, synth, pairs, args, world, ctx=None, p80=None):
+    """One registration at a time (the reference's deployment: ONE candidate pair per 2 Hz timer tick, fast_lio_sam_qn.cpp:213-219): single-stream latency,
+    PCIe-inclusive latency, align()-only, the per-kernel roofline leg, the CPU baseline, the parity spot check, the 80 %-overlap pairs, the reference's
+    operating point and the Quatro stage - on the first of the in-flight contexts, after the throughput legs.  (The latency depends on the PAIR far more than
+    on anything else: a 10-degree initial yaw error costs 0.3 ms more than a 1-degree one, tools/gpu_probe_pairs.py; medians are over 8 distinct pairs.)"""
+    own = ctx is None
+    if own:
+        ctx = engine.Context(N_PTS + 1024, device=torch.cuda.current_device())
+    g = engine.NanoGICP(ctx)
+    g.setCorrespondenceRandomness(K_COV); g.setMaximumIterations(GN_ITERS); g.setMaxCorrespondenceDistance(52.5)
+    g.setOptimizer("gn"); g.setForceIterations(GN_ITERS)
+
+    def register(j):
+        s, t, _ = pairs[j % len(pairs)]
+        g.setInputSourceDevice(s.data_ptr(), N_PTS, 12); g.calculateSourceCovariances()
+        g.setInputTargetDevice(t.data_ptr(), N_PTS, 12); g.calculateTargetCovariances()
+        return g.align()
+
+    # ---- one registration at a time on one stream (latency view): median / p10 / p90 over distinct pairs
+    for j in range(2):
+        register(j)
+    lat = []
+    for j in range(30):
+        tl = time.perf_counter(); register(j); lat.append(1e3 * (time.perf_counter() - tl))
+    single = pct(lat)
+    # ---- PCIe-inclusive view: the same registration with the clouds handed over as HOST buffers (never `value`)
+    s_host, t_host = pairs[0][0].cpu().numpy(), pairs[0][1].cpu().numpy()
+    def register_host():
+        g.setInputSource(s_host); g.calculateSourceCovariances()
+        g.setInputTarget(t_host); g.calculateTargetCovariances()
+        return g.align()
+    register_host()
+    lat = []
+    for _ in range(10):
+        th = time.perf_counter(); register_host(); lat.append(1e3 * (time.perf_counter() - th))
+    host = pct(lat)
+    # ---- align-only timing (clouds + covariances resident): BASELINE's "ms/align"
+    register(0); ctx.synchronize(); torch.cuda.synchronize()
+    lat = []
+    for _ in range(max(30, args.steps // 4)):
+        ta = time.perf_counter(); g.align(); lat.append(1e3 * (time.perf_counter() - ta))
+    align = pct(lat); align_ms = align["median"]
+
+    roofline = roofline_leg(ctx, register, None, align_ms)
+
+    cpu = None
+    if world == 1 and not args.no_cpu_baseline:
+        from oracle import oracle as orc                      # CPU baseline leg only
+        s_np, t_np = pairs[0][0].cpu().numpy(), pairs[0][1].cpu().numpy()
+        nthreads = orc.num_threads()
+        def cpu_once():
+            o = orc.GicpOracle(k=K_COV, max_iter=GN_ITERS, max_corr_dist=52.5, optimizer="gn", force_iterations=GN_ITERS)
+            o.set_source(s_np); o.compute_covariances(0); o.set_target(t_np); o.compute_covariances(1)
+            return o.align()
+        tc = time.perf_counter(); ro = cpu_once(); first = time.perf_counter() - tc
+        nrep = max(1, min(8, int(15.0 / max(first, 1e-3))))
+        times = []
+        for _ in range(nrep):
+            tc = time.perf_counter(); cpu_once(); times.append(time.perf_counter() - tc)
+        cpu_s = float(np.median(times))
+        cpu = {"value": round(1.0 / cpu_s, 4), "unit": "registrations/s", "cores": nthreads, "kind": "port",
+               "ms_per_registration": round(cpu_s * 1e3, 2), "ms_range": [round(1e3 * min(times), 2), round(1e3 * max(times), 2)],
+               "sample": "%d full registrations of pair 0 (100k x 100k, k=20, 20 GN iterations) with the OpenMP C++ oracle; shared host, wall time varies run to run" % nrep}
+        # parity spot check of the benched workload against the oracle: pair 0, the bench's own parameters re-bound to the context
+        # (other NanoGICP objects may have used it), BEFORE any extra runs
+        g.bind(); r = register(0)
+        Tg = np.array(r.T64).reshape(4, 4)
+        dtp = float(np.abs(Tg - ro["T"]).max()); dt_m, dr_rad = synth.pose_error(Tg, ro["T"])
+        parity = {"pair": 0, "max_abs_T_diff": dtp, "dt_m": dt_m, "dr_rad": dr_rad, "iterations": [int(r.iterations), int(ro["iterations"])],
+                  "score_rel_diff": abs(r.fitness - ro["fitness"]) / max(ro["fitness"], 1e-300), "ok": bool(dtp <= 1e-9 and r.iterations == ro["iterations"])}
+    else:
+        dtp, parity = None, None
+    out = {"single": single, "host": host, "align": align, "roofline": roofline, "cpu": cpu, "dtp": dtp, "parity": parity,
+           "persistent_align_launches": int(ctx.debug_get("persist_launches")), "alone_in_process": bool(own)}
+    if p80:
+        # ---- SURVEY 8d's generator case (80 % overlap), one registration at a time: percentiles over 8 distinct pairs + kernel-family breakdown
+        g.bind()
+        def register80(j):
+            s_, t_, _ = p80[j % len(p80)]
+            g.setInputSourceDevice(s_.data_ptr(), N_PTS, 12); g.calculateSourceCovariances()
+            g.setInputTargetDevice(t_.data_ptr(), N_PTS, 12); g.calculateTargetCovariances()
+            return g.align()
+        register80(0); register80(1); lat = []
+        for j in range(24):
+            tl = time.perf_counter(); register80(j); lat.append(1e3 * (time.perf_counter() - tl))
+        out["overlap80_single"] = pct(lat)
+        register80(0); ctx.synchronize(); lat = []
+        for _ in range(20):
+            ta = time.perf_counter(); g.align(); lat.append(1e3 * (time.perf_counter() - ta))
+        out["overlap80_align"] = pct(lat)
+        ctx.prof_reset(); ctx.prof_enable(True)
+        for j in range(4):
+            register80(j)
+        ctx.synchronize(); ctx.prof_enable(False)
+        st8 = ctx.prof_stats()
+        out["overlap80_family_ms"] = {k: round(v[0] / 4, 4) for k, v in st8.items() if v[1] > 0}
+    if not args.no_extras:
+        # ---- BASELINE configs[0]: the reference's operating point (SURVEY App. C): k = 15, LM, <= 32 iterations, real stopping rule,
+        # clouds handed over as HOST buffers through qn_icp_alignment (PCIe inclusive), 30k and 100k points; CPU oracle beside it
+        try:
+            rop = {}
+            for npts in (30000, N_PTS):
+                sr, tr_, _ = synth.make_pair(700 + npts // 1000, npts)
+                engine.icp_alignment(ctx, sr, tr_)
+                lat = []
+                for _ in range(15):
+                    tq = time.perf_counter(); rr = engine.icp_alignment(ctx, sr, tr_); lat.append(1e3 * (time.perf_counter() - tq))
+                e = {"gpu_ms_from_host_buffers": pct(lat), "iterations": rr["iterations"], "converged": rr["converged"], "score": rr["score"]}
+                if not args.no_cpu_baseline:
+                    from oracle import oracle as orc
+                    tc = time.perf_counter(); ro2 = orc.icp_alignment(sr, tr_); c1 = time.perf_counter() - tc
+                    reps = max(1, min(5, int(4.0 / max(c1, 1e-3)))); tc = time.perf_counter()
+                    for _ in range(reps):
+                        orc.icp_alignment(sr, tr_)
+                    e["cpu_oracle_ms"] = round(1e3 * (time.perf_counter() - tc) / reps, 2); e["cpu_threads"] = orc.num_threads()
+                    e["same_iterations_as_oracle"] = bool(ro2["iterations"] == rr["iterations"])
+                    e["dT_vs_oracle_m_rad"] = list(synth.pose_error(rr["T"], ro2["T"]))
+                rop["%dk" % (npts // 1000)] = e
+            out["rop"] = {"config": "k=15, LM, max 32 iterations, eps_t 0.01, eps_r 2e-3, max_corr_dist 52.5 m, score thr 1.5 (SURVEY App. C)", **rop}
+        except Exception as ex:
+            out["rop"] = {"error": repr(ex)}
+    # ---- Quatro coarse stage (BASELINE configs[2]): FPFH + optimizedMatching (cap 200) + GNC solve, 30k and 100k pairs from the host
+    quatro = None
+    if world == 1 and not args.no_quatro and not args.no_extras:
+        try:
+            from scipy.spatial import cKDTree
+            quatro = {}
+            for npts in (30000, N_PTS):
+                qs, qt, _ = synth.make_pair(400 + npts // 1000, npts, mode="quatro")
+                q = engine.Quatro(ctx)
+                q.align(qs, qt)
+                lat = []
+                for _ in range(5):
+                    tq = time.perf_counter(); Tq, qvalid = q.align(qs, qt); lat.append(1e3 * (time.perf_counter() - tq))
+                host_wall = {"uploads_grids_enqueue": round(ctx.debug_get("quatro_wall_features_ms"), 3), "fpfh_wait_matching_tail": round(ctx.debug_get("quatro_wall_match_ms"), 3),
+                             "clique_gnc_solve": round(ctx.debug_get("quatro_wall_solve_ms"), 3)}          # of the last timed align (before the profiled one)
+                n_surv, n_fb = int(ctx.debug_get("feat_survivors")), int(ctx.debug_get("feat_fallbacks"))
+                ctx.prof_reset(); ctx.prof_enable(True); q.align(qs, qt); ctx.synchronize(); ctx.prof_enable(False)
+                st = ctx.prof_stats()
+                stage = {k: round(st[k][0], 4) for k in ("grid_build", "fpfh_normals", "fpfh_spfh", "fpfh_fpfh", "feat_match", "match_tail") if st[k][1] > 0}
+                tree = cKDTree(qs.astype(np.float64)); sel = np.random.default_rng(0).choice(len(qs), 4000, replace=False)
+                m_n = float(np.mean(tree.query_ball_point(qs[sel].astype(np.float64), 0.9, return_length=True)))
+                m_f = float(np.mean(tree.query_ball_point(qs[sel].astype(np.float64), 1.5, return_length=True)))
+                ab_q = {"normals": npts * (16 + 16 * m_n + 12), "spfh": npts * (28 + 28 * m_f + 132), "fpfh": npts * (136 * m_f + 132)}     # per cloud, SURVEY 8d
+                fm_ms = stage.get("feat_match", 0.0)
+                flops = 2.0 * 33 * npts * npts                                   # forward direction; the lazy reverse search adds the hit fraction
+                mm_flops = 2.0 * 112 * npts * npts * 1.25                        # what the matrix cores execute for it (K = 112, full pass + 1/4 sample)
+                e = {"ms_per_align": pct(lat), "valid": bool(qvalid), "stage_ms": stage, "m_n": round(m_n, 1), "m_f": round(m_f, 1),
+                     "algorithmic_bytes_per_cloud": {k: int(v) for k, v in ab_q.items()},
+                     "frac_hbm": {k: round(ab_q[k] * 2 / (stage[s] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) for k, s in (("normals", "fpfh_normals"), ("spfh", "fpfh_spfh"), ("fpfh", "fpfh_fpfh")) if s in stage},
+                     "feat_match": {"bound": "mfma", "kernel": "k_feat_mm<2>", "flops_f16_mfma": mm_flops, "achieved_TF_lower_bound": round(mm_flops / (fm_ms * 1e-3) / 1e12, 1) if fm_ms else None,
+                                    "peak_TF": MFMA_F16_PEAK_TF, "frac_of_mfma_f16_peak": round(mm_flops / (fm_ms * 1e-3) / 1e12 / MFMA_F16_PEAK_TF, 4) if fm_ms else None,
+                                    "effective_f32_TF": round(flops / (fm_ms * 1e-3) / 1e12, 2) if fm_ms else None,
+                                    "survivors_exactly_re_evaluated": n_surv, "fallbacks_to_valu_search": n_fb,
+                                    "note": "screening GEMM on v_mfma_f32_32x32x16_f16: K = 112 (f16 hi/lo split of 33 bins + bound terms), full pass + 1/4 sampled pass, forward search only "
+                                            "(Ns x Nt); time = BOTH searches + de-duplication + operand images + exact stage, so the fraction is a lower bound. effective_f32_TF = 2*33*Ns*Nt / time"},
+                     "host_wall_ms": host_wall}
+                quatro["%dk" % (npts // 1000)] = e
+        except Exception as ex:
+            quatro = {"error": repr(ex)}
+    out["quatro"] = quatro
+    if own:
+        ctx.close()
+    return out
 
 
 def single_process(args, engine, synth, json_fd):
@@ -263,6 +435,15 @@ def main():
         pairs.append((torch.from_numpy(src).cuda(), torch.from_numpy(tgt).cuda(), T))
     torch.cuda.synchronize()
 
+    p80 = None
+    if rank == 0 and not args.no_extras:      # SURVEY 8d's generator case: 80 % overlap (target window shifted 24 m; the headline pairs overlap ~96 %), 8 DISTINCT pairs
+        p80 = []
+        for j in range(8):
+            s80, t80, _ = synth.make_pair(9000 + j, N_PTS, shift=24.0)
+            p80.append((torch.from_numpy(s80).cuda(), torch.from_numpy(t80).cuda(), None))
+        torch.cuda.synchronize()
+    lat_legs = None
+
     def register(j, gg=g):
         s, t, _ = pairs[j % len(pairs)]
         gg.setInputSourceDevice(s.data_ptr(), N_PTS, 12); gg.calculateSourceCovariances()
@@ -397,155 +578,31 @@ def main():
     out = None
     if rank == 0:
         ms_step = 1e3 * elapsed / args.steps
-        # ---- one registration at a time on one stream (latency view): median / p10 / p90 over distinct pairs
-        for j in range(2):
-            register(j)
-        lat = []
-        for j in range(30):
-            tl = time.perf_counter(); register(j); lat.append(1e3 * (time.perf_counter() - tl))
-        single = pct(lat)
-        # ---- PCIe-inclusive view: the same registration with the clouds handed over as HOST buffers (never `value`)
-        s_host, t_host = pairs[0][0].cpu().numpy(), pairs[0][1].cpu().numpy()
-        def register_host():
-            g.setInputSource(s_host); g.calculateSourceCovariances()
-            g.setInputTarget(t_host); g.calculateTargetCovariances()
-            return g.align()
-        register_host()
-        lat = []
-        for _ in range(10):
-            th = time.perf_counter(); register_host(); lat.append(1e3 * (time.perf_counter() - th))
-        host = pct(lat)
-        # ---- align-only timing (clouds + covariances resident): BASELINE's "ms/align"
-        register(0); ctx.synchronize(); torch.cuda.synchronize()
-        lat = []
-        for _ in range(max(30, args.steps // 4)):
-            ta = time.perf_counter(); g.align(); lat.append(1e3 * (time.perf_counter() - ta))
-        align = pct(lat); align_ms = align["median"]
+        L = lat_legs if lat_legs is not None else latency_legs(engine, synth, pairs, args, world, ctx, p80=p80)
+        single, host, align, roofline, cpu, dtp, parity = L["single"], L["host"], L["align"], L["roofline"], L["cpu"], L["dtp"], L["parity"]
+        align_ms = align["median"]; roofline["whole_registration"] = whole_registration(ms_step)
 
-        roofline = roofline_leg(ctx, register, ms_step, align_ms)
-
-        cpu = None
-        if world == 1 and not args.no_cpu_baseline:
-            from oracle import oracle as orc                      # CPU baseline leg only
-            s_np, t_np = pairs[0][0].cpu().numpy(), pairs[0][1].cpu().numpy()
-            nthreads = orc.num_threads()
-            def cpu_once():
-                o = orc.GicpOracle(k=K_COV, max_iter=GN_ITERS, max_corr_dist=52.5, optimizer="gn", force_iterations=GN_ITERS)
-                o.set_source(s_np); o.compute_covariances(0); o.set_target(t_np); o.compute_covariances(1)
-                return o.align()
-            tc = time.perf_counter(); ro = cpu_once(); first = time.perf_counter() - tc
-            nrep = max(1, min(8, int(15.0 / max(first, 1e-3))))
-            times = []
-            for _ in range(nrep):
-                tc = time.perf_counter(); cpu_once(); times.append(time.perf_counter() - tc)
-            cpu_s = float(np.median(times))
-            cpu = {"value": round(1.0 / cpu_s, 4), "unit": "registrations/s", "cores": nthreads, "kind": "port",
-                   "ms_per_registration": round(cpu_s * 1e3, 2), "ms_range": [round(1e3 * min(times), 2), round(1e3 * max(times), 2)],
-                   "sample": "%d full registrations of pair 0 (100k x 100k, k=20, 20 GN iterations) with the OpenMP C++ oracle; shared host, wall time varies run to run" % nrep}
-            # parity spot check of the benched workload against the oracle: pair 0, the bench's own parameters re-bound to the context
-            # (other NanoGICP objects may have used it), BEFORE any extra runs
-            g.bind(); r = register(0)
-            Tg = np.array(r.T64).reshape(4, 4)
-            dtp = float(np.abs(Tg - ro["T"]).max()); dt_m, dr_rad = synth.pose_error(Tg, ro["T"])
-            parity = {"pair": 0, "max_abs_T_diff": dtp, "dt_m": dt_m, "dr_rad": dr_rad, "iterations": [int(r.iterations), int(ro["iterations"])],
-                      "score_rel_diff": abs(r.fitness - ro["fitness"]) / max(ro["fitness"], 1e-300), "ok": bool(dtp <= 1e-9 and r.iterations == ro["iterations"])}
-        else:
-            dtp, parity = None, None
-
-
-        extras = {}
+        extras = {"latency_legs": {"alone_in_process": L["alone_in_process"], "persistent_align_launches": L["persistent_align_launches"],
+                                   "note": "ms_per_registration_single_stream, ..._from_host_buffers, ms_per_align, overlap80 single-stream, reference_operating_point and quatro are one-registration-at-a-time figures "
+                                           "(the reference's deployment: one candidate pair per timer tick), measured on the first in-flight context after the throughput legs"}}
         if not args.no_extras:
             try:
-                # ---- SURVEY 8d's generator case: 80 % overlap (target window shifted 24 m; the headline pairs overlap ~96 %).  Same workload, same
-                # in-flight setting, 8 DISTINCT pairs, `steps` timed registrations; single-stream percentiles and the kernel-family breakdown beside it
-                g.bind()
-                p80 = []
-                for j in range(8):
-                    s80, t80, _ = synth.make_pair(9000 + j, N_PTS, shift=24.0)
-                    p80.append((torch.from_numpy(s80).cuda(), torch.from_numpy(t80).cuda(), None))
+                # ---- SURVEY 8d's generator case as a throughput figure: same workload and in-flight setting as `value`, 8 DISTINCT 80 %-overlap pairs, `steps` timed registrations
+                for gg in gs:
+                    gg.bind()
                 batch(8, p80); torch.cuda.synchronize()
                 n80 = max(40, args.steps)
                 t8 = time.perf_counter(); _, _, st80 = batch(n80, p80); torch.cuda.synchronize(); w80 = time.perf_counter() - t8
                 assert all(x == 0 for x in st80), st80
-                def register80(j):
-                    s_, t_, _ = p80[j % len(p80)]
-                    g.setInputSourceDevice(s_.data_ptr(), N_PTS, 12); g.calculateSourceCovariances()
-                    g.setInputTargetDevice(t_.data_ptr(), N_PTS, 12); g.calculateTargetCovariances()
-                    return g.align()
-                register80(0); lat = []
-                for j in range(16):
-                    tl = time.perf_counter(); register80(j); lat.append(1e3 * (time.perf_counter() - tl))
-                ctx.prof_reset(); ctx.prof_enable(True)
-                for j in range(4):
-                    register80(j)
-                ctx.synchronize(); ctx.prof_enable(False)
-                st8 = ctx.prof_stats()
                 extras["overlap80"] = {"registrations_per_s": round(n80 / w80, 2), "ms_per_step": round(1e3 * w80 / n80, 4), "steps": n80, "distinct_pairs": len(p80), "in_flight": len(ctxs),
-                                       "ms_per_registration_single_stream_stats": pct(lat),
-                                       "family_ms_per_registration": {k: round(v[0] / 4, 4) for k, v in st8.items() if v[1] > 0},
+                                       "ms_per_registration_single_stream_stats": L.get("overlap80_single"), "ms_per_align_stats": L.get("overlap80_align"),
+                                       "family_ms_per_registration": L.get("overlap80_family_ms"),
                                        "note": "SURVEY 8d generator: target scene window shifted so that the clouds overlap 80 % (20 % of the source has no counterpart)"}
-                # ---- BASELINE configs[0]: the reference's operating point: k = 15, LM, <= 32 iterations, real stopping rule,
-                # clouds handed over as HOST buffers through qn_icp_alignment (PCIe inclusive), 30k and 100k points; CPU oracle beside it
-                rop = {}
-                for npts in (30000, N_PTS):
-                    sr, tr_, _ = synth.make_pair(700 + npts // 1000, npts)
-                    engine.icp_alignment(ctx, sr, tr_)
-                    lat = []
-                    for _ in range(15):
-                        tq = time.perf_counter(); rr = engine.icp_alignment(ctx, sr, tr_); lat.append(1e3 * (time.perf_counter() - tq))
-                    e = {"gpu_ms_from_host_buffers": pct(lat), "iterations": rr["iterations"], "converged": rr["converged"], "score": rr["score"]}
-                    if not args.no_cpu_baseline:
-                        from oracle import oracle as orc
-                        tc = time.perf_counter(); ro = orc.icp_alignment(sr, tr_); c1 = time.perf_counter() - tc
-                        reps = max(1, min(5, int(4.0 / max(c1, 1e-3)))); tc = time.perf_counter()
-                        for _ in range(reps):
-                            orc.icp_alignment(sr, tr_)
-                        e["cpu_oracle_ms"] = round(1e3 * (time.perf_counter() - tc) / reps, 2); e["cpu_threads"] = orc.num_threads()
-                        e["same_iterations_as_oracle"] = bool(ro["iterations"] == rr["iterations"])
-                    rop["%dk" % (npts // 1000)] = e
-                extras["reference_operating_point"] = {"config": "k=15, LM, max 32 iterations, eps_t 0.01, eps_r 2e-3, max_corr_dist 52.5 m, score thr 1.5 (SURVEY App. C)", **rop}
+                extras["reference_operating_point"] = L.get("rop")
             except Exception as ex:                                      # an extra must never cost the headline line
                 extras["extras_error"] = repr(ex)
 
-        # ---- Quatro coarse stage (BASELINE configs[2]): FPFH + optimizedMatching (cap 200) + GNC solve, 30k and 100k pairs from the host
-        quatro = None
-        if world == 1 and not args.no_quatro and not args.no_extras:
-            try:
-                from scipy.spatial import cKDTree
-                quatro = {}
-                for npts in (30000, N_PTS):
-                    qs, qt, _ = synth.make_pair(400 + npts // 1000, npts, mode="quatro")
-                    q = engine.Quatro(ctx)
-                    q.align(qs, qt)
-                    lat = []
-                    for _ in range(5):
-                        tq = time.perf_counter(); Tq, qvalid = q.align(qs, qt); lat.append(1e3 * (time.perf_counter() - tq))
-                    host_wall = {"uploads_grids_enqueue": round(ctx.debug_get("quatro_wall_features_ms"), 3), "fpfh_wait_matching_tail": round(ctx.debug_get("quatro_wall_match_ms"), 3),
-                                 "clique_gnc_solve": round(ctx.debug_get("quatro_wall_solve_ms"), 3)}          # of the last timed align (before the profiled one)
-                    n_surv, n_fb = int(ctx.debug_get("feat_survivors")), int(ctx.debug_get("feat_fallbacks"))
-                    ctx.prof_reset(); ctx.prof_enable(True); q.align(qs, qt); ctx.synchronize(); ctx.prof_enable(False)
-                    st = ctx.prof_stats()
-                    stage = {k: round(st[k][0], 4) for k in ("grid_build", "fpfh_normals", "fpfh_spfh", "fpfh_fpfh", "feat_match", "match_tail") if st[k][1] > 0}
-                    tree = cKDTree(qs.astype(np.float64)); sel = np.random.default_rng(0).choice(len(qs), 4000, replace=False)
-                    m_n = float(np.mean(tree.query_ball_point(qs[sel].astype(np.float64), 0.9, return_length=True)))
-                    m_f = float(np.mean(tree.query_ball_point(qs[sel].astype(np.float64), 1.5, return_length=True)))
-                    ab_q = {"normals": npts * (16 + 16 * m_n + 12), "spfh": npts * (28 + 28 * m_f + 132), "fpfh": npts * (136 * m_f + 132)}     # per cloud, SURVEY 8d
-                    fm_ms = stage.get("feat_match", 0.0)
-                    flops = 2.0 * 33 * npts * npts                                   # forward direction; the lazy reverse search adds the hit fraction
-                    mm_flops = 2.0 * 112 * npts * npts * 1.25                        # what the matrix cores execute for it (K = 112, full pass + 1/4 sample)
-                    e = {"ms_per_align": pct(lat), "valid": bool(qvalid), "stage_ms": stage, "m_n": round(m_n, 1), "m_f": round(m_f, 1),
-                         "algorithmic_bytes_per_cloud": {k: int(v) for k, v in ab_q.items()},
-                         "frac_hbm": {k: round(ab_q[k] * 2 / (stage[s] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) for k, s in (("normals", "fpfh_normals"), ("spfh", "fpfh_spfh"), ("fpfh", "fpfh_fpfh")) if s in stage},
-                         "feat_match": {"bound": "mfma", "kernel": "k_feat_mm<2>", "flops_f16_mfma": mm_flops, "achieved_TF_lower_bound": round(mm_flops / (fm_ms * 1e-3) / 1e12, 1) if fm_ms else None,
-                                        "peak_TF": MFMA_F16_PEAK_TF, "frac_of_mfma_f16_peak": round(mm_flops / (fm_ms * 1e-3) / 1e12 / MFMA_F16_PEAK_TF, 4) if fm_ms else None,
-                                        "effective_f32_TF": round(flops / (fm_ms * 1e-3) / 1e12, 2) if fm_ms else None,
-                                        "survivors_exactly_re_evaluated": n_surv, "fallbacks_to_valu_search": n_fb,
-                                        "note": "screening GEMM on v_mfma_f32_32x32x16_f16: K = 112 (f16 hi/lo split of 33 bins + bound terms), full pass + 1/4 sampled pass, forward search only "
-                                                "(Ns x Nt); time = BOTH searches + de-duplication + operand images + exact stage, so the fraction is a lower bound. effective_f32_TF = 2*33*Ns*Nt / time"},
-                         "host_wall_ms": host_wall}
-                    quatro["%dk" % (npts // 1000)] = e
-            except Exception as ex:
-                quatro = {"error": repr(ex)}
+        quatro = L.get("quatro")
 
         # ---- BASELINE configs[4]: loopTimerFunc replay on a synthetic keyframe stream (tools/replay.py): candidate search, submaps assembled on the
         # device, registration (Nano-GICP scan-to-submap, and Quatro + Nano-GICP scan-to-scan), loop factors into a host pose graph (iSAM2 stand-in)

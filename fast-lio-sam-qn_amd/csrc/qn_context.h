@@ -24,6 +24,7 @@ struct qn_ctx {
   int device = 0;
   uint32_t max_points = 0, max_cells = 0;
   hipStream_t stream = nullptr;
+  void* slab = nullptr;                 // ONE device allocation behind every per-context buffer of the GICP path (qn_ctx_create)
   qn_gicp_params params{};
   CloudBuf cloud[2];
   char* staging = nullptr;              // [max_points * 32] H2D landing zone for strided host clouds
@@ -59,6 +60,9 @@ struct qn_ctx {
   int nn_rounds = 1;                    // rounds of an unseeded NN search before a query goes to the list pass
   int track_from_tick = 3;              // NN passes before this tick search unseeded (ball around the query) instead of tracking the previous neighbour
   int fused_from_tick = 3;
+  int unseeded_until = 3; bool count_far_now = false; int last_extra_unseeded = 0;   // per align: ticks below this index search unseeded; far-query statistics of this pass; the adaptive decision (debug read-back)
+  int single_from_tick = 2;             // the same hand-over for a registration that is alone on the GPU (not a batch member): one tick earlier - the tracked tick is the slower
+                                        // kernel for the large early steps, but it saves four launches and the persistent kernel starts sooner (align 0.506 -> 0.477 ms; batches: 2268 -> 2031 /s)
   bool fused_final = true;              // closing pass (last controller step + fitness sweep + output cloud) in one launch
   int knn_rounds = 2;                   // rounds of the first k-NN pass before a query goes to the list pass
   int knn_hist = 1;                     // 1: k-NN by histogram selection (wave_knn_hist), 0: sorted-list sink (wave_search + BestK)

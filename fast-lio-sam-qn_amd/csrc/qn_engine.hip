@@ -66,15 +66,25 @@ extern "C" void qn_gicp_default_params(qn_gicp_params* p) {
   p->ransac_iterations = 0; p->ransac_outlier_threshold = 0.05; p->euclidean_fitness_epsilon = -DBL_MAX;
 }
 
-static int alloc_cloud(qn_ctx* c, CloudBuf& b) {
-  HIPCHK(c, hipMalloc(&b.raw, sizeof(float4) * c->max_points));
-  HIPCHK(c, hipMalloc(&b.sorted, sizeof(float4) * c->max_points));
-  HIPCHK(c, hipMalloc(&b.sorted_tmp, sizeof(float4) * c->max_points));
-  HIPCHK(c, hipMalloc(&b.cell_of_pt, sizeof(uint32_t) * c->max_points));
-  HIPCHK(c, hipMalloc(&b.cell_start, sizeof(uint32_t) * ((size_t)c->max_cells + 1)));
-  HIPCHK(c, hipMalloc(&b.counts, sizeof(uint32_t) * ((size_t)c->max_cells + 1)));
-  HIPCHK(c, hipMalloc(&b.nrm, sizeof(double) * 3 * c->max_points));
-  return QN_OK;
+// Device memory of a context comes from ONE slab (a single hipMalloc, 2 MiB aligned pieces of it handed out below): fifty separate allocations made late in a
+// process - after another allocator (PyTorch's, a host's own) has fragmented the address space - ended up on small pages, and the gather-heavy kernels paid for
+// it in TLB misses: the same 4-in-flight benchmark gave 1975 registrations/s with the contexts created after the point clouds and 2260 with them created first.
+struct Slab {
+  char* base = nullptr; size_t off = 0, cap = 0;
+  template <class T> void take(T*& p, size_t bytes) {
+    const size_t a = (off + 255) & ~(size_t)255;
+    if (base) p = (T*)(base + a);
+    off = a + bytes;
+  }
+};
+static void carve_cloud(qn_ctx* c, Slab& sl, CloudBuf& b) {
+  sl.take(b.raw, sizeof(float4) * c->max_points);
+  sl.take(b.sorted, sizeof(float4) * c->max_points);
+  sl.take(b.sorted_tmp, sizeof(float4) * c->max_points);
+  sl.take(b.cell_of_pt, sizeof(uint32_t) * c->max_points);
+  sl.take(b.cell_start, sizeof(uint32_t) * ((size_t)c->max_cells + 1));
+  sl.take(b.counts, sizeof(uint32_t) * ((size_t)c->max_cells + 1));
+  sl.take(b.nrm, sizeof(double) * 3 * c->max_points);
 }
 
 extern "C" int qn_ctx_create(int device, uint32_t max_points, qn_ctx** out) {
@@ -92,52 +102,58 @@ extern "C" int qn_ctx_create(int device, uint32_t max_points, qn_ctx** out) {
   auto fail = [&](int code) { qn_ctx_destroy(c); return code; };
   if (hipSetDevice(device) != hipSuccess) return fail(QN_ERR_NO_DEVICE);
   if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) return fail(QN_ERR_HIP);
-  if ((rc = alloc_cloud(c, c->cloud[0])) != QN_OK) return fail(rc);
-  if ((rc = alloc_cloud(c, c->cloud[1])) != QN_OK) return fail(rc);
 #define CA(call) if ((call) != hipSuccess) return fail(QN_ERR_HIP)
-  CA(hipMalloc(&c->staging, (size_t)max_points * 32));
-  CA(hipMalloc(&c->scan_sums, sizeof(uint32_t) * (c->max_cells / (QN_BLOCK * QN_SCAN_ITEMS) + 2)));
-  CA(hipMalloc(&c->bbox, sizeof(BBoxOut)));
-  CA(hipMalloc(&c->state, 2 * sizeof(GicpState)));
-  CA(hipMalloc(&c->partials, 2 * sizeof(double) * (QN_ACC_MAX_BLOCKS + 8) * QN_NPART));
-  CA(hipMalloc(&c->nn_idx, sizeof(int32_t) * max_points));
-  CA(hipMalloc(&c->knn_idx, sizeof(int32_t) * (size_t)max_points * 32));
-  CA(hipMalloc(&c->nn_ref, sizeof(float4) * max_points));
-  CA(hipMalloc(&c->nrm_s_sorted, sizeof(double) * 3 * max_points));
-  CA(hipMalloc(&c->tgt_rec, sizeof(TargetRec) * max_points));
-  CA(hipMalloc(&c->fit_psum, sizeof(double) * (QN_ACC_MAX_BLOCKS + 8)));
-  CA(hipMalloc(&c->fit_pcnt, sizeof(uint32_t) * (QN_ACC_MAX_BLOCKS + 8)));
-  CA(hipMalloc(&c->trace, sizeof(qn_iter_trace) * QN_MAX_TRACE));
-  CA(hipMalloc(&c->corr, sizeof(int32_t) * max_points));
-  CA(hipMalloc(&c->sqd, sizeof(float) * max_points));
-  CA(hipMalloc(&c->sqd_fit, sizeof(float) * max_points));
-  CA(hipMalloc(&c->far_cand, sizeof(int32_t) * QN_FAR_M * (size_t)max_points));
-  CA(hipMalloc(&c->far_cand_ref, sizeof(float4) * max_points));
-  CA(hipMalloc(&c->far_req, sizeof(unsigned long long) * (max_points / 64 + 2)));
-  CA(hipMalloc(&c->far_stats, 4 * sizeof(uint32_t)));
-  CA(hipMalloc(&c->far_rows, sizeof(double) * QN_FAR_BLOCKS * QN_NPART));
+  auto carve = [&](Slab& sl) {
+    carve_cloud(c, sl, c->cloud[0]);
+    carve_cloud(c, sl, c->cloud[1]);
+    sl.take(c->staging, (size_t)max_points * 32);
+    sl.take(c->scan_sums, sizeof(uint32_t) * (c->max_cells / (QN_BLOCK * QN_SCAN_ITEMS) + 2));
+    sl.take(c->bbox, sizeof(BBoxOut));
+    sl.take(c->state, 2 * sizeof(GicpState));
+    sl.take(c->partials, 2 * sizeof(double) * (QN_ACC_MAX_BLOCKS + 8) * QN_NPART);
+    sl.take(c->nn_idx, sizeof(int32_t) * max_points);
+    sl.take(c->knn_idx, sizeof(int32_t) * (size_t)max_points * 32);
+    sl.take(c->nn_ref, sizeof(float4) * max_points);
+    sl.take(c->nrm_s_sorted, sizeof(double) * 3 * max_points);
+    sl.take(c->tgt_rec, sizeof(TargetRec) * max_points);
+    sl.take(c->fit_psum, sizeof(double) * (QN_ACC_MAX_BLOCKS + 8));
+    sl.take(c->fit_pcnt, sizeof(uint32_t) * (QN_ACC_MAX_BLOCKS + 8));
+    sl.take(c->trace, sizeof(qn_iter_trace) * QN_MAX_TRACE);
+    sl.take(c->corr, sizeof(int32_t) * max_points);
+    sl.take(c->sqd, sizeof(float) * max_points);
+    sl.take(c->sqd_fit, sizeof(float) * max_points);
+    sl.take(c->far_cand, sizeof(int32_t) * QN_FAR_M * (size_t)max_points);
+    sl.take(c->far_cand_ref, sizeof(float4) * max_points);
+    sl.take(c->far_req, sizeof(unsigned long long) * (max_points / 64 + 2));
+    sl.take(c->far_stats, 4 * sizeof(uint32_t));
+    sl.take(c->far_rows, sizeof(double) * QN_FAR_BLOCKS * QN_NPART);
+    sl.take(c->fb_list, sizeof(uint2) * max_points);
+    sl.take(c->big_list, sizeof(uint2) * max_points);
+    sl.take(c->fb_count2, 4 * sizeof(uint32_t));
+    sl.take(c->aligned, sizeof(float4) * max_points);
+    sl.take(c->pose_tmp, sizeof(double) * 16);
+    sl.take(c->guess_tmp, sizeof(float) * 16);
+    // scratch of the second stream (TargetScope): scan sums, k-NN lists and index table, bounding box; then the persistent kernel's hand-off buffers
+    sl.take(c->scan_sums2, sizeof(uint32_t) * (c->max_cells / (QN_BLOCK * QN_SCAN_ITEMS) + 2));
+    sl.take(c->fb_list2, sizeof(uint2) * max_points);
+    sl.take(c->big_list2, sizeof(uint2) * max_points);
+    sl.take(c->fb_count2b, 4 * sizeof(uint32_t));
+    sl.take(c->knn_idx2, sizeof(int32_t) * (size_t)max_points * 32);
+    sl.take(c->bbox2, sizeof(BBoxOut));
+    sl.take(c->pg_rows, sizeof(unsigned long long) * 3 * QN_PERSIST_ROWS * QN_PERSIST_RSTRIDE);
+    sl.take(c->pg_bc, sizeof(unsigned long long) * 64);
+    sl.take(c->pg_fit, sizeof(unsigned long long) * (QN_PERSIST_MAX_BLOCKS + 1) * 4);
+    sl.take(c->pg_status, 4 * sizeof(uint32_t));
+  };
+  { Slab dry; carve(dry);                                             // pass 1: the size; pass 2: the pointers
+    Slab sl; sl.cap = (dry.off + ((size_t)2 << 20) - 1) & ~(((size_t)2 << 20) - 1);
+    CA(hipMalloc(&c->slab, sl.cap)); sl.base = (char*)c->slab; carve(sl); }
   CA(hipMemsetAsync(c->far_stats, 0, 4 * sizeof(uint32_t), c->stream));
-  CA(hipMalloc(&c->fb_list, sizeof(uint2) * max_points));
-  CA(hipMalloc(&c->big_list, sizeof(uint2) * max_points));
-  CA(hipMalloc(&c->fb_count2, 4 * sizeof(uint32_t)));
-  CA(hipMalloc(&c->aligned, sizeof(float4) * max_points));
-  CA(hipMalloc(&c->pose_tmp, sizeof(double) * 16));
-  CA(hipMalloc(&c->guess_tmp, sizeof(float) * 16));
   CA(hipHostMalloc(&c->result_host, sizeof(ResultBlock), hipHostMallocDefault));
   CA(hipHostMalloc(&c->bbox_host, sizeof(BBoxOut), hipHostMallocDefault));
   CA(hipHostMalloc(&c->scalar_host, 64 * sizeof(double), hipHostMallocDefault));
   // scratch of the second stream (TargetScope): scan sums, k-NN lists and index table, bounding box
-  CA(hipMalloc(&c->scan_sums2, sizeof(uint32_t) * (c->max_cells / (QN_BLOCK * QN_SCAN_ITEMS) + 2)));
-  CA(hipMalloc(&c->fb_list2, sizeof(uint2) * max_points));
-  CA(hipMalloc(&c->big_list2, sizeof(uint2) * max_points));
-  CA(hipMalloc(&c->fb_count2b, 4 * sizeof(uint32_t)));
-  CA(hipMalloc(&c->knn_idx2, sizeof(int32_t) * (size_t)max_points * 32));
-  CA(hipMalloc(&c->bbox2, sizeof(BBoxOut)));
   CA(hipHostMalloc(&c->bbox_host2, sizeof(BBoxOut), hipHostMallocDefault));
-  CA(hipMalloc(&c->pg_rows, sizeof(unsigned long long) * 3 * QN_PERSIST_ROWS * QN_PERSIST_RSTRIDE));
-  CA(hipMalloc(&c->pg_bc, sizeof(unsigned long long) * 64));
-  CA(hipMalloc(&c->pg_fit, sizeof(unsigned long long) * (QN_PERSIST_MAX_BLOCKS + 1) * 4));
-  CA(hipMalloc(&c->pg_status, 4 * sizeof(uint32_t)));
   CA(hipHostMalloc(&c->pg_status_host, 4 * sizeof(uint32_t), hipHostMallocDefault));
   CA(hipMemsetAsync(c->pg_rows, 0xFF, sizeof(unsigned long long) * 3 * QN_PERSIST_ROWS * QN_PERSIST_RSTRIDE, c->stream));      // every slot = QN_PERSIST_SENTINEL
   CA(hipMemsetAsync(c->pg_bc, 0, sizeof(unsigned long long) * 64, c->stream));
@@ -156,20 +172,18 @@ extern "C" void qn_ctx_destroy(qn_ctx* c) {
   if (c->stream) hipStreamSynchronize(c->stream);
   if (c->stream2) hipStreamSynchronize(c->stream2);                     // a target may still be in preparation there (TargetScope)
   c->prof_collect();
-  for (int w = 0; w < 2; w++) { CloudBuf& b = c->cloud[w]; hipFree(b.raw); hipFree(b.sorted); hipFree(b.sorted_tmp); hipFree(b.cell_of_pt); hipFree(b.cell_start); hipFree(b.counts); hipFree(b.nrm); }
-  hipFree(c->staging); hipFree(c->scan_sums); hipFree(c->bbox); hipFree(c->state); hipFree(c->partials); hipFree(c->trace);
-  hipFree(c->nn_idx); hipFree(c->knn_idx); hipFree(c->nn_ref); hipFree(c->nrm_s_sorted); hipFree(c->tgt_rec); hipFree(c->fit_psum); hipFree(c->fit_pcnt); hipFree(c->corr); hipFree(c->sqd); hipFree(c->sqd_fit); hipFree(c->far_cand); hipFree(c->far_cand_ref); hipFree(c->far_req); hipFree(c->far_stats); hipFree(c->far_rows); hipFree(c->fb_list); hipFree(c->big_list); hipFree(c->fb_count2); hipFree(c->aligned);
+  hipFree(c->slab);                                                      // every per-context device buffer of the GICP path lives in it (qn_ctx_create)
   hipFree(c->q_mm_c); hipFree(c->q_mm_q); hipFree(c->q_mm_qn); hipFree(c->q_mm_L); hipFree(c->q_mm_table); hipFree(c->q_mm_pairs); hipFree(c->q_mm_cnt); hipFree(c->q_mm_vkeys); hipFree(c->q_mm_vcnt);
   for (int w = 0; w < 2; w++) { hipFree(c->q_normals[w]); hipFree(c->q_spfh[w]); hipFree(c->q_fpfh_s[w]); hipFree(c->q_fpfh[w]); hipFree(c->q_key[w]); hipFree(c->q_pair[w]); hipFree(c->q_pair_hash[w]); }
   hipFree(c->q_hit); hipFree(c->q_list); hipFree(c->q_sel); hipFree(c->q_pairs); hipFree(c->q_counts); hipFree(c->q_T); hipFree(c->q_mean); hipFree(c->q_mean_psum);
   if (c->q_host) hipHostFree(c->q_host);
-  hipFree(c->pose_tmp); hipFree(c->guess_tmp); hipFree(c->dbg_knn_idx); hipFree(c->dbg_knn_d2); hipFree(c->dbg_counters);
+  hipFree(c->dbg_knn_idx); hipFree(c->dbg_knn_d2); hipFree(c->dbg_counters);
   hipFree(c->v_corr); hipFree(c->v_nn_idx); hipFree(c->v_sqd); hipFree(c->v_nn_ref); hipFree(c->v_counters);
   if (c->result_host) hipHostFree(c->result_host);
   if (c->bbox_host) hipHostFree(c->bbox_host);
   if (c->scalar_host) hipHostFree(c->scalar_host);
-  hipFree(c->pg_clk); hipFree(c->pg_rows); hipFree(c->pg_bc); hipFree(c->pg_fit); hipFree(c->pg_status); if (c->pg_status_host) hipHostFree(c->pg_status_host);
-  hipFree(c->scan_sums2); hipFree(c->fb_list2); hipFree(c->big_list2); hipFree(c->fb_count2b); hipFree(c->knn_idx2); hipFree(c->bbox2); if (c->bbox_host2) hipHostFree(c->bbox_host2);
+  hipFree(c->pg_clk); if (c->pg_status_host) hipHostFree(c->pg_status_host);
+  if (c->bbox_host2) hipHostFree(c->bbox_host2);
   if (c->ev_pair) hipEventDestroy(c->ev_pair);
   if (c->stream2) { hipStreamSynchronize(c->stream2); hipStreamDestroy(c->stream2); }
   if (c->stream) hipStreamDestroy(c->stream);
@@ -397,9 +411,10 @@ static void enqueue_nn(qn_ctx* c, int mode /*0 align, 1 fitness*/, float* sqd_ou
   const double thr2 = c->params.max_corr_dist * c->params.max_corr_dist;
   GicpState* st = st_cur(c);
   uint32_t* fbc = &st->fb_count; uint32_t* bgc = &st->big_count;
-  uint32_t* far_stats = (mode == 0 && !seeded && tick == std::max(1, std::min(c->track_from_tick, c->fused_from_tick)) - 1) ? c->far_stats : nullptr;
-  const int big_blocks = tick <= 2 ? c->big_blocks0 : 1024;                                           // waves with one far query each (idle blocks exit at once)
-  const uint32_t fbb = std::min<uint32_t>(nb4, tick <= 2 ? (uint32_t)c->fb_blocks0 : 256u);                     // list pass: wave-stride over the leftovers
+  uint32_t* far_stats = (mode == 0 && !seeded && c->count_far_now) ? c->far_stats : nullptr;      // the LAST unseeded pass before the host's look (the clouds are best aligned then)
+  const bool wide = tick <= 2 || (mode == 0 && !seeded);                                              // every unseeded pass of an align leaves thousands of queries to the lists, whatever its index
+  const int big_blocks = wide ? c->big_blocks0 : 1024;                                                // waves with one far query each (idle blocks exit at once)
+  const uint32_t fbb = std::min<uint32_t>(nb4, wide ? (uint32_t)c->fb_blocks0 : 256u);                           // list pass: wave-stride over the leftovers
   const float r0 = (tick == 0 && mode == 0 && c->margin_nn_t0 > 0.f ? c->margin_nn_t0 : c->margin_nn) * T.grid.cell;
   if (mode == 0) {
     { ProfScope ps(c, QN_K_NN_SEARCH);
@@ -444,7 +459,7 @@ static void enqueue_solve(qn_ctx* c, int mode, int will_produce) {
   ProfScope ps(c, QN_K_SOLVE);
   if (c->tick_tb == 256) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_solve<256>), dim3(1), dim3(256), 0, c->stream, st_cur(c), st_nxt(c), part_cur(c), c->part_rows, make_cfg(c), c->trace, mode, will_produce);
   else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_solve<512>), dim3(1), dim3(512), 0, c->stream, st_cur(c), st_nxt(c), part_cur(c), c->part_rows, make_cfg(c), c->trace, mode, will_produce);
-  c->gen++;
+  c->gen++; c->part_rows = -1;                                      // consumed: whatever controller comes next (k_tick's prologue, the persistent kernel, another k_solve) must not step again
 }
 // One "tick" of the device-side state machine = [controller step on the previous tick's partial rows] + [body under the new state].
 // Tracked regime: ONE kernel (k_tick: controller in the prologue of every block, tracked NN + accumulation, LM trial passes included).
@@ -484,9 +499,10 @@ static void enqueue_tick_fused(qn_ctx* c) {
 }
 // Unseeded regime (the first outer iterations, while the pose still moves by more than a few cells): controller launch, grid search +
 // list passes, accumulation.  `first`: the very first tick of an align has nothing to consume.
-static void enqueue_tick(qn_ctx* c, bool seeded, int tick, bool first) {
-  if (tick < c->track_from_tick) seeded = false;
-  if (seeded && tick >= c->fused_from_tick && c->fused_ticks) { enqueue_tick_fused(c); return; }
+static void enqueue_tick(qn_ctx* c, bool seeded, int tick_no, bool first) {
+  const int per_outer = c->params.optimizer == QN_OPT_LM ? 2 : 1, tick = tick_no / per_outer;      // tick = outer iteration (list-pass grid sizes)
+  if (tick_no < c->unseeded_until) seeded = false;
+  if (seeded && c->fused_ticks) { enqueue_tick_fused(c); return; }
   if (!first) enqueue_solve(c, 0, 1);
   enqueue_nn(c, 0, c->sqd, seeded, tick);
   if (c->verify_track && seeded) enqueue_verify(c, false);
@@ -583,11 +599,20 @@ static int gicp_align(qn_ctx* c, const float guess[16], qn_gicp_result* out, boo
   // Ticks are enqueued in chunks with NO host round trip inside a chunk; kernels of ticks past
   // convergence exit on the `phase` word.  LM needs two ticks per outer iteration (linearize, trial error).
   const int per_outer = p.optimizer == QN_OPT_LM ? 2 : 1;
-  // Chunks: [the unseeded ticks] -> host looks at how many source points have a FAR neighbour (no overlap there / occlusion) and decides
-  // whether the tracked ticks get the refresh kernel (k_far) behind them -> [a few tracked ticks] -> [the rest], re-deciding at every
-  // chunk end from the refresh requests actually seen.  One more stream synchronisation per align (~15 us) buys a 4x faster
-  // registration of partially overlapping clouds and keeps the extra launch out of the chain when nobody needs it.
-  const int unseeded = std::max(1, std::min(c->track_from_tick, c->fused_from_tick)) * per_outer;
+  // Chunks: [the unseeded ticks] -> ONE host look at the state -> [everything else].  The look decides (i) whether the tracked ticks get the far-query refresh
+  // kernel (k_far) behind them: how many source points have a FAR neighbour (no overlap there / occlusion) - a 4x faster registration of partially overlapping
+  // clouds, and no extra launch in the chain when nobody needs it; (ii) for a registration that is alone on the GPU, WHEN tracking takes over.  A tracked tick
+  // re-finds every neighbour inside the ball of its previous one: cheap when the pose step before it moved the points by less than half a cell, several times
+  // the cost of the dedicated unseeded search when it moved them by metres (a 10-degree initial yaw error moves the far end of a 120 m scene by 10 m, and the
+  // second step still by 0.5-2 m).  The steps shrink by 10x or more per iteration, so after two unseeded iterations and the controller step that follows them
+  // (step_dt / step_dr in the result block) the host knows whether a third one should run unseeded as well.  A batch member keeps the fixed three (other
+  // streams fill the chip; measured best for throughput).
+  // (only runs that are known to be long pay for the look - a forced iteration count: with the real stopping rule the reference's operating point converges in
+  //  3-7 iterations, and the extra round trip cost it 0.03-0.07 ms; knob single_from_tick = 0: the fixed hand-over everywhere; an explicitly earlier one wins too)
+  const bool adaptive = !c->persist_batch_off && c->fused_ticks && c->far_enabled && c->single_from_tick > 0 && p.force_iterations > 0 && p.optimizer == QN_OPT_GN && maxit >= 8 &&
+                        std::min(c->track_from_tick, c->fused_from_tick) > c->single_from_tick;
+  const int fixed_unseeded = std::max(1, std::min(c->track_from_tick, c->fused_from_tick)) * per_outer;
+  const int unseeded = adaptive ? std::max(1, std::min(fixed_unseeded / per_outer, c->single_from_tick)) * per_outer : fixed_unseeded;
   // The number of ticks is known in advance only for forced Gauss-Newton runs (one tick per iteration).  A forced LM run needs one more tick
   // per rejected trial step, so it is driven like an unforced one: chunks until the device reports `done`, bounded by `budget`.
   const bool exact_ticks = p.force_iterations > 0 && p.optimizer == QN_OPT_GN;
@@ -596,10 +621,17 @@ static int gicp_align(qn_ctx* c, const float guess[16], qn_gicp_result* out, boo
   bool first_chunk = true;
   long budget = (long)maxit * (p.optimizer == QN_OPT_LM ? (p.lm_max_iterations + 1) : 1) + 2;
   c->result_host->phase = 0;
+  c->unseeded_until = adaptive ? chunk : fixed_unseeded;           // ticks below this index search unseeded (enqueue_tick)
   bool seeded = false; int tick_no = 0;   // the first linearisation runs the full grid search; every later NN pass tracks from it
   for (;;) {
-    for (int t = 0; t < chunk; t++) { enqueue_tick(c, seeded, tick_no / per_outer, tick_no == 0); tick_no++; seeded = true; }
-    if (exact_ticks && ticks_left > chunk) {                      // forced GN iterations cannot be done yet: only the statistics block is needed at this chunk end
+    for (int t = 0; t < chunk; t++) {
+      c->count_far_now = first_chunk && (t / per_outer == (chunk - 1) / per_outer);      // far-query statistics: the chunk's last unseeded linearisation
+      enqueue_tick(c, seeded, tick_no, tick_no == 0 || c->part_rows < 0); tick_no++; seeded = true;
+    }
+    c->count_far_now = false;
+    const bool look = adaptive && first_chunk && ticks_left > chunk;      // the adaptive look: the controller step behind the chunk's last tick, then the state
+    if (look) enqueue_solve(c, 0, 1);
+    if (look || (exact_ticks && ticks_left > chunk)) {            // forced GN iterations cannot be done yet: only the statistics block is needed at this chunk end
       hipLaunchKernelGGL(k_finalize, dim3(1), dim3(64), 0, s, st_cur(c), c->result_host, c->far_stats);
     } else {
       enqueue_epilogue(c, DBL_MAX, maxit > 0 && tick_no > 0);
@@ -607,7 +639,14 @@ static int gicp_align(qn_ctx* c, const float guess[16], qn_gicp_result* out, boo
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipStreamSynchronize(s));
     budget -= std::max(chunk, 1); ticks_left -= chunk;
-    if (c->result_host->phase == 2) break;
+    if (c->result_host->phase == 2) {
+      if (!look) break;
+      enqueue_epilogue(c, DBL_MAX, true);                          // the look's controller step finished the state machine: the closing pass is still to run
+      HIPCHK(c, hipGetLastError());
+      HIPCHK(c, hipStreamSynchronize(s));
+      if (c->result_host->phase == 2) break;
+      c->last_error = "align: closing pass did not complete"; return QN_ERR_HIP;
+    }
     // far queries: keep the refresh kernel in the chain only while ticks actually ask for refreshes (a launch costs ~4 us per tick)
     if (c->far_enabled) {
       const qn::ResultBlock* rb = c->result_host;
@@ -617,6 +656,24 @@ static int gicp_align(qn_ctx* c, const float guess[16], qn_gicp_result* out, boo
     if (!exact_ticks) chunk = first_chunk ? c->ticks_per_chunk : std::max(2 * per_outer, c->ticks_per_chunk / 2);   // convergence is usually near after the first chunks: ticks past it are wasted launches
     else chunk = first_chunk && c->far_mode == 1 ? std::min(ticks_left, c->ticks_per_chunk) : ticks_left;
     if (budget <= 0) { c->last_error = "align: device state machine did not terminate"; return QN_ERR_HIP; }
+    if (look) {
+      // how far the NEXT step will move the source points at most: the step just taken (translation + rotation x the cloud's reach from the origin), shrunk
+      // by 10 (what the optimiser does per iteration at this stage, measured on the synthetic pairs: 12x - 50x)
+      const GridView& sg = c->cloud[0].grid;
+      double reach2 = 0; const double lo[3] = {sg.ox, sg.oy, sg.oz}, ext[3] = {sg.nx * (double)sg.cell, sg.ny * (double)sg.cell, sg.nz * (double)sg.cell};
+      for (int d = 0; d < 3; d++) { const double m = std::max(std::fabs(lo[d]), std::fabs(lo[d] + ext[d])); reach2 += m * m; }
+      const double moved = c->result_host->step_dt + c->result_host->step_dr * std::sqrt(reach2), ok = 0.4 * (double)c->cloud[1].grid.cell;
+      // (one more unseeded iteration at most: a fourth one measured slower than the tracked tick it replaces - at a nearly converged pose the list pass ends with a
+      // few one-per-wave far queries of 100-300 us each, tools/gpu_probe_lists4.py - so a large second step hands over at iteration 3 like the fixed schedule)
+      int extra = moved <= ok ? 0 : 1;
+      extra = std::min(extra * per_outer, std::max(0, std::min(ticks_left - 1, per_outer)));
+      if (!(moved == moved)) extra = 0;
+      c->unseeded_until = tick_no + extra;
+      for (int t = 0; t < extra; t++) { enqueue_tick(c, seeded, tick_no, c->part_rows < 0); tick_no++; }
+      budget -= extra; ticks_left -= extra;
+      if (exact_ticks) chunk = c->far_mode == 1 ? std::min(ticks_left, c->ticks_per_chunk) : ticks_left;
+      c->last_extra_unseeded = extra;
+    }
     if (first_chunk && tick_no > 0 && persist_usable(c, alone)) {          // everything that is left - ticks, closing pass, result - in ONE persistent launch
       if ((rc = launch_persist(c, (uint32_t)budget + 2u)) != QN_OK) return rc;
       HIPCHK(c, hipGetLastError());
@@ -849,6 +906,7 @@ extern "C" int qn_debug_set(qn_ctx* c, const char* key, double v) {
   else if (k == "knn_hist") c->knn_hist = v != 0;
   else if (k == "nn_rounds") c->nn_rounds = v < 1 ? 1 : (int)v;
   else if (k == "track_from_tick") c->track_from_tick = v < 1 ? 1 : (int)v;
+  else if (k == "single_from_tick") c->single_from_tick = v < 1 ? 1 : (int)v;
   else if (k == "fused_from_tick") c->fused_from_tick = v < 1 ? 1 : (int)v;
   else if (k == "knn_rounds") c->knn_rounds = v < 1 ? 1 : (int)v;
   else if (k == "fused_ticks") c->fused_ticks = v != 0;
@@ -914,6 +972,7 @@ extern "C" int qn_debug_get(qn_ctx* c, const char* key, double* value) {
   if (k == "quatro_wall_features_ms") { *value = c->q_wall_ms[0]; return QN_OK; }   // host wall clock of the latest Quatro align, by section
   if (k == "quatro_wall_match_ms") { *value = c->q_wall_ms[1]; return QN_OK; }
   if (k == "quatro_wall_solve_ms") { *value = c->q_wall_ms[2]; return QN_OK; }
+  if (k == "extra_unseeded") { *value = c->last_extra_unseeded; return QN_OK; }          // the adaptive hand-over's decision in the latest align (ticks)
   if (k == "persist_launches") { *value = c->persist_launches; return QN_OK; }      // aligns of this context that ran the persistent kernel
   if (k == "feat_fallbacks") { *value = c->feat_fallbacks; return QN_OK; }      // matrix-core feature searches repeated with the VALU kernel (survivor overflow)
   if (k == "feat_survivors") { *value = c->feat_survivors; return QN_OK; }      // survivors of the latest forward search (exactly re-evaluated pairs)

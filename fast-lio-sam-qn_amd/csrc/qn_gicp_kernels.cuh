@@ -297,7 +297,16 @@ __global__ void __launch_bounds__(BLOCK, 6) k_nn_search(GridView src, GridView t
           if (B <= prev_d + 3.f * tgt.cell) r = B * 1.000002f + 2.f * tgt.eps;           // (an entry from elsewhere in the cloud: the bound is worthless, keep the growth rounds)
         }
         unsigned long long key; float second, d_unseen;
+#ifdef QN_DBG_LIST_TIMING                                                // developer build only (tools/gpu_probe_lists4.py): the slowest one-per-wave entry of the launches so far
+        const unsigned long long dbg_t0 = tgt.dbg ? wall_clock64() : 0ull;
+#endif
         wave_search_single(tgt, qx, qy, qz, r, __int_as_float(0x7f800000), key, second, d_unseen, &lds[threadIdx.x >> 6]);
+#ifdef QN_DBG_LIST_TIMING
+        if (tgt.dbg && (threadIdx.x & 63) == 0) {
+          const uint32_t dt = (uint32_t)(wall_clock64() - dbg_t0);
+          if (atomicMax(&tgt.dbg[10], dt) < dt) { tgt.dbg[11] = rec.x; tgt.dbg[12] = __float_as_uint(r); tgt.dbg[13] = key != QN_INF_KEY ? __float_as_uint(sqrtf(key_d2(key))) : 0xffffffffu; tgt.dbg[14] = __float_as_uint(qx); tgt.dbg[15] = __float_as_uint(qy); }
+        }
+#endif
         prev = key; prev_d = key != QN_INF_KEY ? sqrtf(key_d2(key)) : 0.f;
         if ((threadIdx.x & 63) == 0) {
           store_nn<MODE>(key, __float_as_uint(p.w), rec.x, thr2, corr, sqd, nn_idx);
@@ -848,7 +857,7 @@ static __global__ void __launch_bounds__(NT) k_solve(const GicpState* __restrict
   for (int i = threadIdx.x; i < (int)(sizeof(GicpState) / 8); i += NT) ((unsigned long long*)&sh)[i] = ((const unsigned long long*)st_in)[i];
   __syncthreads();
   const int phase = sh.phase;
-  if (mode != 0 || (sh.pending && phase != 2)) {
+  if (mode != 0 || (sh.pending && phase != 2 && rows >= 0)) {        // rows < 0: the pending rows were consumed by an earlier stand-alone controller step
     reduce_partial_rows<NT>(partials, rows, part8, sums);
     if (threadIdx.x == 0) solve_controller(&sh, sums, cfg, trace, mode, phase, Awork);
   }
@@ -919,7 +928,7 @@ static __global__ void k_transform_cloud(const float4* __restrict__ in, uint32_t
   out[i] = make_float4(x, y, z, 1.0f);
 }
 
-struct ResultBlock { qn_gicp_result r; int32_t phase; uint32_t trace_len; uint32_t far_requests, far_misses, far_queries, pad; };
+struct ResultBlock { qn_gicp_result r; int32_t phase; uint32_t trace_len; uint32_t far_requests, far_misses, far_queries, pad; double step_dt, step_dr; };   // step_*: max |t| and max |R - I| of the latest pose step (host: hand-over policy)
 
 static __global__ void k_finalize(const GicpState* __restrict__ st, ResultBlock* out, uint32_t* __restrict__ far_stats) {   // out lives in pinned host memory
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
@@ -930,6 +939,9 @@ static __global__ void k_finalize(const GicpState* __restrict__ st, ResultBlock*
   for (int i = 0; i < 36; i++) out->r.H[i] = st->final_H[i];
   out->r.fitness = st->fitness; out->r.iterations = st->outer; out->r.converged = st->converged; out->r.lm_failed = st->lm_failed; out->r.reserved = 0;
   out->phase = st->phase; out->trace_len = st->trace_len;
+  double mr = 0, mt = 0;
+  for (int a = 0; a < 3; a++) { for (int b = 0; b < 3; b++) mr = fmax(mr, fabs(st->delta[4 * a + b] - (a == b ? 1.0 : 0.0))); mt = fmax(mt, fabs(st->delta[4 * a + 3])); }
+  out->step_dt = mt; out->step_dr = mr;
 }
 
 }  // namespace qn

@@ -144,7 +144,7 @@ __global__ void __launch_bounds__(TB, TB / 256) k_align_persist(PersistArgs A) {
         if (tid == 0 && !bc_fail) {
           if (PROBE && g < 64) A.clk[16 * g + 1] = wall_clock64();
           const int phase_in = sh.phase;
-          if (sh.pending && phase_in != 2) solve_controller(&sh, sums, a.cfg, a.trace, 0, phase_in, &Awork_s);
+          if (sh.pending && phase_in != 2 && (g > 0 || a.rows_in >= 0)) solve_controller(&sh, sums, a.cfg, a.trace, 0, phase_in, &Awork_s);      // (rows_in < 0: the launch starts behind a stand-alone controller step)
           sh.fb_count = 0; sh.big_count = 0; sh.pending = sh.phase != 2 ? 1 : 0;
           if (g + 1 >= A.max_ticks && sh.phase != 2) { atomicCAS(A.status, 0u, 2u); bc_fail = 1; }
           bc_phase = sh.phase;

@@ -26,7 +26,7 @@ struct TickArgs {
   GridView src, tgt;
   const GicpState* st_in; GicpState* st_out;
   const double* part_in; double* part_out;
-  int rows_in;                         // rows of part_in written by the previous producer (read only when st_in->pending)
+  int rows_in;                         // rows of part_in written by the previous producer (read only when st_in->pending); < 0: a stand-alone controller step consumed them already
   GicpConfig cfg;
   qn_iter_trace* trace;
   double thr2;
@@ -483,7 +483,7 @@ __global__ void __launch_bounds__(TB, OCC) k_tick(TickArgs a) {
   reduce_partial_rows<TB>(a.part_in, a.rows_in, part8, sums);        // (rows of a state that is not pending are summed and ignored: rows_in is what matters)
   if (probe) a.clk[1] = wall_clock64();
   const int pending = sh.pending, phase_in = sh.phase;
-  if (pending && phase_in != 2 && tid == 0) solve_controller(&sh, sums, a.cfg, blockIdx.x == 0 ? a.trace : nullptr, 0, phase_in, Awork);
+  if (pending && phase_in != 2 && a.rows_in >= 0 && tid == 0) solve_controller(&sh, sums, a.cfg, blockIdx.x == 0 ? a.trace : nullptr, 0, phase_in, Awork);      // (rows_in < 0: already consumed by a stand-alone k_solve)
   if (PROBE) {
     if (probe) a.clk[2] = wall_clock64();
     if (MODE == 0 && threadIdx.x == 0) a.clk_blk[8 * blockIdx.x + 1] = wall_clock64();
