@@ -26,6 +26,19 @@ __global__ void k_kf_transform(const float4* __restrict__ in, uint32_t n, const 
   out[i] = make_float4((float)(((T[0] * x + T[1] * y) + T[2] * z) + T[3]), (float)(((T[4] * x + T[5] * y) + T[6] * z) + T[7]),
                        (float)(((T[8] * x + T[9] * y) + T[10] * z) + T[11]), 1.0f);
 }
+// pcl::VoxelGrid on a cloud that is not dense (utilities.hpp:38-51 -> pcl::VoxelGrid::applyFilter: `if (!input_->is_dense) if (!isXYZFinite(p)) continue;`,
+// getMinMax3D skips them as well): non-finite points take no part - they are dropped by a stable compaction (flag, exclusive scan, scatter).
+__global__ void k_finite_flags(const float4* __restrict__ pts, uint32_t n, uint32_t* __restrict__ flag) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float4 p = pts[i];
+  flag[i] = (isfinite(p.x) && isfinite(p.y) && isfinite(p.z)) ? 1u : 0u;
+}
+__global__ void k_compact_finite(const float4* __restrict__ pts, uint32_t n, const uint32_t* __restrict__ flag, const uint32_t* __restrict__ pos, float4* __restrict__ out) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  if (flag[i]) out[pos[i]] = pts[i];
+}
 struct VoxelDims { float inv; int minb[3]; int div0, div01; };
 __global__ void k_voxel_keys(const float4* __restrict__ pts, uint32_t n, VoxelDims d, unsigned long long* __restrict__ keys) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -182,7 +195,7 @@ extern "C" int qn_kf_assemble(qn_kf_store* s, const int32_t* ids, const double* 
     if (n) hipLaunchKernelGGL(qn::k_kf_transform, dim3((n + 255) / 256), dim3(256), 0, st, s->clouds[ids[k]], n, s->poses + 16 * k, s->concat + off);
     off += n;
   }
-  const uint32_t n = (uint32_t)total;
+  uint32_t n = (uint32_t)total;
   // pcl::VoxelGrid::applyFilter: bounds, leaf indices
   qn::BBoxOut init; for (int d = 0; d < 3; d++) { init.mn[d] = 0x7fffffff; init.mx[d] = (int)0x80000000; } init.nonfinite = 0;
   *s->bbox_host = init;
@@ -190,7 +203,22 @@ extern "C" int qn_kf_assemble(qn_kf_store* s, const int32_t* ids, const double* 
   hipLaunchKernelGGL(qn::k_bbox, dim3(std::min<uint32_t>((n + QN_BLOCK - 1) / QN_BLOCK, 128)), dim3(QN_BLOCK), 0, st, s->concat, n, s->bbox);
   KFCHK(s, hipMemcpyAsync(s->bbox_host, s->bbox, sizeof(qn::BBoxOut), hipMemcpyDeviceToHost, st));
   KFCHK(s, hipStreamSynchronize(st));
-  if (s->bbox_host->nonfinite) { s->last_error = "assembled cloud contains non-finite coordinates"; return QN_ERR_INVALID_ARG; }
+  if (s->bbox_host->nonfinite) {                                  // rare path: drop the non-finite points like pcl::VoxelGrid does for a non-dense cloud (order of the others kept)
+    const uint32_t nbf = (n + 255) / 256, sbf = (n + QN_BLOCK * QN_SCAN_ITEMS - 1) / (QN_BLOCK * QN_SCAN_ITEMS);
+    hipLaunchKernelGGL(qn::k_finite_flags, dim3(nbf), dim3(256), 0, st, s->concat, n, s->flag);
+    hipLaunchKernelGGL(qn::k_scan_block, dim3(sbf), dim3(QN_BLOCK), 0, st, s->flag, n, s->pos, s->sums);
+    hipLaunchKernelGGL(qn::k_scan_top, dim3(1), dim3(QN_BLOCK), 0, st, s->sums, sbf);
+    hipLaunchKernelGGL(qn::k_scan_add_total, dim3(sbf), dim3(QN_BLOCK), 0, st, s->pos, n, s->sums, s->flag);
+    if (n > s->out_cap[slot]) { (void)hipFree(s->out[slot]); s->out[slot] = nullptr; s->out_cap[slot] = 0; KFCHK(s, hipMalloc(&s->out[slot], sizeof(float4) * (n + n / 2))); s->out_cap[slot] = n + n / 2; }
+    hipLaunchKernelGGL(qn::k_compact_finite, dim3(nbf), dim3(256), 0, st, (const float4*)s->concat, n, (const uint32_t*)s->flag, (const uint32_t*)s->pos, s->out[slot]);      // (the output slot as scratch)
+    uint32_t kept = 0;
+    KFCHK(s, hipMemcpyAsync(&kept, s->pos + n, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    KFCHK(s, hipStreamSynchronize(st));
+    if (kept == 0) return QN_ERR_EMPTY_CLOUD;
+    KFCHK(s, hipMemcpyAsync(s->concat, s->out[slot], sizeof(float4) * kept, hipMemcpyDeviceToDevice, st));
+    n = kept;
+    s->last_error = "note: non-finite points dropped (pcl::VoxelGrid on a non-dense cloud)";
+  }
   qn::VoxelDims vd; vd.inv = 1.0f / (float)leaf;
   long long cells = 1; int divb[3];
   for (int d = 0; d < 3; d++) {

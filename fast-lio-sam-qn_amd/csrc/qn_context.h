@@ -37,7 +37,7 @@ struct qn_ctx {
   qn_iter_trace* trace = nullptr; uint32_t trace_len = 0;
   int32_t* corr = nullptr; int32_t* nn_idx = nullptr; int32_t* knn_idx = nullptr; float4* nn_ref = nullptr; double* nrm_s_sorted = nullptr; qn::TargetRec* tgt_rec = nullptr; float* sqd = nullptr; float* sqd_fit = nullptr;
   // far queries (qn_tick.cuh): candidate cache, refresh request bits, counters; far_mode: 0 off, 1 refresh kernel after every tick, 2 cache only
-  int32_t* far_cand = nullptr; float4* far_cand_ref = nullptr; unsigned long long* far_req = nullptr; uint32_t* far_stats = nullptr; double* far_rows = nullptr; int far_mode = 2; bool far_enabled = true;
+  int32_t* far_cand = nullptr; float4* far_cand_ref = nullptr; float2* far_cand_b = nullptr; unsigned long long* far_req = nullptr; uint32_t* far_stats = nullptr; double* far_rows = nullptr; int far_mode = 2; bool far_enabled = true;
   uint2* fb_list = nullptr; uint2* big_list = nullptr; uint32_t* fb_count2 = nullptr;
   float4* aligned = nullptr; bool aligned_valid = false;
   double* pose_tmp = nullptr; float* guess_tmp = nullptr;

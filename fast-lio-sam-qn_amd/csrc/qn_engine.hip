@@ -124,6 +124,7 @@ extern "C" int qn_ctx_create(int device, uint32_t max_points, qn_ctx** out) {
     sl.take(c->sqd_fit, sizeof(float) * max_points);
     sl.take(c->far_cand, sizeof(int32_t) * QN_FAR_M * (size_t)max_points);
     sl.take(c->far_cand_ref, sizeof(float4) * max_points);
+    sl.take(c->far_cand_b, sizeof(float2) * max_points);
     sl.take(c->far_req, sizeof(unsigned long long) * (max_points / 64 + 2));
     sl.take(c->far_stats, 4 * sizeof(uint32_t));
     sl.take(c->far_rows, sizeof(double) * QN_FAR_BLOCKS * QN_NPART);
@@ -469,7 +470,7 @@ static TickArgs tick_args(qn_ctx* c) {
   a.src = S.grid; a.tgt = T.grid; a.st_in = st_cur(c); a.st_out = st_nxt(c); a.part_in = part_cur(c); a.part_out = part_nxt(c); a.rows_in = c->part_rows;
   a.cfg = make_cfg(c); a.trace = c->trace; a.thr2 = c->params.max_corr_dist * c->params.max_corr_dist;
   a.nn_idx = c->nn_idx; a.nn_ref = c->nn_ref; a.nrm_s = c->nrm_s_sorted; a.tgt_rec = c->tgt_rec; a.ppt = tick_ppt(c);
-  a.far_mode = c->far_enabled ? c->far_mode : 0; a.tgt_raw = T.raw; a.cand = c->far_cand; a.cand_ref = c->far_cand_ref; a.far_req = c->far_req; a.far_stats = c->far_stats;
+  a.far_mode = c->far_enabled ? c->far_mode : 0; a.tgt_raw = T.raw; a.cand = c->far_cand; a.cand_ref = c->far_cand_ref; a.cand_b = c->far_cand_b; a.far_req = c->far_req; a.far_stats = c->far_stats;
   a.aligned = c->aligned; a.fit_psum = c->fit_psum; a.fit_pcnt = c->fit_pcnt;
   a.clk = c->clk_probe ? c->clk_probe + 8 * (c->clk_n++ % 256) : nullptr; a.clk_blk = c->clk_probe ? c->clk_probe + 8 * 256 : nullptr;
   return a;
@@ -489,7 +490,7 @@ static void enqueue_tick_fused(qn_ctx* c) {
   if (a.far_mode == 1) {                       // the tick's refresh requests, chip-wide, one query per wave; its rows follow the tick's
     FarArgs f;
     f.src = S.grid; f.tgt = T.grid; f.st = st_cur(c); f.thr2 = a.thr2; f.nn_idx = c->nn_idx; f.nn_ref = c->nn_ref; f.nrm_s = c->nrm_s_sorted; f.tgt_rec = c->tgt_rec; f.tgt_raw = T.raw;
-    f.cand = c->far_cand; f.cand_ref = c->far_cand_ref; f.far_req = c->far_req; f.far_rows = c->far_rows; f.far_stats = c->far_stats;
+    f.cand = c->far_cand; f.cand_ref = c->far_cand_ref; f.cand_b = c->far_cand_b; f.far_req = c->far_req; f.far_rows = c->far_rows; f.far_stats = c->far_stats;
     { ProfScope ps(c, QN_K_FAR);
       hipLaunchKernelGGL(k_far, dim3(QN_FAR_BLOCKS), dim3(QN_FAR_THREADS), 0, c->stream, f);
       hipLaunchKernelGGL(k_far_reduce, dim3(1), dim3(QN_FAR_BLOCKS), 0, c->stream, c->far_rows, part_cur(c) + (size_t)c->part_rows * QN_NPART); }
@@ -674,7 +675,7 @@ static int gicp_align(qn_ctx* c, const float guess[16], qn_gicp_result* out, boo
       if (exact_ticks) chunk = c->far_mode == 1 ? std::min(ticks_left, c->ticks_per_chunk) : ticks_left;
       c->last_extra_unseeded = extra;
     }
-    if (first_chunk && tick_no > 0 && persist_usable(c, alone)) {          // everything that is left - ticks, closing pass, result - in ONE persistent launch
+    if (tick_no > 0 && persist_usable(c, alone)) {          // everything that is left - ticks, closing pass, result - in ONE persistent launch (first chunk end, or once the far-query refreshes have died down)
       if ((rc = launch_persist(c, (uint32_t)budget + 2u)) != QN_OK) return rc;
       HIPCHK(c, hipGetLastError());
       HIPCHK(c, hipStreamSynchronize(s));

@@ -37,7 +37,8 @@ struct TickArgs {
   // far queries (neighbour several cells away: no overlap there, occlusion): candidate cache + refresh requests (below)
   int far_mode;                        // 0: resolve big balls in the kernel; 1: cache, misses go to k_far (request bits); 2: cache, misses resolved in the kernel
   const float4* tgt_raw;
-  int32_t* cand; float4* cand_ref;     // [n][QN_FAR_M] candidate indices, [n] (q_ref, bound); cell-sorted source order
+  int32_t* cand; float4* cand_ref;     // [n][QN_FAR_M] candidate indices in ascending distance from q_ref, [n] (q_ref, bound); cell-sorted source order
+  float2* cand_b;                      // [n] prefix bounds of the list: everything but its first 4 / first 16 candidates is at least this far from q_ref
   unsigned long long* far_req;         // [ceil(n / 64)] request bits, one word per 64 consecutive source positions
   uint32_t* far_stats;                 // [0] refresh requests, [1] cache hits
   // MODE 1 (closing pass)
@@ -305,24 +306,31 @@ __device__ __forceinline__ void tick_point(const TickArgs& a, const float (&Tf)[
       const float4 cr = a.cand_ref[t];
       if (cr.w > 0.f) {                                            // candidate list made at cr.xyz, everything else is >= cr.w away from there
         const float dc = sqrtf(sqdist(qx, qy, qz, cr.x, cr.y, cr.z));
-        unsigned long long b1 = QN_INF_KEY; float s2 = INF;
+        const float2 pb = a.cand_b[t];                               // ... and everything but the first 4 / 16 candidates is >= pb.x / pb.y away
+        unsigned long long b1 = QN_INF_KEY; float s2 = INF, used = 0.f;
         const int4* cl = (const int4*)(a.cand + (size_t)t * QN_FAR_M);
-#pragma unroll 2
-        for (int u = 0; u < QN_FAR_M / 4; u++) {
-          const int4 c4 = cl[u];
-          const int cj[4] = {c4.x, c4.y, c4.z, c4.w};
+        bool proven = false;
+#pragma unroll 1
+        for (int stage = 0; stage < 3 && !proven; stage++) {           // 4, then 16, then all 64 candidates
+          const int u0 = stage == 0 ? 0 : (stage == 1 ? 1 : 4), u1 = stage == 0 ? 1 : (stage == 1 ? 4 : QN_FAR_M / 4);
+          for (int u = u0; u < u1; u++) {
+            const int4 c4 = cl[u];
+            const int cj[4] = {c4.x, c4.y, c4.z, c4.w};
 #pragma unroll
-          for (int v = 0; v < 4; v++) {
-            if ((uint32_t)cj[v] < tg.n) {
-              const float4 cp = a.tgt_raw[cj[v]];
-              const float dd = sqdist(qx, qy, qz, cp.x, cp.y, cp.z);
-              const unsigned long long kk = pack_key(dd, (uint32_t)cj[v]);
-              if (kk < b1) { s2 = b1 != QN_INF_KEY ? key_d2(b1) : s2; b1 = kk; } else if (dd < s2) s2 = dd;
+            for (int v = 0; v < 4; v++) {
+              if ((uint32_t)cj[v] < tg.n) {
+                const float4 cp = a.tgt_raw[cj[v]];
+                const float dd = sqdist(qx, qy, qz, cp.x, cp.y, cp.z);
+                const unsigned long long kk = pack_key(dd, (uint32_t)cj[v]);
+                if (kk < b1) { s2 = b1 != QN_INF_KEY ? key_d2(b1) : s2; b1 = kk; } else if (dd < s2) s2 = dd;
+              }
             }
           }
+          used = stage == 0 ? pb.x : (stage == 1 ? pb.y : cr.w);
+          proven = b1 != QN_INF_KEY && track_bound_holds(key_d2(b1), dc, used);
         }
-        if (b1 != QN_INF_KEY && track_bound_holds(key_d2(b1), dc, cr.w)) {      // the nearest neighbour is one of the candidates
-          best = b1; second = s2; d_unseen = cr.w - dc - tg.eps; rescanned = true; big = false;
+        if (proven) {                                                // the nearest neighbour is one of the candidates looked at; every other point is >= used - dc away
+          best = b1; second = s2; d_unseen = used - dc - tg.eps; rescanned = true; big = false;
         }
       }
     }
@@ -556,7 +564,7 @@ struct FarArgs {
   double thr2;
   int32_t* nn_idx; float4* nn_ref;
   const double* nrm_s; const TargetRec* tgt_rec; const float4* tgt_raw;
-  int32_t* cand; float4* cand_ref;
+  int32_t* cand; float4* cand_ref; float2* cand_b;
   const unsigned long long* far_req;
   double* far_rows;                    // [QN_FAR_BLOCKS][28] side table
   uint32_t* far_stats;
@@ -591,7 +599,7 @@ static __global__ void __launch_bounds__(QN_FAR_THREADS) k_far(FarArgs a) {
         float r = 2.f * a.tgt.cell;
         if (j0 < a.tgt.n) { const float4 p0 = a.tgt_raw[j0]; r = sqrtf(sqdist(qx, qy, qz, p0.x, p0.y, p0.z)) * 1.002f + 0.4f * a.tgt.cell; }    // the M nearest of a far query lie within centimetres of the nearest
         int32_t* cl = a.cand + (size_t)t * QN_FAR_M;
-        unsigned long long best = QN_INF_KEY; float second = __int_as_float(0x7f800000), bound = 0.f, other = __int_as_float(0x7f800000);
+        unsigned long long best = QN_INF_KEY; float second = __int_as_float(0x7f800000), bound = 0.f, other = __int_as_float(0x7f800000), b4 = 0.f, b16 = 0.f;
         float dnn = -1.f;                                              // an upper bound on the nearest-neighbour distance
         if (j0 < a.tgt.n) { const float4 p0 = a.tgt_raw[j0]; dnn = sqrtf(sqdist(qx, qy, qz, p0.x, p0.y, p0.z)); }
         else { float du; wave_search_single(a.tgt, qx, qy, qz, r, __int_as_float(0x7f800000), best, second, du, &lds[wid].s); if (best != QN_INF_KEY) dnn = sqrtf(key_d2(best)); other = fminf(sqrtf(second), du); }
@@ -608,8 +616,16 @@ static __global__ void __launch_bounds__(QN_FAR_THREADS) k_far(FarArgs a) {
             const uint32_t cnt = wave_ball_collect(a.tgt, qx, qy, qz, R, &lds[wid].s, lds[wid].list, &lds[wid].cnt, best, second);
             other = fminf(sqrtf(second), R * 0.9999995f);              // the runner-up inside the ball, or the ball's radius: nothing else is closer
             if (cnt <= (uint32_t)QN_FAR_M && cnt > 0) {
-              if (lane < QN_FAR_M) cl[lane] = (uint32_t)lane < cnt ? (int32_t)key_idx(lds[wid].list[lane]) : -1;
+              // the list in ascending (distance, index) order, and two prefix bounds: every point but the first 4 (16) is at least as far from q as the 5th (17th)
+              // - so once the optimiser's steps are millimetres a tick checks FOUR candidates of a far query, not 64
+              const unsigned long long own = (uint32_t)lane < cnt ? lds[wid].list[lane] : QN_INF_KEY;
+              int rank = 0;
+              for (uint32_t f = 0; f < cnt; f++) rank += lds[wid].list[f] < own ? 1 : 0;
+              if ((uint32_t)lane < cnt) cl[rank] = (int32_t)key_idx(own); else if (lane < QN_FAR_M) cl[lane] = -1;
               bound = R * 0.9999995f;
+              const unsigned long long k5 = wave_min_u64(rank == 4 && own != QN_INF_KEY ? own : QN_INF_KEY), k17 = wave_min_u64(rank == 16 && own != QN_INF_KEY ? own : QN_INF_KEY);
+              b4 = k5 != QN_INF_KEY ? fminf(sqrtf(key_d2(k5)) * 0.9999995f, bound) : bound;
+              b16 = k17 != QN_INF_KEY ? fminf(sqrtf(key_d2(k17)) * 0.9999995f, bound) : bound;
               break;
             }
           }
@@ -617,7 +633,7 @@ static __global__ void __launch_bounds__(QN_FAR_THREADS) k_far(FarArgs a) {
         if (lane == 0) {
           a.nn_idx[t] = best != QN_INF_KEY ? (int32_t)key_idx(best) : -1;
           a.nn_ref[t] = make_float4(qx, qy, qz, other);
-          a.cand_ref[t] = make_float4(qx, qy, qz, bound);
+          a.cand_ref[t] = make_float4(qx, qy, qz, bound); a.cand_b[t] = make_float2(b4, b16);
           if (best != QN_INF_KEY && (double)key_d2(best) < a.thr2) {
             const TargetRec* rec = a.tgt_rec + key_idx(best);
             const double na[3] = {a.nrm_s[(size_t)t * 3], a.nrm_s[(size_t)t * 3 + 1], a.nrm_s[(size_t)t * 3 + 2]};

@@ -59,6 +59,34 @@ def test_assemble_and_voxelize_bit_exact(oracle):
 
 
 @pytest.mark.gpu
+def test_assemble_drops_non_finite_points_like_pcl_voxelgrid(oracle):
+    """pcl::VoxelGrid (include/utilities.hpp:38-51) on a non-dense cloud skips non-finite points - in the bounds and in the leaves - and carries on;
+    so does qn_kf_assemble: a keyframe with NaN / inf points gives exactly the submap of the same keyframe without them."""
+    from qn_amd import engine
+    kfs, poses = _keyframes()
+    rng = np.random.default_rng(3)
+    dirty = []
+    for k in kfs:
+        d = k.copy(); bad = rng.choice(len(d), 37, replace=False)
+        d[bad[:20], rng.integers(0, 3, 20)] = np.nan; d[bad[20:], 0] = np.inf
+        dirty.append((d, np.setdiff1d(np.arange(len(d)), bad)))
+    store = engine.KeyframeStore()
+    ids_dirty = [store.add(d) for d, _ in dirty]
+    sel = [1, 2, 3]
+    ptr, n = store.assemble([ids_dirty[i] for i in sel], [poses[i] for i in sel], 0.3, 0)
+    got = store.download(0, n)
+    clean = [d[keep] for d, keep in dirty]
+    exp = oracle.assemble_submap(clean, poses, sel, 0.3)
+    assert n == len(exp) and np.array_equal(got, exp)
+    only_nan = np.full((5, 3), np.nan, np.float32)
+    kid = store.add(only_nan)
+    with pytest.raises(engine.EngineError) as ei:
+        store.assemble([kid], [np.eye(4)], 0.3, 0)
+    assert ei.value.status == engine.QN_ERR_EMPTY_CLOUD
+    store.close()
+
+
+@pytest.mark.gpu
 def test_loop_attempt_on_device_matches_oracle_pipeline(oracle):
     """setSrcAndDstCloud (scan-to-submap branch, loop_closure.cpp:94-105) + icpAlignment with nothing leaving the GPU."""
     from qn_amd import engine

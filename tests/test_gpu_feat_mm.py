@@ -100,3 +100,79 @@ def test_advanced_matching(eng):
     a = run(engine, ctx, src, tgt, True, verify=True, use_optimized_matching=False)
     assert a["mismatches"] == 0
     assert same(a, run(engine, ctx, src, tgt, False, use_optimized_matching=False))
+
+
+def _adversarial_descriptors(seed, ns, nt):
+    """FPFH-shaped rows (three 11-bin groups summing to 100) built to sit on the screening bound of csrc/qn_feat_mm.cuh: exact duplicates and rows that differ
+    in ONE bin by 1-2 ulp (near ties: the defining f32 sum must decide, ties to the lowest index), rows within 1e-5..1e-3 of the exact-plane row P (the centred
+    value x' = x - P falls into f16's subnormal range and below), rows with their 100s in OTHER bins (|x'| ~ 140: the largest products), all-equal blocks, NaN rows."""
+    rng = np.random.default_rng(seed)
+    P = np.zeros(33, np.float32); P[[5, 16, 27]] = 100.0
+
+    def generic(n):
+        r = rng.gamma(0.6, 1.0, (n, 3, 11)).astype(np.float64)
+        r = 100.0 * r / r.sum(2, keepdims=True)
+        return r.reshape(n, 33).astype(np.float32)
+
+    def near_plane(n):
+        e = (10.0 ** rng.uniform(-5.5, -2.5, (n, 33))).astype(np.float32) * rng.choice([0.0, 1.0], (n, 33), p=[0.5, 0.5]).astype(np.float32)
+        r = np.abs(P[None, :] - e * (P[None, :] > 0)) + e * (P[None, :] == 0)
+        return r.astype(np.float32)
+
+    def far_peaks(n):
+        r = np.zeros((n, 33), np.float32)
+        for g in range(3):
+            r[np.arange(n), 11 * g + rng.integers(0, 11, n)] = 100.0
+        return r
+
+    def ulp_variants(base, k):
+        out = []
+        for _ in range(k):
+            v = base.copy(); j = rng.integers(0, 33)
+            v[j] = np.nextafter(v[j], np.float32(np.inf if rng.random() < 0.5 else -np.inf)) if v[j] != 0 else np.float32(1e-45) * rng.integers(0, 3)
+            if rng.random() < 0.5:
+                v[j] = np.nextafter(v[j], np.float32(np.inf))
+            out.append(v)
+        return np.array(out, np.float32)
+
+    tg = [generic(nt // 3), near_plane(nt // 6), far_peaks(nt // 12)]
+    seeds = np.concatenate([tg[0][:40], tg[1][:40], tg[2][:10]])
+    tg.append(np.concatenate([ulp_variants(b, 3) for b in seeds]))                # clusters of near-tied candidates
+    tg.append(np.repeat(generic(4), 60, axis=0))                                  # all-equal blocks
+    tg.append(np.repeat(P[None, :], 200, axis=0))                                 # the plane row itself, many times
+    t = np.concatenate(tg)
+    t = np.concatenate([t, generic(max(0, nt - len(t)))])[:nt]
+    t[rng.choice(nt, 15, replace=False)] = np.nan
+    rng.shuffle(t, axis=0)
+    ok = np.flatnonzero(~np.isnan(t[:, 0]))
+    sq = [t[rng.choice(ok, ns // 3)], np.concatenate([ulp_variants(t[i], 1) for i in rng.choice(ok, ns // 3)]), near_plane(ns // 8), far_peaks(ns // 16), np.repeat(P[None, :], 50, axis=0)]
+    s = np.concatenate(sq)
+    s = np.concatenate([s, generic(max(0, ns - len(s)))])[:ns]
+    s[rng.choice(ns, 10, replace=False)] = np.nan
+    rng.shuffle(s, axis=0)
+    return np.ascontiguousarray(s, np.float32), np.ascontiguousarray(t, np.float32)
+
+
+@pytest.mark.parametrize("seed,ns,nt", [(1, 2500, 3000), (2, 4100, 2700), (3, 700, 5000)])
+def test_adversarial_descriptors_through_match_optimized(eng, oracle, seed, ns, nt):
+    """qn_match_optimized takes the caller's descriptors: rows crafted against the matrix-core screening (its bound rests on a measured property of the MFMA
+    rounding, csrc/qn_feat_mm.cuh:11-15) - every query of both search directions must agree with the VALU search (feat_verify) and the outcome with the
+    oracle's matcher, whose nearest neighbour is the plain f32 sum."""
+    engine, ctx = eng
+    fs, ft = _adversarial_descriptors(seed, ns, nt)
+    rng = np.random.default_rng(100 + seed)
+    src = rng.uniform(-20, 20, (ns, 3)).astype(np.float32); tgt = rng.uniform(-20, 20, (nt, 3)).astype(np.float32)
+    engine.Quatro(ctx)                                                    # default Quatro parameters (seed 1) in the context
+    for sample in (4, 1):
+        ctx.debug_set("feat_mfma", 1); ctx.debug_set("feat_sample", sample); ctx.debug_set("feat_verify", 1)
+        got = engine.match_optimized(ctx, src, tgt, fs, ft, thr_dist=1e9, num_max_corres=400, tuple_scale=0.95)
+        assert int(ctx.debug_get("feat_verified")) >= ns - 10 and int(ctx.debug_get("feat_mismatches")) == 0
+        ctx.debug_set("feat_verify", 0)
+        p = oracle.QuatroParams(distance_threshold=1e9, max_num_corres=400)
+        mutual, corres = oracle.quatro_match(src, tgt, fs, ft, p)
+        assert np.array_equal(got, corres), (len(got), len(corres))
+        ctx.debug_set("feat_mfma", 0)
+        assert np.array_equal(engine.match_optimized(ctx, src, tgt, fs, ft, thr_dist=1e9, num_max_corres=400, tuple_scale=0.95), corres)      # and the VALU search alone
+    # the forward nearest neighbours themselves, one query at a time, against the oracle's exact search
+    nn = oracle.quatro_feature_nn(fs, ft)
+    assert len(nn) == ns

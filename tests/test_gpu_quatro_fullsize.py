@@ -63,13 +63,22 @@ def test_quatro_align_parity_fullsize(eng, oracle, pair_id, n):
     assert np.array_equal(r["mutual"], mutual) and np.array_equal(r["corres"], corres)
     o = oracle.quatro_solve(src, tgt, corres)
     assert r["valid"] == o["valid"] and r["clique"].tolist() == o["clique"].tolist() and np.abs(r["T"] - o["T"]).max() < 1e-9
-    # whole coarse stage against the oracle's own descriptors
-    if all(rp["spfh_rows_off"] == 0 for rp in rep) or n <= 30000:
-        oa = oracle.quatro_align(src, tgt)
-        assert r["valid"] == oa["valid"] and np.array_equal(r["corres"], oa["corres"])
-        dt, dr = synth.pose_error(r["T"], oa["T"])
-        assert dt <= 1e-4 and dr <= 1e-4
-    print("  oracle matcher on %d x %d descriptors: %.1f s" % (len(src), len(tgt), t_match))
+    # whole coarse stage against the oracle's OWN descriptors.  Strict (same correspondences, pose <= 1e-4 m / rad) whenever no SPFH row differs - always at 30k;
+    # at 100k a last-bit f32 normal may move one pair feature across a bin edge (spfh_rows_off, capped at 3 above and at 0 + strict for the 30k pairs): then the
+    # correspondence sets may differ by a few pairs and the bar is SURVEY 7.7-7's for the coarse stage, 0.3 m / 2 degrees.  The branch taken is printed and recorded.
+    oa = oracle.quatro_align(src, tgt)
+    strict = all(rp["spfh_rows_off"] == 0 for rp in rep) or n <= 30000
+    assert r["valid"] == oa["valid"]
+    dt, dr = synth.pose_error(r["T"], oa["T"])
+    if strict:
+        assert np.array_equal(r["corres"], oa["corres"])
+        assert dt <= 1e-4 and dr <= 1e-4, (dt, dr)
+    else:
+        assert max(rp["spfh_rows_off"] for rp in rep) <= 3, rep
+        common = len(set(map(tuple, r["corres"].tolist())) & set(map(tuple, oa["corres"].tolist())))
+        assert common >= 0.9 * len(oa["corres"]), (common, len(oa["corres"]))
+        assert dt <= 0.3 and dr <= np.radians(2.0), (dt, dr)
+    print("  coarse stage vs the oracle's own descriptors: branch %s, |dT| = %.2e m / %.2e rad; oracle matcher on %d x %d descriptors: %.1f s" % ("STRICT" if strict else "LOOSE (an SPFH bin differs)", dt, dr, len(src), len(tgt), t_match))
 
 
 def test_advanced_matching_parity_30k(eng, oracle):

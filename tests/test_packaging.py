@@ -21,3 +21,22 @@ def test_package_configures_and_installs(tmp_path, pkg, headers):
         assert (prefix / "include" / h).exists(), h
     xml = open(os.path.join(ROOT, "packaging", pkg, "package.xml")).read()
     assert "<name>%s</name>" % pkg in xml and "<buildtool_depend>catkin</buildtool_depend>" in xml
+
+
+@pytest.mark.parametrize("pkg", ["nano_gicp", "quatro"])
+def test_catkin_branch_puts_the_library_into_devel_space(tmp_path, pkg):
+    """The catkin branch of the packages, configured against a stand-in catkin (tests/standins/cmake_catkin: devel prefix, destinations, a catkin_package()
+    that resolves LIBRARIES under <devel>/lib like the generated <pkg>Config.cmake does): `catkin build` (devel space, the reference's README.md:75-78)
+    finds libqn_engine.so because the prebuilt library is copied there at configure time."""
+    if shutil.which("cmake") is None:
+        pytest.skip("cmake not installed")
+    lib = os.path.join(ROOT, "fast-lio-sam-qn_amd", "libqn_engine.so")
+    if not os.path.exists(lib):
+        pytest.skip("libqn_engine.so not built")
+    b = tmp_path / "build"
+    standin = os.path.join(ROOT, "tests", "standins", "cmake_catkin")
+    subprocess.check_call(["cmake", "-S", os.path.join(ROOT, "packaging", pkg), "-B", str(b), "-DQN_ENGINE_ROOT=%s" % ROOT,
+                           "-Dcatkin_DIR=%s" % standin, "-DPCL_DIR=%s" % standin, "-DEigen3_DIR=%s" % standin], stdout=subprocess.DEVNULL)
+    assert (b / "devel" / "lib" / "libqn_engine.so").exists()
+    args = (b / "devel" / "share" / pkg / "cmake" / ("%sConfig.cmake.args" % pkg)).read_text()
+    assert "LIBRARIES=qn_engine" in args and "include" in args
