@@ -74,7 +74,7 @@ def roofline_leg(ctx, register, ms_step, align_ms, nprof=4):
     ab = algorithmic_bytes()
     # kernel families timed as ONE kernel per span, with the rocprofv3 name of that kernel and its algorithmic bytes per launch
     single_k = {"knn_select": ("k_knn_hist<false, 32>", N_PTS * (16 + 16 * K_COV)),          # k-NN selection of one cloud: point + k neighbour points
-                "gn_tick_fused": ("k_tick<512, 4, 0>", ab["gn_iteration"]),                # one whole GN / LM tick (controller + tracked NN + accumulate)
+                "gn_tick_fused": ("k_tick<512, 4, 0, false>", ab["gn_iteration"]),                # one whole GN / LM tick (controller + tracked NN + accumulate)
                 "nn_search": ("k_nn_search<0, false, 256>", ab["gn_iteration"]),                # first (unseeded) NN passes of an align
                 "nn_fallback": ("k_nn_search<0, true, 256>", ab["gn_iteration"]),
                 "accumulate": ("k_accumulate", ab["gn_iteration"]), "solve": ("k_solve<512>", 28 * 8 * 512)}
@@ -174,6 +174,23 @@ def latency_legs(engine, synth, pairs, args, world, ctx=None, p80=None):
     align = pct(lat); align_ms = align["median"]
 
     roofline = roofline_leg(ctx, register, None, align_ms)
+    # ---- the persistent align kernel (the tracked ticks + closing pass of ONE align in one launch; single registrations only): hipEvent time per launch,
+    # ticks per launch from the forced iteration count, algorithmic bytes = 80 N per tick + 64 N for the closing pass
+    try:
+        ctx.debug_set("prof_persist", 1); ctx.prof_reset(); ctx.prof_enable(True)
+        for j in range(8):
+            register(j)
+        ctx.synchronize(); ctx.prof_enable(False); ctx.debug_set("prof_persist", 0)
+        ps = ctx.prof_stats().get("align_persist", (0.0, 0))
+        if ps[1] > 0:
+            ms_l = ps[0] / ps[1]; ticks = GN_ITERS - 2.5        # hand-over after 2 or 3 unseeded iterations (adaptive), the rest in the launch
+            pb = ab_bytes = 80 * N_PTS * ticks + 64 * N_PTS
+            roofline["persistent_align"] = {"kernel": "k_align_persist<512, false>", "launches": int(ps[1]), "avg_launch_ms": round(ms_l, 5), "ticks_per_launch": ticks,
+                                            "us_per_tick": round(1e3 * ms_l / (ticks + 1), 2), "algorithmic_bytes_per_launch": int(pb), "achieved_GBs": round(pb / (ms_l * 1e-3) / 1e9, 2),
+                                            "frac": round(pb / (ms_l * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                                            "traffic": (json.load(open(os.path.join(ROOT, "profiles", "pmc_latest.json"))).get("align_persist", {}).get("hbm_bytes_per_launch") if os.path.exists(os.path.join(ROOT, "profiles", "pmc_latest.json")) else None)}
+    except Exception as ex:
+        roofline["persistent_align"] = {"error": repr(ex)}
 
     cpu = None
     if world == 1 and not args.no_cpu_baseline:

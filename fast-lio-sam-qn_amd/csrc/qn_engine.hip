@@ -540,7 +540,7 @@ static void enqueue_epilogue(qn_ctx* c, double max_range, bool tracked) {
 static std::atomic<int> g_aligns_in_flight{0};
 static uint32_t persist_ppt(const qn_ctx* c) { const uint32_t cap = QN_PERSIST_TB * QN_PERSIST_MAX_BLOCKS; return (c->cloud[0].n + cap - 1) / cap; }
 static bool persist_usable(const qn_ctx* c, bool alone) {
-  return c->persist && !c->persist_batch_off && alone && c->fused_ticks && c->fused_final && !c->prof_on && !c->verify_track && !c->clk_probe && c->tick_tb == QN_PERSIST_TB &&
+  return c->persist && !c->persist_batch_off && alone && c->fused_ticks && c->fused_final && (!c->prof_on || c->prof_persist) && !c->verify_track && !c->clk_probe && c->tick_tb == QN_PERSIST_TB &&
          (!c->far_enabled || c->far_mode == 2) && c->pg_rows != nullptr;
 }
 static int launch_persist(qn_ctx* c, uint32_t max_ticks) {
@@ -557,9 +557,10 @@ static int launch_persist(qn_ctx* c, uint32_t max_ticks) {
   }
   A.rows_g = c->pg_rows; A.bc_g = c->pg_bc; A.fit_g = c->pg_fit; A.status = c->pg_status; A.result = c->result_host;
   A.epoch0 = c->pg_epoch; A.max_ticks = max_ticks; c->pg_epoch += max_ticks + 8;
+  A.hint_poll = c->persist_hint ? 1 : 0;
   A.timeout = 25000000ull;                                           // 0.25 s of the 100 MHz wall clock: three orders of magnitude above any legitimate wait
   HIPCHK(c, hipMemsetAsync(c->pg_status, 0, 4 * sizeof(uint32_t), c->stream));
-  { ProfScope ps(c, QN_K_GN_TICK_FUSED);
+  { ProfScope ps(c, QN_K_ALIGN_PERSIST);
     A.clk = c->pg_clk;
     if (c->pg_clk) { (void)hipMemsetAsync(c->pg_clk, 0, 8 * (64 * 16 + 16), c->stream); for (int g = 0; g < 64; g++) (void)hipMemsetAsync(c->pg_clk + 16 * g + 12, 0xff, 8, c->stream); }
     if (c->pg_clk) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_align_persist<QN_PERSIST_TB, true>), dim3(A.nblk + 1), dim3(QN_PERSIST_TB), 0, c->stream, A);
@@ -897,6 +898,8 @@ extern "C" int qn_debug_set(qn_ctx* c, const char* key, double v) {
   else if (k == "bbox_blocks") c->bbox_blocks = std::max(1, (int)v);
   else if (k == "pair_pipeline") c->pair_pipeline = v != 0;
   else if (k == "persist") c->persist = v != 0;
+  else if (k == "persist_hint") c->persist_hint = v != 0;
+  else if (k == "prof_persist") c->prof_persist = v != 0;      // profiling (qn_prof_enable) normally times the k_tick chain; 1: let the persistent kernel run and time it as its own family
   else if (k == "persist_probe") {                              // developer probe: wall-clock stamps inside k_align_persist (qn_debug_get_persist_clk)
     if (v != 0 && !c->pg_clk) { if (hipMalloc(&c->pg_clk, 8 * (64 * 16 + 16)) != hipSuccess) return QN_ERR_HIP; }
     if (c->pg_clk) (void)hipMemset(c->pg_clk, 0, 8 * (64 * 16 + 16));

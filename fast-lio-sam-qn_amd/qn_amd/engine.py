@@ -11,7 +11,7 @@ QN_OK, QN_ERR_INVALID_ARG, QN_ERR_EMPTY_CLOUD, QN_ERR_CAPACITY, QN_ERR_NOT_READY
 QN_SOURCE, QN_TARGET = 0, 1
 FLOAT_MAX = 3.4028234663852886e38
 KERNEL_FAMILIES = ["grid_build", "knn_cov", "nn_search", "nn_fallback", "accumulate", "solve", "fitness", "transform",
-                   "fpfh_normals", "fpfh_spfh", "fpfh_fpfh", "feat_match", "gn_tick_fused", "knn_select", "match_tail", "far_refresh"]
+                   "fpfh_normals", "fpfh_spfh", "fpfh_fpfh", "feat_match", "gn_tick_fused", "knn_select", "match_tail", "far_refresh", "align_persist"]
 
 
 class GicpParams(C.Structure):

@@ -88,7 +88,8 @@ enum {                     /* kernel families for qn_prof_get */
   QN_K_KNN_SELECT = 13,      /* k-NN selection kernel alone (QN_K_KNN_COV then holds its list tail + covariances)  */
   QN_K_FAR = 15,             /* refresh of far queries' candidate lists (k_far)                                     */
   QN_K_MATCH_TAIL = 14,      /* Matcher tail on the device: means, cross-check + gate, tuple test, hand-over        */
-  QN_K_COUNT = 16
+  QN_K_ALIGN_PERSIST = 16,   /* the persistent align kernel: every tracked tick + closing pass of one align in ONE launch */
+  QN_K_COUNT = 17
 };
 
 /* ---- lifetime ------------------------------------------------------------------------- */

@@ -9,7 +9,7 @@ bench.py reads the committed copy (profiles/pmc_latest.json) for the `roofline.t
 import csv, json, os, sys
 from collections import defaultdict
 
-FAMILY = [("k_knn_hist<false, 32>", "knn_select"), ("k_tick<512, 4, 0>", "gn_tick_fused"), ("k_tick<512, 4, 1>", "closing_pass"), ("k_far(", "far_refresh"),
+FAMILY = [("k_knn_hist<false, 32>", "knn_select"), ("k_tick<512, 4, 0,", "gn_tick_fused"), ("k_tick<512, 4, 1,", "closing_pass"), ("k_align_persist<512, false>", "align_persist"), ("k_far(", "far_refresh"),
           ("k_nn_search<0, false,", "nn_search"), ("k_nn_search<0, true,", "nn_fallback"), ("k_accumulate", "accumulate"),
           ("k_solve<512>", "solve"), ("k_cov_from_idx", "cov_from_idx"), ("k_scatter", "grid_scatter"), ("k_fitness_partial", "fitness")]
 
