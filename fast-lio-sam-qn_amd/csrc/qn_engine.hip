@@ -174,7 +174,7 @@ extern "C" void qn_ctx_destroy(qn_ctx* c) {
   if (c->stream2) hipStreamSynchronize(c->stream2);                     // a target may still be in preparation there (TargetScope)
   c->prof_collect();
   hipFree(c->slab);                                                      // every per-context device buffer of the GICP path lives in it (qn_ctx_create)
-  hipFree(c->q_mm_c); hipFree(c->q_mm_q); hipFree(c->q_mm_qn); hipFree(c->q_mm_L); hipFree(c->q_mm_table); hipFree(c->q_mm_pairs); hipFree(c->q_mm_cnt); hipFree(c->q_mm_vkeys); hipFree(c->q_mm_vcnt);
+  hipFree(c->q_mm_c); hipFree(c->q_mm_q); hipFree(c->q_mm_qn); hipFree(c->q_mm_L); hipFree(c->q_mm_table); hipFree(c->q_mm_table_q); hipFree(c->q_mm_pairs); hipFree(c->q_mm_cnt); hipFree(c->q_mm_vkeys); hipFree(c->q_mm_vcnt);
   for (int w = 0; w < 2; w++) { hipFree(c->q_normals[w]); hipFree(c->q_spfh[w]); hipFree(c->q_fpfh_s[w]); hipFree(c->q_fpfh[w]); hipFree(c->q_key[w]); hipFree(c->q_pair[w]); hipFree(c->q_pair_hash[w]); }
   hipFree(c->q_hit); hipFree(c->q_list); hipFree(c->q_sel); hipFree(c->q_pairs); hipFree(c->q_counts); hipFree(c->q_T); hipFree(c->q_mean); hipFree(c->q_mean_psum);
   if (c->q_host) hipHostFree(c->q_host);
@@ -929,6 +929,7 @@ extern "C" int qn_debug_set(qn_ctx* c, const char* key, double v) {
   else if (k == "fused_final") c->fused_final = v != 0;
   else if (k == "feat_mfma") c->feat_mfma = v != 0;
   else if (k == "feat_sample") c->feat_sample = (int)v;
+  else if (k == "feat_query_dedupe") c->feat_query_dedupe = v != 0;
   else if (k == "feat_min_blocks") c->feat_min_blocks = (int)v;
   else if (k == "feat_verify") { c->feat_verify = v != 0; if (c->q_mm_vcnt) (void)hipMemset(c->q_mm_vcnt, 0, 16); }
   else if (k == "clk_probe") {                                  // developer probe: device-clock stamps inside k_tick (qn_debug_get_clk)

@@ -81,6 +81,50 @@ static __global__ void k_feat_dedupe(const float* __restrict__ rows, uint32_t n,
     }
   }
 }
+// the representative (lowest index) of row i's distinct row, or 0xffffffff for a NaN row (never inserted)
+__device__ __forceinline__ uint32_t feat_rep_of(const float* __restrict__ rows, uint32_t i, const unsigned long long* __restrict__ table, uint32_t mask, const uint32_t* __restrict__ plane_min) {
+  const uint32_t* r = (const uint32_t*)(rows + (size_t)i * QN_FROW);
+  bool plane = true;
+#pragma unroll
+  for (int d = 0; d < 33; d++) plane = plane && (__uint_as_float(r[d]) == mm_plane(d));
+  if (plane) return ~*plane_min;
+  if ((r[0] & 0x7fffffffu) > 0x7f800000u) return 0xffffffffu;
+  const uint32_t h = r[34];
+  for (uint32_t slot = h & mask;; slot = (slot + 1) & mask) {
+    const unsigned long long e = table[slot];
+    if (e == QN_MM_EMPTY) return i;                                     // (not reached for an inserted row)
+    if ((uint32_t)(e >> 32) == h) {
+      if ((uint32_t)e == i) return i;
+      const uint32_t* o = (const uint32_t*)(rows + (size_t)(uint32_t)e * QN_FROW);
+      bool same = true;
+#pragma unroll
+      for (int d = 0; d < 33; d++) same = same && (o[d] == r[d]);
+      if (same) return (uint32_t)e;
+    }
+  }
+}
+// QUERY-side de-duplication: rows that are bit for bit equal have the same nearest neighbour (same distances, ties to the lowest candidate index either way), so
+// only the lowest index of every distinct query row is searched (k_query_reps builds that list) and the others copy its key afterwards (k_query_propagate).
+// Every point of an exact plane has the same FPFH row - 57 % of a noise-free synthetic source; a noisy real cloud has next to none, and pays two small kernels.
+static __global__ void k_query_reps(const float* __restrict__ rows, uint32_t n, const unsigned long long* __restrict__ table, uint32_t mask, const uint32_t* __restrict__ plane_min,
+                                    uint32_t* __restrict__ list, uint32_t* __restrict__ count) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool rep = i < n && feat_rep_of(rows, i, table, mask, plane_min) == i;
+  const unsigned long long m = __ballot(rep);
+  if (m == 0ull) return;
+  const int lane = threadIdx.x & 63, leader = __ffsll((long long)m) - 1;
+  uint32_t base = 0;
+  if (lane == leader) base = atomicAdd(count, (uint32_t)__popcll(m));
+  base = (uint32_t)__builtin_amdgcn_readfirstlane((int)__shfl(base, leader));
+  if (rep) list[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = i;
+}
+static __global__ void k_query_propagate(const float* __restrict__ rows, uint32_t n, const unsigned long long* __restrict__ table, uint32_t mask, const uint32_t* __restrict__ plane_min,
+                                         unsigned long long* __restrict__ keys) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t r = feat_rep_of(rows, i, table, mask, plane_min);
+  if (r != i && r != 0xffffffffu) keys[i] = keys[r];
+}
 __device__ __forceinline__ bool feat_is_rep(const float* __restrict__ rows, uint32_t i, const unsigned long long* __restrict__ table, uint32_t mask, const uint32_t* __restrict__ plane_min) {
   const uint32_t* r = (const uint32_t*)(rows + (size_t)i * QN_FROW);
   bool plane = true;

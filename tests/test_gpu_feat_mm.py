@@ -176,3 +176,17 @@ def test_adversarial_descriptors_through_match_optimized(eng, oracle, seed, ns, 
     # the forward nearest neighbours themselves, one query at a time, against the oracle's exact search
     nn = oracle.quatro_feature_nn(fs, ft)
     assert len(nn) == ns
+
+
+@pytest.mark.parametrize("n,pair_id", [(3000, 7), (30000, 331)])
+def test_query_side_deduplication_changes_nothing(eng, n, pair_id):
+    """The forward search looks up only the lowest index of every distinct QUERY row and copies its key to the duplicates (57 % of a noise-free synthetic
+    source is the exact-plane row): the same mutual pairs, correspondences and transform as searching every query."""
+    engine, ctx = eng
+    src, tgt, _ = synth.make_pair(pair_id, n, mode="quatro")
+    ctx.debug_set("feat_query_dedupe", 1); a = run(engine, ctx, src, tgt, True)
+    ctx.debug_set("feat_query_dedupe", 0); b = run(engine, ctx, src, tgt, True)
+    ctx.debug_set("feat_query_dedupe", 1)
+    assert same(a, b) and same(a, run(engine, ctx, src, tgt, False))
+    a2 = run(engine, ctx, src, src.copy(), True); ctx.debug_set("feat_query_dedupe", 0); b2 = run(engine, ctx, src, src.copy(), True); ctx.debug_set("feat_query_dedupe", 1)
+    assert same(a2, b2)
