@@ -15,7 +15,9 @@ struct CloudBuf {                       // one point cloud, resident in HBM
   uint32_t* cell_start = nullptr;       // [max_cells + 1]
   uint32_t* counts = nullptr;           // [max_cells + 1] histogram / scatter cursors
   double* nrm = nullptr;                // [max_points][3] plane normal (f64), original order: C = I - 0.999 n n^T
-  qn::GridView grid{};
+  qn::GridView grid{};                  // pointers + the pointer to the device-side numbers (`dims`); the numeric fields are NOT valid on the host
+  qn::GridDims* dims = nullptr;         // device: the grid's numbers (k_grid_dims)
+  qn::GridDims* dims_host = nullptr;    // pinned mirror, copied behind every grid build: valid after the next synchronisation of the stream that built the grid
 };
 
 struct ProfSpan { int family; hipEvent_t a, b; };
@@ -27,6 +29,7 @@ struct qn_ctx {
   void* slab = nullptr;                 // ONE device allocation behind every per-context buffer of the GICP path (qn_ctx_create)
   qn_gicp_params params{};
   CloudBuf cloud[2];
+  char* staging2 = nullptr;             // the second stream's landing zone (TargetScope)
   char* staging = nullptr;              // [max_points * 32] H2D landing zone for strided host clouds
   uint32_t* scan_sums = nullptr;
   qn::BBoxOut* bbox = nullptr; qn::BBoxOut* bbox_host = nullptr;

@@ -36,6 +36,14 @@ namespace qn {
 #define QN_TZ 4
 #define QN_TILE_CELLS 128
 
+// The numbers of a grid are computed ON THE DEVICE (k_grid_dims: bounding box -> cell edge -> dimensions) so that setInputSource / setInputTarget need no host round
+// trip; kernels receive a GridView whose pointers the host filled in and whose numbers they fetch themselves (grid_resolve: one uniform 64-byte load).
+struct GridDims {
+  float ox, oy, oz, cell, inv_cell, eps;
+  int nx, ny, nz, ntx, nty, ntz;
+  uint32_t n;                          // points in the grid (0 when the cloud held non-finite coordinates: every kernel then sees an empty cloud)
+  uint32_t ncells, nonfinite, pad;
+};
 struct GridView {
   const float4* pts;
   const uint32_t* cell_start;
@@ -44,7 +52,16 @@ struct GridView {
   int nx, ny, nz;                      // cells per axis
   int ntx, nty, ntz;                   // tiles per axis
   uint32_t n;
+  const GridDims* dims;                // device-resident numbers (null: the fields above are valid as they are)
 };
+__device__ __forceinline__ GridView grid_resolve(GridView g) {
+  if (g.dims) {
+    const GridDims d = *g.dims;
+    g.ox = d.ox; g.oy = d.oy; g.oz = d.oz; g.cell = d.cell; g.inv_cell = d.inv_cell; g.eps = d.eps;
+    g.nx = d.nx; g.ny = d.ny; g.nz = d.nz; g.ntx = d.ntx; g.nty = d.nty; g.ntz = d.ntz; g.n = d.n;
+  }
+  return g;
+}
 
 #define QN_INF_KEY 0xFFFFFFFFFFFFFFFFull
 

@@ -85,6 +85,7 @@ static void carve_cloud(qn_ctx* c, Slab& sl, CloudBuf& b) {
   sl.take(b.cell_start, sizeof(uint32_t) * ((size_t)c->max_cells + 1));
   sl.take(b.counts, sizeof(uint32_t) * ((size_t)c->max_cells + 1));
   sl.take(b.nrm, sizeof(double) * 3 * c->max_points);
+  sl.take(b.dims, sizeof(GridDims));
 }
 
 extern "C" int qn_ctx_create(int device, uint32_t max_points, qn_ctx** out) {
@@ -141,6 +142,7 @@ extern "C" int qn_ctx_create(int device, uint32_t max_points, qn_ctx** out) {
     sl.take(c->fb_count2b, 4 * sizeof(uint32_t));
     sl.take(c->knn_idx2, sizeof(int32_t) * (size_t)max_points * 32);
     sl.take(c->bbox2, sizeof(BBoxOut));
+    sl.take(c->staging2, (size_t)max_points * 32);
     sl.take(c->pg_rows, sizeof(unsigned long long) * 3 * QN_PERSIST_ROWS * QN_PERSIST_RSTRIDE);
     sl.take(c->pg_bc, sizeof(unsigned long long) * 64);
     sl.take(c->pg_fit, sizeof(unsigned long long) * (QN_PERSIST_MAX_BLOCKS + 1) * 4);
@@ -151,6 +153,7 @@ extern "C" int qn_ctx_create(int device, uint32_t max_points, qn_ctx** out) {
     CA(hipMalloc(&c->slab, sl.cap)); sl.base = (char*)c->slab; carve(sl); }
   CA(hipMemsetAsync(c->far_stats, 0, 4 * sizeof(uint32_t), c->stream));
   CA(hipHostMalloc(&c->result_host, sizeof(ResultBlock), hipHostMallocDefault));
+  for (int w = 0; w < 2; w++) { CA(hipHostMalloc(&c->cloud[w].dims_host, sizeof(GridDims), hipHostMallocDefault)); memset(c->cloud[w].dims_host, 0, sizeof(GridDims)); }
   CA(hipHostMalloc(&c->bbox_host, sizeof(BBoxOut), hipHostMallocDefault));
   CA(hipHostMalloc(&c->scalar_host, 64 * sizeof(double), hipHostMallocDefault));
   // scratch of the second stream (TargetScope): scan sums, k-NN lists and index table, bounding box
@@ -181,6 +184,7 @@ extern "C" void qn_ctx_destroy(qn_ctx* c) {
   hipFree(c->dbg_knn_idx); hipFree(c->dbg_knn_d2); hipFree(c->dbg_counters);
   hipFree(c->v_corr); hipFree(c->v_nn_idx); hipFree(c->v_sqd); hipFree(c->v_nn_ref); hipFree(c->v_counters);
   if (c->result_host) hipHostFree(c->result_host);
+  for (int w = 0; w < 2; w++) if (c->cloud[w].dims_host) hipHostFree(c->cloud[w].dims_host);
   if (c->bbox_host) hipHostFree(c->bbox_host);
   if (c->scalar_host) hipHostFree(c->scalar_host);
   hipFree(c->pg_clk); if (c->pg_status_host) hipHostFree(c->pg_status_host);
@@ -246,6 +250,7 @@ static bool pair_pipeline_ready(qn_ctx* c) {
 static void swap_scratch(qn_ctx* c) {
   std::swap(c->stream, c->stream2); std::swap(c->scan_sums, c->scan_sums2); std::swap(c->fb_list, c->fb_list2); std::swap(c->big_list, c->big_list2);
   std::swap(c->fb_count2, c->fb_count2b); std::swap(c->knn_idx, c->knn_idx2); std::swap(c->bbox, c->bbox2); std::swap(c->bbox_host, c->bbox_host2);
+  std::swap(c->staging, c->staging2);       // (setInputSource no longer waits for its pack kernel: the target's upload must not land in the source's landing zone)
 }
 struct TargetScope {                    // RAII: the body of set_cloud / compute_cov runs with the second stream's scratch; the event marks its end
   qn_ctx* c; bool on;
@@ -258,55 +263,43 @@ static int join_target(qn_ctx* c) {
   return hipStreamWaitEvent(c->stream, c->ev_pair, 0) == hipSuccess ? QN_OK : QN_ERR_HIP;
 }
 
-// K1: pack -> bbox -> (host picks the cell size) -> count -> exclusive scan -> scatter.
+// K1: pack -> bbox -> grid numbers (k_grid_dims, on the device) -> count -> exclusive scan -> scatter.  No host round trip: the kernels read the numbers from
+// device memory (GridView::dims, grid_resolve); the table-sized launches (zeroing, scan) use the grid of the largest table and leave early.  What the host
+// needs to know - "the cloud held non-finite coordinates" - arrives with the pinned mirror at the next synchronisation (clouds_valid).
 static int build_grid(qn_ctx* c, CloudBuf& b) {
   const uint32_t n = b.n;
   hipStream_t s = c->stream;
   BBoxOut init; for (int d = 0; d < 3; d++) { init.mn[d] = 0x7fffffff; init.mx[d] = (int)0x80000000; } init.nonfinite = 0;
-  *c->bbox_host = init;
+  *c->bbox_host = init;                                               // (constant: only ever the source of this upload)
   HIPCHK(c, hipMemcpyAsync(c->bbox, c->bbox_host, sizeof(BBoxOut), hipMemcpyHostToDevice, s));
-  { ProfScope ps(c, QN_K_GRID_BUILD);
-    hipLaunchKernelGGL(k_bbox, dim3(std::min<uint32_t>((n + QN_BLOCK - 1) / QN_BLOCK, (uint32_t)c->bbox_blocks)), dim3(QN_BLOCK), 0, s, b.raw, n, c->bbox); }
-  HIPCHK(c, hipMemcpyAsync(c->bbox_host, c->bbox, sizeof(BBoxOut), hipMemcpyDeviceToHost, s));
-  HIPCHK(c, hipStreamSynchronize(s));
-  if (c->bbox_host->nonfinite) { c->last_error = "cloud contains non-finite coordinates (is_dense == false clouds are not supported)"; return QN_ERR_INVALID_ARG; }
-  float mn[3], mx[3];
-  for (int d = 0; d < 3; d++) { mn[d] = ord2f(c->bbox_host->mn[d]); mx[d] = ord2f(c->bbox_host->mx[d]); }
-  // cell edge: ~4 points per ground-plane cell (the clouds are voxel-grid centroids sampled on surfaces,
-  // loop_closure.cpp:107), then coarsened until the dense cell table fits max_cells.
-  double L[3]; for (int d = 0; d < 3; d++) L[d] = std::max((double)mx[d] - (double)mn[d], 0.0);
-  double Lmax = std::max(L[0], std::max(L[1], L[2]));
-  double area = std::max(L[0] * L[1], std::max(L[0] * L[2], L[1] * L[2]));
-  double cell = std::sqrt(4.0 * area / (double)n);
-  cell = std::max(cell, std::max(Lmax / 2048.0, 1e-6));
-  if (c->cell_override > 0) cell = c->cell_override;
-  int dims[3], tdims[3]; const int tile[3] = {QN_TX, QN_TY, QN_TZ};
-  for (int iter = 0; iter < 64; iter++) {
-    double tot = 1;   // the dense cell table is padded to whole 8x4x4 tiles
-    for (int d = 0; d < 3; d++) { dims[d] = (int)std::floor(L[d] / cell) + 1; tdims[d] = (dims[d] + tile[d] - 1) / tile[d]; tot *= (double)tdims[d] * tile[d]; }
-    if (tot <= (double)c->max_cells) break;
-    cell *= std::max(std::cbrt(tot / (double)c->max_cells), 1.02);
-  }
   GridView& g = b.grid;
-  g.pts = b.sorted; g.cell_start = b.cell_start; g.dbg = c->dbg_counters; g.ox = mn[0]; g.oy = mn[1]; g.oz = mn[2];
-  g.cell = (float)cell; g.inv_cell = 1.0f / g.cell; g.nx = dims[0]; g.ny = dims[1]; g.nz = dims[2]; g.n = n;
-  g.ntx = tdims[0]; g.nty = tdims[1]; g.ntz = tdims[2];
-  float amax = 0; for (int d = 0; d < 3; d++) amax = std::max(amax, std::max(std::fabs(mn[d]), std::fabs(mx[d])));
-  g.eps = 1e-3f * g.cell + 1e-6f * (amax + (float)Lmax);
-  const uint32_t ncells = (uint32_t)tdims[0] * tdims[1] * tdims[2] * QN_TILE_CELLS;
-  b.ncells = ncells;
+  memset(&g, 0, sizeof(g));
+  g.pts = b.sorted; g.cell_start = b.cell_start; g.dbg = c->dbg_counters; g.n = n; g.dims = b.dims;
   const uint32_t nb = (n + QN_BLOCK - 1) / QN_BLOCK;
-  const uint32_t sb = (ncells + QN_BLOCK * QN_SCAN_ITEMS - 1) / (QN_BLOCK * QN_SCAN_ITEMS);
-  HIPCHK(c, hipMemsetAsync(b.counts, 0, sizeof(uint32_t) * ncells, s));
+  const uint32_t sb_max = (c->max_cells + QN_BLOCK * QN_SCAN_ITEMS - 1) / (QN_BLOCK * QN_SCAN_ITEMS);
   { ProfScope ps(c, QN_K_GRID_BUILD);
+    hipLaunchKernelGGL(k_bbox, dim3(std::min<uint32_t>((n + QN_BLOCK - 1) / QN_BLOCK, (uint32_t)c->bbox_blocks)), dim3(QN_BLOCK), 0, s, b.raw, n, c->bbox);
+    hipLaunchKernelGGL(k_grid_dims, dim3(1), dim3(64), 0, s, (const BBoxOut*)c->bbox, n, c->max_cells, c->cell_override, b.dims);
+    hipLaunchKernelGGL(k_zero_counts, dim3(256), dim3(QN_BLOCK), 0, s, b.counts, (const GridDims*)b.dims);
     hipLaunchKernelGGL(k_cell_count, dim3(nb), dim3(QN_BLOCK), 0, s, b.raw, n, g, b.counts, b.cell_of_pt);
-    hipLaunchKernelGGL(k_scan_block, dim3(sb), dim3(QN_BLOCK), 0, s, b.counts, ncells, b.cell_start, c->scan_sums);
-    hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(QN_BLOCK), 0, s, c->scan_sums, sb);
-    hipLaunchKernelGGL(k_scan_add, dim3(sb), dim3(QN_BLOCK), 0, s, b.cell_start, ncells, c->scan_sums, n);
+    hipLaunchKernelGGL(k_scan_block_d, dim3(sb_max), dim3(QN_BLOCK), 0, s, (const uint32_t*)b.counts, (const GridDims*)b.dims, b.cell_start, c->scan_sums);
+    hipLaunchKernelGGL(k_scan_top_d, dim3(1), dim3(QN_BLOCK), 0, s, c->scan_sums, (const GridDims*)b.dims);
+    hipLaunchKernelGGL(k_scan_add_d, dim3(sb_max), dim3(QN_BLOCK), 0, s, b.cell_start, (const GridDims*)b.dims, (const uint32_t*)c->scan_sums, n);
     hipLaunchKernelGGL(k_scatter, dim3(nb), dim3(QN_BLOCK), 0, s, b.raw, n, b.cell_of_pt, b.cell_start, b.counts, c->stable_cells ? b.sorted_tmp : b.sorted);
     if (c->stable_cells) hipLaunchKernelGGL(k_stable_cells, dim3(nb), dim3(QN_BLOCK), 0, s, (const float4*)b.sorted_tmp, n, (const uint32_t*)b.cell_of_pt, (const uint32_t*)b.cell_start, b.sorted); }
+  HIPCHK(c, hipMemcpyAsync(b.dims_host, b.dims, sizeof(GridDims), hipMemcpyDeviceToHost, s));
   HIPCHK(c, hipGetLastError());
   b.has_grid = true; b.has_cov = false;
+  return QN_OK;
+}
+// after a synchronisation: did a cloud hold non-finite coordinates?  (is_dense == false clouds are not supported: the reference's KD-tree build would not survive them)
+static int clouds_valid(qn_ctx* c) {
+  for (int w = 0; w < 2; w++)
+    if (c->cloud[w].has_grid && c->cloud[w].dims_host && c->cloud[w].dims_host->nonfinite) {
+      c->last_error = w == 0 ? "source cloud contains non-finite coordinates (is_dense == false clouds are not supported)" : "target cloud contains non-finite coordinates (is_dense == false clouds are not supported)";
+      c->cloud[w].has_grid = c->cloud[w].has_cov = false;
+      return QN_ERR_INVALID_ARG;
+    }
   return QN_OK;
 }
 
@@ -350,7 +343,7 @@ static void launch_knn_cov(qn_ctx* c, CloudBuf& b, int k, int32_t* kidx, float* 
   // its slowest wave, and a wave that has to retry with a doubled radius is 3-4x slower - a wider first radius (fewer retries) wins there
   // (30k points: 174 -> 116 us); beyond that the retries hide behind the next round of waves and the smaller radius wins (100k: 100 vs 131 us);
   // at 10k points the wider radius measured slower again (few waves, each with more candidates): 2.5 only between 16k and 64k.
-  const float r0 = (c->margin_knn > 0.f ? c->margin_knn : (b.n > 16384u && b.n <= 65536u ? 2.5f : 2.0f)) * b.grid.cell;
+  const float r0 = -(c->margin_knn > 0.f ? c->margin_knn : (b.n > 16384u && b.n <= 65536u ? 2.5f : 2.0f));      // negative = in cells (the kernels know the cell edge, the host does not)
   if (c->knn_hist) {                        // histogram selection (default); its leftovers -> hist list pass -> general sorted-list pass
     const uint32_t nb = (b.n + QN_KNN_BLOCK / 4 - 1) / (QN_KNN_BLOCK / 4);     // 16 queries per wave
     uint32_t* genc = c->fb_count2 + 1;
@@ -416,7 +409,7 @@ static void enqueue_nn(qn_ctx* c, int mode /*0 align, 1 fitness*/, float* sqd_ou
   const bool wide = tick <= 2 || (mode == 0 && !seeded);                                              // every unseeded pass of an align leaves thousands of queries to the lists, whatever its index
   const int big_blocks = wide ? c->big_blocks0 : 1024;                                                // waves with one far query each (idle blocks exit at once)
   const uint32_t fbb = std::min<uint32_t>(nb4, wide ? (uint32_t)c->fb_blocks0 : 256u);                           // list pass: wave-stride over the leftovers
-  const float r0 = (tick == 0 && mode == 0 && c->margin_nn_t0 > 0.f ? c->margin_nn_t0 : c->margin_nn) * T.grid.cell;
+  const float r0 = -(tick == 0 && mode == 0 && c->margin_nn_t0 > 0.f ? c->margin_nn_t0 : c->margin_nn);      // negative = in cells
   if (mode == 0) {
     { ProfScope ps(c, QN_K_NN_SEARCH);
       if (seeded) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_nn_track<0>), dim3(nbt), dim3(QN_BLOCK), 0, s, S.grid, T.grid, T.raw, st, thr2, c->corr, sqd_out, c->nn_idx, c->nn_ref, c->fb_list, fbc, c->big_list, bgc);
@@ -439,7 +432,7 @@ static void enqueue_verify(qn_ctx* c, bool fused) {
   const double thr2 = c->params.max_corr_dist * c->params.max_corr_dist;
   GicpState* st = st_cur(c);
   uint32_t* fbc = &st->fb_count; uint32_t* bgc = &st->big_count;
-  const float r0 = c->margin_nn * T.grid.cell;
+  const float r0 = -c->margin_nn;
   hipLaunchKernelGGL(k_reset_lists, dim3(1), dim3(64), 0, s, st);
   hipLaunchKernelGGL(HIP_KERNEL_NAME(k_nn_search<0, false, QN_NN_BLOCK>), dim3(nb), dim3(QN_NN_BLOCK), 0, s, S.grid, T.grid, st, thr2, r0, c->nn_rounds, c->v_corr, c->v_sqd, c->v_nn_idx, c->v_nn_ref, c->fb_list, fbc, c->big_list, bgc, 0, c->big_ratio, (uint32_t*)nullptr, (const float4*)nullptr);
   hipLaunchKernelGGL(HIP_KERNEL_NAME(k_nn_search<0, true, QN_BLOCK>), dim3(std::min<uint32_t>(nb4, 512) + 4096), dim3(QN_BLOCK), 0, s, S.grid, T.grid, st, thr2, r0, 64, c->v_corr, c->v_sqd, c->v_nn_idx, c->v_nn_ref, c->fb_list, fbc, c->big_list, bgc, 4096, c->big_ratio, (uint32_t*)nullptr, (const float4*)nullptr);
@@ -640,6 +633,7 @@ static int gicp_align(qn_ctx* c, const float guess[16], qn_gicp_result* out, boo
     }
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipStreamSynchronize(s));
+    if (first_chunk && (rc = clouds_valid(c)) != QN_OK) return rc;
     budget -= std::max(chunk, 1); ticks_left -= chunk;
     if (c->result_host->phase == 2) {
       if (!look) break;
@@ -661,10 +655,10 @@ static int gicp_align(qn_ctx* c, const float guess[16], qn_gicp_result* out, boo
     if (look) {
       // how far the NEXT step will move the source points at most: the step just taken (translation + rotation x the cloud's reach from the origin), shrunk
       // by 10 (what the optimiser does per iteration at this stage, measured on the synthetic pairs: 12x - 50x)
-      const GridView& sg = c->cloud[0].grid;
+      const GridDims& sg = *c->cloud[0].dims_host;                   // (valid: this stream has been synchronised since the grids were built)
       double reach2 = 0; const double lo[3] = {sg.ox, sg.oy, sg.oz}, ext[3] = {sg.nx * (double)sg.cell, sg.ny * (double)sg.cell, sg.nz * (double)sg.cell};
       for (int d = 0; d < 3; d++) { const double m = std::max(std::fabs(lo[d]), std::fabs(lo[d] + ext[d])); reach2 += m * m; }
-      const double moved = c->result_host->step_dt + c->result_host->step_dr * std::sqrt(reach2), ok = 0.4 * (double)c->cloud[1].grid.cell;
+      const double moved = c->result_host->step_dt + c->result_host->step_dr * std::sqrt(reach2), ok = 0.4 * (double)c->cloud[1].dims_host->cell;
       // (one more unseeded iteration at most: a fourth one measured slower than the tracked tick it replaces - at a nearly converged pose the list pass ends with a
       // few one-per-wave far queries of 100-300 us each, tools/gpu_probe_lists4.py - so a large second step hands over at iteration 3 like the fixed schedule)
       int extra = moved <= ok ? 0 : 1;
@@ -708,6 +702,7 @@ extern "C" int qn_gicp_fitness(qn_ctx* c, double max_range, double* score) {
   HIPCHK(c, hipGetLastError());
   HIPCHK(c, hipStreamSynchronize(c->stream));
   c->prof_collect();
+  if ((rc = clouds_valid(c)) != QN_OK) return rc;
   if (c->result_host->phase != 2) return QN_ERR_NOT_READY;
   *score = c->result_host->r.fitness;
   return QN_OK;
@@ -809,6 +804,7 @@ extern "C" int qn_gicp_get_covariances(qn_ctx* c, int which, double* out9) {
   if (ce == hipSuccess) ce = hipStreamSynchronize(c->stream);
   (void)hipFree(d6);
   if (ce != hipSuccess) { c->set_error("covariance read-back", ce, __LINE__); return QN_ERR_HIP; }
+  { const int vrc = clouds_valid(c); if (vrc != QN_OK) return vrc; }
   for (uint32_t i = 0; i < b.n; i++) {
     const double* s = &h[(size_t)i * 6]; double* o = out9 + (size_t)i * 9;
     o[0] = s[0]; o[1] = s[1]; o[2] = s[2]; o[3] = s[1]; o[4] = s[3]; o[5] = s[4]; o[6] = s[2]; o[7] = s[4]; o[8] = s[5];
@@ -835,7 +831,7 @@ extern "C" int qn_gicp_knn(qn_ctx* c, int which, int k, int32_t* idx_out, float*
   HIPCHK(c, hipMemcpyAsync(d2_out, c->dbg_knn_d2, sizeof(float) * (size_t)b.n * k, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   c->prof_collect();
-  return QN_OK;
+  return clouds_valid(c);
 }
 
 extern "C" int qn_gicp_linearize(qn_ctx* c, const double T[16], double H[36], double b6[6], double* err, int32_t* corr_out, float* sqd_out) {
@@ -872,7 +868,7 @@ extern "C" int qn_gicp_compute_error(qn_ctx* c, const double T[16], double* err)
   HIPCHK(c, hipStreamSynchronize(s));
   *err = c->scalar_host[0];
   c->prof_collect();
-  return QN_OK;
+  return clouds_valid(c);
 }
 
 // ------------------------------------------------------------------ profiling hooks
@@ -1002,7 +998,8 @@ extern "C" int qn_debug_get_partials(qn_ctx* c, double* out /* 2 x (QN_ACC_MAX_B
 }
 extern "C" int qn_debug_get_grid(qn_ctx* c, int which, double out[8]) {
   if (!c || (which != 0 && which != 1) || !c->cloud[which].has_grid) return QN_ERR_INVALID_ARG;
-  const GridView& g = c->cloud[which].grid;
+  if (hipStreamSynchronize(c->stream) != hipSuccess || (c->stream2 && hipStreamSynchronize(c->stream2) != hipSuccess)) return QN_ERR_HIP;
+  const GridDims& g = *c->cloud[which].dims_host;
   out[0] = g.ox; out[1] = g.oy; out[2] = g.oz; out[3] = g.cell; out[4] = g.nx; out[5] = g.ny; out[6] = g.nz; out[7] = g.eps;
   return QN_OK;
 }

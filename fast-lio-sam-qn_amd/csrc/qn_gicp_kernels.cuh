@@ -50,6 +50,7 @@ __device__ __forceinline__ uint32_t xcd_block(uint32_t b, uint32_t nb) {
 
 // ------------------------------------------------------------------ K1 grid build (utility kernels: qn_util_kernels.cuh)
 static __global__ void k_cell_count(const float4* __restrict__ pts, uint32_t n, GridView g, uint32_t* __restrict__ counts, uint32_t* __restrict__ cell_of_pt) {
+  g = grid_resolve(g);
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   float4 p = pts[i];
@@ -57,6 +58,95 @@ static __global__ void k_cell_count(const float4* __restrict__ pts, uint32_t n, 
   uint32_t c = cell_key(g, cx, cy, cz);
   cell_of_pt[i] = c;
   atomicAdd(&counts[c], 1u);
+}
+
+// The grid's numbers from the bounding box, on the device (one thread): cell edge ~4 points per ground-plane cell (the clouds are voxel-grid centroids sampled on
+// surfaces, loop_closure.cpp:107), coarsened until the dense, tile-padded cell table fits max_cells; eps = the slack of cell_coord's f32 rounding.
+static __global__ void k_grid_dims(const BBoxOut* __restrict__ bb, uint32_t n, uint32_t max_cells, double cell_override, GridDims* __restrict__ out) {
+  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  GridDims d;
+  float mn[3], mx[3];
+  for (int a = 0; a < 3; a++) { mn[a] = ord2f(bb->mn[a]); mx[a] = ord2f(bb->mx[a]); }
+  const bool bad = bb->nonfinite != 0u || !(mx[0] >= mn[0]);       // non-finite coordinates (or nothing finite at all)
+  if (bad) { for (int a = 0; a < 3; a++) { mn[a] = 0.f; mx[a] = 0.f; } }
+  double L[3]; for (int a = 0; a < 3; a++) L[a] = fmax((double)mx[a] - (double)mn[a], 0.0);
+  const double Lmax = fmax(L[0], fmax(L[1], L[2]));
+  const double area = fmax(L[0] * L[1], fmax(L[0] * L[2], L[1] * L[2]));
+  double cell = sqrt(4.0 * area / (double)n);
+  cell = fmax(cell, fmax(Lmax / 2048.0, 1e-6));
+  if (cell_override > 0) cell = cell_override;
+  int dims[3] = {1, 1, 1}, tdims[3] = {1, 1, 1}; const int tile[3] = {QN_TX, QN_TY, QN_TZ};
+  for (int iter = 0; iter < 64; iter++) {
+    double tot = 1;                                                  // the dense cell table is padded to whole 8x4x4 tiles
+    for (int a = 0; a < 3; a++) { dims[a] = (int)floor(L[a] / cell) + 1; tdims[a] = (dims[a] + tile[a] - 1) / tile[a]; tot *= (double)tdims[a] * tile[a]; }
+    if (tot <= (double)max_cells) break;
+    cell *= fmax(cbrt(tot / (double)max_cells), 1.02);
+  }
+  d.ox = mn[0]; d.oy = mn[1]; d.oz = mn[2]; d.cell = (float)cell; d.inv_cell = 1.0f / d.cell;
+  d.nx = dims[0]; d.ny = dims[1]; d.nz = dims[2]; d.ntx = tdims[0]; d.nty = tdims[1]; d.ntz = tdims[2];
+  float amax = 0; for (int a = 0; a < 3; a++) amax = fmaxf(amax, fmaxf(fabsf(mn[a]), fabsf(mx[a])));
+  d.eps = 1e-3f * d.cell + 1e-6f * (amax + (float)Lmax);
+  d.n = bad ? 0u : n; d.ncells = (uint32_t)tdims[0] * tdims[1] * tdims[2] * QN_TILE_CELLS; d.nonfinite = bad ? 1u : 0u; d.pad = 0;
+  *out = d;
+}
+// counts[0 .. ncells) = 0, ncells from the device-side dims (fixed grid, stride loop)
+static __global__ void k_zero_counts(uint32_t* __restrict__ counts, const GridDims* __restrict__ dims) {
+  const uint32_t m = dims->ncells;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < m; i += gridDim.x * blockDim.x) counts[i] = 0u;
+}
+// the 3-kernel exclusive scan of qn_util_kernels.cuh with the item count read from the device-side dims: launched with the grid of the LARGEST table,
+// blocks beyond this cloud's table leave at once
+static __global__ void k_scan_block_d(const uint32_t* in, const GridDims* __restrict__ dims, uint32_t* out, uint32_t* __restrict__ block_sums) {
+  __shared__ uint32_t wsum[QN_BLOCK / 64];
+  const uint32_t m = dims->ncells;
+  if (blockIdx.x * (uint32_t)(QN_BLOCK * QN_SCAN_ITEMS) >= m) return;
+  const uint32_t base = (blockIdx.x * QN_BLOCK + threadIdx.x) * QN_SCAN_ITEMS;
+  uint32_t v[QN_SCAN_ITEMS], s = 0;
+#pragma unroll
+  for (int j = 0; j < QN_SCAN_ITEMS; j++) { v[j] = (base + j < m) ? in[base + j] : 0u; s += v[j]; }
+  uint32_t inc = s;
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) { uint32_t t = __shfl_up(inc, o); if (lane >= o) inc += t; }
+  if (lane == 63) wsum[wid] = inc;
+  __syncthreads();
+  uint32_t woff = 0;
+  for (int w = 0; w < wid; w++) woff += wsum[w];
+  uint32_t run = woff + inc - s;
+#pragma unroll
+  for (int j = 0; j < QN_SCAN_ITEMS; j++) { if (base + j < m) out[base + j] = run; run += v[j]; }
+  if (threadIdx.x == QN_BLOCK - 1) block_sums[blockIdx.x] = woff + inc;
+}
+static __global__ void k_scan_top_d(uint32_t* block_sums, const GridDims* __restrict__ dims) {          // single block, serial over chunks of 256
+  __shared__ uint32_t wsum[QN_BLOCK / 64];
+  __shared__ uint32_t carry;
+  const uint32_t nb = (dims->ncells + QN_BLOCK * QN_SCAN_ITEMS - 1) / (QN_BLOCK * QN_SCAN_ITEMS);
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  for (uint32_t base = 0; base < nb; base += QN_BLOCK) {
+    uint32_t i = base + threadIdx.x;
+    uint32_t s = i < nb ? block_sums[i] : 0u, inc = s;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { uint32_t t = __shfl_up(inc, o); if (lane >= o) inc += t; }
+    if (lane == 63) wsum[wid] = inc;
+    __syncthreads();
+    uint32_t woff = carry;
+    for (int w = 0; w < wid; w++) woff += wsum[w];
+    if (i < nb) block_sums[i] = woff + inc - s;
+    __syncthreads();
+    if (threadIdx.x == QN_BLOCK - 1) carry = woff + inc;
+    __syncthreads();
+  }
+}
+static __global__ void k_scan_add_d(uint32_t* __restrict__ out, const GridDims* __restrict__ dims, const uint32_t* __restrict__ block_sums, uint32_t total) {
+  const uint32_t m = dims->ncells;
+  if (blockIdx.x * (uint32_t)(QN_BLOCK * QN_SCAN_ITEMS) >= m) return;
+  const uint32_t base = (blockIdx.x * QN_BLOCK + threadIdx.x) * QN_SCAN_ITEMS;
+  const uint32_t off = block_sums[blockIdx.x];
+#pragma unroll
+  for (int j = 0; j < QN_SCAN_ITEMS; j++) if (base + j < m) out[base + j] += off;
+  if (blockIdx.x == 0 && threadIdx.x == 0) out[m] = total;
 }
 
 // counting-sort scatter: counts[] still holds the per-cell population; slots are handed out from the
@@ -183,6 +273,7 @@ template <bool LIST, int HCAP>
 __global__ void __launch_bounds__(QN_KNN_BLOCK, HCAP <= 32 ? 4 : 3) k_knn_hist(GridView g, int k, float r0, int max_rounds, int32_t* __restrict__ knn_idx, float* __restrict__ knn_d2,
                                                        uint2* __restrict__ fb_list, uint32_t* __restrict__ fb_count, uint2* __restrict__ gen_list, uint32_t* __restrict__ gen_count) {
   __shared__ WaveLdsH<HCAP> lds[QN_KNN_BLOCK / 64];
+  g = grid_resolve(g); if (r0 < 0.f) r0 = -r0 * g.cell;              // (a negative radius is in cells: the host does not know the cell edge)
   WaveLdsH<HCAP>* my = &lds[threadIdx.x >> 6];
   const uint32_t nq = LIST ? *fb_count : g.n;
   if (LIST && g.dbg && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&g.dbg[4], nq);
@@ -210,6 +301,7 @@ __global__ void __launch_bounds__(QN_KNN_BLOCK, HCAP <= 32 ? 4 : 3) k_knn_hist(G
 static __global__ void __launch_bounds__(QN_BLOCK) k_knn_single(GridView g, int k, int32_t* __restrict__ knn_idx, float* __restrict__ knn_d2,
                                                                 const uint2* __restrict__ list, const uint32_t* __restrict__ count, uint2* __restrict__ gen_list, uint32_t* __restrict__ gen_count) {
   __shared__ WaveLdsH1 lds[QN_BLOCK / 64];
+  g = grid_resolve(g);
   WaveLdsH1* my = &lds[threadIdx.x >> 6];
   const uint32_t nq = *count;
   if (g.dbg && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&g.dbg[8], nq);
@@ -268,6 +360,7 @@ __global__ void __launch_bounds__(BLOCK, 6) k_nn_search(GridView src, GridView t
   __shared__ WaveLds lds[BLOCK / 64];
   if (MODE == 0 && st->phase != 0) return;
   if (MODE == 1 && st->phase != 2) return;
+  src = grid_resolve(src); tgt = grid_resolve(tgt); if (r0 < 0.f) r0 = -r0 * tgt.cell;
   float Tf[12];
 #pragma unroll
   for (int j = 0; j < 12; j++) Tf[j] = (float)st->x0[j];
@@ -502,6 +595,7 @@ __global__ void __launch_bounds__(QN_BLOCK, 6) k_nn_track(GridView src, GridView
                                                        uint2* __restrict__ big_list, uint32_t* __restrict__ big_count) {
   if (MODE == 0 && st->phase != 0) return;
   if (MODE == 1 && st->phase != 2) return;
+  src = grid_resolve(src); tgt = grid_resolve(tgt);
   float Tf[12];
 #pragma unroll
   for (int j = 0; j < 12; j++) Tf[j] = (float)st->x0[j];

@@ -31,6 +31,7 @@ __global__ void __launch_bounds__(QN_BLOCK, 3) k_knn_cov(GridView g, const float
                                                       double* __restrict__ cov, int32_t* __restrict__ knn_idx, float* __restrict__ knn_d2,
                                                       uint2* __restrict__ fb_list, uint32_t* __restrict__ fb_count) {
   __shared__ WaveLdsK lds[QN_BLOCK / 64];
+  g = grid_resolve(g); if (r0 < 0.f) r0 = -r0 * g.cell;              // (a negative radius is in cells)
   WaveLdsK* my = &lds[threadIdx.x >> 6];
   const uint32_t nq = LIST ? *fb_count : g.n;
   if (LIST && g.dbg && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&g.dbg[4], nq);

@@ -84,6 +84,7 @@ __global__ void __launch_bounds__(TB, TB / 256) k_align_persist(PersistArgs A) {
   __shared__ double bc_x0[16], bc_xi[16];
   __shared__ int bc_phase, bc_fail;
   __shared__ unsigned long long tie_list[TB / 64][QN_HCAP1]; __shared__ uint32_t tie_cnt[TB / 64];
+  A.t.src = grid_resolve(A.t.src); A.t.tgt = grid_resolve(A.t.tgt);
   const TickArgs& a = A.t;
   const int tid = threadIdx.x, lane = tid & 63;
   const uint32_t nblk = A.nblk;

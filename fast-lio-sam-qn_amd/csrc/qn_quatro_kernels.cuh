@@ -70,6 +70,7 @@ __device__ __forceinline__ double group_sum_d(double v) { v += __shfl_xor(v, 1);
 
 // K9: PCL NormalEstimation, radius search.  normals[t] = (nx, ny, nz, 1) or NaNs.
 static __global__ void __launch_bounds__(QN_BLOCK) k_normals(GridView g, float r, float r2, float4* __restrict__ normals) {
+  g = grid_resolve(g);
   const uint32_t t = blockIdx.x * QN_BLOCK + threadIdx.x;
   if (t >= g.n) return;
   const float4 p = g.pts[t];
@@ -114,6 +115,7 @@ __device__ __forceinline__ bool pair_features(const float4 p1, const float4 n1, 
 // K10: SPFH - 3 x 11-bin histograms of (theta, alpha, phi) over the r_f neighbourhood; bin = count * 100 / (n_nbrs - 1).
 // QN_FG lanes per query: integer counts, so the split of the neighbours over the lanes changes nothing.
 static __global__ void __launch_bounds__(QN_BLOCK) k_spfh(GridView g, float r, float r2, const float4* __restrict__ normals, float* __restrict__ spfh) {
+  g = grid_resolve(g);
   const uint32_t t0 = (blockIdx.x * QN_BLOCK + threadIdx.x) / QN_FG; const int gl = threadIdx.x & (QN_FG - 1);
   const bool in_range = t0 < g.n;
   const uint32_t t = in_range ? t0 : 0;
@@ -154,6 +156,7 @@ static __global__ void __launch_bounds__(QN_BLOCK) k_spfh(GridView g, float r, f
 // sums of f32-sized terms are rounded to f32 at the end: the result does not depend on the order except when a sum sits within 1e-16 of a
 // rounding boundary - no difference against the sequential oracle on any cloud tried; the parity tests hold it to 1e-4 per bin.)
 static __global__ void __launch_bounds__(QN_BLOCK) k_fpfh(GridView g, float r, float r2, const float4* __restrict__ normals, const float* __restrict__ spfh, float* __restrict__ fpfh) {
+  g = grid_resolve(g);
   const uint32_t t0 = (blockIdx.x * QN_BLOCK + threadIdx.x) / QN_FG; const int gl = threadIdx.x & (QN_FG - 1);
   const bool in_range = t0 < g.n;
   const uint32_t t = in_range ? t0 : 0;

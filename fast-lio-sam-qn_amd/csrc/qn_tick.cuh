@@ -466,6 +466,7 @@ __global__ void __launch_bounds__(TB, OCC) k_tick(TickArgs a) {
   static_assert(sizeof(GicpState) % 8 == 0, "GicpState is copied as 8-byte words");
   const int tid = threadIdx.x;
   const uint32_t nblk = gridDim.x;
+  a.src = grid_resolve(a.src); a.tgt = grid_resolve(a.tgt);
   const bool probe = PROBE && a.clk != nullptr && blockIdx.x == 0 && threadIdx.x == 0;
   if (PROBE) {
     if (probe) a.clk[0] = wall_clock64();
@@ -574,6 +575,7 @@ static __global__ void __launch_bounds__(QN_FAR_THREADS) k_far(FarArgs a) {
   __shared__ double wsum[QN_FAR_THREADS / 64][QN_NPART];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   constexpr int NW = QN_FAR_THREADS / 64;
+  a.src = grid_resolve(a.src); a.tgt = grid_resolve(a.tgt);
   const int phase = a.st->phase;
   double acc[QN_NPART];
 #pragma unroll

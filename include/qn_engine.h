@@ -107,6 +107,11 @@ int  qn_ctx_synchronize(qn_ctx* ctx);
 void qn_gicp_default_params(qn_gicp_params* p);                       /* NanoGICP()/LsqRegistration() ctor defaults */
 int  qn_gicp_set_params(qn_ctx*, const qn_gicp_params*);              /* loop_closure.cpp:9-16  */
 int  qn_gicp_get_params(const qn_ctx*, qn_gicp_params* out);          /* what the setters above last stored (the getters of pcl::Registration / NanoGICP) */
+/* setInputSource / setInputTarget do not wait for the GPU: upload, packing and the grid build (its numbers are derived from the bounding box ON the
+ * device) are enqueued and the call returns.  Consequences at this boundary: (1) a cloud with non-finite coordinates is refused by the first call that
+ * synchronises (align, fitness, a read-back) with QN_ERR_INVALID_ARG, not by the setter; (2) pageable host buffers are consumed when the setter returns
+ * (hipMemcpyAsync stages them before returning); PAGE-LOCKED host buffers and the device buffers of the *_device variants are read asynchronously and
+ * must stay unchanged until the next synchronising call of this context (qn_gicp_align, qn_ctx_synchronize, ...).                                  */
 int  qn_gicp_set_source(qn_ctx*, const float* xyz, uint32_t n, uint32_t stride_bytes);          /* setInputSource, loop_closure.cpp:120 */
 int  qn_gicp_set_target(qn_ctx*, const float* xyz, uint32_t n, uint32_t stride_bytes);          /* setInputTarget, loop_closure.cpp:122 */
 int  qn_gicp_set_source_device(qn_ctx*, const float* d_xyz, uint32_t n, uint32_t stride_bytes);

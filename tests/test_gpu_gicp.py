@@ -248,9 +248,21 @@ def test_boundary_status_codes(eng):
     g.setInputSource(src)
     assert g.align() is None and not g.hasConverged()            # covariances/target missing -> not ready, never a crash
     bad = src.copy(); bad[5, 1] = np.nan
+    # non-finite coordinates: the grid's numbers are computed on the device (no host round trip in setInputSource), so the refusal
+    # arrives with the first call that synchronises - and the context is usable again afterwards
+    def both(a, b):
+        g.setInputSource(a); g.calculateSourceCovariances(); g.setInputTarget(b); g.calculateTargetCovariances()
+    both(bad, tgt)
     with pytest.raises(engine.EngineError) as ei:
-        g.setInputSource(bad)
-    assert ei.value.status == engine.QN_ERR_INVALID_ARG
+        g.align()
+    assert ei.value.status == engine.QN_ERR_INVALID_ARG and "non-finite" in str(ei.value)
+    assert g.align() is None                                      # the refused cloud is gone: not ready
+    both(src, bad)
+    with pytest.raises(engine.EngineError) as ei:
+        g.align()
+    assert ei.value.status == engine.QN_ERR_INVALID_ARG and "target" in str(ei.value)
+    both(src, tgt)
+    assert g.align() is not None and g.hasConverged()
     with pytest.raises(engine.EngineError) as ei:
         g.setInputSource(np.zeros((ctx.max_points + 1, 3), dtype=np.float32))
     assert ei.value.status == engine.QN_ERR_CAPACITY
