@@ -29,6 +29,8 @@ struct qn_ctx {
   void* slab = nullptr;                 // ONE device allocation behind every per-context buffer of the GICP path (qn_ctx_create)
   qn_gicp_params params{};
   CloudBuf cloud[2];
+  qn::BBoxAcc* bbox_acc = nullptr; qn::BBoxAcc* bbox_acc2 = nullptr;     // bounding-box accumulators (k_pack_bbox_dims), one per stream
+  unsigned long long* scan_status = nullptr; unsigned long long* scan_status2 = nullptr; uint32_t build_epoch = 0;   // look-back scan: tile status words, tagged with the build's epoch
   char* staging2 = nullptr;             // the second stream's landing zone (TargetScope)
   char* staging = nullptr;              // [max_points * 32] H2D landing zone for strided host clouds
   uint32_t* scan_sums = nullptr;
@@ -75,7 +77,7 @@ struct qn_ctx {
   int big_blocks0 = 4096, fb_blocks0 = 512;   // grid of the list pass behind the first (unseeded) ticks: one-far-query-per-wave blocks, wave-stride leftover blocks
   float margin_nn_t0 = 0.f;             // first search radius of tick 0 only (0 = margin_nn)
   float margin_nn = 1.f, margin_knn = 0.f;   // first search radius in cells (1-NN of the first tick / k-NN of the covariances; 0 = by cloud size, launch_knn_cov)
-  int margin_nn_cap = 3, margin_knn_cap = 5, ticks_per_chunk = 8; bool knn_single_all = false, stable_cells = true; int bbox_blocks = 32;
+  int margin_nn_cap = 3, margin_knn_cap = 5, ticks_per_chunk = 8; bool knn_single_all = false, stable_cells = true; int bbox_blocks = 64;
   // pair pipeline of icpAlignment: the target cloud is prepared on a second stream with its own scratch while the source's k-NN runs
   hipStream_t stream2 = nullptr; hipEvent_t ev_pair = nullptr; bool pair_pipeline = true, pair_failed = false, tgt_on_stream2 = false, tgt_pending = false, no_pipe = false;
   uint32_t* scan_sums2 = nullptr; uint2* fb_list2 = nullptr; uint2* big_list2 = nullptr; uint32_t* fb_count2b = nullptr; int32_t* knn_idx2 = nullptr; qn::BBoxOut* bbox2 = nullptr; qn::BBoxOut* bbox_host2 = nullptr;   // 128 blocks = 768 atomics on six words: 10.6 us per cloud; 32: 5 us   // experiment: one selection round, every leftover to the one-query-per-wave pass

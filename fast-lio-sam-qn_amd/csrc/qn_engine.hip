@@ -143,6 +143,8 @@ extern "C" int qn_ctx_create(int device, uint32_t max_points, qn_ctx** out) {
     sl.take(c->knn_idx2, sizeof(int32_t) * (size_t)max_points * 32);
     sl.take(c->bbox2, sizeof(BBoxOut));
     sl.take(c->staging2, (size_t)max_points * 32);
+    sl.take(c->bbox_acc, 2 * sizeof(BBoxAcc)); c->bbox_acc2 = c->bbox_acc ? c->bbox_acc + 1 : nullptr;
+    sl.take(c->scan_status, sizeof(unsigned long long) * 2 * (c->max_cells / (QN_BLOCK * QN_SCAN_ITEMS) + 2)); c->scan_status2 = c->scan_status ? c->scan_status + (c->max_cells / (QN_BLOCK * QN_SCAN_ITEMS) + 2) : nullptr;
     sl.take(c->pg_rows, sizeof(unsigned long long) * 3 * QN_PERSIST_ROWS * QN_PERSIST_RSTRIDE);
     sl.take(c->pg_bc, sizeof(unsigned long long) * 64);
     sl.take(c->pg_fit, sizeof(unsigned long long) * (QN_PERSIST_MAX_BLOCKS + 1) * 4);
@@ -164,6 +166,9 @@ extern "C" int qn_ctx_create(int device, uint32_t max_points, qn_ctx** out) {
   CA(hipMemsetAsync(c->pg_fit, 0, sizeof(unsigned long long) * (QN_PERSIST_MAX_BLOCKS + 1) * 4, c->stream));
   CA(hipMemsetAsync(c->pg_status, 0, 4 * sizeof(uint32_t), c->stream));
   CA(hipMemsetAsync(c->state, 0, 2 * sizeof(GicpState), c->stream));
+  hipLaunchKernelGGL(k_bbox_acc_init, dim3(1), dim3(64), 0, c->stream, c->bbox_acc, 2);
+  CA(hipMemsetAsync(c->scan_status, 0, sizeof(unsigned long long) * 2 * (c->max_cells / (QN_BLOCK * QN_SCAN_ITEMS) + 2), c->stream));
+  for (int w = 0; w < 2; w++) CA(hipMemsetAsync(c->cloud[w].counts, 0, sizeof(uint32_t) * ((size_t)c->max_cells + 1), c->stream));      // the cell counters are handed back at zero by every build (k_scatter)
   CA(hipStreamSynchronize(c->stream));
 #undef CA
   *out = c;
@@ -250,6 +255,7 @@ static bool pair_pipeline_ready(qn_ctx* c) {
 static void swap_scratch(qn_ctx* c) {
   std::swap(c->stream, c->stream2); std::swap(c->scan_sums, c->scan_sums2); std::swap(c->fb_list, c->fb_list2); std::swap(c->big_list, c->big_list2);
   std::swap(c->fb_count2, c->fb_count2b); std::swap(c->knn_idx, c->knn_idx2); std::swap(c->bbox, c->bbox2); std::swap(c->bbox_host, c->bbox_host2);
+  std::swap(c->bbox_acc, c->bbox_acc2); std::swap(c->scan_status, c->scan_status2);
   std::swap(c->staging, c->staging2);       // (setInputSource no longer waits for its pack kernel: the target's upload must not land in the source's landing zone)
 }
 struct TargetScope {                    // RAII: the body of set_cloud / compute_cov runs with the second stream's scratch; the event marks its end
@@ -263,31 +269,26 @@ static int join_target(qn_ctx* c) {
   return hipStreamWaitEvent(c->stream, c->ev_pair, 0) == hipSuccess ? QN_OK : QN_ERR_HIP;
 }
 
-// K1: pack -> bbox -> grid numbers (k_grid_dims, on the device) -> count -> exclusive scan -> scatter.  No host round trip: the kernels read the numbers from
-// device memory (GridView::dims, grid_resolve); the table-sized launches (zeroing, scan) use the grid of the largest table and leave early.  What the host
+// K1: pack + bbox + grid numbers (on the device) -> count -> exclusive scan -> scatter.  No host round trip: the kernels read the numbers from
+// device memory (GridView::dims, grid_resolve); the table-sized scan uses the grid of the largest table and leaves early.  What the host
 // needs to know - "the cloud held non-finite coordinates" - arrives with the pinned mirror at the next synchronisation (clouds_valid).
-static int build_grid(qn_ctx* c, CloudBuf& b) {
+static int build_grid(qn_ctx* c, CloudBuf& b, const char* dsrc, uint32_t stride) {
   const uint32_t n = b.n;
   hipStream_t s = c->stream;
-  BBoxOut init; for (int d = 0; d < 3; d++) { init.mn[d] = 0x7fffffff; init.mx[d] = (int)0x80000000; } init.nonfinite = 0;
-  *c->bbox_host = init;                                               // (constant: only ever the source of this upload)
-  HIPCHK(c, hipMemcpyAsync(c->bbox, c->bbox_host, sizeof(BBoxOut), hipMemcpyHostToDevice, s));
   GridView& g = b.grid;
   memset(&g, 0, sizeof(g));
   g.pts = b.sorted; g.cell_start = b.cell_start; g.dbg = c->dbg_counters; g.n = n; g.dims = b.dims;
   const uint32_t nb = (n + QN_BLOCK - 1) / QN_BLOCK;
   const uint32_t sb_max = (c->max_cells + QN_BLOCK * QN_SCAN_ITEMS - 1) / (QN_BLOCK * QN_SCAN_ITEMS);
+  if (((++c->build_epoch) & 0x3fffffffu) == 0u) ++c->build_epoch;     // (0 = the tag of the zero-initialised status words)
   { ProfScope ps(c, QN_K_GRID_BUILD);
-    hipLaunchKernelGGL(k_bbox, dim3(std::min<uint32_t>((n + QN_BLOCK - 1) / QN_BLOCK, (uint32_t)c->bbox_blocks)), dim3(QN_BLOCK), 0, s, b.raw, n, c->bbox);
-    hipLaunchKernelGGL(k_grid_dims, dim3(1), dim3(64), 0, s, (const BBoxOut*)c->bbox, n, c->max_cells, c->cell_override, b.dims);
-    hipLaunchKernelGGL(k_zero_counts, dim3(256), dim3(QN_BLOCK), 0, s, b.counts, (const GridDims*)b.dims);
+    // 5 launches, nothing else: the bounding-box accumulator and the cell counters clean up after themselves (the last block of the first kernel; k_scatter's
+    // atomicSub hands every counter back at zero), the scan is single-pass, the numbers reach the host through the pinned mirror
+    hipLaunchKernelGGL(k_pack_bbox_dims, dim3(std::min<uint32_t>(nb, (uint32_t)c->bbox_blocks)), dim3(QN_BLOCK), 0, s, dsrc, stride, n, b.raw, c->bbox_acc, c->max_cells, c->cell_override, b.dims, b.dims_host);
     hipLaunchKernelGGL(k_cell_count, dim3(nb), dim3(QN_BLOCK), 0, s, b.raw, n, g, b.counts, b.cell_of_pt);
-    hipLaunchKernelGGL(k_scan_block_d, dim3(sb_max), dim3(QN_BLOCK), 0, s, (const uint32_t*)b.counts, (const GridDims*)b.dims, b.cell_start, c->scan_sums);
-    hipLaunchKernelGGL(k_scan_top_d, dim3(1), dim3(QN_BLOCK), 0, s, c->scan_sums, (const GridDims*)b.dims);
-    hipLaunchKernelGGL(k_scan_add_d, dim3(sb_max), dim3(QN_BLOCK), 0, s, b.cell_start, (const GridDims*)b.dims, (const uint32_t*)c->scan_sums, n);
+    hipLaunchKernelGGL(k_scan_lookback, dim3(sb_max), dim3(QN_BLOCK), 0, s, (const uint32_t*)b.counts, (const GridDims*)b.dims, b.cell_start, c->scan_status, c->build_epoch, n);
     hipLaunchKernelGGL(k_scatter, dim3(nb), dim3(QN_BLOCK), 0, s, b.raw, n, b.cell_of_pt, b.cell_start, b.counts, c->stable_cells ? b.sorted_tmp : b.sorted);
     if (c->stable_cells) hipLaunchKernelGGL(k_stable_cells, dim3(nb), dim3(QN_BLOCK), 0, s, (const float4*)b.sorted_tmp, n, (const uint32_t*)b.cell_of_pt, (const uint32_t*)b.cell_start, b.sorted); }
-  HIPCHK(c, hipMemcpyAsync(b.dims_host, b.dims, sizeof(GridDims), hipMemcpyDeviceToHost, s));
   HIPCHK(c, hipGetLastError());
   b.has_grid = true; b.has_cov = false;
   return QN_OK;
@@ -326,8 +327,7 @@ static int set_cloud(qn_ctx* c, int which, const float* xyz, uint32_t n, uint32_
     dsrc = (const char*)c->staging;
   }
   b.n = n;
-  hipLaunchKernelGGL(k_pack_points, dim3((n + QN_BLOCK - 1) / QN_BLOCK), dim3(QN_BLOCK), 0, s, dsrc, stride, n, b.raw);
-  return build_grid(c, b);
+  return build_grid(c, b, dsrc, stride);
 }
 
 extern "C" int qn_gicp_set_source(qn_ctx* c, const float* xyz, uint32_t n, uint32_t stride) { return set_cloud(c, QN_SOURCE, xyz, n, stride, false); }

@@ -60,14 +60,13 @@ static __global__ void k_cell_count(const float4* __restrict__ pts, uint32_t n, 
   atomicAdd(&counts[c], 1u);
 }
 
-// The grid's numbers from the bounding box, on the device (one thread): cell edge ~4 points per ground-plane cell (the clouds are voxel-grid centroids sampled on
+// The grid's numbers from the bounding box, on the device: cell edge ~4 points per ground-plane cell (the clouds are voxel-grid centroids sampled on
 // surfaces, loop_closure.cpp:107), coarsened until the dense, tile-padded cell table fits max_cells; eps = the slack of cell_coord's f32 rounding.
-static __global__ void k_grid_dims(const BBoxOut* __restrict__ bb, uint32_t n, uint32_t max_cells, double cell_override, GridDims* __restrict__ out) {
-  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+__device__ inline GridDims grid_dims_from_bbox(const int (&omn)[3], const int (&omx)[3], bool bad, uint32_t n, uint32_t max_cells, double cell_override) {
   GridDims d;
   float mn[3], mx[3];
-  for (int a = 0; a < 3; a++) { mn[a] = ord2f(bb->mn[a]); mx[a] = ord2f(bb->mx[a]); }
-  const bool bad = bb->nonfinite != 0u || !(mx[0] >= mn[0]);       // non-finite coordinates (or nothing finite at all)
+  for (int a = 0; a < 3; a++) { mn[a] = ord2f(omn[a]); mx[a] = ord2f(omx[a]); }
+  bad = bad || !(mx[0] >= mn[0]);                                    // non-finite coordinates (or nothing finite at all)
   if (bad) { for (int a = 0; a < 3; a++) { mn[a] = 0.f; mx[a] = 0.f; } }
   double L[3]; for (int a = 0; a < 3; a++) L[a] = fmax((double)mx[a] - (double)mn[a], 0.0);
   const double Lmax = fmax(L[0], fmax(L[1], L[2]));
@@ -87,71 +86,126 @@ static __global__ void k_grid_dims(const BBoxOut* __restrict__ bb, uint32_t n, u
   float amax = 0; for (int a = 0; a < 3; a++) amax = fmaxf(amax, fmaxf(fabsf(mn[a]), fabsf(mx[a])));
   d.eps = 1e-3f * d.cell + 1e-6f * (amax + (float)Lmax);
   d.n = bad ? 0u : n; d.ncells = (uint32_t)tdims[0] * tdims[1] * tdims[2] * QN_TILE_CELLS; d.nonfinite = bad ? 1u : 0u; d.pad = 0;
-  *out = d;
+  return d;
 }
-// counts[0 .. ncells) = 0, ncells from the device-side dims (fixed grid, stride loop)
-static __global__ void k_zero_counts(uint32_t* __restrict__ counts, const GridDims* __restrict__ dims) {
-  const uint32_t m = dims->ncells;
-  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < m; i += gridDim.x * blockDim.x) counts[i] = 0u;
-}
-// the 3-kernel exclusive scan of qn_util_kernels.cuh with the item count read from the device-side dims: launched with the grid of the LARGEST table,
-// blocks beyond this cloud's table leave at once
-static __global__ void k_scan_block_d(const uint32_t* in, const GridDims* __restrict__ dims, uint32_t* out, uint32_t* __restrict__ block_sums) {
-  __shared__ uint32_t wsum[QN_BLOCK / 64];
-  const uint32_t m = dims->ncells;
-  if (blockIdx.x * (uint32_t)(QN_BLOCK * QN_SCAN_ITEMS) >= m) return;
-  const uint32_t base = (blockIdx.x * QN_BLOCK + threadIdx.x) * QN_SCAN_ITEMS;
-  uint32_t v[QN_SCAN_ITEMS], s = 0;
+
+// Grid build, first kernel: pack the caller's strided points into float4 (x, y, z, 1), fold their bounding box into the accumulator (ordered-int atomics, one set
+// per block), and let the LAST block to arrive (ticket) turn the box into the grid's numbers - written to device memory for the kernels that follow and straight
+// into the pinned mirror the host reads after its next synchronisation.  That block also puts the accumulator back into its initial state: no upload, no reset
+// kernel, no read-back in front of or behind the build.  (Accumulator words are only ever touched with agent-scope atomics: the blocks sit on different XCDs.)
+struct BBoxAcc { int mn[3], mx[3]; uint32_t nonfinite, ticket; };
+static __global__ void __launch_bounds__(QN_BLOCK) k_pack_bbox_dims(const char* __restrict__ in, uint32_t stride, uint32_t n, float4* __restrict__ raw, BBoxAcc* acc,
+                                                                    uint32_t max_cells, double cell_override, GridDims* __restrict__ dims_dev, GridDims* __restrict__ dims_host) {
+  __shared__ int smn[QN_BLOCK / 64][3], smx[QN_BLOCK / 64][3], sbad[QN_BLOCK / 64];
+  int mn[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff}, mx[3] = {(int)0x80000000, (int)0x80000000, (int)0x80000000};
+  int bad = 0;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const float* q = (const float*)(in + (size_t)i * stride);
+    const float4 p = make_float4(q[0], q[1], q[2], 1.0f);
+    raw[i] = p;
+    if (!(isfinite(p.x) && isfinite(p.y) && isfinite(p.z))) { bad = 1; continue; }
+    const int ox = f2ord(p.x), oy = f2ord(p.y), oz = f2ord(p.z);
+    mn[0] = min(mn[0], ox); mn[1] = min(mn[1], oy); mn[2] = min(mn[2], oz);
+    mx[0] = max(mx[0], ox); mx[1] = max(mx[1], oy); mx[2] = max(mx[2], oz);
+  }
 #pragma unroll
-  for (int j = 0; j < QN_SCAN_ITEMS; j++) { v[j] = (base + j < m) ? in[base + j] : 0u; s += v[j]; }
+  for (int d = 0; d < 3; d++) { mn[d] = wave_min_i(mn[d]); mx[d] = wave_max_i(mx[d]); }
+  bad = wave_max_i(bad);
+  const int wid = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) { for (int d = 0; d < 3; d++) { smn[wid][d] = mn[d]; smx[wid][d] = mx[d]; } sbad[wid] = bad; }
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  for (int w = 1; w < QN_BLOCK / 64; w++) { for (int d = 0; d < 3; d++) { mn[d] = min(mn[d], smn[w][d]); mx[d] = max(mx[d], smx[w][d]); } bad |= sbad[w]; }
+  for (int d = 0; d < 3; d++) { atomicMin(&acc->mn[d], mn[d]); atomicMax(&acc->mx[d], mx[d]); }
+  if (bad) atomicAdd(&acc->nonfinite, 1u);
+  __threadfence();
+  if (atomicAdd(&acc->ticket, 1u) != gridDim.x - 1u) return;
+  __threadfence();
+  for (int d = 0; d < 3; d++) { mn[d] = __hip_atomic_load(&acc->mn[d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); mx[d] = __hip_atomic_load(&acc->mx[d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+  const uint32_t nf = __hip_atomic_load(&acc->nonfinite, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const GridDims g = grid_dims_from_bbox(mn, mx, nf != 0u, n, max_cells, cell_override);
+  *dims_dev = g; *dims_host = g;
+  for (int d = 0; d < 3; d++) { __hip_atomic_store(&acc->mn[d], 0x7fffffff, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); __hip_atomic_store(&acc->mx[d], (int)0x80000000, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+  __hip_atomic_store(&acc->nonfinite, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store(&acc->ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+static __global__ void k_bbox_acc_init(BBoxAcc* acc, int count) {
+  if (blockIdx.x == 0 && (int)threadIdx.x < count) { BBoxAcc a; for (int d = 0; d < 3; d++) { a.mn[d] = 0x7fffffff; a.mx[d] = (int)0x80000000; } a.nonfinite = 0; a.ticket = 0; acc[threadIdx.x] = a; }
+}
+
+// Exclusive scan of the cell counts in ONE launch (decoupled look-back): tile t = block t publishes its aggregate, sums its predecessors' aggregates back to the
+// nearest published inclusive prefix, publishes its own.  Status words are {epoch : 30 | state : 2 | value : 32} so that nothing has to be reset between builds:
+// a word of another epoch reads "nothing yet".  The launch uses the grid of the LARGEST table (the host does not know this cloud's); blocks past the table leave
+// at once.  All blocks are co-resident (<= 2048 tiles of 256 threads on 256 CUs), so a tile waiting on its predecessors cannot starve them.  out[m] = total.
+#define QN_LB_STATE_AGG 1ull
+#define QN_LB_STATE_INC 2ull
+static __global__ void __launch_bounds__(QN_BLOCK) k_scan_lookback(const uint32_t* __restrict__ in, const GridDims* __restrict__ dims, uint32_t* __restrict__ out,
+                                                                   unsigned long long* status, uint32_t epoch, uint32_t total) {
+  __shared__ uint32_t wsum[QN_BLOCK / 64];
+  __shared__ uint32_t s_prefix;
+  const uint32_t m = dims->ncells;
+  const uint32_t tile = blockIdx.x;
+  if (tile * (uint32_t)(QN_BLOCK * QN_SCAN_ITEMS) >= m) return;
+  const uint32_t base = (tile * QN_BLOCK + threadIdx.x) * QN_SCAN_ITEMS;
+  uint32_t v[QN_SCAN_ITEMS], s = 0;
+  if (base + QN_SCAN_ITEMS <= m) {
+    const uint4* q = (const uint4*)(in + base);
+#pragma unroll
+    for (int j = 0; j < QN_SCAN_ITEMS / 4; j++) { const uint4 x = q[j]; v[4 * j] = x.x; v[4 * j + 1] = x.y; v[4 * j + 2] = x.z; v[4 * j + 3] = x.w; }
+  } else {
+#pragma unroll
+    for (int j = 0; j < QN_SCAN_ITEMS; j++) v[j] = (base + j < m) ? in[base + j] : 0u;
+  }
+#pragma unroll
+  for (int j = 0; j < QN_SCAN_ITEMS; j++) s += v[j];
   uint32_t inc = s;
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
 #pragma unroll
   for (int o = 1; o < 64; o <<= 1) { uint32_t t = __shfl_up(inc, o); if (lane >= o) inc += t; }
   if (lane == 63) wsum[wid] = inc;
   __syncthreads();
-  uint32_t woff = 0;
-  for (int w = 0; w < wid; w++) woff += wsum[w];
-  uint32_t run = woff + inc - s;
+  uint32_t woff = 0, agg = 0;
+  for (int w = 0; w < QN_BLOCK / 64; w++) { if (w < wid) woff += wsum[w]; agg += wsum[w]; }
+  const unsigned long long tag = (unsigned long long)(epoch & 0x3fffffffu) << 34;
+  if (wid == 0) {
+    uint32_t prefix = 0;
+    if (tile == 0) {
+      if (lane == 0) __hip_atomic_store(status, tag | (QN_LB_STATE_INC << 32) | agg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      if (lane == 0) __hip_atomic_store(status + tile, tag | (QN_LB_STATE_AGG << 32) | agg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      int look = (int)tile - 1;                                      // lane l watches tile look - l
+      for (;;) {
+        const int mine = look - lane;
+        unsigned long long x = 0;
+        if (mine >= 0) { do { x = __hip_atomic_load(status + mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } while ((x >> 34) != (tag >> 34)); }
+        const bool is_inc = mine >= 0 && ((x >> 32) & 3ull) == QN_LB_STATE_INC;
+        const unsigned long long incs = __ballot(is_inc);
+        const int first = incs ? __ffsll((long long)incs) - 1 : 64;  // nearest tile with an inclusive prefix, as a lane number
+        uint32_t part = (mine >= 0 && lane <= first) ? (uint32_t)x : 0u;
 #pragma unroll
-  for (int j = 0; j < QN_SCAN_ITEMS; j++) { if (base + j < m) out[base + j] = run; run += v[j]; }
-  if (threadIdx.x == QN_BLOCK - 1) block_sums[blockIdx.x] = woff + inc;
-}
-static __global__ void k_scan_top_d(uint32_t* block_sums, const GridDims* __restrict__ dims) {          // single block, serial over chunks of 256
-  __shared__ uint32_t wsum[QN_BLOCK / 64];
-  __shared__ uint32_t carry;
-  const uint32_t nb = (dims->ncells + QN_BLOCK * QN_SCAN_ITEMS - 1) / (QN_BLOCK * QN_SCAN_ITEMS);
-  if (threadIdx.x == 0) carry = 0;
-  __syncthreads();
-  for (uint32_t base = 0; base < nb; base += QN_BLOCK) {
-    uint32_t i = base + threadIdx.x;
-    uint32_t s = i < nb ? block_sums[i] : 0u, inc = s;
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) { uint32_t t = __shfl_up(inc, o); if (lane >= o) inc += t; }
-    if (lane == 63) wsum[wid] = inc;
-    __syncthreads();
-    uint32_t woff = carry;
-    for (int w = 0; w < wid; w++) woff += wsum[w];
-    if (i < nb) block_sums[i] = woff + inc - s;
-    __syncthreads();
-    if (threadIdx.x == QN_BLOCK - 1) carry = woff + inc;
-    __syncthreads();
+        for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);
+        prefix += part;
+        if (incs || look - 64 < 0) break;
+        look -= 64;
+      }
+      if (lane == 0) __hip_atomic_store(status + tile, tag | (QN_LB_STATE_INC << 32) | (prefix + agg), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (lane == 0) s_prefix = prefix;
   }
-}
-static __global__ void k_scan_add_d(uint32_t* __restrict__ out, const GridDims* __restrict__ dims, const uint32_t* __restrict__ block_sums, uint32_t total) {
-  const uint32_t m = dims->ncells;
-  if (blockIdx.x * (uint32_t)(QN_BLOCK * QN_SCAN_ITEMS) >= m) return;
-  const uint32_t base = (blockIdx.x * QN_BLOCK + threadIdx.x) * QN_SCAN_ITEMS;
-  const uint32_t off = block_sums[blockIdx.x];
+  __syncthreads();
+  uint32_t run = s_prefix + woff + inc - s;
+  if (base + QN_SCAN_ITEMS <= m) {
+    uint4* q = (uint4*)(out + base);
 #pragma unroll
-  for (int j = 0; j < QN_SCAN_ITEMS; j++) if (base + j < m) out[base + j] += off;
-  if (blockIdx.x == 0 && threadIdx.x == 0) out[m] = total;
+    for (int j = 0; j < QN_SCAN_ITEMS / 4; j++) { uint4 x; x.x = run; run += v[4 * j]; x.y = run; run += v[4 * j + 1]; x.z = run; run += v[4 * j + 2]; x.w = run; run += v[4 * j + 3]; q[j] = x; }
+  } else {
+#pragma unroll
+    for (int j = 0; j < QN_SCAN_ITEMS; j++) { if (base + j < m) out[base + j] = run; run += v[j]; }
+  }
+  if (base <= m && m < base + QN_SCAN_ITEMS) out[m] = total;       // (m is a multiple of the 128-cell tile: this is the thread whose first item would be index m ...)
+  if (m == (tile + 1u) * (uint32_t)(QN_BLOCK * QN_SCAN_ITEMS) && threadIdx.x == QN_BLOCK - 1) out[m] = total;      // (... or the table ends with this tile)
 }
 
-// counting-sort scatter: counts[] still holds the per-cell population; slots are handed out from the
-// back of each cell's run.  Order inside a cell is the atomics' arrival order here; k_stable_cells (below) replaces it by ascending
-// original index (carried in .w) before any consumer reads the cloud.
 static __global__ void k_scatter(const float4* __restrict__ pts, uint32_t n, const uint32_t* __restrict__ cell_of_pt,
                           const uint32_t* __restrict__ cell_start, uint32_t* __restrict__ counts, float4* __restrict__ sorted) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;

@@ -3,8 +3,8 @@ import csv, sys, glob
 f = sys.argv[1]
 rows = list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-# last registration starts at the last k_pack_points pair: find the second-to-last k_pack_points
-idx = [i for i, r in enumerate(rows) if "k_pack_points" in r["Kernel_Name"]]
+# last registration starts at the last pair of grid builds: find the second-to-last pack kernel
+idx = [i for i, r in enumerate(rows) if "k_pack_points" in r["Kernel_Name"] or "k_pack_bbox_dims" in r["Kernel_Name"]]
 start = idx[-2]
 t0 = int(rows[start]["Start_Timestamp"]); prev_end = t0
 for r in rows[start:]:
