@@ -396,7 +396,7 @@ extern "C" int qn_gicp_compute_covariances(qn_ctx* c, int which) { return comput
 // tick = index of this NN pass within the align (list-pass grids shrink as the optimiser converges: the first search
 // leaves ~10-20 % of the queries to the list passes, the first tracked pass most of them after the big initial pose
 // step, later passes a handful - any grid is correct, the lists are walked wave-stride)
-static void enqueue_nn(qn_ctx* c, int mode /*0 align, 1 fitness*/, float* sqd_out, bool seeded, int tick = 0) {
+static void enqueue_nn(qn_ctx* c, int mode /*0 align, 1 fitness*/, float* sqd_out, bool seeded, int tick = 0, int cond = 0) {
   hipStream_t s = c->stream;
   CloudBuf &S = c->cloud[0], &T = c->cloud[1];
   const uint32_t nb = (S.n + QN_NN_BLOCK / 4 - 1) / (QN_NN_BLOCK / 4);   // grid passes: 16 queries per wave
@@ -410,17 +410,20 @@ static void enqueue_nn(qn_ctx* c, int mode /*0 align, 1 fitness*/, float* sqd_ou
   const int big_blocks = wide ? c->big_blocks0 : 1024;                                                // waves with one far query each (idle blocks exit at once)
   const uint32_t fbb = std::min<uint32_t>(nb4, wide ? (uint32_t)c->fb_blocks0 : 256u);                           // list pass: wave-stride over the leftovers
   const float r0 = -(tick == 0 && mode == 0 && c->margin_nn_t0 > 0.f ? c->margin_nn_t0 : c->margin_nn);      // negative = in cells
+  NnOpt opt; opt.clear_ref = (mode == 0 && !seeded && c->clear_far_now) ? c->far_cand_ref : nullptr; opt.cond = cond;
+  NnOpt opt0; opt0.clear_ref = nullptr; opt0.cond = 0;
+  c->clear_far_now = mode == 0 && !seeded ? false : c->clear_far_now;
   if (mode == 0) {
     { ProfScope ps(c, QN_K_NN_SEARCH);
       if (seeded) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_nn_track<0>), dim3(nbt), dim3(QN_BLOCK), 0, s, S.grid, T.grid, T.raw, st, thr2, c->corr, sqd_out, c->nn_idx, c->nn_ref, c->fb_list, fbc, c->big_list, bgc);
-      else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_nn_search<0, false, QN_NN_BLOCK>), dim3(nb), dim3(QN_NN_BLOCK), 0, s, S.grid, T.grid, st, thr2, r0, c->nn_rounds, c->corr, sqd_out, c->nn_idx, c->nn_ref, c->fb_list, fbc, c->big_list, bgc, 0, c->big_ratio, far_stats, (c->seed_lists && tick > 0) ? (const float4*)T.raw : (const float4*)nullptr); }
+      else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_nn_search<0, false, QN_NN_BLOCK>), dim3(nb), dim3(QN_NN_BLOCK), 0, s, S.grid, T.grid, st, thr2, r0, c->nn_rounds, c->corr, sqd_out, c->nn_idx, c->nn_ref, c->fb_list, fbc, c->big_list, bgc, 0, c->big_ratio, far_stats, (c->seed_lists && tick > 0) ? (const float4*)T.raw : (const float4*)nullptr, opt); }
     { ProfScope ps(c, QN_K_NN_FALLBACK);
-      hipLaunchKernelGGL(HIP_KERNEL_NAME(k_nn_search<0, true, QN_BLOCK>), dim3(fbb + big_blocks), dim3(QN_BLOCK), 0, s, S.grid, T.grid, st, thr2, r0, 64, c->corr, sqd_out, c->nn_idx, c->nn_ref, c->fb_list, fbc, c->big_list, bgc, big_blocks, c->big_ratio, far_stats, (c->chain_far && tick == 0) ? (const float4*)T.raw : (const float4*)nullptr); }
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(k_nn_search<0, true, QN_BLOCK>), dim3(fbb + big_blocks), dim3(QN_BLOCK), 0, s, S.grid, T.grid, st, thr2, r0, 64, c->corr, sqd_out, c->nn_idx, c->nn_ref, c->fb_list, fbc, c->big_list, bgc, big_blocks, c->big_ratio, far_stats, (c->chain_far && tick == 0) ? (const float4*)T.raw : (const float4*)nullptr, opt); }
   } else {
     ProfScope ps(c, QN_K_FITNESS);
     if (seeded) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_nn_track<1>), dim3(nbt), dim3(QN_BLOCK), 0, s, S.grid, T.grid, T.raw, st, thr2, c->corr, sqd_out, c->nn_idx, c->nn_ref, c->fb_list, fbc, c->big_list, bgc);
-    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_nn_search<1, false, QN_NN_BLOCK>), dim3(nb), dim3(QN_NN_BLOCK), 0, s, S.grid, T.grid, st, thr2, r0, 1, c->corr, sqd_out, c->nn_idx, c->nn_ref, c->fb_list, fbc, c->big_list, bgc, 0, c->big_ratio, far_stats, (const float4*)nullptr);
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_nn_search<1, true, QN_BLOCK>), dim3(fbb + big_blocks), dim3(QN_BLOCK), 0, s, S.grid, T.grid, st, thr2, r0, 64, c->corr, sqd_out, c->nn_idx, c->nn_ref, c->fb_list, fbc, c->big_list, bgc, big_blocks, c->big_ratio, far_stats, (const float4*)nullptr);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_nn_search<1, false, QN_NN_BLOCK>), dim3(nb), dim3(QN_NN_BLOCK), 0, s, S.grid, T.grid, st, thr2, r0, 1, c->corr, sqd_out, c->nn_idx, c->nn_ref, c->fb_list, fbc, c->big_list, bgc, 0, c->big_ratio, far_stats, (const float4*)nullptr, opt0);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_nn_search<1, true, QN_BLOCK>), dim3(fbb + big_blocks), dim3(QN_BLOCK), 0, s, S.grid, T.grid, st, thr2, r0, 64, c->corr, sqd_out, c->nn_idx, c->nn_ref, c->fb_list, fbc, c->big_list, bgc, big_blocks, c->big_ratio, far_stats, (const float4*)nullptr, opt0);
   }
 }
 // debug knob "verify_track": a fresh, unseeded search of the current pose into scratch buffers, compared query by query with what
@@ -434,18 +437,18 @@ static void enqueue_verify(qn_ctx* c, bool fused) {
   uint32_t* fbc = &st->fb_count; uint32_t* bgc = &st->big_count;
   const float r0 = -c->margin_nn;
   hipLaunchKernelGGL(k_reset_lists, dim3(1), dim3(64), 0, s, st);
-  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_nn_search<0, false, QN_NN_BLOCK>), dim3(nb), dim3(QN_NN_BLOCK), 0, s, S.grid, T.grid, st, thr2, r0, c->nn_rounds, c->v_corr, c->v_sqd, c->v_nn_idx, c->v_nn_ref, c->fb_list, fbc, c->big_list, bgc, 0, c->big_ratio, (uint32_t*)nullptr, (const float4*)nullptr);
-  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_nn_search<0, true, QN_BLOCK>), dim3(std::min<uint32_t>(nb4, 512) + 4096), dim3(QN_BLOCK), 0, s, S.grid, T.grid, st, thr2, r0, 64, c->v_corr, c->v_sqd, c->v_nn_idx, c->v_nn_ref, c->fb_list, fbc, c->big_list, bgc, 4096, c->big_ratio, (uint32_t*)nullptr, (const float4*)nullptr);
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_nn_search<0, false, QN_NN_BLOCK>), dim3(nb), dim3(QN_NN_BLOCK), 0, s, S.grid, T.grid, st, thr2, r0, c->nn_rounds, c->v_corr, c->v_sqd, c->v_nn_idx, c->v_nn_ref, c->fb_list, fbc, c->big_list, bgc, 0, c->big_ratio, (uint32_t*)nullptr, (const float4*)nullptr, NnOpt{nullptr, 0});
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_nn_search<0, true, QN_BLOCK>), dim3(std::min<uint32_t>(nb4, 512) + 4096), dim3(QN_BLOCK), 0, s, S.grid, T.grid, st, thr2, r0, 64, c->v_corr, c->v_sqd, c->v_nn_idx, c->v_nn_ref, c->fb_list, fbc, c->big_list, bgc, 4096, c->big_ratio, (uint32_t*)nullptr, (const float4*)nullptr, NnOpt{nullptr, 0});
   hipLaunchKernelGGL(k_verify_nn, dim3((S.n + 255) / 256), dim3(256), 0, s, S.n, st, c->nn_idx, c->v_nn_idx, fused ? (const float*)nullptr : c->sqd, c->v_sqd, c->corr, c->v_corr, c->v_counters);
   hipLaunchKernelGGL(k_reset_lists, dim3(1), dim3(64), 0, s, st);
 }
 static uint32_t acc_blocks(const qn_ctx* c) { return std::min<uint32_t>((c->cloud[0].n + QN_BLOCK - 1) / QN_BLOCK, QN_ACC_MAX_BLOCKS); }
 static uint32_t tick_ppt(const qn_ctx* c) { return std::max<uint32_t>(c->tick_ppt_min, (c->cloud[0].n + c->tick_tb * QN_ACC_MAX_BLOCKS - 1) / (c->tick_tb * QN_ACC_MAX_BLOCKS)); }
 static uint32_t tick_blocks(const qn_ctx* c) { const uint32_t per = c->tick_tb * tick_ppt(c); return (c->cloud[0].n + per - 1) / per; }
-static void enqueue_accumulate(qn_ctx* c) {          // partial rows of the CURRENT generation
+static void enqueue_accumulate(qn_ctx* c, int cond = 0) {          // partial rows of the CURRENT generation
   ProfScope ps(c, QN_K_ACCUMULATE);
   CloudBuf &S = c->cloud[0];
-  hipLaunchKernelGGL(k_accumulate, dim3(acc_blocks(c)), dim3(QN_BLOCK), 0, c->stream, S.raw, S.n, S.nrm, c->tgt_rec, c->corr, st_cur(c), part_cur(c));
+  hipLaunchKernelGGL(k_accumulate, dim3(acc_blocks(c)), dim3(QN_BLOCK), 0, c->stream, S.raw, S.n, S.nrm, c->tgt_rec, c->corr, st_cur(c), part_cur(c), cond);
   c->part_rows = (int)acc_blocks(c);
 }
 // one controller step as its own launch: generation g -> g + 1 (k_solve)
@@ -536,9 +539,10 @@ static bool persist_usable(const qn_ctx* c, bool alone) {
   return c->persist && !c->persist_batch_off && alone && c->fused_ticks && c->fused_final && (!c->prof_on || c->prof_persist) && !c->verify_track && !c->clk_probe && c->tick_tb == QN_PERSIST_TB &&
          (!c->far_enabled || c->far_mode == 2) && c->pg_rows != nullptr;
 }
-static int launch_persist(qn_ctx* c, uint32_t max_ticks) {
+static int launch_persist(qn_ctx* c, uint32_t max_ticks, int cond = 0, int rows_if_extra = 0) {
   PersistArgs A;
   A.t = tick_args(c);
+  A.cond = cond; A.rows_if_extra = rows_if_extra; A.status_host = c->pg_status_host;
   A.t.ppt = persist_ppt(c); A.t.clk = nullptr; A.t.clk_blk = nullptr;
   A.t.far_mode = c->far_enabled ? 2 : 0;
   const uint32_t per = QN_PERSIST_TB * A.t.ppt;
@@ -552,13 +556,12 @@ static int launch_persist(qn_ctx* c, uint32_t max_ticks) {
   A.epoch0 = c->pg_epoch; A.max_ticks = max_ticks; c->pg_epoch += max_ticks + 8;
   A.hint_poll = c->persist_hint ? 1 : 0;
   A.timeout = 25000000ull;                                           // 0.25 s of the 100 MHz wall clock: three orders of magnitude above any legitimate wait
-  HIPCHK(c, hipMemsetAsync(c->pg_status, 0, 4 * sizeof(uint32_t), c->stream));
+  c->pg_status_host[0] = 0xffffffffu; c->pg_status_host[1] = 0;      // (the reducer overwrites it when it leaves)
   { ProfScope ps(c, QN_K_ALIGN_PERSIST);
     A.clk = c->pg_clk;
     if (c->pg_clk) { (void)hipMemsetAsync(c->pg_clk, 0, 8 * (64 * 16 + 16), c->stream); for (int g = 0; g < 64; g++) (void)hipMemsetAsync(c->pg_clk + 16 * g + 12, 0xff, 8, c->stream); }
     if (c->pg_clk) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_align_persist<QN_PERSIST_TB, true>), dim3(A.nblk + 1), dim3(QN_PERSIST_TB), 0, c->stream, A);
     else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_align_persist<QN_PERSIST_TB, false>), dim3(A.nblk + 1), dim3(QN_PERSIST_TB), 0, c->stream, A); }
-  HIPCHK(c, hipMemcpyAsync(c->pg_status_host, c->pg_status, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
   c->gen++; c->part_rows = 0; c->persist_launches++;
   return QN_OK;
 }
@@ -586,10 +589,11 @@ static int gicp_align(qn_ctx* c, const float guess[16], qn_gicp_result* out, boo
   if (guess) HIPCHK(c, hipMemcpyAsync(c->guess_tmp, guess, sizeof(float) * 16, hipMemcpyHostToDevice, s));
   c->gen = 0; c->part_rows = 0;
   c->far_mode = 2;
-  HIPCHK(c, hipMemsetAsync(c->far_cand_ref, 0, sizeof(float4) * c->cloud[0].n, s));      // no candidate lists yet
-  HIPCHK(c, hipMemsetAsync(c->far_stats, 0, 4 * sizeof(uint32_t), s));
-  hipLaunchKernelGGL(k_init_state, dim3(1), dim3(64), 0, s, st_cur(c), c->guess_tmp, guess ? 1 : 0, 0);
   const int maxit = p.force_iterations > 0 ? p.force_iterations : p.max_iterations;
+  // no far-candidate lists yet: the first (unseeded) search of the align resets the per-query references as it goes (enqueue_nn); an align without iterations has no such search
+  c->clear_far_now = maxit > 0;
+  if (maxit == 0) HIPCHK(c, hipMemsetAsync(c->far_cand_ref, 0, sizeof(float4) * c->cloud[0].n, s));
+  hipLaunchKernelGGL(k_init_state, dim3(1), dim3(64), 0, s, st_cur(c), c->guess_tmp, guess ? 1 : 0, 0, c->far_stats);
   if (maxit == 0) hipLaunchKernelGGL(k_set_pose, dim3(1), dim3(64), 0, s, st_cur(c), c->pose_tmp, 2, 2);   // which=2: touch nothing, phase = done
   // Ticks are enqueued in chunks with NO host round trip inside a chunk; kernels of ticks past
   // convergence exit on the `phase` word.  LM needs two ticks per outer iteration (linearize, trial error).
@@ -625,7 +629,40 @@ static int gicp_align(qn_ctx* c, const float guess[16], qn_gicp_result* out, boo
     }
     c->count_far_now = false;
     const bool look = adaptive && first_chunk && ticks_left > chunk;      // the adaptive look: the controller step behind the chunk's last tick, then the state
+    // A registration that is alone on the GPU takes the look ON THE DEVICE (k_look): the conditional third unseeded iteration and the persistent launch are enqueued
+    // behind it and read its flags - no host round trip between the unseeded ticks and the tracked regime (it cost 15-30 us of a 0.6 ms align).  If the flags
+    // say "not the persistent kernel" (many far neighbours: the k_far regime), that launch returns at once and the chain goes on from the host below.
+    const bool dev_look = look && c->device_look && tick_no > 0 && persist_usable(c, alone);
+    bool declined = false;
     if (look) enqueue_solve(c, 0, 1);
+    if (dev_look) {
+      const int allow_extra = std::min(ticks_left - chunk - 1, per_outer) > 0 ? 1 : 0;
+      c->result_host->look = 0;
+      hipLaunchKernelGGL(k_look, dim3(1), dim3(64), 0, s, st_cur(c), c->result_host, c->far_stats, (const GridDims*)c->cloud[0].dims, (const GridDims*)c->cloud[1].dims, allow_extra);
+      c->unseeded_until = tick_no + 1;
+      enqueue_nn(c, 0, c->sqd, false, tick_no / per_outer, QN_LOOK_EXTRA);
+      enqueue_accumulate(c, QN_LOOK_EXTRA);
+      const int rows_if_extra = c->part_rows;
+      c->part_rows = -1;                                            // (the kernel picks rows_if_extra instead when the extra iteration ran)
+      if ((rc = launch_persist(c, (uint32_t)(budget - chunk) + 2u, QN_LOOK_GO, rows_if_extra)) != QN_OK) return rc;
+      HIPCHK(c, hipGetLastError());
+      HIPCHK(c, hipStreamSynchronize(s));
+      if ((rc = clouds_valid(c)) != QN_OK) return rc;
+      const int extra = (c->result_host->look & QN_LOOK_EXTRA) ? per_outer : 0;
+      c->last_extra_unseeded = extra;
+      if (c->result_host->phase == 2) break;                        // the whole registration ran behind the look
+      if (c->pg_status_host[0] != 5u) {
+        (void)hipMemsetAsync(c->pg_rows, 0xFF, sizeof(unsigned long long) * 3 * QN_PERSIST_ROWS * QN_PERSIST_RSTRIDE, s); (void)hipMemsetAsync(c->pg_status, 0, 4 * sizeof(uint32_t), s); (void)hipStreamSynchronize(s);
+        char buf[160]; snprintf(buf, sizeof(buf), "align: the persistent kernel gave up (code %u after %u ticks: 1 rows, 2 tick budget, 3 closing sums, 4 pose)", c->pg_status_host[0], c->pg_status_host[1]);
+        c->last_error = buf; return QN_ERR_HIP;
+      }
+      // declined: the state is the one the look (and the extra iteration, if it ran) left - carry on with the chain
+      declined = true;
+      c->gen--; c->persist_launches--;                              // (the declined launch wrote no state)
+      c->part_rows = extra ? rows_if_extra : -1;
+      tick_no += extra; budget -= extra; ticks_left -= extra;
+      c->unseeded_until = tick_no;
+    } else {
     if (look || (exact_ticks && ticks_left > chunk)) {            // forced GN iterations cannot be done yet: only the statistics block is needed at this chunk end
       hipLaunchKernelGGL(k_finalize, dim3(1), dim3(64), 0, s, st_cur(c), c->result_host, c->far_stats);
     } else {
@@ -634,6 +671,7 @@ static int gicp_align(qn_ctx* c, const float guess[16], qn_gicp_result* out, boo
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipStreamSynchronize(s));
     if (first_chunk && (rc = clouds_valid(c)) != QN_OK) return rc;
+    }
     budget -= std::max(chunk, 1); ticks_left -= chunk;
     if (c->result_host->phase == 2) {
       if (!look) break;
@@ -652,7 +690,7 @@ static int gicp_align(qn_ctx* c, const float guess[16], qn_gicp_result* out, boo
     if (!exact_ticks) chunk = first_chunk ? c->ticks_per_chunk : std::max(2 * per_outer, c->ticks_per_chunk / 2);   // convergence is usually near after the first chunks: ticks past it are wasted launches
     else chunk = first_chunk && c->far_mode == 1 ? std::min(ticks_left, c->ticks_per_chunk) : ticks_left;
     if (budget <= 0) { c->last_error = "align: device state machine did not terminate"; return QN_ERR_HIP; }
-    if (look) {
+    if (look && !declined) {
       // how far the NEXT step will move the source points at most: the step just taken (translation + rotation x the cloud's reach from the origin), shrunk
       // by 10 (what the optimiser does per iteration at this stage, measured on the synthetic pairs: 12x - 50x)
       const GridDims& sg = *c->cloud[0].dims_host;                   // (valid: this stream has been synchronised since the grids were built)
@@ -675,7 +713,7 @@ static int gicp_align(qn_ctx* c, const float guess[16], qn_gicp_result* out, boo
       HIPCHK(c, hipGetLastError());
       HIPCHK(c, hipStreamSynchronize(s));
       if (c->result_host->phase != 2) {
-        (void)hipMemsetAsync(c->pg_rows, 0xFF, sizeof(unsigned long long) * 3 * QN_PERSIST_ROWS * QN_PERSIST_RSTRIDE, s); (void)hipStreamSynchronize(s);      // a launch that gave up leaves its row buffers in an unknown state
+        (void)hipMemsetAsync(c->pg_rows, 0xFF, sizeof(unsigned long long) * 3 * QN_PERSIST_ROWS * QN_PERSIST_RSTRIDE, s); (void)hipMemsetAsync(c->pg_status, 0, 4 * sizeof(uint32_t), s); (void)hipStreamSynchronize(s);      // a launch that gave up leaves its row buffers in an unknown state
         char buf[160]; snprintf(buf, sizeof(buf), "align: the persistent kernel gave up (code %u after %u ticks: 1 rows, 2 tick budget, 3 closing sums, 4 pose)", c->pg_status_host[0], c->pg_status_host[1]);
         c->last_error = buf; return QN_ERR_HIP;
       }
@@ -892,6 +930,7 @@ extern "C" int qn_debug_set(qn_ctx* c, const char* key, double v) {
   else if (k == "margin_knn") c->margin_knn = (float)v;
   else if (k == "knn_single_all") c->knn_single_all = v != 0;
   else if (k == "bbox_blocks") c->bbox_blocks = std::max(1, (int)v);
+  else if (k == "device_look") c->device_look = v != 0;
   else if (k == "pair_pipeline") c->pair_pipeline = v != 0;
   else if (k == "persist") c->persist = v != 0;
   else if (k == "persist_hint") c->persist_hint = v != 0;

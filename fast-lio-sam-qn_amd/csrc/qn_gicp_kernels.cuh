@@ -28,7 +28,7 @@ struct GicpState {
   uint32_t trace_len;
   uint32_t big_count;                               // one-query-per-wave list length
   int pending;                                      // 1: the partial rows written under THIS state have not been consumed by the controller yet
-  int reserved;
+  int reserved;                                     // look flags (k_look): bit 0 = one more unseeded iteration, bit 1 = the persistent launch may go ahead
 };
 // The state is double buffered: generation g lives in state[g & 1] and the partial rows produced under it in partials[g & 1].  A
 // controller step (k_solve, or the prologue of k_tick in every block) reads generation g and writes generation g + 1, so no block
@@ -400,6 +400,7 @@ __device__ __forceinline__ void store_nn(unsigned long long key, uint32_t i, uin
   }
 }
 
+struct NnOpt { float4* clear_ref; int cond; };       // clear_ref: the first search of an align also resets the far-candidate references (one per query); cond: run only if this look flag is set
 // LIST = false: first search of an align (no seed): every source point, radius margin * cell, two rounds,
 // leftovers to fb_list.  LIST = true: the fb_list entries (leftovers of the first search, or the big-ball
 // queries of k_nn_track with their seed radius), 16 per wave, rounds until exact.
@@ -410,10 +411,11 @@ __global__ void __launch_bounds__(BLOCK, 6) k_nn_search(GridView src, GridView t
                                                         int32_t* __restrict__ corr, float* __restrict__ sqd, int32_t* __restrict__ nn_idx, float4* __restrict__ nn_ref,
                                                         uint2* __restrict__ fb_list, uint32_t* __restrict__ fb_count,
                                                         uint2* __restrict__ big_list, uint32_t* __restrict__ big_count, int big_blocks, float big_ratio, uint32_t* __restrict__ far_stats,
-                                                        const float4* __restrict__ seed_raw) {
+                                                        const float4* __restrict__ seed_raw, NnOpt opt) {
   __shared__ WaveLds lds[BLOCK / 64];
   if (MODE == 0 && st->phase != 0) return;
   if (MODE == 1 && st->phase != 2) return;
+  if (opt.cond && !(st->reserved & opt.cond)) return;                // a conditional launch behind k_look
   src = grid_resolve(src); tgt = grid_resolve(tgt); if (r0 < 0.f) r0 = -r0 * tgt.cell;
   float Tf[12];
 #pragma unroll
@@ -484,6 +486,7 @@ __global__ void __launch_bounds__(BLOCK, 6) k_nn_search(GridView src, GridView t
     const bool cert = wave_search<4>(tgt, qx, qy, qz, active, r, r_cap, max_rounds, sink, &lds[threadIdx.x >> 6], d_unseen);
     const bool mine = active && (threadIdx.x & 48) == 0;
     const bool done = cert || LIST;
+    if (!LIST && MODE == 0 && opt.clear_ref && mine) opt.clear_ref[t] = make_float4(0.f, 0.f, 0.f, 0.f);      // no far-candidate list yet (w = 0)
     if (mine && done) {
       store_nn<MODE>(sink.key, __float_as_uint(p.w), t, thr2, corr, sqd, nn_idx);
       // bound-pruning reference: where this query was scanned and how far away every other point is at least
@@ -590,10 +593,11 @@ __device__ __forceinline__ void reduce_block_partials(const double acc[QN_NPART]
 
 static __global__ void __launch_bounds__(QN_BLOCK) k_accumulate(const float4* __restrict__ src_raw, uint32_t ns, const double* __restrict__ nrm_s, const TargetRec* __restrict__ tgt_rec,
                                                          const int32_t* __restrict__ corr, const GicpState* __restrict__ st,
-                                                         double* __restrict__ partials) {
+                                                         double* __restrict__ partials, int cond) {
   __shared__ double red[QN_BLOCK / 64][QN_NPART];
   const int phase = st->phase;
   if (phase == 2) return;
+  if (cond && !(st->reserved & cond)) return;                        // a conditional launch behind k_look
   double R[3][4], T[3][4];
 #pragma unroll
   for (int a = 0; a < 3; a++)
@@ -1014,11 +1018,14 @@ static __global__ void __launch_bounds__(NT) k_solve(const GicpState* __restrict
   for (int i = threadIdx.x; i < (int)(sizeof(GicpState) / 8); i += NT) ((unsigned long long*)st_out)[i] = ((const unsigned long long*)&sh)[i];
 }
 
-static __global__ void k_init_state(GicpState* st, const float* __restrict__ guess /* 16 or null */, int has_guess, int phase) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  for (int i = 0; i < 16; i++) { double v = has_guess ? (double)guess[i] : ((i % 5 == 0) ? 1.0 : 0.0); st->x0[i] = v; st->xi[i] = v; st->delta[i] = (i % 5 == 0) ? 1.0 : 0.0; }
-  for (int i = 0; i < 36; i++) { st->H[i] = 0; st->final_H[i] = (i % 7 == 0) ? 1.0 : 0.0; }
-  for (int i = 0; i < 6; i++) { st->b[i] = 0; st->d[i] = 0; }
+static __global__ void k_init_state(GicpState* st, const float* __restrict__ guess /* 16 or null */, int has_guess, int phase, uint32_t* __restrict__ far_stats /* 4 words or null: zeroed */) {
+  if (blockIdx.x != 0) return;
+  const int i = threadIdx.x;                                         // one wave: lane i writes element i of every array
+  if (i < 16) { const double v = has_guess ? (double)guess[i] : ((i % 5 == 0) ? 1.0 : 0.0); st->x0[i] = v; st->xi[i] = v; st->delta[i] = (i % 5 == 0) ? 1.0 : 0.0; }
+  if (i < 36) { st->H[i] = 0; st->final_H[i] = (i % 7 == 0) ? 1.0 : 0.0; }
+  if (i < 6) { st->b[i] = 0; st->d[i] = 0; }
+  if (i >= 60 && far_stats) far_stats[i - 60] = 0u;
+  if (i != 0) return;
   st->y0 = st->yi = st->den = 0; st->lambda = -1.0; st->nu = 2.0; st->fitness = 0;
   st->outer = st->inner = 0; st->phase = phase; st->converged = 0; st->lm_failed = 0; st->fb_count = 0; st->big_count = 0; st->trace_len = 0;
   st->pending = phase != 2 ? 1 : 0; st->reserved = 0;      // the first tick's body writes partial rows under this state
@@ -1076,7 +1083,7 @@ static __global__ void k_transform_cloud(const float4* __restrict__ in, uint32_t
   out[i] = make_float4(x, y, z, 1.0f);
 }
 
-struct ResultBlock { qn_gicp_result r; int32_t phase; uint32_t trace_len; uint32_t far_requests, far_misses, far_queries, pad; double step_dt, step_dr; };   // step_*: max |t| and max |R - I| of the latest pose step (host: hand-over policy)
+struct ResultBlock { qn_gicp_result r; int32_t phase; uint32_t trace_len; uint32_t far_requests, far_misses, far_queries, look; double step_dt, step_dr; };   // step_*: max |t| and max |R - I| of the latest pose step (host: hand-over policy)
 
 static __global__ void k_finalize(const GicpState* __restrict__ st, ResultBlock* out, uint32_t* __restrict__ far_stats) {   // out lives in pinned host memory
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
@@ -1092,4 +1099,31 @@ static __global__ void k_finalize(const GicpState* __restrict__ st, ResultBlock*
   out->step_dt = mt; out->step_dr = mr;
 }
 
+
+// The hand-over decision of a forced Gauss-Newton run, on the device (the host's "look" without the round trip): k_finalize's statistics block, plus
+//   bit 0  one more unseeded iteration: the step just taken (translation + rotation x the source cloud's reach from the origin) would move the points by more
+//          than 0.4 target cells - a tracked tick would re-search most neighbourhoods;
+//   bit 1  the persistent launch may go ahead: at most ~6 % of the source has a far neighbour (otherwise the k_far refresh regime of the chain pays).
+// The flags go into the state (the conditional launches behind this kernel read them: k_nn_search / k_accumulate with cond, k_align_persist) and to the host.
+#define QN_LOOK_EXTRA 1
+#define QN_LOOK_GO 2
+static __global__ void k_look(GicpState* st, ResultBlock* out, uint32_t* __restrict__ far_stats, const GridDims* __restrict__ sdims, const GridDims* __restrict__ tdims, int allow_extra) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const uint32_t fq = far_stats ? far_stats[3] : 0u;
+  out->far_requests = far_stats ? far_stats[1] : 0u; out->far_misses = far_stats ? far_stats[0] : 0u; out->far_queries = fq;
+  if (far_stats) { far_stats[0] = 0u; far_stats[1] = 0u; far_stats[3] = 0u; }
+  out->r.iterations = st->outer; out->r.converged = st->converged; out->r.lm_failed = st->lm_failed; out->r.reserved = 0;
+  out->phase = st->phase; out->trace_len = st->trace_len;
+  double mr = 0, mt = 0;
+  for (int a = 0; a < 3; a++) { for (int b = 0; b < 3; b++) mr = fmax(mr, fabs(st->delta[4 * a + b] - (a == b ? 1.0 : 0.0))); mt = fmax(mt, fabs(st->delta[4 * a + 3])); }
+  out->step_dt = mt; out->step_dr = mr;
+  const GridDims sg = *sdims;
+  double reach2 = 0; const double lo[3] = {sg.ox, sg.oy, sg.oz}, ext[3] = {sg.nx * (double)sg.cell, sg.ny * (double)sg.cell, sg.nz * (double)sg.cell};
+  for (int d = 0; d < 3; d++) { const double m = fmax(fabs(lo[d]), fabs(lo[d] + ext[d])); reach2 += m * m; }
+  const double moved = mt + mr * sqrt(reach2), ok = 0.4 * (double)tdims->cell;
+  int flags = 0;
+  if (allow_extra && moved > ok) flags |= QN_LOOK_EXTRA;             // (NaN compares false: no extra iteration)
+  if (fq * 16u <= sg.n && st->phase != 2) flags |= QN_LOOK_GO;
+  st->reserved = flags; out->look = (uint32_t)flags | 0x100u;        // (0x100: "a device look ran")
+}
 }  // namespace qn

@@ -43,6 +43,9 @@ struct PersistArgs {
   ResultBlock* result;                     // pinned host memory
   uint32_t nblk, epoch0, max_ticks;
   unsigned long long timeout;              // wall_clock64 units (100 MHz) a spin may last
+  uint32_t* status_host;                   // pinned mirror of `status`, written by the reducer when it leaves (no memset in front of, no copy behind the launch)
+  int cond;                                // != 0: launched behind k_look without a host look - go ahead only if the state's QN_LOOK_GO flag is set
+  int rows_if_extra;                       // cond: the partial rows the conditional unseeded iteration leaves (QN_LOOK_EXTRA set), else rows_in = -1
   int hint_poll;                           // reducer: watch one slot per row line before fetching the rows (knob persist_hint)
   unsigned long long* clk;                 // developer probe (PROBE = true): [tick < 64][16] wall-clock stamps: 0 rows complete, 1 sums, 2 controller, 3 pose published (reducer);
                                            // 4 pose seen, 5 body done, 6 row published (worker block 0); 8..10 the same for the last worker block; [64 * 16] = launch start
@@ -85,6 +88,11 @@ __global__ void __launch_bounds__(TB, TB / 256) k_align_persist(PersistArgs A) {
   __shared__ int bc_phase, bc_fail;
   __shared__ unsigned long long tie_list[TB / 64][QN_HCAP1]; __shared__ uint32_t tie_cnt[TB / 64];
   A.t.src = grid_resolve(A.t.src); A.t.tgt = grid_resolve(A.t.tgt);
+  if (A.cond) {                                                      // behind k_look: its flags decide (uniform over the launch: the state is not written before the reducer's last step)
+    const int flags = A.t.st_in->reserved;
+    if (!(flags & QN_LOOK_GO)) { if (blockIdx.x == A.nblk && threadIdx.x == 0) { A.status_host[0] = 5u; A.status_host[1] = 0u; } return; }      // declined: nothing touched
+    A.t.rows_in = (flags & QN_LOOK_EXTRA) ? A.rows_if_extra : -1;
+  }
   const TickArgs& a = A.t;
   const int tid = threadIdx.x, lane = tid & 63;
   const uint32_t nblk = A.nblk;
@@ -176,7 +184,11 @@ __global__ void __launch_bounds__(TB, TB / 256) k_align_persist(PersistArgs A) {
       if (bc_fail || bc_phase == 2) break;
       __builtin_amdgcn_s_sleep(100);                                 // ~3 us: no row can land before the workers have seen the pose and run the body; polling meanwhile only loads the memory system
     }
-    if (bc_fail) { if (tid == 0) { A.status[1] = g; A.result->phase = -1; } return; }
+    if (bc_fail) {
+      if (tid == 0) { A.status_host[0] = __hip_atomic_load(A.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); A.status_host[1] = g; A.result->phase = -1;
+        __hip_atomic_store(A.status, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }      // (a worker that gives up later may set it again: the host clears the word after a failed launch)
+      return;
+    }
     // the buffer gathered last goes back to "not arrived" for the next launch (the one before it was reset in the last iteration, the third was never written)
     if (rthread && g >= 1) {
       unsigned long long* last = A.rows_g + (size_t)(g % 3u) * QN_PERSIST_ROWS * QN_PERSIST_RSTRIDE;
@@ -222,7 +234,8 @@ __global__ void __launch_bounds__(TB, TB / 256) k_align_persist(PersistArgs A) {
         out->far_queries = a.far_stats ? __hip_atomic_load(a.far_stats + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
         if (a.far_stats) { for (int i = 0; i < 4; i++) if (i != 2) __hip_atomic_store(a.far_stats + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
         out->phase = fail ? -1 : sh.phase;
-        A.status[1] = g + 1;
+        A.status_host[0] = fail ? __hip_atomic_load(A.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u; A.status_host[1] = g + 1;
+        if (fail) __hip_atomic_store(A.status, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     }
     __syncthreads();

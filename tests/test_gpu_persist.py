@@ -47,6 +47,8 @@ def test_persistent_kernel_equals_the_tick_chain_bit_for_bit(case):
     assert a == b
     c, _ = run(engine, src, tgt, **kw)
     assert a == c                             # and it reproduces itself
+    d, _ = run(engine, src, tgt, knobs={"device_look": 0}, **kw)
+    assert a == d                             # the hand-over decision taken on the device (k_look) is the host's
 
 
 def test_concurrent_aligns_of_several_contexts():
