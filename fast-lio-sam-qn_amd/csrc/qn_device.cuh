@@ -598,6 +598,12 @@ __device__ __forceinline__ void wave_search_single(const GridView& g, float qx, 
   const float INF = __int_as_float(0x7f800000);
   const CapBox cap = cap_of(g, qx, qy, qz);
   if (cap.S > 0.f) r = fminf(fmaxf(r, sqrtf(cap.S) + g.cell), fmaxf(r_cap, r));   // nothing is closer than the grid box itself: do not spend rounds below that
+  // Growth rounds scan SHELLS: a tile-mode round scans whole tiles, so once the tiles within r (box distance <= r^2, the inclusion rule below) are done, the next
+  // round only needs the tiles between the two radii and the running best / runner-up carry over - the scanned set after any round is exactly the set a fresh
+  // scan of that round's ball would visit, each point once.  (Row-mode rounds - small boxes, partial tiles - start afresh.)
+  float done2 = -1.f;                                                // tiles of the previous round's range [ptx0..ptx1] x [pty0..pty1] x [ptz0..ptz1] with box distance <= done2 are scanned
+  int ptx0 = 0, ptx1 = -1, pty0 = 0, pty1 = -1, ptz0 = 0, ptz1 = -1; // (the ranges nest: r never shrinks.  A tile the f32 cell arithmetic left out of an earlier range is NOT skipped)
+  unsigned long long best = QN_INF_KEY; float second = INF;
   for (int round = 0;; round++) {
     const float rx = cap_extent(g, cap, r, 0), ry = cap_extent(g, cap, r, 1), rz = cap_extent(g, cap, r, 2);
     int x0 = rfl(cell_coord(qx - rx, g.ox, g.inv_cell, g.nx)), x1 = rfl(cell_coord(qx + rx, g.ox, g.inv_cell, g.nx));
@@ -615,16 +621,19 @@ __device__ __forceinline__ void wave_search_single(const GridView& g, float qx, 
       nseg = ntr * ntyr * ((z1 >> 2) - (z0 >> 2) + 1);
     }
     const int nyr = y1 - y0 + 1;
-    unsigned long long best = QN_INF_KEY; float second = INF;
+    if (!tile_mode || done2 < 0.f) { best = QN_INF_KEY; second = INF; done2 = -1.f; }
+    const float in2 = r * r * 1.000002f;
     for (int sb = 0; sb < nseg; sb += 64) {
       const int sidx = sb + lane;
       uint32_t s = 0, len = 0;
       if (sidx < nseg) {
         const int t = sidx % ntr, rr = sidx / ntr;
-        if (tile_mode) {                                               // only the tiles that reach into the ball of radius r
+        if (tile_mode) {                                               // only the tiles that reach into the ball of radius r and were not scanned by an earlier round
           const int tzz = (z0 >> 2) + rr / ntyr, tyy = ty0 + rr % ntyr, txx = tx0 + t;
           const uint32_t tile = ((uint32_t)tzz * g.nty + tyy) * g.ntx + txx;
-          if (!(tile_box_d2(g, txx, tyy, tzz, qx, qy, qz) > r * r * 1.000002f)) { s = g.cell_start[tile << 7]; len = g.cell_start[(tile + 1) << 7] - s; }
+          const float tb2 = tile_box_d2(g, txx, tyy, tzz, qx, qy, qz);
+          const bool seen = tb2 <= done2 && txx >= ptx0 && txx <= ptx1 && tyy >= pty0 && tyy <= pty1 && tzz >= ptz0 && tzz <= ptz1;
+          if (!(tb2 > in2) && !seen) { s = g.cell_start[tile << 7]; len = g.cell_start[(tile + 1) << 7] - s; }
         } else {
           const int ry = y0 + rr % nyr, rz = z0 + rr / nyr, tx = tx0 + t;
           const int xa = max(x0, tx << 3), xb = min(x1, (tx << 3) + 7);
@@ -652,6 +661,7 @@ __device__ __forceinline__ void wave_search_single(const GridView& g, float qx, 
         }
       }
     }
+    if (tile_mode) { done2 = in2; ptx0 = tx0; ptx1 = tx0 + ntr - 1; pty0 = ty0; pty1 = ty0 + ntyr - 1; ptz0 = z0 >> 2; ptz1 = z1 >> 2; }
     const unsigned long long b = wave_min_u64(best);
     float c = (best == b) ? second : key_d2(best);
     if (best == QN_INF_KEY) c = INF;
