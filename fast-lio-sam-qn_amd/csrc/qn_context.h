@@ -31,6 +31,7 @@ struct qn_ctx {
   CloudBuf cloud[2];
   qn::BBoxAcc* bbox_acc = nullptr; qn::BBoxAcc* bbox_acc2 = nullptr;     // bounding-box accumulators (k_pack_bbox_dims), one per stream
   unsigned long long* scan_status = nullptr; unsigned long long* scan_status2 = nullptr; uint32_t build_epoch = 0;   // look-back scan: tile status words, tagged with the build's epoch
+  int far_group = -1;                   // far-list grouping (wave_search_far16): -1 = by regime (enqueue_nn), 0 = off, n = ceil(list length / n) entries per wave for every list
   bool device_look = true;              // the hand-over decision of a lone forced-GN registration on the device (k_look) instead of a host round trip
   bool clear_far_now = false;           // the next unseeded search resets the far-candidate references (first search of an align)
   char* staging2 = nullptr;             // the second stream's landing zone (TargetScope)
@@ -63,6 +64,7 @@ struct qn_ctx {
   float* q_mean = nullptr; double* q_mean_psum = nullptr; void* q_host = nullptr;   // Matcher tail: cloud means, pinned hand-over block (header + one record per selected correspondence)
   // tuning knobs
   double cell_override = 0.0;
+  float big_ratio_late = 1.0f;          // the same threshold for the unseeded passes after the first
   float big_ratio = 2.5f;               // first-search leftovers whose next radius exceeds big_ratio * r0 go one-per-wave
   bool fused_ticks = true;              // GN ticks >= 3: tracking + leftovers + accumulation in one kernel
   int nn_rounds = 1;                    // rounds of an unseeded NN search before a query goes to the list pass

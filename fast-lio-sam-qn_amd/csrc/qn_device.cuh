@@ -644,6 +644,7 @@ __device__ __forceinline__ void wave_search_single(const GridView& g, float qx, 
       const uint32_t incl = wave_incl_scan_u32(len, lane);
       const uint32_t total = rflu(__shfl(incl, 63));
       if (total == 0) continue;
+      if (g.dbg && lane == 0) atomicAdd(&g.dbg[11], total);          // developer counter: candidates scanned
       wave_lds_fence();
       lds->seg_excl[lane] = incl - len; lds->seg_start[lane] = s;
       wave_lds_fence();
@@ -661,6 +662,7 @@ __device__ __forceinline__ void wave_search_single(const GridView& g, float qx, 
         }
       }
     }
+    if (g.dbg && lane == 0) { atomicAdd(&g.dbg[10], 1u); atomicAdd(&g.dbg[12], (uint32_t)nseg); if (round == 0) atomicAdd(&g.dbg[13], 1u); }      // developer counters: rounds, enumerated segments, entries
     if (tile_mode) { done2 = in2; ptx0 = tx0; ptx1 = tx0 + ntr - 1; pty0 = ty0; pty1 = ty0 + ntyr - 1; ptz0 = z0 >> 2; ptz1 = z1 >> 2; }
     const unsigned long long b = wave_min_u64(best);
     float c = (best == b) ? second : key_d2(best);
@@ -682,6 +684,131 @@ __device__ __forceinline__ void wave_search_single(const GridView& g, float qx, 
     r = (b != QN_INF_KEY) ? fmaxf(sqrtf(key_d2(b)) * 1.000001f + g.eps, r) : (r > 6.f * g.cell ? r + (2.f + round) * g.cell : 2.f * r + g.cell);   // far away: grow by cells, not by factors (the cap's width grows with sqrt(r^2 - o^2))
     r = fminf(r, r_cap);
   }
+}
+
+// ------------------------------------------------------------------ far queries that are neighbours: up to 16 per wave, ONE shared candidate stream
+// The far leftovers of an unseeded pass come in the cell-sorted order of the source: consecutive list entries are spatial neighbours whose search balls (radius:
+// several cells to tens of metres) overlap almost completely, and one-per-wave each of them pays the same dependent chain - tile table look-ups, point gathers -
+// for the same tiles.  Here the `member` queries of a wave (lane l: query l & 15, candidate sub-slot l >> 4, as in wave_search<4>) share ONE tile-mode scan of the
+// ball (c, R) around their bounding-box centre c, R >= r_i + |q_i - c|: every staged 64-candidate chunk is scored by all members from LDS.  Shell rounds as in
+// wave_search_single.  Query i is certified when its best distance is below R - |q_i - c| (everything unscanned inside the grid is farther than R from c), or
+// when nothing is left unscanned.  Exact for any spread of the members; efficient when the spread is small against the radii (the caller groups by that).
+// Outputs per member (identical in its 4 lanes): best key, runner-up d2, lower bound on everything unscanned.  All 64 lanes must call.
+__device__ __forceinline__ float wave_min_f(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o));
+  return v;
+}
+__device__ __forceinline__ float wave_max_f(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+  return v;
+}
+__device__ __forceinline__ void wave_search_far16(const GridView& g, float qx_in, float qy_in, float qz_in, bool member_in, float r_in,
+                                                  unsigned long long& best_out, float& second_out, float& d_unseen_out, WaveLds* lds) {
+  const int lane = threadIdx.x & 63;
+  const float INF = __int_as_float(0x7f800000);
+  // ---- re-layout: the m members get 64 / m2 lanes each (m2 = m rounded up to a power of two): lane l works for the member of rank l & (m2 - 1) as candidate
+  // sub-slot l / m2 - two members score 32 candidates per step each, sixteen members 4 (the caller's layout: query l & 15 in lanes l, l + 16, l + 32, l + 48)
+  const unsigned long long mm = __ballot(member_in) & 0xffffull;     // member queries, by their sub-slot-0 lane
+  const int m = __popcll(mm);
+  int m2 = 1; while (m2 < m) m2 <<= 1;
+  const int S = 64 / m2;
+  const int my_rank = __popcll(mm & ((1ull << (lane & 15)) - 1ull)); // (meaningful in member lanes)
+  wave_lds_fence();
+  if (member_in && lane < 16) lds->seg_cid[my_rank] = (uint32_t)lane;
+  wave_lds_fence();
+  const int rk = lane & (m2 - 1);
+  const bool has_q = rk < m;
+  const int src_lane = has_q ? (int)lds->seg_cid[rk] : 0;
+  const float qx = __shfl(qx_in, src_lane), qy = __shfl(qy_in, src_lane), qz = __shfl(qz_in, src_lane), r = __shfl(r_in, src_lane);
+  const uint32_t sub = (uint32_t)(lane / m2);
+  const float cqx = 0.5f * (wave_min_f(has_q ? qx : INF) + wave_max_f(has_q ? qx : -INF));
+  const float cqy = 0.5f * (wave_min_f(has_q ? qy : INF) + wave_max_f(has_q ? qy : -INF));
+  const float cqz = 0.5f * (wave_min_f(has_q ? qz : INF) + wave_max_f(has_q ? qz : -INF));
+  const float off = has_q ? sqrtf(sqdist(qx, qy, qz, cqx, cqy, cqz)) * 1.000002f + 1e-30f : 0.f;      // >= |q - c|
+  float R = wave_max_f(has_q ? r + off : 0.f);
+  const CapBox cap = cap_of(g, cqx, cqy, cqz);
+  if (cap.S > 0.f) R = fmaxf(R, sqrtf(cap.S) + g.cell);
+  Best1 sink; sink.init();
+  bool open = has_q;                                                 // not certified yet
+  unsigned long long fin_b = QN_INF_KEY; float fin_s = INF, fin_d = INF;
+  float done2 = -1.f; int ptx0 = 0, ptx1 = -1, pty0 = 0, pty1 = -1, ptz0 = 0, ptz1 = -1;
+  for (int round = 0;; round++) {
+    const float rx = cap_extent(g, cap, R, 0), ry = cap_extent(g, cap, R, 1), rz = cap_extent(g, cap, R, 2);
+    int x0 = rfl(cell_coord(cqx - rx, g.ox, g.inv_cell, g.nx)), x1 = rfl(cell_coord(cqx + rx, g.ox, g.inv_cell, g.nx));
+    int y0 = rfl(cell_coord(cqy - ry, g.oy, g.inv_cell, g.ny)), y1 = rfl(cell_coord(cqy + ry, g.oy, g.inv_cell, g.ny));
+    int z0 = rfl(cell_coord(cqz - rz, g.oz, g.inv_cell, g.nz)), z1 = rfl(cell_coord(cqz + rz, g.oz, g.inv_cell, g.nz));
+    x0 = (x0 >> 3) << 3; x1 = min(((x1 >> 3) << 3) + 7, g.nx - 1);   // whole tiles
+    y0 = (y0 >> 2) << 2; y1 = min(((y1 >> 2) << 2) + 3, g.ny - 1);
+    z0 = (z0 >> 2) << 2; z1 = min(((z1 >> 2) << 2) + 3, g.nz - 1);
+    const int tx0 = x0 >> 3, ntr = (x1 >> 3) - tx0 + 1, ty0 = y0 >> 2, ntyr = (y1 >> 2) - ty0 + 1, tz0 = z0 >> 2;
+    const int nseg = ntr * ntyr * ((z1 >> 2) - tz0 + 1);
+    const float in2 = R * R * 1.000002f;
+    bool left_out = false;                                           // a tile of the range lies beyond the ball
+    for (int sb = 0; sb < nseg; sb += 64) {
+      const int sidx = sb + lane;
+      uint32_t s = 0, len = 0;
+      if (sidx < nseg) {
+        const int t = sidx % ntr, rr = sidx / ntr;
+        const int tzz = tz0 + rr / ntyr, tyy = ty0 + rr % ntyr, txx = tx0 + t;
+        const uint32_t tile = ((uint32_t)tzz * g.nty + tyy) * g.ntx + txx;
+        const float tb2 = tile_box_d2(g, txx, tyy, tzz, cqx, cqy, cqz);
+        const bool seen = tb2 <= done2 && txx >= ptx0 && txx <= ptx1 && tyy >= pty0 && tyy <= pty1 && tzz >= ptz0 && tzz <= ptz1;
+        if (tb2 > in2) left_out = true;
+        else if (!seen) { s = g.cell_start[tile << 7]; len = g.cell_start[(tile + 1) << 7] - s; }
+      }
+      const uint32_t incl = wave_incl_scan_u32(len, lane);
+      const uint32_t total = rflu(__shfl(incl, 63));
+      if (total == 0) continue;
+      if (g.dbg && lane == 0) atomicAdd(&g.dbg[11], total);
+      wave_lds_fence();
+      lds->seg_excl[lane] = incl - len; lds->seg_start[lane] = s;
+      wave_lds_fence();
+      for (uint32_t cb = 0; cb < total; cb += 64) {
+        const uint32_t slot = cb + lane;
+        int j = 0;
+#pragma unroll
+        for (int step = 32; step > 0; step >>= 1) { const int t = j + step; if (t < 64 && lds->seg_excl[t] <= slot) j = t; }
+        const uint32_t cnt = min(64u, total - cb);
+        wave_lds_fence();
+        if (slot < total) lds->tile[lane] = g.pts[lds->seg_start[j] + (slot - lds->seg_excl[j])];
+        wave_lds_fence();
+        for (uint32_t c = 0; c < cnt; c += 4u * (uint32_t)S) {       // S candidates per member and step, 4 steps per trip: the four LDS reads issued before any scoring
+          float4 cp[4]; uint32_t ci[4];
+#pragma unroll
+          for (int u = 0; u < 4; u++) { ci[u] = c + (uint32_t)(u * S) + sub; cp[u] = lds->tile[ci[u] & 63u]; }
+#pragma unroll
+          for (int u = 0; u < 4; u++) sink.consider(open && ci[u] < cnt, sqdist(qx, qy, qz, cp[u].x, cp[u].y, cp[u].z), __float_as_uint(cp[u].w));
+        }
+      }
+    }
+    if (g.dbg && lane == 0) { atomicAdd(&g.dbg[10], 1u); atomicAdd(&g.dbg[12], (uint32_t)nseg); if (round == 0) atomicAdd(&g.dbg[13], 1u); }
+    done2 = in2; ptx0 = tx0; ptx1 = tx0 + ntr - 1; pty0 = ty0; pty1 = ty0 + ntyr - 1; ptz0 = tz0; ptz1 = z1 >> 2;
+    const bool everything = !__any(left_out) && x0 == 0 && x1 == g.nx - 1 && y0 == 0 && y1 == g.ny - 1 && z0 == 0 && z1 == g.nz - 1;
+    // the member's merged result so far (its S sub-slots hold disjoint candidates)
+    unsigned long long b = sink.key;
+    for (int o = m2; o < 64; o <<= 1) { const unsigned long long t = __shfl_xor(b, o); b = t < b ? t : b; }
+    float sc = (sink.key == b) ? sink.second : key_d2(sink.key);
+    if (sink.key == QN_INF_KEY) sc = INF;
+    for (int o = m2; o < 64; o <<= 1) sc = fminf(sc, __shfl_xor(sc, o));
+    float need = 0.f;
+    if (open) {
+      const float d = R * 0.999998f - off - g.eps;                   // everything unscanned (inside the grid) is farther than R from c
+      bool cert;
+      if (everything || round > 160 || !(R == R)) { cert = true; fin_d = INF; }
+      else { cert = d > 0.f && b != QN_INF_KEY && key_d2(b) < d * d; fin_d = fmaxf(d, 0.f); }
+      if (cert) { fin_b = b; fin_s = sc; open = false; }
+      else if (b != QN_INF_KEY) need = sqrtf(key_d2(b)) * 1.000002f + 2.f * g.eps + off;      // the ball that proves this member's candidate
+    }
+    if (!__any(open)) break;
+    const float want = wave_max_f(need);
+    const float grown = want > 0.f ? want : (R > 6.f * g.cell ? R + (2.f + round) * g.cell : 2.f * R + g.cell);
+    R = fmaxf(grown, R * 1.0001f + g.eps);
+  }
+  // back to the caller's layout: member of rank k reads lane k (sub-slot 0 of that rank)
+  const unsigned long long ob = __shfl(fin_b, my_rank & 63); const float os = __shfl(fin_s, my_rank & 63), od = __shfl(fin_d, my_rank & 63);
+  if (member_in) { best_out = ob; second_out = os; d_unseen_out = od; }
 }
 
 // ------------------------------------------------------------------ pass B, k-NN: one query per LANE

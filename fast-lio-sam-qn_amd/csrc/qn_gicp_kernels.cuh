@@ -400,14 +400,14 @@ __device__ __forceinline__ void store_nn(unsigned long long key, uint32_t i, uin
   }
 }
 
-struct NnOpt { float4* clear_ref; int cond; };       // clear_ref: the first search of an align also resets the far-candidate references (one per query); cond: run only if this look flag is set
+struct NnOpt { float4* clear_ref; int cond; int group, group_min; };       // group: far lists of at least group_min entries are served ceil(length / group) consecutive entries per wave, neighbours sharing a scan (0: one per wave); clear_ref: the first search of an align also resets the far-candidate references (one per query); cond: run only if this look flag is set
 // LIST = false: first search of an align (no seed): every source point, radius margin * cell, two rounds,
 // leftovers to fb_list.  LIST = true: the fb_list entries (leftovers of the first search, or the big-ball
 // queries of k_nn_track with their seed radius), 16 per wave, rounds until exact.
 // In the LIST launch the last `big_blocks` blocks serve big_list instead, one query per wave (wave_search_single).
 // BLOCK = threads per block: the grid passes run one wave per block (finer refill of the CUs), the list passes four.
-template <int MODE, bool LIST, int BLOCK>
-__global__ void __launch_bounds__(BLOCK, 6) k_nn_search(GridView src, GridView tgt, const GicpState* __restrict__ st, double thr2, float r0, int max_rounds,
+template <int MODE, bool LIST, int BLOCK, bool GROUP = false>      // GROUP: the far list may be served in groups of neighbours (its own instantiation: the grouped search costs registers)
+__global__ void __launch_bounds__(BLOCK, GROUP ? 5 : 6) k_nn_search(GridView src, GridView tgt, const GicpState* __restrict__ st, double thr2, float r0, int max_rounds,
                                                         int32_t* __restrict__ corr, float* __restrict__ sqd, int32_t* __restrict__ nn_idx, float4* __restrict__ nn_ref,
                                                         uint2* __restrict__ fb_list, uint32_t* __restrict__ fb_count,
                                                         uint2* __restrict__ big_list, uint32_t* __restrict__ big_count, int big_blocks, float big_ratio, uint32_t* __restrict__ far_stats,
@@ -429,6 +429,56 @@ __global__ void __launch_bounds__(BLOCK, 6) k_nn_search(GridView src, GridView t
     // neighbours in space - and the neighbour p* found for one entry bounds the next entry's neighbour distance from above by |q - p*| (p* is a target point):
     // one scan of exactly that ball instead of growth rounds from the failed radius (3 -> 7 -> 10 cells ...) that rescan the inner region and overshoot.
     const uint32_t CH = (MODE == 0 && seed_raw) ? 4u : 1u;
+    // Long lists (the first unseeded ticks of a misaligned pair, the non-overlapping part of a partial overlap): a wave takes E CONSECUTIVE entries - the list keeps
+    // the cell-sorted order of the queries, so they are neighbours in space - and serves the ones whose balls overlap with ONE shared scan (wave_search_far16);
+    // loners still get the whole wave (wave_search_single).  Short lists stay one entry per wave: nothing to share, and every entry starts at once.
+    const uint32_t E = (GROUP && opt.group && nbig >= (uint32_t)opt.group_min) ? min(16u, (nbig + (uint32_t)opt.group - 1u) / (uint32_t)opt.group) : 1u;
+    if (GROUP && CH == 1u && E > 1u) {
+      const int lane = threadIdx.x & 63, qs = lane & 15;
+      WaveLds* wl = &lds[threadIdx.x >> 6];
+      const float INF = __int_as_float(0x7f800000);
+      for (uint32_t w0 = bw0 * E; w0 < nbig; w0 += nbw * E) {
+        const uint32_t slot = w0 + (uint32_t)qs;
+        const bool active = (uint32_t)qs < E && slot < nbig;
+        const uint2 rec = active ? big_list[slot] : make_uint2(0u, 0u);
+        const float4 p = active ? src.pts[rec.x] : make_float4(0.f, 0.f, 0.f, 0.f);
+        float qx, qy, qz; xform_query<MODE>(Tf, p.x, p.y, p.z, qx, qy, qz);
+        const float v = __uint_as_float(rec.y);
+        const float r = v > 0.f ? v * 1.1f + 0.5f * tgt.cell : -v;
+        const bool finite_q = (qx - qx == 0.f) && (qy - qy == 0.f) && (qz - qz == 0.f) && (r - r == 0.f);
+        unsigned long long key = QN_INF_KEY; float second = INF, d_unseen = INF;
+        unsigned long long todo = __ballot(active);
+        while (todo) {
+          const int al = __ffsll((long long)todo) - 1;                 // anchor: the first open query (its sub-slot 0 lane)
+          const float ax = __shfl(qx, al), ay = __shfl(qy, al), az = __shfl(qz, al), ar = __shfl(r, al);
+          const bool afin = __shfl((int)finite_q, al) != 0;
+          const bool open_q = (todo >> lane) & 1ull;
+          // members: within half the anchor's radius of it (their balls then share most of their volume); a non-finite entry is served alone
+          const bool member = open_q && (qs == (al & 15) || (afin && finite_q && sqdist(qx, qy, qz, ax, ay, az) <= 0.25f * ar * ar));
+          const unsigned long long mm = __ballot(member);
+          if (__popcll(mm) <= 4) {                                     // a loner (4 lanes): the whole wave on its ball
+            unsigned long long k1; float s1, du1;
+            wave_search_single(tgt, ax, ay, az, ar, INF, k1, s1, du1, wl);
+            if (member) { key = k1; second = s1; d_unseen = du1; }
+          } else {
+            wave_search_far16(tgt, qx, qy, qz, member, r, key, second, d_unseen, wl);
+          }
+          todo &= ~mm;
+        }
+        if (active && lane < 16) {
+          store_nn<MODE>(key, __float_as_uint(p.w), rec.x, thr2, corr, sqd, nn_idx);
+          // (the bound every OTHER target point respects is the canonical one here - the neighbour's own distance - not the scan's runner-up / unseen radius: those
+          //  depend on which entries shared a scan, i.e. on the order the list was appended in, and the tracked ticks' regime decisions must not)
+          if (MODE == 0) nn_ref[rec.x] = make_float4(qx, qy, qz, key != QN_INF_KEY ? sqrtf(key_d2(key)) : INF);
+        }
+        if (far_stats && MODE == 0) {
+          const unsigned long long fm = __ballot(active && lane < 16 && key != QN_INF_KEY && key_d2(key) > 36.f * tgt.cell * tgt.cell);
+          if (lane == 0) nfar += (uint32_t)__popcll(fm);
+        }
+      }
+      if (far_stats && MODE == 0 && (threadIdx.x & 63) == 0 && nfar) atomicAdd(&far_stats[3], nfar);
+      return;
+    }
     for (uint32_t w0 = bw0 * CH; w0 < nbig; w0 += nbw * CH) {
       unsigned long long prev = QN_INF_KEY; float prev_d = 0.f;
       const uint32_t w1 = min(w0 + CH, nbig);

@@ -33,6 +33,7 @@ QN_G1 __global__ void k_knn_hist<false, 48> QN_KNN_HIST_ARGS;
 QN_G1 __global__ void k_knn_hist<true, 48> QN_KNN_HIST_ARGS;
 QN_G1 __global__ void k_nn_search<0, false, QN_NN_BLOCK> QN_NN_SEARCH_ARGS;
 QN_G1 __global__ void k_nn_search<0, true, QN_BLOCK> QN_NN_SEARCH_ARGS;
+QN_G1 __global__ void k_nn_search<0, true, QN_BLOCK, true> QN_NN_SEARCH_ARGS;
 QN_G1 __global__ void k_nn_search<1, false, QN_NN_BLOCK> QN_NN_SEARCH_ARGS;
 QN_G1 __global__ void k_nn_search<1, true, QN_BLOCK> QN_NN_SEARCH_ARGS;
 QN_G1 __global__ void k_nn_track<0> QN_NN_TRACK_ARGS;

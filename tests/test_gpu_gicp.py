@@ -340,3 +340,24 @@ def test_randomized_configurations(eng, oracle):
         assert r["iterations"] == ro["iterations"] and r["converged"] == ro["converged"], (case, n, k, opt)
         assert dt <= TOL_T and dr <= TOL_R, (case, dt, dr)
         assert abs(r["fitness"] - ro["fitness"]) <= 1e-6 * max(ro["fitness"], 1e-12)
+
+
+@pytest.mark.parametrize("group", [2048, 16384])
+def test_grouped_far_queries_equal_one_per_wave(eng, group):
+    """Far-list entries served in groups of neighbours (wave_search_far16, the batch regime's list pass) find the neighbours the one-entry-per-wave search
+    finds: same correspondences and squared distances for a misaligned pair, a partially overlapping pair and a scene 8 km from the origin."""
+    engine, ctx = eng
+    cases = [synth.make_pair(90, 30000)[:2], synth.make_pair(91, 30000, shift=24.0)[:2]]
+    s8, t8, _ = synth.make_pair(92, 20000)
+    off = np.array([8000.0, -7500.0, 120.0])
+    cases.append(((s8.astype(np.float64) + off).astype(np.float32), (t8.astype(np.float64) + off).astype(np.float32)))
+    for src, tgt in cases:
+        out = []
+        for fg in (0, group):
+            ctx.debug_set("far_group", fg)
+            g = engine.NanoGICP(ctx)
+            g.setInputSource(src); g.calculateSourceCovariances(); g.setInputTarget(tgt); g.calculateTargetCovariances()
+            H, b, e, corr, sqd = g.linearize(np.eye(4))
+            out.append((np.array(corr).copy(), np.array(sqd).copy(), np.array(H).copy()))
+        ctx.debug_set("far_group", -1)
+        assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1]) and np.array_equal(out[0][2], out[1][2])

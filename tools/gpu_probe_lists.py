@@ -22,5 +22,7 @@ for it in (1, 2, 3):
     ctx.debug_set("dbg_counters", 1); r = g.align(); ctx.synchronize(); c = counters(); ctx.debug_set("dbg_counters", 0)
     # the closing pass (fitness sweep) of a forced run is tracked, not a list pass of k_nn_search<0>; counters 5 / 7 also see the fitness search's lists (MODE 1) when it runs unseeded
     print("forced %d iteration(s): list entries so far  16-per-wave %7d  one-per-wave %7d   (this tick: %7d / %7d of %d queries)" % (it, c[5], c[7], c[5] - prev[0], c[7] - prev[1], N))
+    if c[13]:
+        print("      one-per-wave searches so far: %d entries, %.2f rounds, %.0f candidates, %.0f enumerated segments per entry" % (c[13], c[10] / c[13], c[11] / c[13], c[12] / c[13]))
     prev = (c[5], c[7])
 ctx.close()
