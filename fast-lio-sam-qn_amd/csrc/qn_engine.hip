@@ -462,10 +462,11 @@ static void enqueue_accumulate(qn_ctx* c, int cond = 0) {          // partial ro
   c->part_rows = (int)acc_blocks(c);
 }
 // one controller step as its own launch: generation g -> g + 1 (k_solve)
-static void enqueue_solve(qn_ctx* c, int mode, int will_produce) {
+static void enqueue_solve(qn_ctx* c, int mode, int will_produce, const LookArgs* look = nullptr) {
   ProfScope ps(c, QN_K_SOLVE);
-  if (c->tick_tb == 256) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_solve<256>), dim3(1), dim3(256), 0, c->stream, st_cur(c), st_nxt(c), part_cur(c), c->part_rows, make_cfg(c), c->trace, mode, will_produce);
-  else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_solve<512>), dim3(1), dim3(512), 0, c->stream, st_cur(c), st_nxt(c), part_cur(c), c->part_rows, make_cfg(c), c->trace, mode, will_produce);
+  LookArgs la; memset(&la, 0, sizeof(la)); if (look) la = *look;
+  if (c->tick_tb == 256) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_solve<256>), dim3(1), dim3(256), 0, c->stream, st_cur(c), st_nxt(c), part_cur(c), c->part_rows, make_cfg(c), c->trace, mode, will_produce, la);
+  else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_solve<512>), dim3(1), dim3(512), 0, c->stream, st_cur(c), st_nxt(c), part_cur(c), c->part_rows, make_cfg(c), c->trace, mode, will_produce, la);
   c->gen++; c->part_rows = -1;                                      // consumed: whatever controller comes next (k_tick's prologue, the persistent kernel, another k_solve) must not step again
 }
 // One "tick" of the device-side state machine = [controller step on the previous tick's partial rows] + [body under the new state].
@@ -639,16 +640,17 @@ static int gicp_align(qn_ctx* c, const float guess[16], qn_gicp_result* out, boo
     }
     c->count_far_now = false;
     const bool look = adaptive && first_chunk && ticks_left > chunk;      // the adaptive look: the controller step behind the chunk's last tick, then the state
-    // A registration that is alone on the GPU takes the look ON THE DEVICE (k_look): the conditional third unseeded iteration and the persistent launch are enqueued
+    // A registration that is alone on the GPU takes the look ON THE DEVICE (look_decide): the conditional third unseeded iteration and the persistent launch are enqueued
     // behind it and read its flags - no host round trip between the unseeded ticks and the tracked regime (it cost 15-30 us of a 0.6 ms align).  If the flags
     // say "not the persistent kernel" (many far neighbours: the k_far regime), that launch returns at once and the chain goes on from the host below.
     const bool dev_look = look && c->device_look && tick_no > 0 && persist_usable(c, alone);
     bool declined = false;
-    if (look) enqueue_solve(c, 0, 1);
+    if (look && !dev_look) enqueue_solve(c, 0, 1);
     if (dev_look) {
-      const int allow_extra = std::min(ticks_left - chunk - 1, per_outer) > 0 ? 1 : 0;
+      LookArgs la; la.out = c->result_host; la.far_stats = c->far_stats; la.sdims = c->cloud[0].dims; la.tdims = c->cloud[1].dims; la.enabled = 1;
+      la.allow_extra = std::min(ticks_left - chunk - 1, per_outer) > 0 ? 1 : 0;
       c->result_host->look = 0;
-      hipLaunchKernelGGL(k_look, dim3(1), dim3(64), 0, s, st_cur(c), c->result_host, c->far_stats, (const GridDims*)c->cloud[0].dims, (const GridDims*)c->cloud[1].dims, allow_extra);
+      enqueue_solve(c, 0, 1, &la);                                   // the controller step behind the chunk's last tick, and the decision at its end
       c->unseeded_until = tick_no + 1;
       enqueue_nn(c, 0, c->sqd, false, tick_no / per_outer, QN_LOOK_EXTRA);
       enqueue_accumulate(c, QN_LOOK_EXTRA);

@@ -28,7 +28,7 @@ struct GicpState {
   uint32_t trace_len;
   uint32_t big_count;                               // one-query-per-wave list length
   int pending;                                      // 1: the partial rows written under THIS state have not been consumed by the controller yet
-  int reserved;                                     // look flags (k_look): bit 0 = one more unseeded iteration, bit 1 = the persistent launch may go ahead
+  int reserved;                                     // look flags (look_decide): bit 0 = one more unseeded iteration, bit 1 = the persistent launch may go ahead
 };
 // The state is double buffered: generation g lives in state[g & 1] and the partial rows produced under it in partials[g & 1].  A
 // controller step (k_solve, or the prologue of k_tick in every block) reads generation g and writes generation g + 1, so no block
@@ -415,7 +415,7 @@ __global__ void __launch_bounds__(BLOCK, GROUP ? 5 : 6) k_nn_search(GridView src
   __shared__ WaveLds lds[BLOCK / 64];
   if (MODE == 0 && st->phase != 0) return;
   if (MODE == 1 && st->phase != 2) return;
-  if (opt.cond && !(st->reserved & opt.cond)) return;                // a conditional launch behind k_look
+  if (opt.cond && !(st->reserved & opt.cond)) return;                // a conditional launch behind look_decide
   src = grid_resolve(src); tgt = grid_resolve(tgt); if (r0 < 0.f) r0 = -r0 * tgt.cell;
   float Tf[12];
 #pragma unroll
@@ -647,7 +647,7 @@ static __global__ void __launch_bounds__(QN_BLOCK) k_accumulate(const float4* __
   __shared__ double red[QN_BLOCK / 64][QN_NPART];
   const int phase = st->phase;
   if (phase == 2) return;
-  if (cond && !(st->reserved & cond)) return;                        // a conditional launch behind k_look
+  if (cond && !(st->reserved & cond)) return;                        // a conditional launch behind look_decide
   double R[3][4], T[3][4];
 #pragma unroll
   for (int a = 0; a < 3; a++)
@@ -1045,12 +1045,41 @@ __device__ __forceinline__ void reduce_partial_rows(const double* __restrict__ p
   __syncthreads();
 }
 
+struct ResultBlock { qn_gicp_result r; int32_t phase; uint32_t trace_len; uint32_t far_requests, far_misses, far_queries, look; double step_dt, step_dr; };   // step_*: max |t| and max |R - I| of the latest pose step (host: hand-over policy)
+// The hand-over decision of a forced Gauss-Newton run, on the device (the host's "look" without the round trip): k_finalize's statistics block, plus
+//   bit 0  one more unseeded iteration: the step just taken (translation + rotation x the source cloud's reach from the origin) would move the points by more
+//          than 0.4 target cells - a tracked tick would re-search most neighbourhoods;
+//   bit 1  the persistent launch may go ahead: at most ~6 % of the source has a far neighbour (otherwise the k_far refresh regime of the chain pays).
+// The flags go into the state (the conditional launches behind the controller step read them: k_nn_search / k_accumulate with cond, k_align_persist) and to the
+// host.  Runs at the end of the stand-alone controller step (k_solve with LookArgs): no launch of its own.
+#define QN_LOOK_EXTRA 1
+#define QN_LOOK_GO 2
+struct LookArgs { ResultBlock* out; uint32_t* far_stats; const GridDims* sdims; const GridDims* tdims; int allow_extra; int enabled; };
+__device__ inline void look_decide(GicpState* st, ResultBlock* out, uint32_t* __restrict__ far_stats, const GridDims* __restrict__ sdims, const GridDims* __restrict__ tdims, int allow_extra) {      // one thread
+  const uint32_t fq = far_stats ? far_stats[3] : 0u;
+  out->far_requests = far_stats ? far_stats[1] : 0u; out->far_misses = far_stats ? far_stats[0] : 0u; out->far_queries = fq;
+  if (far_stats) { far_stats[0] = 0u; far_stats[1] = 0u; far_stats[3] = 0u; }
+  out->r.iterations = st->outer; out->r.converged = st->converged; out->r.lm_failed = st->lm_failed; out->r.reserved = 0;
+  out->phase = st->phase; out->trace_len = st->trace_len;
+  double mr = 0, mt = 0;
+  for (int a = 0; a < 3; a++) { for (int b = 0; b < 3; b++) mr = fmax(mr, fabs(st->delta[4 * a + b] - (a == b ? 1.0 : 0.0))); mt = fmax(mt, fabs(st->delta[4 * a + 3])); }
+  out->step_dt = mt; out->step_dr = mr;
+  const GridDims sg = *sdims;
+  double reach2 = 0; const double lo[3] = {sg.ox, sg.oy, sg.oz}, ext[3] = {sg.nx * (double)sg.cell, sg.ny * (double)sg.cell, sg.nz * (double)sg.cell};
+  for (int d = 0; d < 3; d++) { const double m = fmax(fabs(lo[d]), fabs(lo[d] + ext[d])); reach2 += m * m; }
+  const double moved = mt + mr * sqrt(reach2), ok = 0.4 * (double)tdims->cell;
+  int flags = 0;
+  if (allow_extra && moved > ok) flags |= QN_LOOK_EXTRA;             // (NaN compares false: no extra iteration)
+  if (fq * 16u <= sg.n && st->phase != 2) flags |= QN_LOOK_GO;
+  st->reserved = flags; out->look = (uint32_t)flags | 0x100u;        // (0x100: "a device look ran")
+}
+
 // One controller step as its own launch (unseeded first ticks, the end of a chunk, the debug entry points): generation g -> g + 1.
 // mode 0: the LM / GN controller, if partial rows are pending under st_in.  mode 1 / 2: reduce a linearisation / an error pass only.
 // will_produce: a body that writes partial rows under the NEW state follows (so they are pending for the next controller step).
 template <int NT>      // NT = the thread count of the k_tick variant in use: both run the same row reduction, bit for bit
 static __global__ void __launch_bounds__(NT) k_solve(const GicpState* __restrict__ st_in, GicpState* __restrict__ st_out, const double* __restrict__ partials, int rows,
-                                                                   GicpConfig cfg, qn_iter_trace* trace, int mode, int will_produce) {
+                                                                   GicpConfig cfg, qn_iter_trace* trace, int mode, int will_produce, LookArgs look) {
   __shared__ double sums[QN_NPART];
   __shared__ double part8[QN_NPART][NT / QN_NPART + 1];
   __shared__ GicpState sh;                       // the controller works on an LDS copy: one coalesced read, one coalesced write-back
@@ -1064,6 +1093,7 @@ static __global__ void __launch_bounds__(NT) k_solve(const GicpState* __restrict
     if (threadIdx.x == 0) solve_controller(&sh, sums, cfg, trace, mode, phase, Awork);
   }
   if (threadIdx.x == 0) { sh.fb_count = 0; sh.big_count = 0; sh.pending = (will_produce && sh.phase != 2) ? 1 : 0; }
+  if (threadIdx.x == 0 && look.enabled) look_decide(&sh, look.out, look.far_stats, look.sdims, look.tdims, look.allow_extra);
   __syncthreads();
   for (int i = threadIdx.x; i < (int)(sizeof(GicpState) / 8); i += NT) ((unsigned long long*)st_out)[i] = ((const unsigned long long*)&sh)[i];
 }
@@ -1133,7 +1163,6 @@ static __global__ void k_transform_cloud(const float4* __restrict__ in, uint32_t
   out[i] = make_float4(x, y, z, 1.0f);
 }
 
-struct ResultBlock { qn_gicp_result r; int32_t phase; uint32_t trace_len; uint32_t far_requests, far_misses, far_queries, look; double step_dt, step_dr; };   // step_*: max |t| and max |R - I| of the latest pose step (host: hand-over policy)
 
 static __global__ void k_finalize(const GicpState* __restrict__ st, ResultBlock* out, uint32_t* __restrict__ far_stats) {   // out lives in pinned host memory
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
@@ -1150,30 +1179,4 @@ static __global__ void k_finalize(const GicpState* __restrict__ st, ResultBlock*
 }
 
 
-// The hand-over decision of a forced Gauss-Newton run, on the device (the host's "look" without the round trip): k_finalize's statistics block, plus
-//   bit 0  one more unseeded iteration: the step just taken (translation + rotation x the source cloud's reach from the origin) would move the points by more
-//          than 0.4 target cells - a tracked tick would re-search most neighbourhoods;
-//   bit 1  the persistent launch may go ahead: at most ~6 % of the source has a far neighbour (otherwise the k_far refresh regime of the chain pays).
-// The flags go into the state (the conditional launches behind this kernel read them: k_nn_search / k_accumulate with cond, k_align_persist) and to the host.
-#define QN_LOOK_EXTRA 1
-#define QN_LOOK_GO 2
-static __global__ void k_look(GicpState* st, ResultBlock* out, uint32_t* __restrict__ far_stats, const GridDims* __restrict__ sdims, const GridDims* __restrict__ tdims, int allow_extra) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  const uint32_t fq = far_stats ? far_stats[3] : 0u;
-  out->far_requests = far_stats ? far_stats[1] : 0u; out->far_misses = far_stats ? far_stats[0] : 0u; out->far_queries = fq;
-  if (far_stats) { far_stats[0] = 0u; far_stats[1] = 0u; far_stats[3] = 0u; }
-  out->r.iterations = st->outer; out->r.converged = st->converged; out->r.lm_failed = st->lm_failed; out->r.reserved = 0;
-  out->phase = st->phase; out->trace_len = st->trace_len;
-  double mr = 0, mt = 0;
-  for (int a = 0; a < 3; a++) { for (int b = 0; b < 3; b++) mr = fmax(mr, fabs(st->delta[4 * a + b] - (a == b ? 1.0 : 0.0))); mt = fmax(mt, fabs(st->delta[4 * a + 3])); }
-  out->step_dt = mt; out->step_dr = mr;
-  const GridDims sg = *sdims;
-  double reach2 = 0; const double lo[3] = {sg.ox, sg.oy, sg.oz}, ext[3] = {sg.nx * (double)sg.cell, sg.ny * (double)sg.cell, sg.nz * (double)sg.cell};
-  for (int d = 0; d < 3; d++) { const double m = fmax(fabs(lo[d]), fabs(lo[d] + ext[d])); reach2 += m * m; }
-  const double moved = mt + mr * sqrt(reach2), ok = 0.4 * (double)tdims->cell;
-  int flags = 0;
-  if (allow_extra && moved > ok) flags |= QN_LOOK_EXTRA;             // (NaN compares false: no extra iteration)
-  if (fq * 16u <= sg.n && st->phase != 2) flags |= QN_LOOK_GO;
-  st->reserved = flags; out->look = (uint32_t)flags | 0x100u;        // (0x100: "a device look ran")
-}
 }  // namespace qn

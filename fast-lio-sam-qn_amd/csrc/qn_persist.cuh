@@ -44,7 +44,7 @@ struct PersistArgs {
   uint32_t nblk, epoch0, max_ticks;
   unsigned long long timeout;              // wall_clock64 units (100 MHz) a spin may last
   uint32_t* status_host;                   // pinned mirror of `status`, written by the reducer when it leaves (no memset in front of, no copy behind the launch)
-  int cond;                                // != 0: launched behind k_look without a host look - go ahead only if the state's QN_LOOK_GO flag is set
+  int cond;                                // != 0: launched behind look_decide without a host look - go ahead only if the state's QN_LOOK_GO flag is set
   int rows_if_extra;                       // cond: the partial rows the conditional unseeded iteration leaves (QN_LOOK_EXTRA set), else rows_in = -1
   int hint_poll;                           // reducer: watch one slot per row line before fetching the rows (knob persist_hint)
   unsigned long long* clk;                 // developer probe (PROBE = true): [tick < 64][16] wall-clock stamps: 0 rows complete, 1 sums, 2 controller, 3 pose published (reducer);
@@ -88,7 +88,7 @@ __global__ void __launch_bounds__(TB, TB / 256) k_align_persist(PersistArgs A) {
   __shared__ int bc_phase, bc_fail;
   __shared__ unsigned long long tie_list[TB / 64][QN_HCAP1]; __shared__ uint32_t tie_cnt[TB / 64];
   A.t.src = grid_resolve(A.t.src); A.t.tgt = grid_resolve(A.t.tgt);
-  if (A.cond) {                                                      // behind k_look: its flags decide (uniform over the launch: the state is not written before the reducer's last step)
+  if (A.cond) {                                                      // behind look_decide: its flags decide (uniform over the launch: the state is not written before the reducer's last step)
     const int flags = A.t.st_in->reserved;
     if (!(flags & QN_LOOK_GO)) { if (blockIdx.x == A.nblk && threadIdx.x == 0) { A.status_host[0] = 5u; A.status_host[1] = 0u; } return; }      // declined: nothing touched
     A.t.rows_in = (flags & QN_LOOK_EXTRA) ? A.rows_if_extra : -1;
