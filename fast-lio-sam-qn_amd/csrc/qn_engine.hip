@@ -500,7 +500,7 @@ static void enqueue_tick_fused(qn_ctx* c) {
     f.cand = c->far_cand; f.cand_ref = c->far_cand_ref; f.cand_b = c->far_cand_b; f.far_req = c->far_req; f.far_rows = c->far_rows; f.far_stats = c->far_stats;
     { ProfScope ps(c, QN_K_FAR);
       hipLaunchKernelGGL(k_far, dim3(QN_FAR_BLOCKS), dim3(QN_FAR_THREADS), 0, c->stream, f);
-      hipLaunchKernelGGL(k_far_reduce, dim3(1), dim3(QN_FAR_BLOCKS), 0, c->stream, c->far_rows, part_cur(c) + (size_t)c->part_rows * QN_NPART); }
+      hipLaunchKernelGGL(k_far_reduce, dim3(1), dim3(QN_FAR_BLOCKS), 0, c->stream, c->far_rows, part_cur(c) + (size_t)c->part_rows * QN_NPART, c->far_stats); }
     c->part_rows += 1;
   }
   if (c->verify_track) enqueue_verify(c, true);

@@ -61,6 +61,7 @@ struct TickArgs {
 #define QN_FAR_RMIN_CELLS 6.f           // a neighbour farther than this many cells makes a query "far"
 #define QN_FAR_BLOCKS 512            // x 8 waves: the refreshes are latency-bound (dependent LDS / global round trips), they need many waves in flight
 #define QN_FAR_THREADS 512
+#define QN_FAR_WORDS 4096            // request words ranked in LDS (clouds of up to 262144 points; larger ones keep the word-per-block distribution)
 
 
 // Block-level sum of the 28 per-thread accumulators.  Per wave: an LDS transpose in 4 rounds of 7 components through the wave's own
@@ -177,7 +178,7 @@ __device__ __forceinline__ uint32_t wave_ball_collect(const GridView& g, float q
   wave_lds_fence();
   const float R2 = R * R;
   unsigned long long b = QN_INF_KEY; float s2 = __int_as_float(0x7f800000);
-  stream_box(g, x0, x1, y0, y1, z0, z1, tile_mode, ws, [&](const float4& p, bool valid, uint32_t) __attribute__((always_inline)) {
+  const uint32_t streamed = stream_box(g, x0, x1, y0, y1, z0, z1, tile_mode, ws, [&](const float4& p, bool valid, uint32_t) __attribute__((always_inline)) {
     const float d2 = sqdist(qx, qy, qz, p.x, p.y, p.z);
     if (valid && d2 <= R2) {
       const unsigned long long k = pack_key(d2, __float_as_uint(p.w));
@@ -187,6 +188,7 @@ __device__ __forceinline__ uint32_t wave_ball_collect(const GridView& g, float q
     }
   }, qx, qy, qz, tile_mode ? R2 * 1.000002f : -1.f);                    // (tiles outside the ball are not streamed: only points with d2 <= R2 are used)
   wave_lds_fence();
+  if (g.dbg && lane == 0) { atomicAdd(&g.dbg[14], 1u); atomicAdd(&g.dbg[15], streamed); atomicAdd(&g.dbg[9], (uint32_t)(tile_mode ? ((x1 >> 3) - (x0 >> 3) + 1) * ((y1 >> 2) - (y0 >> 2) + 1) * ((z1 >> 2) - (z0 >> 2) + 1) : ((x1 >> 3) - (x0 >> 3) + 1) * (y1 - y0 + 1) * (z1 - z0 + 1))); }      // developer counters: calls, candidates, segments
   const unsigned long long wb = wave_min_u64(b);
   float c = (b == wb) ? s2 : key_d2(b);
   if (b == QN_INF_KEY) c = __int_as_float(0x7f800000);
@@ -573,6 +575,8 @@ struct FarArgs {
 static __global__ void __launch_bounds__(QN_FAR_THREADS) k_far(FarArgs a) {
   __shared__ WaveLdsH1 lds[QN_FAR_THREADS / 64];
   __shared__ double wsum[QN_FAR_THREADS / 64][QN_NPART];
+  __shared__ uint32_t wpre[QN_FAR_WORDS];                           // exclusive popcount prefix of the request words
+  __shared__ uint32_t wtot[QN_FAR_THREADS / 64];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   constexpr int NW = QN_FAR_THREADS / 64;
   a.src = grid_resolve(a.src); a.tgt = grid_resolve(a.tgt);
@@ -589,12 +593,55 @@ static __global__ void __launch_bounds__(QN_FAR_THREADS) k_far(FarArgs a) {
 #pragma unroll
       for (int c = 0; c < 4; c++) X0[r][c] = a.st->x0[4 * r + c];
     const uint32_t nchunks = (a.src.n + 63u) >> 6;
-    uint32_t seen = 0;                                              // requests of this block so far (block-uniform)
-    for (uint32_t ch = blockIdx.x; ch < nchunks; ch += QN_FAR_BLOCKS) {
-      unsigned long long word = a.far_req[ch];
-      for (; word != 0; word &= word - 1, seen++) {
-        if ((int)(seen % NW) != wid) continue;                      // request e of the block goes to wave e mod NW
-        const uint32_t t = ch * 64u + (uint32_t)(__ffsll((long long)word) - 1);
+    // Work distribution.  The requests are bits in far_req (one word per 64 consecutive source positions) and they are CLUSTERED: the part of the source that has
+    // no counterpart in the target is one stretch of the cell-sorted order.  Handing words to blocks (the first version) left most of the chip idle while a few
+    // blocks worked through dozens of requests per wave.  Instead every block ranks the requests globally (popcount prefix over all words, in LDS) and request e
+    // goes to wave e mod (all waves of the launch): balanced, and still a fixed assignment - the sums below are formed in a reproducible order.
+    const bool ranked = nchunks <= (uint32_t)QN_FAR_WORDS;
+    uint32_t total_req = 0;
+    if (ranked && a.far_stats[0] != 0u) {                            // ([0]: the requests the tick counted - none: nothing to rank, nothing to serve)
+      for (uint32_t w = tid; w < nchunks; w += QN_FAR_THREADS) wpre[w] = (uint32_t)__popcll(a.far_req[w]);
+      __syncthreads();
+      // exclusive prefix over nchunks <= QN_FAR_WORDS values: thread i owns the run [i * PER, (i + 1) * PER)
+      constexpr uint32_t PER = (QN_FAR_WORDS + QN_FAR_THREADS - 1) / QN_FAR_THREADS;
+      uint32_t loc[PER], sum = 0;
+#pragma unroll
+      for (uint32_t u = 0; u < PER; u++) { const uint32_t w = tid * PER + u; loc[u] = w < nchunks ? wpre[w] : 0u; sum += loc[u]; }
+      uint32_t inc = wave_incl_scan_u32(sum, lane);
+      if (lane == 63) wtot[wid] = inc;
+      __syncthreads();
+      uint32_t base = inc - sum;
+      for (int w2 = 0; w2 < wid; w2++) base += wtot[w2];
+      for (int w2 = 0; w2 < NW; w2++) total_req += wtot[w2];
+      __syncthreads();
+#pragma unroll
+      for (uint32_t u = 0; u < PER; u++) { const uint32_t w = tid * PER + u; if (w < nchunks) wpre[w] = base; base += loc[u]; }
+      __syncthreads();
+    }
+    const uint32_t gw = blockIdx.x * NW + wid, ngw = QN_FAR_BLOCKS * NW;
+    uint32_t seen = 0;                                              // requests of this block so far (block-uniform; the unranked path)
+    uint32_t e = gw;                                                  // ranked path: this wave's next request
+    uint32_t ch = ranked ? 0u : blockIdx.x;
+    unsigned long long word = 0;
+    for (;;) {
+      uint32_t t;
+      if (ranked) {
+        if (e >= total_req) break;
+        uint32_t lo = 0;                                               // last word with wpre[w] <= e
+        for (uint32_t step = 1u << 11; step > 0; step >>= 1) { const uint32_t w = lo + step; if (w < nchunks && wpre[w] <= e) lo = w; }
+        unsigned long long wd = a.far_req[lo];
+        for (uint32_t skip = e - wpre[lo]; skip > 0; skip--) wd &= wd - 1;       // the (e - wpre[lo])-th set bit
+        t = lo * 64u + (uint32_t)(__ffsll((long long)wd) - 1);
+        e += ngw;
+      } else {
+        while (word == 0) { if (ch >= nchunks) break; word = a.far_req[ch]; if (word == 0) ch += QN_FAR_BLOCKS; }
+        if (word == 0) break;
+        t = ch * 64u + (uint32_t)(__ffsll((long long)word) - 1);
+        word &= word - 1; if (word == 0) ch += QN_FAR_BLOCKS;
+        const bool mine_req = (int)(seen % NW) == wid; seen++;
+        if (!mine_req) continue;                                    // request e of the block goes to wave e mod NW
+      }
+      {
         const float4 p = a.src.pts[t];
         float qx, qy, qz; xform_query<0>(Tf, p.x, p.y, p.z, qx, qy, qz);
         const uint32_t j0 = (uint32_t)a.nn_idx[t];
@@ -654,11 +701,11 @@ static __global__ void __launch_bounds__(QN_FAR_THREADS) k_far(FarArgs a) {
   if (tid < QN_NPART) { double v = 0;
 #pragma unroll
     for (int w = 0; w < NW; w++) v += wsum[w][tid]; a.far_rows[(size_t)blockIdx.x * QN_NPART + tid] = v; }
-  if (blockIdx.x == 0 && tid == 0) { a.far_stats[1] = a.far_stats[0]; a.far_stats[0] = 0u; }      // [1] = requests of the tick just served
 }
-static __global__ void __launch_bounds__(QN_FAR_BLOCKS) k_far_reduce(const double* __restrict__ far_rows, double* __restrict__ part_row) {
+static __global__ void __launch_bounds__(QN_FAR_BLOCKS) k_far_reduce(const double* __restrict__ far_rows, double* __restrict__ part_row, uint32_t* __restrict__ far_stats) {
   __shared__ double sh[QN_FAR_BLOCKS / 32][QN_NPART];
   const int tid = threadIdx.x, c = tid % 32, seg = tid / 32;          // 16 segments of 32 rows; threads c >= 28 idle
+  if (tid == 0) { far_stats[1] = far_stats[0]; far_stats[0] = 0u; }   // [1] = requests of the tick just served (here, not in k_far: every block of k_far reads [0] when it starts)
   if (c < QN_NPART) {
     double v[32];
 #pragma unroll
