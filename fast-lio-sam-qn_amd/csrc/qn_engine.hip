@@ -143,7 +143,7 @@ extern "C" int qn_ctx_create(int device, uint32_t max_points, qn_ctx** out) {
     sl.take(c->knn_idx2, sizeof(int32_t) * (size_t)max_points * 32);
     sl.take(c->bbox2, sizeof(BBoxOut));
     sl.take(c->staging2, (size_t)max_points * 32);
-    sl.take(c->bbox_acc, 2 * sizeof(BBoxAcc)); c->bbox_acc2 = c->bbox_acc ? c->bbox_acc + 1 : nullptr;
+    sl.take(c->bbox_acc, 2 * (QN_BBOX_MAX_BLOCKS + 1) * sizeof(BBoxAcc)); c->bbox_acc2 = c->bbox_acc ? c->bbox_acc + (QN_BBOX_MAX_BLOCKS + 1) : nullptr;      // [0]: ticket, [1 + b]: block b's box
     sl.take(c->scan_status, sizeof(unsigned long long) * 2 * (c->max_cells / (QN_BLOCK * QN_SCAN_ITEMS) + 2)); c->scan_status2 = c->scan_status ? c->scan_status + (c->max_cells / (QN_BLOCK * QN_SCAN_ITEMS) + 2) : nullptr;
     sl.take(c->pg_rows, sizeof(unsigned long long) * 3 * QN_PERSIST_ROWS * QN_PERSIST_RSTRIDE);
     sl.take(c->pg_bc, sizeof(unsigned long long) * 64);
@@ -166,7 +166,8 @@ extern "C" int qn_ctx_create(int device, uint32_t max_points, qn_ctx** out) {
   CA(hipMemsetAsync(c->pg_fit, 0, sizeof(unsigned long long) * (QN_PERSIST_MAX_BLOCKS + 1) * 4, c->stream));
   CA(hipMemsetAsync(c->pg_status, 0, 4 * sizeof(uint32_t), c->stream));
   CA(hipMemsetAsync(c->state, 0, 2 * sizeof(GicpState), c->stream));
-  hipLaunchKernelGGL(k_bbox_acc_init, dim3(1), dim3(64), 0, c->stream, c->bbox_acc, 2);
+  hipLaunchKernelGGL(k_bbox_acc_init, dim3(1), dim3(256), 0, c->stream, c->bbox_acc, 2 * (QN_BBOX_MAX_BLOCKS + 1));
+  CA(hipMemsetAsync(c->fb_count2, 0, 4 * sizeof(uint32_t), c->stream)); CA(hipMemsetAsync(c->fb_count2b, 0, 4 * sizeof(uint32_t), c->stream));      // the k-NN list counters: every covariance stage hands them back at zero (k_cov_from_idx)
   CA(hipMemsetAsync(c->scan_status, 0, sizeof(unsigned long long) * 2 * (c->max_cells / (QN_BLOCK * QN_SCAN_ITEMS) + 2), c->stream));
   for (int w = 0; w < 2; w++) CA(hipMemsetAsync(c->cloud[w].counts, 0, sizeof(uint32_t) * ((size_t)c->max_cells + 1), c->stream));      // the cell counters are handed back at zero by every build (k_scatter)
   CA(hipStreamSynchronize(c->stream));
@@ -284,7 +285,7 @@ static int build_grid(qn_ctx* c, CloudBuf& b, const char* dsrc, uint32_t stride)
   { ProfScope ps(c, QN_K_GRID_BUILD);
     // 5 launches, nothing else: the bounding-box accumulator and the cell counters clean up after themselves (the last block of the first kernel; k_scatter's
     // atomicSub hands every counter back at zero), the scan is single-pass, the numbers reach the host through the pinned mirror
-    hipLaunchKernelGGL(k_pack_bbox_dims, dim3(std::min<uint32_t>(nb, (uint32_t)c->bbox_blocks)), dim3(QN_BLOCK), 0, s, dsrc, stride, n, b.raw, c->bbox_acc, c->max_cells, c->cell_override, b.dims, b.dims_host);
+    hipLaunchKernelGGL(k_pack_bbox_dims, dim3(std::min<uint32_t>(nb, (uint32_t)std::min(c->bbox_blocks, QN_BBOX_MAX_BLOCKS))), dim3(QN_BLOCK), 0, s, dsrc, stride, n, b.raw, c->bbox_acc, c->max_cells, c->cell_override, b.dims, b.dims_host);
     hipLaunchKernelGGL(k_cell_count, dim3(nb), dim3(QN_BLOCK), 0, s, b.raw, n, g, b.counts, b.cell_of_pt);
     hipLaunchKernelGGL(k_scan_lookback, dim3(sb_max), dim3(QN_BLOCK), 0, s, (const uint32_t*)b.counts, (const GridDims*)b.dims, b.cell_start, c->scan_status, c->build_epoch, n);
     hipLaunchKernelGGL(k_scatter, dim3(nb), dim3(QN_BLOCK), 0, s, b.raw, n, b.cell_of_pt, b.cell_start, b.counts, c->stable_cells ? b.sorted_tmp : b.sorted);
@@ -357,7 +358,7 @@ static void launch_knn_cov(qn_ctx* c, CloudBuf& b, int k, int32_t* kidx, float* 
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_knn_cov<KMAX, true, 4>), dim3(std::min<uint32_t>((b.n + 63) / 64, 1024)), dim3(QN_BLOCK), 0, s, b.grid, b.raw, k, r0, 64, b.nrm, kidx, kd2, c->fb_list, c->fb_count2 + 2);
     const uint32_t nbp = (b.n + QN_BLOCK - 1) / QN_BLOCK;
     hipLaunchKernelGGL(k_cov_from_idx, dim3(nbp), dim3(QN_BLOCK), 0, s, b.raw, b.sorted, b.n, k, kidx, b.nrm,
-                       &b == &c->cloud[0] ? c->nrm_s_sorted : (double*)nullptr, &b == &c->cloud[0] ? (TargetRec*)nullptr : c->tgt_rec);   // + the optimiser ticks' layouts
+                       &b == &c->cloud[0] ? c->nrm_s_sorted : (double*)nullptr, &b == &c->cloud[0] ? (TargetRec*)nullptr : c->tgt_rec, c->fb_count2);   // + the optimiser ticks' layouts
     return;
   }
   ProfScope ps(c, QN_K_KNN_COV);
@@ -368,7 +369,7 @@ static void launch_knn_cov(qn_ctx* c, CloudBuf& b, int k, int32_t* kidx, float* 
   hipLaunchKernelGGL(HIP_KERNEL_NAME(k_knn_cov<KMAX, true, 4>), dim3(std::min<uint32_t>((b.n + 63) / 64, 512)), dim3(QN_BLOCK), 0, s, b.grid, b.raw, k, r0, 64, b.nrm, kidx, kd2, c->fb_list, c->fb_count2);
   const uint32_t nbp = (b.n + QN_BLOCK - 1) / QN_BLOCK;
   hipLaunchKernelGGL(k_cov_from_idx, dim3(nbp), dim3(QN_BLOCK), 0, s, b.raw, b.sorted, b.n, k, kidx, b.nrm,
-                     &b == &c->cloud[0] ? c->nrm_s_sorted : (double*)nullptr, &b == &c->cloud[0] ? (TargetRec*)nullptr : c->tgt_rec);   // + the optimiser ticks' layouts
+                     &b == &c->cloud[0] ? c->nrm_s_sorted : (double*)nullptr, &b == &c->cloud[0] ? (TargetRec*)nullptr : c->tgt_rec, c->fb_count2);   // + the optimiser ticks' layouts
 }
 static int compute_cov(qn_ctx* c, int which, int32_t* kidx, float* kd2) {
   if (!c || (which != 0 && which != 1)) return QN_ERR_INVALID_ARG;
@@ -380,7 +381,6 @@ static int compute_cov(qn_ctx* c, int which, int32_t* kidx, float* kd2) {
   if (which == QN_TARGET && !on2 && join_target(c) != QN_OK) return QN_ERR_HIP;
   if (on2) kidx = c->knn_idx2;
   TargetScope scope(c, on2);
-  HIPCHK(c, hipMemsetAsync(c->fb_count2, 0, 4 * sizeof(uint32_t), c->stream));
   if (k <= 16) launch_knn_cov<16>(c, b, k, kidx, kd2);
   else if (k <= 20) launch_knn_cov<20>(c, b, k, kidx, kd2);
   else if (k <= 24) launch_knn_cov<24>(c, b, k, kidx, kd2);

@@ -93,6 +93,7 @@ __device__ inline GridDims grid_dims_from_bbox(const int (&omn)[3], const int (&
 // per block), and let the LAST block to arrive (ticket) turn the box into the grid's numbers - written to device memory for the kernels that follow and straight
 // into the pinned mirror the host reads after its next synchronisation.  That block also puts the accumulator back into its initial state: no upload, no reset
 // kernel, no read-back in front of or behind the build.  (Accumulator words are only ever touched with agent-scope atomics: the blocks sit on different XCDs.)
+#define QN_BBOX_MAX_BLOCKS 256
 struct BBoxAcc { int mn[3], mx[3]; uint32_t nonfinite, ticket; };
 static __global__ void __launch_bounds__(QN_BLOCK) k_pack_bbox_dims(const char* __restrict__ in, uint32_t stride, uint32_t n, float4* __restrict__ raw, BBoxAcc* acc,
                                                                     uint32_t max_cells, double cell_override, GridDims* __restrict__ dims_dev, GridDims* __restrict__ dims_host) {
@@ -116,21 +117,26 @@ static __global__ void __launch_bounds__(QN_BLOCK) k_pack_bbox_dims(const char* 
   __syncthreads();
   if (threadIdx.x != 0) return;
   for (int w = 1; w < QN_BLOCK / 64; w++) { for (int d = 0; d < 3; d++) { mn[d] = min(mn[d], smn[w][d]); mx[d] = max(mx[d], smx[w][d]); } bad |= sbad[w]; }
-  for (int d = 0; d < 3; d++) { atomicMin(&acc->mn[d], mn[d]); atomicMax(&acc->mx[d], mx[d]); }
-  if (bad) atomicAdd(&acc->nonfinite, 1u);
+  // the block's box goes to a slot of its own (six contended atomics per block on the same words cost more than the whole reduction: 64 blocks, 10 us);
+  // the one contended operation left is the ticket
+  BBoxAcc* mine = acc + 1 + blockIdx.x;
+  for (int d = 0; d < 3; d++) { __hip_atomic_store(&mine->mn[d], mn[d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); __hip_atomic_store(&mine->mx[d], mx[d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+  __hip_atomic_store(&mine->nonfinite, (uint32_t)bad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   __threadfence();
   if (atomicAdd(&acc->ticket, 1u) != gridDim.x - 1u) return;
   __threadfence();
-  for (int d = 0; d < 3; d++) { mn[d] = __hip_atomic_load(&acc->mn[d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); mx[d] = __hip_atomic_load(&acc->mx[d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-  const uint32_t nf = __hip_atomic_load(&acc->nonfinite, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  uint32_t nf = 0;
+  for (uint32_t b = 0; b < gridDim.x; b++) {
+    const BBoxAcc* o = acc + 1 + b;
+    for (int d = 0; d < 3; d++) { mn[d] = min(mn[d], __hip_atomic_load(&o->mn[d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)); mx[d] = max(mx[d], __hip_atomic_load(&o->mx[d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)); }
+    nf |= __hip_atomic_load(&o->nonfinite, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
   const GridDims g = grid_dims_from_bbox(mn, mx, nf != 0u, n, max_cells, cell_override);
   *dims_dev = g; *dims_host = g;
-  for (int d = 0; d < 3; d++) { __hip_atomic_store(&acc->mn[d], 0x7fffffff, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); __hip_atomic_store(&acc->mx[d], (int)0x80000000, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-  __hip_atomic_store(&acc->nonfinite, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   __hip_atomic_store(&acc->ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 static __global__ void k_bbox_acc_init(BBoxAcc* acc, int count) {
-  if (blockIdx.x == 0 && (int)threadIdx.x < count) { BBoxAcc a; for (int d = 0; d < 3; d++) { a.mn[d] = 0x7fffffff; a.mx[d] = (int)0x80000000; } a.nonfinite = 0; a.ticket = 0; acc[threadIdx.x] = a; }
+  for (int i = threadIdx.x; blockIdx.x == 0 && i < count; i += blockDim.x) { BBoxAcc a; for (int d = 0; d < 3; d++) { a.mn[d] = 0x7fffffff; a.mx[d] = (int)0x80000000; } a.nonfinite = 0; a.ticket = 0; acc[i] = a; }
 }
 
 // Exclusive scan of the cell counts in ONE launch (decoupled look-back): tile t = block t publishes its aggregate, sums its predecessors' aggregates back to the
@@ -246,7 +252,8 @@ static_assert(sizeof(TargetRec) == 64, "TargetRec is one 64-byte line");
 // Threads walk the points in cell-sorted order (a block's points are spatial neighbours, so their k-NN gathers overlap in
 // L1/L2), blocks in XCD-aware order.
 static __global__ void __launch_bounds__(QN_BLOCK) k_cov_from_idx(const float4* __restrict__ raw, const float4* __restrict__ sorted, uint32_t n, int k, const int32_t* __restrict__ knn_idx, double* __restrict__ nrm,
-                                                                  double* __restrict__ nrm_sorted, TargetRec* __restrict__ rec) {
+                                                                  double* __restrict__ nrm_sorted, TargetRec* __restrict__ rec, uint32_t* __restrict__ list_counts) {
+  if (blockIdx.x == 0 && threadIdx.x < 4) list_counts[threadIdx.x] = 0u;      // the selection passes' list counters go back to zero behind their last reader (no memset in front of the next cloud)
   const uint32_t spos = xcd_block(blockIdx.x, gridDim.x) * QN_BLOCK + threadIdx.x;
   if (spos >= n) return;
   const uint32_t i = __float_as_uint(sorted[spos].w);
