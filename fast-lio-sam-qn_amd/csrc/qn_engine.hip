@@ -700,7 +700,7 @@ static int gicp_align(qn_ctx* c, const float guess[16], qn_gicp_result* out, boo
       else c->far_mode = (c->far_mode == 1 ? rb->far_requests : rb->far_misses / (uint32_t)std::max(1, chunk)) > 256u ? 1 : 2;   // stray misses are cheaper inside k_tick
     }
     if (!exact_ticks) chunk = first_chunk ? c->ticks_per_chunk : std::max(2 * per_outer, c->ticks_per_chunk / 2);   // convergence is usually near after the first chunks: ticks past it are wasted launches
-    else chunk = first_chunk && c->far_mode == 1 ? std::min(ticks_left, c->ticks_per_chunk) : ticks_left;
+    else chunk = first_chunk && c->far_mode == 1 ? std::min(ticks_left, c->far_chunk) : ticks_left;      // the refresh regime is needed for the first few tracked ticks only: an empty k_far + k_far_reduce behind every later tick cost 14 us each (80 %-overlap pairs: 1384 -> 1429 registrations/s with 4 instead of 8)
     if (budget <= 0) { c->last_error = "align: device state machine did not terminate"; return QN_ERR_HIP; }
     if (look && !declined) {
       // how far the NEXT step will move the source points at most: the step just taken (translation + rotation x the cloud's reach from the origin), shrunk
@@ -717,7 +717,7 @@ static int gicp_align(qn_ctx* c, const float guess[16], qn_gicp_result* out, boo
       c->unseeded_until = tick_no + extra;
       for (int t = 0; t < extra; t++) { enqueue_tick(c, seeded, tick_no, c->part_rows < 0); tick_no++; }
       budget -= extra; ticks_left -= extra;
-      if (exact_ticks) chunk = c->far_mode == 1 ? std::min(ticks_left, c->ticks_per_chunk) : ticks_left;
+      if (exact_ticks) chunk = c->far_mode == 1 ? std::min(ticks_left, c->far_chunk) : ticks_left;
       c->last_extra_unseeded = extra;
     }
     if (tick_no > 0 && persist_usable(c, alone)) {          // everything that is left - ticks, closing pass, result - in ONE persistent launch (first chunk end, or once the far-query refreshes have died down)
@@ -945,6 +945,7 @@ extern "C" int qn_debug_set(qn_ctx* c, const char* key, double v) {
   else if (k == "device_look") c->device_look = v != 0;
   else if (k == "far_group") c->far_group = (int)v;
   else if (k == "big_ratio_late") c->big_ratio_late = (float)v;
+  else if (k == "far_chunk") c->far_chunk = std::max(1, (int)v);
   else if (k == "pair_pipeline") c->pair_pipeline = v != 0;
   else if (k == "persist") c->persist = v != 0;
   else if (k == "persist_hint") c->persist_hint = v != 0;
