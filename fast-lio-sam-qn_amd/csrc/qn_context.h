@@ -33,6 +33,7 @@ struct qn_ctx {
   unsigned long long* scan_status = nullptr; unsigned long long* scan_status2 = nullptr; uint32_t build_epoch = 0;   // look-back scan: tile status words, tagged with the build's epoch
   int far_group = -1;                   // far-list grouping (wave_search_far16): -1 = by regime (enqueue_nn), 0 = off, n = ceil(list length / n) entries per wave for every list
   int far_chunk = 4;                    // tracked ticks of a forced run that keep the far-query refresh kernel behind them before the host looks again
+  bool batch_look = false;              // batch members take the device-side look as well (third unseeded iteration conditional): measured neutral for throughput (2239-2253 vs 2246-2247), off
   bool device_look = true;              // the hand-over decision of a lone forced-GN registration on the device (look_decide) instead of a host round trip
   bool clear_far_now = false;           // the next unseeded search resets the far-candidate references (first search of an align)
   char* staging2 = nullptr;             // the second stream's landing zone (TargetScope)

@@ -619,7 +619,7 @@ static int gicp_align(qn_ctx* c, const float guess[16], qn_gicp_result* out, boo
   // streams fill the chip; measured best for throughput).
   // (only runs that are known to be long pay for the look - a forced iteration count: with the real stopping rule the reference's operating point converges in
   //  3-7 iterations, and the extra round trip cost it 0.03-0.07 ms; knob single_from_tick = 0: the fixed hand-over everywhere; an explicitly earlier one wins too)
-  const bool adaptive = !c->persist_batch_off && c->fused_ticks && c->far_enabled && c->single_from_tick > 0 && p.force_iterations > 0 && p.optimizer == QN_OPT_GN && maxit >= 8 &&
+  const bool adaptive = (!c->persist_batch_off || (c->device_look && c->batch_look)) && c->fused_ticks && c->far_enabled && c->single_from_tick > 0 && p.force_iterations > 0 && p.optimizer == QN_OPT_GN && maxit >= 8 &&
                         std::min(c->track_from_tick, c->fused_from_tick) > c->single_from_tick;
   const int fixed_unseeded = std::max(1, std::min(c->track_from_tick, c->fused_from_tick)) * per_outer;
   const int unseeded = adaptive ? std::max(1, std::min(fixed_unseeded / per_outer, c->single_from_tick)) * per_outer : fixed_unseeded;
@@ -643,7 +643,8 @@ static int gicp_align(qn_ctx* c, const float guess[16], qn_gicp_result* out, boo
     // A registration that is alone on the GPU takes the look ON THE DEVICE (look_decide): the conditional third unseeded iteration and the persistent launch are enqueued
     // behind it and read its flags - no host round trip between the unseeded ticks and the tracked regime (it cost 15-30 us of a 0.6 ms align).  If the flags
     // say "not the persistent kernel" (many far neighbours: the k_far regime), that launch returns at once and the chain goes on from the host below.
-    const bool dev_look = look && c->device_look && tick_no > 0 && persist_usable(c, alone);
+    const bool dev_look = look && c->device_look && tick_no > 0;
+    const bool with_persist = dev_look && persist_usable(c, alone);   // (a batch member takes the same look - its third unseeded iteration is conditional too - and carries on with the chain)
     bool declined = false;
     if (look && !dev_look) enqueue_solve(c, 0, 1);
     if (dev_look) {
@@ -656,21 +657,21 @@ static int gicp_align(qn_ctx* c, const float guess[16], qn_gicp_result* out, boo
       enqueue_accumulate(c, QN_LOOK_EXTRA);
       const int rows_if_extra = c->part_rows;
       c->part_rows = -1;                                            // (the kernel picks rows_if_extra instead when the extra iteration ran)
-      if ((rc = launch_persist(c, (uint32_t)(budget - chunk) + 2u, QN_LOOK_GO, rows_if_extra)) != QN_OK) return rc;
+      if (with_persist && (rc = launch_persist(c, (uint32_t)(budget - chunk) + 2u, QN_LOOK_GO, rows_if_extra)) != QN_OK) return rc;
       HIPCHK(c, hipGetLastError());
       HIPCHK(c, hipStreamSynchronize(s));
       if ((rc = clouds_valid(c)) != QN_OK) return rc;
       const int extra = (c->result_host->look & QN_LOOK_EXTRA) ? per_outer : 0;
       c->last_extra_unseeded = extra;
-      if (c->result_host->phase == 2) break;                        // the whole registration ran behind the look
-      if (c->pg_status_host[0] != 5u) {
+      if (with_persist && c->result_host->phase == 2) break;        // the whole registration ran behind the look
+      if (with_persist && c->pg_status_host[0] != 5u) {
         (void)hipMemsetAsync(c->pg_rows, 0xFF, sizeof(unsigned long long) * 3 * QN_PERSIST_ROWS * QN_PERSIST_RSTRIDE, s); (void)hipMemsetAsync(c->pg_status, 0, 4 * sizeof(uint32_t), s); (void)hipStreamSynchronize(s);
         char buf[160]; snprintf(buf, sizeof(buf), "align: the persistent kernel gave up (code %u after %u ticks: 1 rows, 2 tick budget, 3 closing sums, 4 pose)", c->pg_status_host[0], c->pg_status_host[1]);
         c->last_error = buf; return QN_ERR_HIP;
       }
       // declined: the state is the one the look (and the extra iteration, if it ran) left - carry on with the chain
       declined = true;
-      c->gen--; c->persist_launches--;                              // (the declined launch wrote no state)
+      if (with_persist) { c->gen--; c->persist_launches--; }        // (the declined launch wrote no state)
       c->part_rows = extra ? rows_if_extra : -1;
       tick_no += extra; budget -= extra; ticks_left -= extra;
       c->unseeded_until = tick_no;
@@ -946,6 +947,7 @@ extern "C" int qn_debug_set(qn_ctx* c, const char* key, double v) {
   else if (k == "far_group") c->far_group = (int)v;
   else if (k == "big_ratio_late") c->big_ratio_late = (float)v;
   else if (k == "far_chunk") c->far_chunk = std::max(1, (int)v);
+  else if (k == "batch_look") c->batch_look = v != 0;
   else if (k == "pair_pipeline") c->pair_pipeline = v != 0;
   else if (k == "persist") c->persist = v != 0;
   else if (k == "persist_hint") c->persist_hint = v != 0;
