@@ -497,7 +497,7 @@ static void enqueue_tick_fused(qn_ctx* c) {
   if (a.far_mode == 1) {                       // the tick's refresh requests, chip-wide, one query per wave; its rows follow the tick's
     FarArgs f;
     f.src = S.grid; f.tgt = T.grid; f.st = st_cur(c); f.thr2 = a.thr2; f.nn_idx = c->nn_idx; f.nn_ref = c->nn_ref; f.nrm_s = c->nrm_s_sorted; f.tgt_rec = c->tgt_rec; f.tgt_raw = T.raw;
-    f.cand = c->far_cand; f.cand_ref = c->far_cand_ref; f.cand_b = c->far_cand_b; f.far_req = c->far_req; f.far_rows = c->far_rows; f.far_stats = c->far_stats;
+    f.cand = c->far_cand; f.cand_ref = c->far_cand_ref; f.cand_b = c->far_cand_b; f.far_req = c->far_req; f.far_rows = c->far_rows; f.far_stats = c->far_stats; f.ranked_max = c->far_ranked ? (uint32_t)QN_FAR_WORDS : 0u;
     { ProfScope ps(c, QN_K_FAR);
       hipLaunchKernelGGL(k_far, dim3(QN_FAR_BLOCKS), dim3(QN_FAR_THREADS), 0, c->stream, f);
       hipLaunchKernelGGL(k_far_reduce, dim3(1), dim3(QN_FAR_BLOCKS), 0, c->stream, c->far_rows, part_cur(c) + (size_t)c->part_rows * QN_NPART, c->far_stats); }
@@ -947,6 +947,7 @@ extern "C" int qn_debug_set(qn_ctx* c, const char* key, double v) {
   else if (k == "far_group") c->far_group = (int)v;
   else if (k == "big_ratio_late") c->big_ratio_late = (float)v;
   else if (k == "far_chunk") c->far_chunk = std::max(1, (int)v);
+  else if (k == "far_ranked") c->far_ranked = v != 0;
   else if (k == "batch_look") c->batch_look = v != 0;
   else if (k == "pair_pipeline") c->pair_pipeline = v != 0;
   else if (k == "persist") c->persist = v != 0;

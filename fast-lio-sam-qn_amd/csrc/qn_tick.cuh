@@ -570,6 +570,7 @@ struct FarArgs {
   int32_t* cand; float4* cand_ref; float2* cand_b;
   const unsigned long long* far_req;
   double* far_rows;                    // [QN_FAR_BLOCKS][28] side table
+  uint32_t ranked_max;                 // request words up to which the requests are ranked globally (QN_FAR_WORDS; 0 = word-per-block distribution: clouds beyond 262144 points, and the test of that path)
   uint32_t* far_stats;
 };
 static __global__ void __launch_bounds__(QN_FAR_THREADS) k_far(FarArgs a) {
@@ -597,7 +598,7 @@ static __global__ void __launch_bounds__(QN_FAR_THREADS) k_far(FarArgs a) {
     // no counterpart in the target is one stretch of the cell-sorted order.  Handing words to blocks (the first version) left most of the chip idle while a few
     // blocks worked through dozens of requests per wave.  Instead every block ranks the requests globally (popcount prefix over all words, in LDS) and request e
     // goes to wave e mod (all waves of the launch): balanced, and still a fixed assignment - the sums below are formed in a reproducible order.
-    const bool ranked = nchunks <= (uint32_t)QN_FAR_WORDS;
+    const bool ranked = nchunks <= min((uint32_t)QN_FAR_WORDS, a.ranked_max);
     uint32_t total_req = 0;
     if (ranked && a.far_stats[0] != 0u) {                            // ([0]: the requests the tick counted - none: nothing to rank, nothing to serve)
       for (uint32_t w = tid; w < nchunks; w += QN_FAR_THREADS) wpre[w] = (uint32_t)__popcll(a.far_req[w]);

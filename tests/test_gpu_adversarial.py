@@ -112,3 +112,22 @@ def test_partial_overlap_far_queries(eng, oracle, optimizer, force):
     dt, dr = synth.pose_error(np.array(r.T64).reshape(4, 4), ro["T"])
     assert dt <= 1e-4 and dr <= 1e-4, (dt, dr)
     assert abs(r.fitness - ro["fitness"]) <= 1e-6 * ro["fitness"]
+
+
+def test_far_refresh_distributions_agree():
+    """k_far deals its refresh requests by global rank (balanced) or, for clouds beyond 262144 points, word by word to the blocks: both serve every request with the
+    same exact search - same iteration count, same neighbours (score) and the same pose to rounding (the far contributions are summed in a different order)."""
+    from qn_amd import engine
+    src, tgt, _ = synth.make_pair(77, 40000, shift=24.0)
+    out = []
+    for ranked in (1, 0):
+        ctx = engine.Context(41024)
+        ctx.debug_set("far_ranked", ranked); ctx.debug_set("persist", 0)
+        g = engine.NanoGICP(ctx)
+        g.setCorrespondenceRandomness(15); g.setMaximumIterations(12); g.setMaxCorrespondenceDistance(52.5); g.setOptimizer("gn"); g.setForceIterations(12)
+        g.setInputSource(src); g.calculateSourceCovariances(); g.setInputTarget(tgt); g.calculateTargetCovariances()
+        r = g.align()
+        out.append((np.array(r.T64).reshape(4, 4).copy(), r.fitness, r.iterations))
+        ctx.close()
+    assert out[0][2] == out[1][2]
+    assert np.max(np.abs(out[0][0] - out[1][0])) < 1e-9 and abs(out[0][1] - out[1][1]) <= 1e-9 * abs(out[0][1])
