@@ -115,23 +115,34 @@ static __global__ void __launch_bounds__(QN_BLOCK) k_pack_bbox_dims(const char* 
   const int wid = threadIdx.x >> 6;
   if ((threadIdx.x & 63) == 0) { for (int d = 0; d < 3; d++) { smn[wid][d] = mn[d]; smx[wid][d] = mx[d]; } sbad[wid] = bad; }
   __syncthreads();
-  if (threadIdx.x != 0) return;
-  for (int w = 1; w < QN_BLOCK / 64; w++) { for (int d = 0; d < 3; d++) { mn[d] = min(mn[d], smn[w][d]); mx[d] = max(mx[d], smx[w][d]); } bad |= sbad[w]; }
-  // the block's box goes to a slot of its own (six contended atomics per block on the same words cost more than the whole reduction: 64 blocks, 10 us);
-  // the one contended operation left is the ticket
-  BBoxAcc* mine = acc + 1 + blockIdx.x;
-  for (int d = 0; d < 3; d++) { __hip_atomic_store(&mine->mn[d], mn[d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); __hip_atomic_store(&mine->mx[d], mx[d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-  __hip_atomic_store(&mine->nonfinite, (uint32_t)bad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __shared__ int s_last;
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < QN_BLOCK / 64; w++) { for (int d = 0; d < 3; d++) { mn[d] = min(mn[d], smn[w][d]); mx[d] = max(mx[d], smx[w][d]); } bad |= sbad[w]; }
+    // the block's box goes to a slot of its own (six contended atomics per block on the same words cost more than the whole reduction: 64 blocks, 10 us);
+    // the one contended operation left is the ticket
+    BBoxAcc* mine = acc + 1 + blockIdx.x;
+    for (int d = 0; d < 3; d++) { __hip_atomic_store(&mine->mn[d], mn[d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); __hip_atomic_store(&mine->mx[d], mx[d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+    __hip_atomic_store(&mine->nonfinite, (uint32_t)bad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __threadfence();
+    s_last = atomicAdd(&acc->ticket, 1u) == gridDim.x - 1u ? 1 : 0;
+  }
+  __syncthreads();
+  if (!s_last) return;
+  // the last block: its first wave folds the slots (one per lane, QN_BBOX_MAX_BLOCKS <= 256: four rounds at most), lane 0 derives the numbers
+  if (threadIdx.x >= 64) return;
   __threadfence();
-  if (atomicAdd(&acc->ticket, 1u) != gridDim.x - 1u) return;
-  __threadfence();
-  uint32_t nf = 0;
-  for (uint32_t b = 0; b < gridDim.x; b++) {
+  for (int d = 0; d < 3; d++) { mn[d] = 0x7fffffff; mx[d] = (int)0x80000000; }
+  int nf = 0;
+  for (uint32_t b = threadIdx.x; b < gridDim.x; b += 64) {
     const BBoxAcc* o = acc + 1 + b;
     for (int d = 0; d < 3; d++) { mn[d] = min(mn[d], __hip_atomic_load(&o->mn[d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)); mx[d] = max(mx[d], __hip_atomic_load(&o->mx[d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)); }
-    nf |= __hip_atomic_load(&o->nonfinite, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    nf |= (int)__hip_atomic_load(&o->nonfinite, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
-  const GridDims g = grid_dims_from_bbox(mn, mx, nf != 0u, n, max_cells, cell_override);
+#pragma unroll
+  for (int d = 0; d < 3; d++) { mn[d] = wave_min_i(mn[d]); mx[d] = wave_max_i(mx[d]); }
+  nf = wave_max_i(nf);
+  if (threadIdx.x != 0) return;
+  const GridDims g = grid_dims_from_bbox(mn, mx, nf != 0, n, max_cells, cell_override);
   *dims_dev = g; *dims_host = g;
   __hip_atomic_store(&acc->ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
