@@ -80,6 +80,7 @@ __device__ inline GridDims grid_dims_from_bbox(const int (&omn)[3], const int (&
     for (int a = 0; a < 3; a++) { dims[a] = (int)floor(L[a] / cell) + 1; tdims[a] = (dims[a] + tile[a] - 1) / tile[a]; tot *= (double)tdims[a] * tile[a]; }
     if (tot <= (double)max_cells) break;
     cell *= fmax(cbrt(tot / (double)max_cells), 1.02);
+    if (iter == 63) { cell = Lmax + 1.0; for (int a = 0; a < 3; a++) { dims[a] = 1; tdims[a] = 1; } }      // (never seen: one tile always fits - the table must not outgrow its allocation whatever the box)
   }
   d.ox = mn[0]; d.oy = mn[1]; d.oz = mn[2]; d.cell = (float)cell; d.inv_cell = 1.0f / d.cell;
   d.nx = dims[0]; d.ny = dims[1]; d.nz = dims[2]; d.ntx = tdims[0]; d.nty = tdims[1]; d.ntz = tdims[2];
