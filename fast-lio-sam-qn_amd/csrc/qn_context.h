@@ -40,7 +40,7 @@ struct qn_ctx {
   char* staging2 = nullptr;             // the second stream's landing zone (TargetScope)
   char* staging = nullptr;              // [max_points * 32] H2D landing zone for strided host clouds
   uint32_t* scan_sums = nullptr;
-  qn::BBoxOut* bbox = nullptr; qn::BBoxOut* bbox_host = nullptr;
+
   qn::GicpState* state = nullptr;       // [2], double buffered: generation g in state[g & 1] (qn_gicp_kernels.cuh)
   uint32_t gen = 0; int part_rows = 0;  // current generation; rows of the partial buffer written under it
   double* partials = nullptr;           // [2][QN_ACC_MAX_BLOCKS][28]
@@ -87,7 +87,7 @@ struct qn_ctx {
   int margin_nn_cap = 3, margin_knn_cap = 5, ticks_per_chunk = 8; bool knn_single_all = false, stable_cells = true; int bbox_blocks = 64;
   // pair pipeline of icpAlignment: the target cloud is prepared on a second stream with its own scratch while the source's k-NN runs
   hipStream_t stream2 = nullptr; hipEvent_t ev_pair = nullptr; bool pair_pipeline = true, pair_failed = false, tgt_on_stream2 = false, tgt_pending = false, no_pipe = false;
-  uint32_t* scan_sums2 = nullptr; uint2* fb_list2 = nullptr; uint2* big_list2 = nullptr; uint32_t* fb_count2b = nullptr; int32_t* knn_idx2 = nullptr; qn::BBoxOut* bbox2 = nullptr; qn::BBoxOut* bbox_host2 = nullptr;   // 128 blocks = 768 atomics on six words: 10.6 us per cloud; 32: 5 us   // experiment: one selection round, every leftover to the one-query-per-wave pass
+  uint32_t* scan_sums2 = nullptr; uint2* fb_list2 = nullptr; uint2* big_list2 = nullptr; uint32_t* fb_count2b = nullptr; int32_t* knn_idx2 = nullptr;   // 128 blocks = 768 atomics on six words: 10.6 us per cloud; 32: 5 us   // experiment: one selection round, every leftover to the one-query-per-wave pass
   uint32_t tick_ppt_min = 1;            // source points per lane of k_tick (knob: fewer, longer blocks)
   uint32_t tick_tb = 512;               // threads per block of k_tick (and of k_solve: both run the same row reduction)
   int tick_occ = 4;                     // k_tick variant: waves per SIMD the register budget allows (4 = 128 VGPRs: other streams' kernels keep half of the register file)

@@ -109,7 +109,6 @@ extern "C" int qn_ctx_create(int device, uint32_t max_points, qn_ctx** out) {
     carve_cloud(c, sl, c->cloud[1]);
     sl.take(c->staging, (size_t)max_points * 32);
     sl.take(c->scan_sums, sizeof(uint32_t) * (c->max_cells / (QN_BLOCK * QN_SCAN_ITEMS) + 2));
-    sl.take(c->bbox, sizeof(BBoxOut));
     sl.take(c->state, 2 * sizeof(GicpState));
     sl.take(c->partials, 2 * sizeof(double) * (QN_ACC_MAX_BLOCKS + 8) * QN_NPART);
     sl.take(c->nn_idx, sizeof(int32_t) * max_points);
@@ -141,7 +140,6 @@ extern "C" int qn_ctx_create(int device, uint32_t max_points, qn_ctx** out) {
     sl.take(c->big_list2, sizeof(uint2) * max_points);
     sl.take(c->fb_count2b, 4 * sizeof(uint32_t));
     sl.take(c->knn_idx2, sizeof(int32_t) * (size_t)max_points * 32);
-    sl.take(c->bbox2, sizeof(BBoxOut));
     sl.take(c->staging2, (size_t)max_points * 32);
     sl.take(c->bbox_acc, 2 * (QN_BBOX_MAX_BLOCKS + 1) * sizeof(BBoxAcc)); c->bbox_acc2 = c->bbox_acc ? c->bbox_acc + (QN_BBOX_MAX_BLOCKS + 1) : nullptr;      // [0]: ticket, [1 + b]: block b's box
     sl.take(c->scan_status, sizeof(unsigned long long) * 2 * (c->max_cells / (QN_BLOCK * QN_SCAN_ITEMS) + 2)); c->scan_status2 = c->scan_status ? c->scan_status + (c->max_cells / (QN_BLOCK * QN_SCAN_ITEMS) + 2) : nullptr;
@@ -156,10 +154,8 @@ extern "C" int qn_ctx_create(int device, uint32_t max_points, qn_ctx** out) {
   CA(hipMemsetAsync(c->far_stats, 0, 4 * sizeof(uint32_t), c->stream));
   CA(hipHostMalloc(&c->result_host, sizeof(ResultBlock), hipHostMallocDefault));
   for (int w = 0; w < 2; w++) { CA(hipHostMalloc(&c->cloud[w].dims_host, sizeof(GridDims), hipHostMallocDefault)); memset(c->cloud[w].dims_host, 0, sizeof(GridDims)); }
-  CA(hipHostMalloc(&c->bbox_host, sizeof(BBoxOut), hipHostMallocDefault));
   CA(hipHostMalloc(&c->scalar_host, 64 * sizeof(double), hipHostMallocDefault));
   // scratch of the second stream (TargetScope): scan sums, k-NN lists and index table, bounding box
-  CA(hipHostMalloc(&c->bbox_host2, sizeof(BBoxOut), hipHostMallocDefault));
   CA(hipHostMalloc(&c->pg_status_host, 4 * sizeof(uint32_t), hipHostMallocDefault));
   CA(hipMemsetAsync(c->pg_rows, 0xFF, sizeof(unsigned long long) * 3 * QN_PERSIST_ROWS * QN_PERSIST_RSTRIDE, c->stream));      // every slot = QN_PERSIST_SENTINEL
   CA(hipMemsetAsync(c->pg_bc, 0, sizeof(unsigned long long) * 64, c->stream));
@@ -191,10 +187,8 @@ extern "C" void qn_ctx_destroy(qn_ctx* c) {
   hipFree(c->v_corr); hipFree(c->v_nn_idx); hipFree(c->v_sqd); hipFree(c->v_nn_ref); hipFree(c->v_counters);
   if (c->result_host) hipHostFree(c->result_host);
   for (int w = 0; w < 2; w++) if (c->cloud[w].dims_host) hipHostFree(c->cloud[w].dims_host);
-  if (c->bbox_host) hipHostFree(c->bbox_host);
   if (c->scalar_host) hipHostFree(c->scalar_host);
   hipFree(c->pg_clk); if (c->pg_status_host) hipHostFree(c->pg_status_host);
-  if (c->bbox_host2) hipHostFree(c->bbox_host2);
   if (c->ev_pair) hipEventDestroy(c->ev_pair);
   if (c->stream2) { hipStreamSynchronize(c->stream2); hipStreamDestroy(c->stream2); }
   if (c->stream) hipStreamDestroy(c->stream);
@@ -255,7 +249,7 @@ static bool pair_pipeline_ready(qn_ctx* c) {
 // kernels read both grids on the first stream right away) and for contexts that work in a batch.
 static void swap_scratch(qn_ctx* c) {
   std::swap(c->stream, c->stream2); std::swap(c->scan_sums, c->scan_sums2); std::swap(c->fb_list, c->fb_list2); std::swap(c->big_list, c->big_list2);
-  std::swap(c->fb_count2, c->fb_count2b); std::swap(c->knn_idx, c->knn_idx2); std::swap(c->bbox, c->bbox2); std::swap(c->bbox_host, c->bbox_host2);
+  std::swap(c->fb_count2, c->fb_count2b); std::swap(c->knn_idx, c->knn_idx2);
   std::swap(c->bbox_acc, c->bbox_acc2); std::swap(c->scan_status, c->scan_status2);
   std::swap(c->staging, c->staging2);       // (setInputSource no longer waits for its pack kernel: the target's upload must not land in the source's landing zone)
 }
