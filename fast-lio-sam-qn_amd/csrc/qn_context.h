@@ -35,6 +35,7 @@ struct qn_ctx {
   int far_chunk = 4;                    // tracked ticks of a forced run that keep the far-query refresh kernel behind them before the host looks again
   bool batch_look = false;              // batch members take the device-side look as well (third unseeded iteration conditional): measured neutral for throughput (2239-2253 vs 2246-2247), off
   bool far_ranked = true;               // k_far deals its requests by global rank (off: the word-per-block distribution that clouds beyond 262144 points use)
+  unsigned long long* list_probe = nullptr;   // developer probe (knob list_probe)
   bool device_look = true;              // the hand-over decision of a lone forced-GN registration on the device (look_decide) instead of a host round trip
   bool clear_far_now = false;           // the next unseeded search resets the far-candidate references (first search of an align)
   char* staging2 = nullptr;             // the second stream's landing zone (TargetScope)

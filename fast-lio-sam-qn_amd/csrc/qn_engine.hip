@@ -188,7 +188,7 @@ extern "C" void qn_ctx_destroy(qn_ctx* c) {
   if (c->result_host) hipHostFree(c->result_host);
   for (int w = 0; w < 2; w++) if (c->cloud[w].dims_host) hipHostFree(c->cloud[w].dims_host);
   if (c->scalar_host) hipHostFree(c->scalar_host);
-  hipFree(c->pg_clk); if (c->pg_status_host) hipHostFree(c->pg_status_host);
+  hipFree(c->pg_clk); if (c->list_probe) hipFree(c->list_probe); if (c->pg_status_host) hipHostFree(c->pg_status_host);
   if (c->ev_pair) hipEventDestroy(c->ev_pair);
   if (c->stream2) { hipStreamSynchronize(c->stream2); hipStreamDestroy(c->stream2); }
   if (c->stream) hipStreamDestroy(c->stream);
@@ -414,7 +414,9 @@ static void enqueue_nn(qn_ctx* c, int mode /*0 align, 1 fitness*/, float* sqd_ou
   // wave starts them all at once, and the leaner kernel keeps 6 blocks per CU (ms_per_align 0.552 against 0.570 / 0.609 with the grouped variant)
   const bool batch = c->persist_batch_off;
   opt.group = c->far_group >= 0 ? c->far_group : (batch ? 4096 : 0); opt.group_min = 0;
-  NnOpt opt0; opt0.clear_ref = nullptr; opt0.cond = 0; opt0.group = 0; opt0.group_min = 0;
+  opt.probe = (mode == 0 && !seeded) ? c->list_probe : nullptr;
+  if (opt.probe) (void)hipMemsetAsync(c->list_probe, 0, sizeof(unsigned long long) * 2 * 16384, s);
+  NnOpt opt0; opt0.clear_ref = nullptr; opt0.cond = 0; opt0.group = 0; opt0.group_min = 0; opt0.probe = nullptr;
   c->clear_far_now = mode == 0 && !seeded ? false : c->clear_far_now;
   if (mode == 0) {
     { ProfScope ps(c, QN_K_NN_SEARCH);
@@ -441,8 +443,8 @@ static void enqueue_verify(qn_ctx* c, bool fused) {
   uint32_t* fbc = &st->fb_count; uint32_t* bgc = &st->big_count;
   const float r0 = -c->margin_nn;
   hipLaunchKernelGGL(k_reset_lists, dim3(1), dim3(64), 0, s, st);
-  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_nn_search<0, false, QN_NN_BLOCK>), dim3(nb), dim3(QN_NN_BLOCK), 0, s, S.grid, T.grid, st, thr2, r0, c->nn_rounds, c->v_corr, c->v_sqd, c->v_nn_idx, c->v_nn_ref, c->fb_list, fbc, c->big_list, bgc, 0, c->big_ratio, (uint32_t*)nullptr, (const float4*)nullptr, NnOpt{nullptr, 0, 0, 0});
-  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_nn_search<0, true, QN_BLOCK>), dim3(std::min<uint32_t>(nb4, 512) + 4096), dim3(QN_BLOCK), 0, s, S.grid, T.grid, st, thr2, r0, 64, c->v_corr, c->v_sqd, c->v_nn_idx, c->v_nn_ref, c->fb_list, fbc, c->big_list, bgc, 4096, c->big_ratio, (uint32_t*)nullptr, (const float4*)nullptr, NnOpt{nullptr, 0, 0, 0});
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_nn_search<0, false, QN_NN_BLOCK>), dim3(nb), dim3(QN_NN_BLOCK), 0, s, S.grid, T.grid, st, thr2, r0, c->nn_rounds, c->v_corr, c->v_sqd, c->v_nn_idx, c->v_nn_ref, c->fb_list, fbc, c->big_list, bgc, 0, c->big_ratio, (uint32_t*)nullptr, (const float4*)nullptr, NnOpt{nullptr, 0, 0, 0, nullptr});
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_nn_search<0, true, QN_BLOCK>), dim3(std::min<uint32_t>(nb4, 512) + 4096), dim3(QN_BLOCK), 0, s, S.grid, T.grid, st, thr2, r0, 64, c->v_corr, c->v_sqd, c->v_nn_idx, c->v_nn_ref, c->fb_list, fbc, c->big_list, bgc, 4096, c->big_ratio, (uint32_t*)nullptr, (const float4*)nullptr, NnOpt{nullptr, 0, 0, 0, nullptr});
   hipLaunchKernelGGL(k_verify_nn, dim3((S.n + 255) / 256), dim3(256), 0, s, S.n, st, c->nn_idx, c->v_nn_idx, fused ? (const float*)nullptr : c->sqd, c->v_sqd, c->corr, c->v_corr, c->v_counters);
   hipLaunchKernelGGL(k_reset_lists, dim3(1), dim3(64), 0, s, st);
 }
@@ -979,6 +981,10 @@ extern "C" int qn_debug_set(qn_ctx* c, const char* key, double v) {
   else if (k == "feat_query_dedupe") c->feat_query_dedupe = v != 0;
   else if (k == "feat_min_blocks") c->feat_min_blocks = (int)v;
   else if (k == "feat_verify") { c->feat_verify = v != 0; if (c->q_mm_vcnt) (void)hipMemset(c->q_mm_vcnt, 0, 16); }
+  else if (k == "list_probe") {                                  // developer probe: wall-clock time of the one-per-wave entries of the LAST unseeded list pass (qn_debug_get_list_probe)
+    if (v != 0 && !c->list_probe) { if (hipMalloc(&c->list_probe, sizeof(unsigned long long) * 2 * 16384) != hipSuccess) return QN_ERR_HIP; }
+    if (v == 0 && c->list_probe) { (void)hipFree(c->list_probe); c->list_probe = nullptr; }
+  }
   else if (k == "clk_probe") {                                  // developer probe: device-clock stamps inside k_tick (qn_debug_get_clk)
     if (v != 0 && !c->clk_probe) { if (hipMalloc(&c->clk_probe, 8 * 8 * 256 + 8 * 12 * 1024) != hipSuccess) return QN_ERR_HIP; }
     if (c->clk_probe) (void)hipMemset(c->clk_probe, 0, 8 * 8 * 256 + 8 * 12 * 1024);
@@ -1034,6 +1040,11 @@ extern "C" int qn_debug_get_clk(qn_ctx* c, unsigned long long* out /* 256 x 8, t
   if (!c || !out || !n || !c->clk_probe) return QN_ERR_INVALID_ARG;
   if (hipStreamSynchronize(c->stream) != hipSuccess || hipMemcpy(out, c->clk_probe, 8 * 8 * 256 + 8 * 12 * 1024, hipMemcpyDeviceToHost) != hipSuccess) return QN_ERR_HIP;
   *n = c->clk_n; return QN_OK;
+}
+extern "C" int qn_debug_get_list_probe(qn_ctx* c, unsigned long long* out /* [2 * 16384] */) {
+  if (!c || !out || !c->list_probe) return QN_ERR_INVALID_ARG;
+  if (hipStreamSynchronize(c->stream) != hipSuccess || hipMemcpy(out, c->list_probe, sizeof(unsigned long long) * 2 * 16384, hipMemcpyDeviceToHost) != hipSuccess) return QN_ERR_HIP;
+  return QN_OK;
 }
 extern "C" int qn_debug_get_persist_clk(qn_ctx* c, unsigned long long* out /* 64 x 16 + 16 */) {
   if (!c || !out || !c->pg_clk) return QN_ERR_INVALID_ARG;

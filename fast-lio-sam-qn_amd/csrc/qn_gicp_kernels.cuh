@@ -419,7 +419,7 @@ __device__ __forceinline__ void store_nn(unsigned long long key, uint32_t i, uin
   }
 }
 
-struct NnOpt { float4* clear_ref; int cond; int group, group_min; };       // group: far lists of at least group_min entries are served ceil(length / group) consecutive entries per wave, neighbours sharing a scan (0: one per wave); clear_ref: the first search of an align also resets the far-candidate references (one per query); cond: run only if this look flag is set
+struct NnOpt { float4* clear_ref; int cond; int group, group_min; unsigned long long* probe; };       // probe: developer timing of the one-per-wave entries (knob list_probe): [2 w] = slowest entry << 32 | entries, [2 w + 1] = busy time of wave w, 100 MHz ticks; group: far lists of at least group_min entries are served ceil(length / group) consecutive entries per wave, neighbours sharing a scan (0: one per wave); clear_ref: the first search of an align also resets the far-candidate references (one per query); cond: run only if this look flag is set
 // LIST = false: first search of an align (no seed): every source point, radius margin * cell, two rounds,
 // leftovers to fb_list.  LIST = true: the fb_list entries (leftovers of the first search, or the big-ball
 // queries of k_nn_track with their seed radius), 16 per wave, rounds until exact.
@@ -498,6 +498,7 @@ __global__ void __launch_bounds__(BLOCK, GROUP ? 5 : 6) k_nn_search(GridView src
       if (far_stats && MODE == 0 && (threadIdx.x & 63) == 0 && nfar) atomicAdd(&far_stats[3], nfar);
       return;
     }
+    unsigned long long pr_sum = 0, pr_max = 0; uint32_t pr_n = 0;
     for (uint32_t w0 = bw0 * CH; w0 < nbig; w0 += nbw * CH) {
       unsigned long long prev = QN_INF_KEY; float prev_d = 0.f;
       const uint32_t w1 = min(w0 + CH, nbig);
@@ -515,16 +516,9 @@ __global__ void __launch_bounds__(BLOCK, GROUP ? 5 : 6) k_nn_search(GridView src
           if (B <= prev_d + 3.f * tgt.cell) r = B * 1.000002f + 2.f * tgt.eps;           // (an entry from elsewhere in the cloud: the bound is worthless, keep the growth rounds)
         }
         unsigned long long key; float second, d_unseen;
-#ifdef QN_DBG_LIST_TIMING                                                // developer build only (tools/gpu_probe_lists4.py): the slowest one-per-wave entry of the launches so far
-        const unsigned long long dbg_t0 = tgt.dbg ? wall_clock64() : 0ull;
-#endif
+        const unsigned long long pt0 = opt.probe ? wall_clock64() : 0ull;
         wave_search_single(tgt, qx, qy, qz, r, __int_as_float(0x7f800000), key, second, d_unseen, &lds[threadIdx.x >> 6]);
-#ifdef QN_DBG_LIST_TIMING
-        if (tgt.dbg && (threadIdx.x & 63) == 0) {
-          const uint32_t dt = (uint32_t)(wall_clock64() - dbg_t0);
-          if (atomicMax(&tgt.dbg[10], dt) < dt) { tgt.dbg[11] = rec.x; tgt.dbg[12] = __float_as_uint(r); tgt.dbg[13] = key != QN_INF_KEY ? __float_as_uint(sqrtf(key_d2(key))) : 0xffffffffu; tgt.dbg[14] = __float_as_uint(qx); tgt.dbg[15] = __float_as_uint(qy); }
-        }
-#endif
+        if (opt.probe) { const unsigned long long dt = wall_clock64() - pt0; pr_sum += dt; pr_max = dt > pr_max ? dt : pr_max; pr_n++; }
         prev = key; prev_d = key != QN_INF_KEY ? sqrtf(key_d2(key)) : 0.f;
         if ((threadIdx.x & 63) == 0) {
           store_nn<MODE>(key, __float_as_uint(p.w), rec.x, thr2, corr, sqd, nn_idx);
@@ -534,6 +528,7 @@ __global__ void __launch_bounds__(BLOCK, GROUP ? 5 : 6) k_nn_search(GridView src
       }
     }
     if (far_stats && MODE == 0 && (threadIdx.x & 63) == 0 && nfar) atomicAdd(&far_stats[3], nfar);
+    if (opt.probe && (threadIdx.x & 63) == 0 && bw0 < 16384u) { opt.probe[2 * bw0] = (pr_max << 32) | pr_n; opt.probe[2 * bw0 + 1] = pr_sum; }
     return;
   }
   const uint32_t nq = LIST ? *fb_count : src.n;
