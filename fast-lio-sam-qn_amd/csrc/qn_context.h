@@ -80,8 +80,6 @@ struct qn_ctx {
   bool fused_final = true;              // closing pass (last controller step + fitness sweep + output cloud) in one launch
   int knn_rounds = 2;                   // rounds of the first k-NN pass before a query goes to the list pass
   int knn_hist = 1;                     // 1: k-NN by histogram selection (wave_knn_hist), 0: sorted-list sink (wave_search + BestK)
-  bool chain_far = false;               // first tick: a wave serves 4 consecutive far leftovers, each one's neighbour bounds the next one's search radius
-  bool seed_lists = false;              // unseeded re-searches (ticks 1..track_from_tick-1) hand their leftovers to the list passes with the radius |q - previous neighbour|
   int big_blocks0 = 4096, fb_blocks0 = 512;   // grid of the list pass behind the first (unseeded) ticks: one-far-query-per-wave blocks, wave-stride leftover blocks
   float margin_nn_t0 = 0.f;             // first search radius of tick 0 only (0 = margin_nn)
   float margin_nn = 1.f, margin_knn = 0.f;   // first search radius in cells (1-NN of the first tick / k-NN of the covariances; 0 = by cloud size, launch_knn_cov)

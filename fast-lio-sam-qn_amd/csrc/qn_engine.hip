@@ -421,15 +421,15 @@ static void enqueue_nn(qn_ctx* c, int mode /*0 align, 1 fitness*/, float* sqd_ou
   if (mode == 0) {
     { ProfScope ps(c, QN_K_NN_SEARCH);
       if (seeded) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_nn_track<0>), dim3(nbt), dim3(QN_BLOCK), 0, s, S.grid, T.grid, T.raw, st, thr2, c->corr, sqd_out, c->nn_idx, c->nn_ref, c->fb_list, fbc, c->big_list, bgc);
-      else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_nn_search<0, false, QN_NN_BLOCK>), dim3(nb), dim3(QN_NN_BLOCK), 0, s, S.grid, T.grid, st, thr2, r0, c->nn_rounds, c->corr, sqd_out, c->nn_idx, c->nn_ref, c->fb_list, fbc, c->big_list, bgc, 0, big_ratio, far_stats, (c->seed_lists && tick > 0) ? (const float4*)T.raw : (const float4*)nullptr, opt); }
+      else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_nn_search<0, false, QN_NN_BLOCK>), dim3(nb), dim3(QN_NN_BLOCK), 0, s, S.grid, T.grid, st, thr2, r0, c->nn_rounds, c->corr, sqd_out, c->nn_idx, c->nn_ref, c->fb_list, fbc, c->big_list, bgc, 0, big_ratio, far_stats, opt); }
     { ProfScope ps(c, QN_K_NN_FALLBACK);
-      if (opt.group > 0 && !(c->chain_far && tick == 0)) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_nn_search<0, true, QN_BLOCK, true>), dim3(fbb + big_blocks), dim3(QN_BLOCK), 0, s, S.grid, T.grid, st, thr2, r0, 64, c->corr, sqd_out, c->nn_idx, c->nn_ref, c->fb_list, fbc, c->big_list, bgc, big_blocks, big_ratio, far_stats, (const float4*)nullptr, opt);
-      else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_nn_search<0, true, QN_BLOCK>), dim3(fbb + big_blocks), dim3(QN_BLOCK), 0, s, S.grid, T.grid, st, thr2, r0, 64, c->corr, sqd_out, c->nn_idx, c->nn_ref, c->fb_list, fbc, c->big_list, bgc, big_blocks, big_ratio, far_stats, (c->chain_far && tick == 0) ? (const float4*)T.raw : (const float4*)nullptr, opt); }
+      if (opt.group > 0) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_nn_search<0, true, QN_BLOCK, true>), dim3(fbb + big_blocks), dim3(QN_BLOCK), 0, s, S.grid, T.grid, st, thr2, r0, 64, c->corr, sqd_out, c->nn_idx, c->nn_ref, c->fb_list, fbc, c->big_list, bgc, big_blocks, big_ratio, far_stats, opt);
+      else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_nn_search<0, true, QN_BLOCK>), dim3(fbb + big_blocks), dim3(QN_BLOCK), 0, s, S.grid, T.grid, st, thr2, r0, 64, c->corr, sqd_out, c->nn_idx, c->nn_ref, c->fb_list, fbc, c->big_list, bgc, big_blocks, big_ratio, far_stats, opt); }
   } else {
     ProfScope ps(c, QN_K_FITNESS);
     if (seeded) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_nn_track<1>), dim3(nbt), dim3(QN_BLOCK), 0, s, S.grid, T.grid, T.raw, st, thr2, c->corr, sqd_out, c->nn_idx, c->nn_ref, c->fb_list, fbc, c->big_list, bgc);
-    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_nn_search<1, false, QN_NN_BLOCK>), dim3(nb), dim3(QN_NN_BLOCK), 0, s, S.grid, T.grid, st, thr2, r0, 1, c->corr, sqd_out, c->nn_idx, c->nn_ref, c->fb_list, fbc, c->big_list, bgc, 0, big_ratio, far_stats, (const float4*)nullptr, opt0);
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_nn_search<1, true, QN_BLOCK>), dim3(fbb + big_blocks), dim3(QN_BLOCK), 0, s, S.grid, T.grid, st, thr2, r0, 64, c->corr, sqd_out, c->nn_idx, c->nn_ref, c->fb_list, fbc, c->big_list, bgc, big_blocks, big_ratio, far_stats, (const float4*)nullptr, opt0);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_nn_search<1, false, QN_NN_BLOCK>), dim3(nb), dim3(QN_NN_BLOCK), 0, s, S.grid, T.grid, st, thr2, r0, 1, c->corr, sqd_out, c->nn_idx, c->nn_ref, c->fb_list, fbc, c->big_list, bgc, 0, big_ratio, far_stats, opt0);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_nn_search<1, true, QN_BLOCK>), dim3(fbb + big_blocks), dim3(QN_BLOCK), 0, s, S.grid, T.grid, st, thr2, r0, 64, c->corr, sqd_out, c->nn_idx, c->nn_ref, c->fb_list, fbc, c->big_list, bgc, big_blocks, big_ratio, far_stats, opt0);
   }
 }
 // debug knob "verify_track": a fresh, unseeded search of the current pose into scratch buffers, compared query by query with what
@@ -443,8 +443,8 @@ static void enqueue_verify(qn_ctx* c, bool fused) {
   uint32_t* fbc = &st->fb_count; uint32_t* bgc = &st->big_count;
   const float r0 = -c->margin_nn;
   hipLaunchKernelGGL(k_reset_lists, dim3(1), dim3(64), 0, s, st);
-  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_nn_search<0, false, QN_NN_BLOCK>), dim3(nb), dim3(QN_NN_BLOCK), 0, s, S.grid, T.grid, st, thr2, r0, c->nn_rounds, c->v_corr, c->v_sqd, c->v_nn_idx, c->v_nn_ref, c->fb_list, fbc, c->big_list, bgc, 0, c->big_ratio, (uint32_t*)nullptr, (const float4*)nullptr, NnOpt{nullptr, 0, 0, 0, nullptr});
-  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_nn_search<0, true, QN_BLOCK>), dim3(std::min<uint32_t>(nb4, 512) + 4096), dim3(QN_BLOCK), 0, s, S.grid, T.grid, st, thr2, r0, 64, c->v_corr, c->v_sqd, c->v_nn_idx, c->v_nn_ref, c->fb_list, fbc, c->big_list, bgc, 4096, c->big_ratio, (uint32_t*)nullptr, (const float4*)nullptr, NnOpt{nullptr, 0, 0, 0, nullptr});
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_nn_search<0, false, QN_NN_BLOCK>), dim3(nb), dim3(QN_NN_BLOCK), 0, s, S.grid, T.grid, st, thr2, r0, c->nn_rounds, c->v_corr, c->v_sqd, c->v_nn_idx, c->v_nn_ref, c->fb_list, fbc, c->big_list, bgc, 0, c->big_ratio, (uint32_t*)nullptr, NnOpt{nullptr, 0, 0, 0, nullptr});
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_nn_search<0, true, QN_BLOCK>), dim3(std::min<uint32_t>(nb4, 512) + 4096), dim3(QN_BLOCK), 0, s, S.grid, T.grid, st, thr2, r0, 64, c->v_corr, c->v_sqd, c->v_nn_idx, c->v_nn_ref, c->fb_list, fbc, c->big_list, bgc, 4096, c->big_ratio, (uint32_t*)nullptr, NnOpt{nullptr, 0, 0, 0, nullptr});
   hipLaunchKernelGGL(k_verify_nn, dim3((S.n + 255) / 256), dim3(256), 0, s, S.n, st, c->nn_idx, c->v_nn_idx, fused ? (const float*)nullptr : c->sqd, c->v_sqd, c->corr, c->v_corr, c->v_counters);
   hipLaunchKernelGGL(k_reset_lists, dim3(1), dim3(64), 0, s, st);
 }
@@ -932,8 +932,6 @@ extern "C" int qn_debug_set(qn_ctx* c, const char* key, double v) {
   if (k == "cell") { c->cell_override = v; c->cloud[0].has_grid = c->cloud[1].has_grid = false; }
   else if (k == "margin_nn") c->margin_nn = (float)v;
   else if (k == "margin_nn_t0") c->margin_nn_t0 = (float)v;
-  else if (k == "seed_lists") c->seed_lists = v != 0;
-  else if (k == "chain_far") c->chain_far = v != 0;
   else if (k == "big_blocks0") c->big_blocks0 = v < 64 ? 64 : (int)v;
   else if (k == "fb_blocks0") c->fb_blocks0 = v < 64 ? 64 : (int)v;
   else if (k == "margin_knn") c->margin_knn = (float)v;

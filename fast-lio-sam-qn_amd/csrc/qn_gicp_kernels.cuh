@@ -429,8 +429,7 @@ template <int MODE, bool LIST, int BLOCK, bool GROUP = false>      // GROUP: the
 __global__ void __launch_bounds__(BLOCK, GROUP ? 5 : 6) k_nn_search(GridView src, GridView tgt, const GicpState* __restrict__ st, double thr2, float r0, int max_rounds,
                                                         int32_t* __restrict__ corr, float* __restrict__ sqd, int32_t* __restrict__ nn_idx, float4* __restrict__ nn_ref,
                                                         uint2* __restrict__ fb_list, uint32_t* __restrict__ fb_count,
-                                                        uint2* __restrict__ big_list, uint32_t* __restrict__ big_count, int big_blocks, float big_ratio, uint32_t* __restrict__ far_stats,
-                                                        const float4* __restrict__ seed_raw, NnOpt opt) {
+                                                        uint2* __restrict__ big_list, uint32_t* __restrict__ big_count, int big_blocks, float big_ratio, uint32_t* __restrict__ far_stats, NnOpt opt) {
   __shared__ WaveLds lds[BLOCK / 64];
   if (MODE == 0 && st->phase != 0) return;
   if (MODE == 1 && st->phase != 2) return;
@@ -444,15 +443,11 @@ __global__ void __launch_bounds__(BLOCK, GROUP ? 5 : 6) k_nn_search(GridView src
     if (tgt.dbg && blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) atomicAdd(&tgt.dbg[7], nbig);
     uint32_t nfar = 0;                                                     // far queries of this pass (the host hands far_stats only to the LAST unseeded pass, when the clouds are nearly aligned)
     const uint32_t bw0 = (blockIdx.x - (gridDim.x - big_blocks)) * (BLOCK / 64) + (threadIdx.x >> 6), nbw = big_blocks * (BLOCK / 64);
-    // seed_raw in a LIST launch (knob chain_far, first tick): a wave takes CH CONSECUTIVE entries - the list keeps the cell-sorted order of the queries, so they are
-    // neighbours in space - and the neighbour p* found for one entry bounds the next entry's neighbour distance from above by |q - p*| (p* is a target point):
-    // one scan of exactly that ball instead of growth rounds from the failed radius (3 -> 7 -> 10 cells ...) that rescan the inner region and overshoot.
-    const uint32_t CH = (MODE == 0 && seed_raw) ? 4u : 1u;
     // Long lists (the first unseeded ticks of a misaligned pair, the non-overlapping part of a partial overlap): a wave takes E CONSECUTIVE entries - the list keeps
     // the cell-sorted order of the queries, so they are neighbours in space - and serves the ones whose balls overlap with ONE shared scan (wave_search_far16);
     // loners still get the whole wave (wave_search_single).  Short lists stay one entry per wave: nothing to share, and every entry starts at once.
     const uint32_t E = (GROUP && opt.group && nbig >= (uint32_t)opt.group_min) ? min(16u, (nbig + (uint32_t)opt.group - 1u) / (uint32_t)opt.group) : 1u;
-    if (GROUP && CH == 1u && E > 1u) {
+    if (GROUP && E > 1u) {
       const int lane = threadIdx.x & 63, qs = lane & 15;
       WaveLds* wl = &lds[threadIdx.x >> 6];
       const float INF = __int_as_float(0x7f800000);
@@ -499,32 +494,22 @@ __global__ void __launch_bounds__(BLOCK, GROUP ? 5 : 6) k_nn_search(GridView src
       return;
     }
     unsigned long long pr_sum = 0, pr_max = 0; uint32_t pr_n = 0;
-    for (uint32_t w0 = bw0 * CH; w0 < nbig; w0 += nbw * CH) {
-      unsigned long long prev = QN_INF_KEY; float prev_d = 0.f;
-      const uint32_t w1 = min(w0 + CH, nbig);
-      for (uint32_t w = w0; w < w1; w++) {
-        const uint2 rec = big_list[w];
-        const float4 p = src.pts[rec.x];
-        float qx, qy, qz; xform_query<MODE>(Tf, p.x, p.y, p.z, qx, qy, qz);
-        const float v = __uint_as_float(rec.y);
-        // v > 0: tight seed (the query barely moved since its last scan): scan a little wider than the bound so that the
-        // following iterations can prove the neighbour unchanged; v < 0: unseeded, continue from |v|
-        float r = v > 0.f ? v * 1.1f + 0.5f * tgt.cell : -v;
-        if (CH > 1 && prev != QN_INF_KEY) {
-          const float4 ps = seed_raw[key_idx(prev)];
-          const float B = sqrtf(sqdist(qx, qy, qz, ps.x, ps.y, ps.z));
-          if (B <= prev_d + 3.f * tgt.cell) r = B * 1.000002f + 2.f * tgt.eps;           // (an entry from elsewhere in the cloud: the bound is worthless, keep the growth rounds)
-        }
-        unsigned long long key; float second, d_unseen;
-        const unsigned long long pt0 = opt.probe ? wall_clock64() : 0ull;
-        wave_search_single(tgt, qx, qy, qz, r, __int_as_float(0x7f800000), key, second, d_unseen, &lds[threadIdx.x >> 6]);
-        if (opt.probe) { const unsigned long long dt = wall_clock64() - pt0; pr_sum += dt; pr_max = dt > pr_max ? dt : pr_max; pr_n++; }
-        prev = key; prev_d = key != QN_INF_KEY ? sqrtf(key_d2(key)) : 0.f;
-        if ((threadIdx.x & 63) == 0) {
-          store_nn<MODE>(key, __float_as_uint(p.w), rec.x, thr2, corr, sqd, nn_idx);
-          if (MODE == 0) nn_ref[rec.x] = make_float4(qx, qy, qz, fminf(sqrtf(second), d_unseen));
-          if (key != QN_INF_KEY && key_d2(key) > 36.f * tgt.cell * tgt.cell) nfar++;        // neighbour beyond 6 cells (QN_FAR_RMIN_CELLS)
-        }
+    for (uint32_t w = bw0; w < nbig; w += nbw) {
+      const uint2 rec = big_list[w];
+      const float4 p = src.pts[rec.x];
+      float qx, qy, qz; xform_query<MODE>(Tf, p.x, p.y, p.z, qx, qy, qz);
+      const float v = __uint_as_float(rec.y);
+      // v > 0: tight seed (the query barely moved since its last scan): scan a little wider than the bound so that the
+      // following iterations can prove the neighbour unchanged; v < 0: unseeded, continue from |v|
+      const float r = v > 0.f ? v * 1.1f + 0.5f * tgt.cell : -v;
+      unsigned long long key; float second, d_unseen;
+      const unsigned long long pt0 = opt.probe ? wall_clock64() : 0ull;
+      wave_search_single(tgt, qx, qy, qz, r, __int_as_float(0x7f800000), key, second, d_unseen, &lds[threadIdx.x >> 6]);
+      if (opt.probe) { const unsigned long long dt = wall_clock64() - pt0; pr_sum += dt; pr_max = dt > pr_max ? dt : pr_max; pr_n++; }
+      if ((threadIdx.x & 63) == 0) {
+        store_nn<MODE>(key, __float_as_uint(p.w), rec.x, thr2, corr, sqd, nn_idx);
+        if (MODE == 0) nn_ref[rec.x] = make_float4(qx, qy, qz, fminf(sqrtf(second), d_unseen));
+        if (key != QN_INF_KEY && key_d2(key) > 36.f * tgt.cell * tgt.cell) nfar++;        // neighbour beyond 6 cells (QN_FAR_RMIN_CELLS)
       }
     }
     if (far_stats && MODE == 0 && (threadIdx.x & 63) == 0 && nfar) atomicAdd(&far_stats[3], nfar);
@@ -557,17 +542,7 @@ __global__ void __launch_bounds__(BLOCK, GROUP ? 5 : 6) k_nn_search(GridView src
       if (MODE == 0) nn_ref[t] = make_float4(qx, qy, qz, fminf(sqrtf(sink.second), d_unseen));
     }
     if (!LIST) {
-      // seed_raw (the target in original order; knob seed_lists): the unseeded re-search of a later tick knows the PREVIOUS tick's neighbour j0 (nn_idx[t] is
-      // rewritten only when a query is settled).  |q - p_j0| bounds the neighbour distance from above, so a query the first radius does not settle goes to
-      // the list passes with THAT radius (widened like the tracked entries, so that the bound it leaves behind is worth something) instead of the
-      // doubled one: one tight scan instead of growth rounds that overshoot.
-      float r_seed = 0.f;
-      if (MODE == 0 && seed_raw && mine && !done) {
-        const int32_t j0 = nn_idx[t];
-        if ((uint32_t)j0 < tgt.n) { const float4 p0 = seed_raw[j0]; r_seed = sqrtf(sqdist(qx, qy, qz, p0.x, p0.y, p0.z)) * 1.1f + 0.5f * tgt.cell; }
-        if (!(r_seed == r_seed) || r_seed > 3.0e38f) r_seed = 0.f;
-      }
-      const float rn = r_seed > 0.f ? r_seed : r;
+      const float rn = r;
       const bool far = rn > big_ratio * r0;
       wave_append(big_list, big_count, mine && !done && far, make_uint2(t, __float_as_uint(-rn)));     // far: one query per wave
       wave_append(fb_list, fb_count, mine && !done && !far, make_uint2(t, __float_as_uint(-rn)));      // continue from rn

@@ -24,7 +24,7 @@ namespace qn {
 
 #define QN_NN_BLOCK 256        // threads per block of the grid-form 1-NN passes (16 queries per wave)
 #define QN_KNN_HIST_ARGS (GridView, int, float, int, int32_t*, float*, uint2*, uint32_t*, uint2*, uint32_t*)
-#define QN_NN_SEARCH_ARGS (GridView, GridView, const GicpState*, double, float, int, int32_t*, float*, int32_t*, float4*, uint2*, uint32_t*, uint2*, uint32_t*, int, float, uint32_t*, const float4*, NnOpt)
+#define QN_NN_SEARCH_ARGS (GridView, GridView, const GicpState*, double, float, int, int32_t*, float*, int32_t*, float4*, uint2*, uint32_t*, uint2*, uint32_t*, int, float, uint32_t*, NnOpt)
 #define QN_NN_TRACK_ARGS (GridView, GridView, const float4*, const GicpState*, double, int32_t*, float*, int32_t*, float4*, uint2*, uint32_t*, uint2*, uint32_t*)
 
 QN_G1 __global__ void k_knn_hist<false, 32> QN_KNN_HIST_ARGS;
