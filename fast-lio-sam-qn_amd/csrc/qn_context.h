@@ -92,7 +92,7 @@ struct qn_ctx {
   int tick_occ = 4;                     // k_tick variant: waves per SIMD the register budget allows (4 = 128 VGPRs: other streams' kernels keep half of the register file)
   // persistent align kernel (qn_persist.cuh): granule buffers, give-up status, epoch counter; `persist` = knob, `persist_batch_off` = this context works in a batch
   unsigned long long* pg_rows = nullptr; unsigned long long* pg_bc = nullptr; unsigned long long* pg_fit = nullptr; uint32_t* pg_status = nullptr; uint32_t* pg_status_host = nullptr;
-  unsigned long long* pg_clk = nullptr; uint32_t pg_epoch = 0; bool persist_hint = false, prof_persist = false, persist = true, persist_batch_off = false; uint32_t persist_launches = 0;
+  unsigned long long* pg_clk = nullptr; uint32_t pg_epoch = 0; bool prof_persist = false, persist = true, persist_batch_off = false; uint32_t persist_launches = 0;
   uint32_t* dbg_counters = nullptr;
   unsigned long long* clk_probe = nullptr; uint32_t clk_n = 0;   // developer probe: device-clock stamps of k_tick
   // verify_track (debug): scratch of the fresh search every tracked pass is compared with

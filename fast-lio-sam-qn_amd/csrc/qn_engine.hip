@@ -561,7 +561,6 @@ static int launch_persist(qn_ctx* c, uint32_t max_ticks, int cond = 0, int rows_
   }
   A.rows_g = c->pg_rows; A.bc_g = c->pg_bc; A.fit_g = c->pg_fit; A.status = c->pg_status; A.result = c->result_host;
   A.epoch0 = c->pg_epoch; A.max_ticks = max_ticks; c->pg_epoch += max_ticks + 8;
-  A.hint_poll = c->persist_hint ? 1 : 0;
   A.timeout = 25000000ull;                                           // 0.25 s of the 100 MHz wall clock: three orders of magnitude above any legitimate wait
   c->pg_status_host[0] = 0xffffffffu; c->pg_status_host[1] = 0;      // (the reducer overwrites it when it leaves)
   { ProfScope ps(c, QN_K_ALIGN_PERSIST);
@@ -945,7 +944,6 @@ extern "C" int qn_debug_set(qn_ctx* c, const char* key, double v) {
   else if (k == "batch_look") c->batch_look = v != 0;
   else if (k == "pair_pipeline") c->pair_pipeline = v != 0;
   else if (k == "persist") c->persist = v != 0;
-  else if (k == "persist_hint") c->persist_hint = v != 0;
   else if (k == "prof_persist") c->prof_persist = v != 0;      // profiling (qn_prof_enable) normally times the k_tick chain; 1: let the persistent kernel run and time it as its own family
   else if (k == "persist_probe") {                              // developer probe: wall-clock stamps inside k_align_persist (qn_debug_get_persist_clk)
     if (v != 0 && !c->pg_clk) { if (hipMalloc(&c->pg_clk, 8 * (64 * 16 + 16)) != hipSuccess) return QN_ERR_HIP; }

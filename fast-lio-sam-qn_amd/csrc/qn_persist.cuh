@@ -46,7 +46,6 @@ struct PersistArgs {
   uint32_t* status_host;                   // pinned mirror of `status`, written by the reducer when it leaves (no memset in front of, no copy behind the launch)
   int cond;                                // != 0: launched behind look_decide without a host look - go ahead only if the state's QN_LOOK_GO flag is set
   int rows_if_extra;                       // cond: the partial rows the conditional unseeded iteration leaves (QN_LOOK_EXTRA set), else rows_in = -1
-  int hint_poll;                           // reducer: watch one slot per row line before fetching the rows (knob persist_hint)
   unsigned long long* clk;                 // developer probe (PROBE = true): [tick < 64][16] wall-clock stamps: 0 rows complete, 1 sums, 2 controller, 3 pose published (reducer);
                                            // 4 pose seen, 5 body done, 6 row published (worker block 0); 8..10 the same for the last worker block; [64 * 16] = launch start
 };
@@ -121,18 +120,7 @@ __global__ void __launch_bounds__(TB, TB / 256) k_align_persist(PersistArgs A) {
 #pragma unroll
           for (int u = 0; u < UMAX; u++) { v[u] = 0.0; if ((uint32_t)(rs + SEGS * u) < nblk) need |= 1u << u; }
         }
-        // A light first phase: ONE slot per 128-byte line of every row (2 per row, one load per thread) is watched until nothing reads "not arrived" - eight waves
-        // asking for all 44 KB on every pass queue up in this CU's own memory pipeline (1.35 us per pass, and the last row is only seen by the pass that starts
-        // after it landed); the full fetch below then normally completes in ONE pass, and still re-asks for whatever slot a torn line left behind.
-        if (A.hint_poll) {
-          const bool watcher = (uint32_t)tid < 2u * nblk;
-          const unsigned long long* w = buf + (size_t)(tid >> 1) * QN_PERSIST_RSTRIDE + ((tid & 1) ? 27 : 15);
-          for (uint32_t spins = 0; watcher; spins++) {
-            if (pr_load(w) != QN_PERSIST_SENTINEL) break;
-            if ((spins & 255u) == 255u && pg_expired(t_start, A.timeout, A.status, 1u)) { bc_fail = 1; break; }
-          }
-          __syncthreads();
-        }
+        // (a light first phase - one watched slot per row line before the full fetch - measured slower: 14.4 vs 13.4 us per tick; removed)
         const uint32_t need0 = need; bool seen_first = false;
         for (uint32_t spins = 0; need != 0; spins++) {
           if (PROBE && tid == 0 && g < 64) { A.clk[16 * g + 14] = spins + 1; if (!seen_first && need != need0) { seen_first = true; A.clk[16 * g + 15] = wall_clock64(); } }
