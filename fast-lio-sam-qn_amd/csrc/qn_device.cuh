@@ -592,12 +592,14 @@ __device__ __forceinline__ float cap_face_dist(const CapBox& c, float f, int axi
 // than in the 16-query layout.  The ball's cell box is enumerated row by row, or tile by tile when it is
 // large (the inside of the ball is empty space - the neighbour sits on its surface - so most tiles cost
 // one look-up and contribute no candidates).  Same certification and growth rule as wave_search.
+struct SingleStats { uint32_t rounds, cand, segs; float r_first, r_last; };      // developer probe (list_probe): what one search did
 __device__ __forceinline__ void wave_search_single(const GridView& g, float qx, float qy, float qz, float r, const float r_cap,
-                                                   unsigned long long& best_out, float& second_out, float& d_unseen, WaveLds* lds) {
+                                                   unsigned long long& best_out, float& second_out, float& d_unseen, WaveLds* lds, SingleStats* stats = nullptr) {
   const int lane = threadIdx.x & 63;
   const float INF = __int_as_float(0x7f800000);
   const CapBox cap = cap_of(g, qx, qy, qz);
   if (cap.S > 0.f) r = fminf(fmaxf(r, sqrtf(cap.S) + g.cell), fmaxf(r_cap, r));   // nothing is closer than the grid box itself: do not spend rounds below that
+  if (stats) { stats->rounds = 0; stats->cand = 0; stats->segs = 0; stats->r_first = r; }
   // Growth rounds scan SHELLS: a tile-mode round scans whole tiles, so once the tiles within r (box distance <= r^2, the inclusion rule below) are done, the next
   // round only needs the tiles between the two radii and the running best / runner-up carry over - the scanned set after any round is exactly the set a fresh
   // scan of that round's ball would visit, each point once.  (Row-mode rounds - small boxes, partial tiles - start afresh.)
@@ -645,6 +647,7 @@ __device__ __forceinline__ void wave_search_single(const GridView& g, float qx, 
       const uint32_t total = rflu(__shfl(incl, 63));
       if (total == 0) continue;
       if (g.dbg && lane == 0) atomicAdd(&g.dbg[11], total);          // developer counter: candidates scanned
+      if (stats) stats->cand += total;
       wave_lds_fence();
       lds->seg_excl[lane] = incl - len; lds->seg_start[lane] = s;
       wave_lds_fence();
@@ -663,6 +666,7 @@ __device__ __forceinline__ void wave_search_single(const GridView& g, float qx, 
       }
     }
     if (g.dbg && lane == 0) { atomicAdd(&g.dbg[10], 1u); atomicAdd(&g.dbg[12], (uint32_t)nseg); if (round == 0) atomicAdd(&g.dbg[13], 1u); }      // developer counters: rounds, enumerated segments, entries
+    if (stats) { stats->rounds++; stats->segs += (uint32_t)nseg; stats->r_last = r; }
     if (tile_mode) { done2 = in2; ptx0 = tx0; ptx1 = tx0 + ntr - 1; pty0 = ty0; pty1 = ty0 + ntyr - 1; ptz0 = z0 >> 2; ptz1 = z1 >> 2; }
     const unsigned long long b = wave_min_u64(best);
     float c = (best == b) ? second : key_d2(best);

@@ -415,7 +415,7 @@ static void enqueue_nn(qn_ctx* c, int mode /*0 align, 1 fitness*/, float* sqd_ou
   const bool batch = c->persist_batch_off;
   opt.group = c->far_group >= 0 ? c->far_group : (batch ? 4096 : 0); opt.group_min = 0;
   opt.probe = (mode == 0 && !seeded) ? c->list_probe : nullptr;
-  if (opt.probe) (void)hipMemsetAsync(c->list_probe, 0, sizeof(unsigned long long) * 2 * 16384, s);
+  if (opt.probe) (void)hipMemsetAsync(c->list_probe, 0, sizeof(unsigned long long) * 4 * 16384, s);
   NnOpt opt0; opt0.clear_ref = nullptr; opt0.cond = 0; opt0.group = 0; opt0.group_min = 0; opt0.probe = nullptr;
   c->clear_far_now = mode == 0 && !seeded ? false : c->clear_far_now;
   if (mode == 0) {
@@ -978,7 +978,7 @@ extern "C" int qn_debug_set(qn_ctx* c, const char* key, double v) {
   else if (k == "feat_min_blocks") c->feat_min_blocks = (int)v;
   else if (k == "feat_verify") { c->feat_verify = v != 0; if (c->q_mm_vcnt) (void)hipMemset(c->q_mm_vcnt, 0, 16); }
   else if (k == "list_probe") {                                  // developer probe: wall-clock time of the one-per-wave entries of the LAST unseeded list pass (qn_debug_get_list_probe)
-    if (v != 0 && !c->list_probe) { if (hipMalloc(&c->list_probe, sizeof(unsigned long long) * 2 * 16384) != hipSuccess) return QN_ERR_HIP; }
+    if (v != 0 && !c->list_probe) { if (hipMalloc(&c->list_probe, sizeof(unsigned long long) * 4 * 16384) != hipSuccess) return QN_ERR_HIP; }
     if (v == 0 && c->list_probe) { (void)hipFree(c->list_probe); c->list_probe = nullptr; }
   }
   else if (k == "clk_probe") {                                  // developer probe: device-clock stamps inside k_tick (qn_debug_get_clk)
@@ -1037,9 +1037,9 @@ extern "C" int qn_debug_get_clk(qn_ctx* c, unsigned long long* out /* 256 x 8, t
   if (hipStreamSynchronize(c->stream) != hipSuccess || hipMemcpy(out, c->clk_probe, 8 * 8 * 256 + 8 * 12 * 1024, hipMemcpyDeviceToHost) != hipSuccess) return QN_ERR_HIP;
   *n = c->clk_n; return QN_OK;
 }
-extern "C" int qn_debug_get_list_probe(qn_ctx* c, unsigned long long* out /* [2 * 16384] */) {
+extern "C" int qn_debug_get_list_probe(qn_ctx* c, unsigned long long* out /* [4 * 16384] */) {
   if (!c || !out || !c->list_probe) return QN_ERR_INVALID_ARG;
-  if (hipStreamSynchronize(c->stream) != hipSuccess || hipMemcpy(out, c->list_probe, sizeof(unsigned long long) * 2 * 16384, hipMemcpyDeviceToHost) != hipSuccess) return QN_ERR_HIP;
+  if (hipStreamSynchronize(c->stream) != hipSuccess || hipMemcpy(out, c->list_probe, sizeof(unsigned long long) * 4 * 16384, hipMemcpyDeviceToHost) != hipSuccess) return QN_ERR_HIP;
   return QN_OK;
 }
 extern "C" int qn_debug_get_persist_clk(qn_ctx* c, unsigned long long* out /* 64 x 16 + 16 */) {

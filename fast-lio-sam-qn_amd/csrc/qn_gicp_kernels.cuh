@@ -419,7 +419,7 @@ __device__ __forceinline__ void store_nn(unsigned long long key, uint32_t i, uin
   }
 }
 
-struct NnOpt { float4* clear_ref; int cond; int group, group_min; unsigned long long* probe; };       // probe: developer timing of the one-per-wave entries (knob list_probe): [2 w] = slowest entry << 32 | entries, [2 w + 1] = busy time of wave w, 100 MHz ticks; group: far lists of at least group_min entries are served ceil(length / group) consecutive entries per wave, neighbours sharing a scan (0: one per wave); clear_ref: the first search of an align also resets the far-candidate references (one per query); cond: run only if this look flag is set
+struct NnOpt { float4* clear_ref; int cond; int group, group_min; unsigned long long* probe; };       // probe: developer timing of the one-per-wave entries (knob list_probe): [4 w] = slowest entry << 32 | entries, [4 w + 1] = busy time of wave w (100 MHz ticks), [4 w + 2] = rounds << 48 | segments << 24 | candidates and [4 w + 3] = first radius | neighbour distance (f32 bits) of that slowest entry; group: far lists of at least group_min entries are served ceil(length / group) consecutive entries per wave, neighbours sharing a scan (0: one per wave); clear_ref: the first search of an align also resets the far-candidate references (one per query); cond: run only if this look flag is set
 // LIST = false: first search of an align (no seed): every source point, radius margin * cell, two rounds,
 // leftovers to fb_list.  LIST = true: the fb_list entries (leftovers of the first search, or the big-ball
 // queries of k_nn_track with their seed radius), 16 per wave, rounds until exact.
@@ -493,7 +493,7 @@ __global__ void __launch_bounds__(BLOCK, GROUP ? 5 : 6) k_nn_search(GridView src
       if (far_stats && MODE == 0 && (threadIdx.x & 63) == 0 && nfar) atomicAdd(&far_stats[3], nfar);
       return;
     }
-    unsigned long long pr_sum = 0, pr_max = 0; uint32_t pr_n = 0;
+    unsigned long long pr_sum = 0, pr_max = 0, pr_a = 0, pr_b = 0; uint32_t pr_n = 0;
     for (uint32_t w = bw0; w < nbig; w += nbw) {
       const uint2 rec = big_list[w];
       const float4 p = src.pts[rec.x];
@@ -504,8 +504,11 @@ __global__ void __launch_bounds__(BLOCK, GROUP ? 5 : 6) k_nn_search(GridView src
       const float r = v > 0.f ? v * 1.1f + 0.5f * tgt.cell : -v;
       unsigned long long key; float second, d_unseen;
       const unsigned long long pt0 = opt.probe ? wall_clock64() : 0ull;
-      wave_search_single(tgt, qx, qy, qz, r, __int_as_float(0x7f800000), key, second, d_unseen, &lds[threadIdx.x >> 6]);
-      if (opt.probe) { const unsigned long long dt = wall_clock64() - pt0; pr_sum += dt; pr_max = dt > pr_max ? dt : pr_max; pr_n++; }
+      SingleStats sst;
+      wave_search_single(tgt, qx, qy, qz, r, __int_as_float(0x7f800000), key, second, d_unseen, &lds[threadIdx.x >> 6], opt.probe ? &sst : nullptr);
+      if (opt.probe) { const unsigned long long dt = wall_clock64() - pt0; pr_sum += dt; pr_n++;
+        if (dt > pr_max) { pr_max = dt; pr_a = ((unsigned long long)sst.rounds << 48) | ((unsigned long long)min(sst.segs, 0xffffffu) << 24) | (unsigned long long)min(sst.cand, 0xffffffu);
+          pr_b = ((unsigned long long)__float_as_uint(sst.r_first) << 32) | __float_as_uint(key != QN_INF_KEY ? sqrtf(key_d2(key)) : -1.f); } }
       if ((threadIdx.x & 63) == 0) {
         store_nn<MODE>(key, __float_as_uint(p.w), rec.x, thr2, corr, sqd, nn_idx);
         if (MODE == 0) nn_ref[rec.x] = make_float4(qx, qy, qz, fminf(sqrtf(second), d_unseen));
@@ -513,7 +516,7 @@ __global__ void __launch_bounds__(BLOCK, GROUP ? 5 : 6) k_nn_search(GridView src
       }
     }
     if (far_stats && MODE == 0 && (threadIdx.x & 63) == 0 && nfar) atomicAdd(&far_stats[3], nfar);
-    if (opt.probe && (threadIdx.x & 63) == 0 && bw0 < 16384u) { opt.probe[2 * bw0] = (pr_max << 32) | pr_n; opt.probe[2 * bw0 + 1] = pr_sum; }
+    if (opt.probe && (threadIdx.x & 63) == 0 && bw0 < 16384u) { opt.probe[4 * bw0] = (pr_max << 32) | pr_n; opt.probe[4 * bw0 + 1] = pr_sum; opt.probe[4 * bw0 + 2] = pr_a; opt.probe[4 * bw0 + 3] = pr_b; }
     return;
   }
   const uint32_t nq = LIST ? *fb_count : src.n;

@@ -260,7 +260,7 @@ int  qn_debug_get_counters(qn_ctx*, uint32_t out[16]);
 int  qn_debug_get(qn_ctx*, const char* key, double* value);   /* "verify_mismatches" / "verify_passes" / "verify_first" after qn_debug_set("verify_track", 1); "feat_survivors" / "feat_fallbacks" (matrix-core feature matching) */
 int  qn_debug_get_grid(qn_ctx*, int which, double out[8]);
 int  qn_debug_get_partials(qn_ctx*, double* out, uint32_t* rows_per_buffer, double* state);   /* developer: both partial-row buffers and both state buffers after an align */
-int  qn_debug_get_list_probe(qn_ctx*, unsigned long long* out /* [2 * 16384]: per wave of the last unseeded list pass: slowest entry << 32 | entries, busy time; 100 MHz ticks (knob list_probe) */);
+int  qn_debug_get_list_probe(qn_ctx*, unsigned long long* out /* [4 * 16384]: per wave of the last unseeded list pass: slowest entry << 32 | entries, busy time (100 MHz ticks), and of that slowest entry rounds << 48 | segments << 24 | candidates, first radius | neighbour distance as f32 bits (knob list_probe) */);
 int  qn_debug_get_persist_clk(qn_ctx*, unsigned long long* out /* 64 x 16 + 16 wall-clock stamps of the latest persistent align */);   /* after qn_debug_set("persist_probe", 1) */
 int  qn_debug_get_clk(qn_ctx*, unsigned long long* out /* 256 x 8 + 1024 x 12 device-clock stamps / counters */, uint32_t* n);   /* after qn_debug_set("clk_probe", 1) */
 
