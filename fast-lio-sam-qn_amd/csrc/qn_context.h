@@ -68,7 +68,7 @@ struct qn_ctx {
   float* q_mean = nullptr; double* q_mean_psum = nullptr; void* q_host = nullptr;   // Matcher tail: cloud means, pinned hand-over block (header + one record per selected correspondence)
   // tuning knobs
   double cell_override = 0.0;
-  float big_ratio_late = 1.0f;          // the same threshold for the unseeded passes after the first
+  int list_small = 6000;                // lone registration: a 16-per-wave leftover list of at most this many entries is served one entry per wave (k_nn_search LIST)
   float big_ratio = 2.5f;               // first-search leftovers whose next radius exceeds big_ratio * r0 go one-per-wave
   bool fused_ticks = true;              // GN ticks >= 3: tracking + leftovers + accumulation in one kernel
   int nn_rounds = 1;                    // rounds of an unseeded NN search before a query goes to the list pass

@@ -538,7 +538,7 @@ __device__ __forceinline__ bool wave_search(const GridView& g, float qx, float q
       if (d == INF || !(r == r)) { certified = true; d_unseen = INF; }   // the whole grid was scanned (or a non-finite query: nothing to find)
       else { d -= g.eps; d_unseen = d; certified = d > 0.f && sink.full() && sink.worst_d2() < d * d; }
       if (!certified) {
-        if (sink.full()) r = fmaxf(sqrtf(sink.worst_d2()) * 1.000001f + g.eps, r);
+        if (sink.full()) r = fmaxf(sqrtf(sink.worst_d2()) * 1.000001f + g.eps, r + g.eps);      // (never the same radius twice: see wave_search_single)
         else {                                                // fewer than k points in the box: extrapolate from the count (surface-like data: count ~ r^2)
           const int f = sink.found();                         // instead of doubling blindly (a sparse-region k-NN query then re-scans far less)
           r = f > 0 ? fmaxf(r * sqrtf((float)sink.wanted() / (float)f) * 1.25f, r + g.cell) : 2.f * r + g.cell;
@@ -685,7 +685,9 @@ __device__ __forceinline__ void wave_search_single(const GridView& g, float qx, 
     if (d == INF || !(r == r) || round > 160) { cert = true; d_unseen = INF; }
     else { d -= g.eps; d_unseen = d; cert = d > 0.f && b != QN_INF_KEY && key_d2(b) < d * d; }
     if (cert) { best_out = b; second_out = c; return; }
-    r = (b != QN_INF_KEY) ? fmaxf(sqrtf(key_d2(b)) * 1.000001f + g.eps, r) : (r > 6.f * g.cell ? r + (2.f + round) * g.cell : 2.f * r + g.cell);   // far away: grow by cells, not by factors (the cap's width grows with sqrt(r^2 - o^2))
+    // (found but not certified: the candidate's own radius - and always at least eps MORE than this round's, or a candidate within rounding noise of r, whose
+    //  box face comes out a few ulps of the coordinates short, would repeat the same round until the round limit: one such entry cost a list pass 390 us)
+    r = (b != QN_INF_KEY) ? fmaxf(sqrtf(key_d2(b)) * 1.000001f + g.eps, r + g.eps) : (r > 6.f * g.cell ? r + (2.f + round) * g.cell : 2.f * r + g.cell);   // far away: grow by cells, not by factors (the cap's width grows with sqrt(r^2 - o^2))
     r = fminf(r, r_cap);
   }
 }

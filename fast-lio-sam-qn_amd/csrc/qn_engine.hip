@@ -404,10 +404,7 @@ static void enqueue_nn(qn_ctx* c, int mode /*0 align, 1 fitness*/, float* sqd_ou
   const int big_blocks = wide ? c->big_blocks0 : 1024;                                                // waves with one far query each (idle blocks exit at once)
   const uint32_t fbb = std::min<uint32_t>(nb4, wide ? (uint32_t)c->fb_blocks0 : 256u);                           // list pass: wave-stride over the leftovers
   const float r0 = -(tick == 0 && mode == 0 && c->margin_nn_t0 > 0.f ? c->margin_nn_t0 : c->margin_nn);      // negative = in cells
-  // which leftovers of the grid pass go one per wave: at the first tick of a misaligned pair a fifth of the cloud is "far" and only the really far ones can have a
-  // wave each; from the second tick on the lists are short (a few thousand entries) and a 16-per-wave list wave grinding through growth rounds is the long pole
-  // of the pass (55 us against 20 with every leftover on a wave of its own)
-  const float big_ratio = (mode == 0 && tick > 0 && !c->persist_batch_off) ? c->big_ratio_late : c->big_ratio;      // (a batch member keeps the 16-per-wave lists: fewer wave-instructions per query, +2 % throughput)
+  const float big_ratio = c->big_ratio;
   NnOpt opt; opt.clear_ref = (mode == 0 && !seeded && c->clear_far_now) ? c->far_cand_ref : nullptr; opt.cond = cond;
   // far-list grouping (wave_search_far16): with several registrations in flight throughput counts and long far lists are shared (partial overlap: 1110 -> 1330
   // registrations/s; the aligned-scene headline is unchanged); a lone registration wants latency - its lists fit a few rounds of resident waves, one entry per
@@ -415,8 +412,9 @@ static void enqueue_nn(qn_ctx* c, int mode /*0 align, 1 fitness*/, float* sqd_ou
   const bool batch = c->persist_batch_off;
   opt.group = c->far_group >= 0 ? c->far_group : (batch ? 4096 : 0); opt.group_min = 0;
   opt.probe = (mode == 0 && !seeded) ? c->list_probe : nullptr;
+  opt.fb_small = (mode == 0 && !c->persist_batch_off) ? (uint32_t)c->list_small : 0u;      // (a batch member keeps the 16-per-wave lists: fewer wave-instructions per query, +2 % throughput)
   if (opt.probe) (void)hipMemsetAsync(c->list_probe, 0, sizeof(unsigned long long) * 4 * 16384, s);
-  NnOpt opt0; opt0.clear_ref = nullptr; opt0.cond = 0; opt0.group = 0; opt0.group_min = 0; opt0.probe = nullptr;
+  NnOpt opt0; opt0.clear_ref = nullptr; opt0.cond = 0; opt0.group = 0; opt0.group_min = 0; opt0.probe = nullptr; opt0.fb_small = 0;
   c->clear_far_now = mode == 0 && !seeded ? false : c->clear_far_now;
   if (mode == 0) {
     { ProfScope ps(c, QN_K_NN_SEARCH);
@@ -443,8 +441,8 @@ static void enqueue_verify(qn_ctx* c, bool fused) {
   uint32_t* fbc = &st->fb_count; uint32_t* bgc = &st->big_count;
   const float r0 = -c->margin_nn;
   hipLaunchKernelGGL(k_reset_lists, dim3(1), dim3(64), 0, s, st);
-  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_nn_search<0, false, QN_NN_BLOCK>), dim3(nb), dim3(QN_NN_BLOCK), 0, s, S.grid, T.grid, st, thr2, r0, c->nn_rounds, c->v_corr, c->v_sqd, c->v_nn_idx, c->v_nn_ref, c->fb_list, fbc, c->big_list, bgc, 0, c->big_ratio, (uint32_t*)nullptr, NnOpt{nullptr, 0, 0, 0, nullptr});
-  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_nn_search<0, true, QN_BLOCK>), dim3(std::min<uint32_t>(nb4, 512) + 4096), dim3(QN_BLOCK), 0, s, S.grid, T.grid, st, thr2, r0, 64, c->v_corr, c->v_sqd, c->v_nn_idx, c->v_nn_ref, c->fb_list, fbc, c->big_list, bgc, 4096, c->big_ratio, (uint32_t*)nullptr, NnOpt{nullptr, 0, 0, 0, nullptr});
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_nn_search<0, false, QN_NN_BLOCK>), dim3(nb), dim3(QN_NN_BLOCK), 0, s, S.grid, T.grid, st, thr2, r0, c->nn_rounds, c->v_corr, c->v_sqd, c->v_nn_idx, c->v_nn_ref, c->fb_list, fbc, c->big_list, bgc, 0, c->big_ratio, (uint32_t*)nullptr, NnOpt{nullptr, 0, 0, 0, nullptr, 0});
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_nn_search<0, true, QN_BLOCK>), dim3(std::min<uint32_t>(nb4, 512) + 4096), dim3(QN_BLOCK), 0, s, S.grid, T.grid, st, thr2, r0, 64, c->v_corr, c->v_sqd, c->v_nn_idx, c->v_nn_ref, c->fb_list, fbc, c->big_list, bgc, 4096, c->big_ratio, (uint32_t*)nullptr, NnOpt{nullptr, 0, 0, 0, nullptr, 0});
   hipLaunchKernelGGL(k_verify_nn, dim3((S.n + 255) / 256), dim3(256), 0, s, S.n, st, c->nn_idx, c->v_nn_idx, fused ? (const float*)nullptr : c->sqd, c->v_sqd, c->corr, c->v_corr, c->v_counters);
   hipLaunchKernelGGL(k_reset_lists, dim3(1), dim3(64), 0, s, st);
 }
@@ -938,7 +936,7 @@ extern "C" int qn_debug_set(qn_ctx* c, const char* key, double v) {
   else if (k == "bbox_blocks") c->bbox_blocks = std::max(1, (int)v);
   else if (k == "device_look") c->device_look = v != 0;
   else if (k == "far_group") c->far_group = (int)v;
-  else if (k == "big_ratio_late") c->big_ratio_late = (float)v;
+  else if (k == "list_small") c->list_small = std::max(0, (int)v);
   else if (k == "far_chunk") c->far_chunk = std::max(1, (int)v);
   else if (k == "far_ranked") c->far_ranked = v != 0;
   else if (k == "batch_look") c->batch_look = v != 0;

@@ -419,7 +419,7 @@ __device__ __forceinline__ void store_nn(unsigned long long key, uint32_t i, uin
   }
 }
 
-struct NnOpt { float4* clear_ref; int cond; int group, group_min; unsigned long long* probe; };       // probe: developer timing of the one-per-wave entries (knob list_probe): [4 w] = slowest entry << 32 | entries, [4 w + 1] = busy time of wave w (100 MHz ticks), [4 w + 2] = rounds << 48 | segments << 24 | candidates and [4 w + 3] = first radius | neighbour distance (f32 bits) of that slowest entry; group: far lists of at least group_min entries are served ceil(length / group) consecutive entries per wave, neighbours sharing a scan (0: one per wave); clear_ref: the first search of an align also resets the far-candidate references (one per query); cond: run only if this look flag is set
+struct NnOpt { float4* clear_ref; int cond; int group, group_min; unsigned long long* probe; uint32_t fb_small; };       // fb_small: a 16-per-wave list of at most this many entries is served one entry per wave like the far list (0: never); probe: developer timing of the one-per-wave entries (knob list_probe): [4 w] = slowest entry << 32 | entries, [4 w + 1] = busy time of wave w (100 MHz ticks), [4 w + 2] = rounds << 48 | segments << 24 | candidates and [4 w + 3] = first radius | neighbour distance (f32 bits) of that slowest entry; group: far lists of at least group_min entries are served ceil(length / group) consecutive entries per wave, neighbours sharing a scan (0: one per wave); clear_ref: the first search of an align also resets the far-candidate references (one per query); cond: run only if this look flag is set
 // LIST = false: first search of an align (no seed): every source point, radius margin * cell, two rounds,
 // leftovers to fb_list.  LIST = true: the fb_list entries (leftovers of the first search, or the big-ball
 // queries of k_nn_track with their seed radius), 16 per wave, rounds until exact.
@@ -494,8 +494,12 @@ __global__ void __launch_bounds__(BLOCK, GROUP ? 5 : 6) k_nn_search(GridView src
       return;
     }
     unsigned long long pr_sum = 0, pr_max = 0, pr_a = 0, pr_b = 0; uint32_t pr_n = 0;
-    for (uint32_t w = bw0; w < nbig; w += nbw) {
-      const uint2 rec = big_list[w];
+    // A SHORT 16-per-wave list is served here as well, one entry per wave: a few hundred list waves grinding through growth rounds for all their queries were the
+    // long pole of the later unseeded passes (55 us against 20).  The decision is taken from the list's actual length: a pair that is still metres off at its
+    // second iteration leaves tens of thousands of leftovers there, and those need the 16-per-wave pass (435 us otherwise).
+    const uint32_t nfb1 = (opt.fb_small && *fb_count <= opt.fb_small) ? *fb_count : 0u;
+    for (uint32_t w = bw0; w < nbig + nfb1; w += nbw) {
+      const uint2 rec = w < nbig ? big_list[w] : fb_list[w - nbig];
       const float4 p = src.pts[rec.x];
       float qx, qy, qz; xform_query<MODE>(Tf, p.x, p.y, p.z, qx, qy, qz);
       const float v = __uint_as_float(rec.y);
@@ -520,6 +524,7 @@ __global__ void __launch_bounds__(BLOCK, GROUP ? 5 : 6) k_nn_search(GridView src
     return;
   }
   const uint32_t nq = LIST ? *fb_count : src.n;
+  if (LIST && opt.fb_small && nq <= opt.fb_small) return;          // (served one per wave by the other blocks of this launch)
   if (LIST && tgt.dbg && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&tgt.dbg[5], nq);
   const uint32_t wave0 = blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6), nwaves = (gridDim.x - (LIST ? big_blocks : 0)) * (BLOCK / 64);   // (XCD remap measured slower here: the leftover lists lose their locality)
   for (uint32_t base = wave0 * 16; base < nq; base += nwaves * 16) {

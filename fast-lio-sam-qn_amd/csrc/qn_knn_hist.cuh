@@ -146,7 +146,7 @@ __device__ __forceinline__ int wave_knn_hist(const GridView& g, float qx, float 
             idx_out[rank[j]] = (int32_t)key_idx(own[j]);
             if (d2_out) d2_out[rank[j]] = key_d2(own[j]);
           }
-        } else { r = fmaxf(sqrtf(kth_d2) * 1.000001f + g.eps, r); retry = true; }
+        } else { r = fmaxf(sqrtf(kth_d2) * 1.000001f + g.eps, r + g.eps); retry = true; }
       }
     }
     todo = __ballot(retry && round + 1 < max_rounds);
@@ -270,7 +270,7 @@ __device__ __forceinline__ int wave_knn_single(const GridView& g, float qx, floa
       wave_lds_fence();
       return 0;
     }
-    r = fmaxf(sqrtf(kth_d2) * 1.000001f + g.eps, r);                        // the k-th best is known: the next ball certifies
+    r = fmaxf(sqrtf(kth_d2) * 1.000001f + g.eps, r + g.eps);                        // the k-th best is known: the next ball certifies
   }
   return 2;
 }
