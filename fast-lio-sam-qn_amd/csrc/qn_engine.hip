@@ -694,7 +694,7 @@ static int gicp_align(qn_ctx* c, const float guess[16], qn_gicp_result* out, boo
       else c->far_mode = (c->far_mode == 1 ? rb->far_requests : rb->far_misses / (uint32_t)std::max(1, chunk)) > 256u ? 1 : 2;   // stray misses are cheaper inside k_tick
     }
     if (!exact_ticks) chunk = first_chunk ? c->ticks_per_chunk : std::max(2 * per_outer, c->ticks_per_chunk / 2);   // convergence is usually near after the first chunks: ticks past it are wasted launches
-    else chunk = first_chunk && c->far_mode == 1 ? std::min(ticks_left, c->far_chunk) : ticks_left;      // the refresh regime is needed for the first few tracked ticks only: an empty k_far + k_far_reduce behind every later tick cost 14 us each (80 %-overlap pairs: 1384 -> 1429 registrations/s with 4 instead of 8)
+    else chunk = c->far_mode == 1 ? std::min(ticks_left, c->far_chunk) : ticks_left;      // the refresh regime is needed for the first few tracked ticks only: an empty k_far + k_far_reduce behind every later tick cost 14 us each (80 %-overlap pairs: 1384 -> 1429 registrations/s with 4 instead of 8)
     if (budget <= 0) { c->last_error = "align: device state machine did not terminate"; return QN_ERR_HIP; }
     if (look && !declined) {
       // how far the NEXT step will move the source points at most: the step just taken (translation + rotation x the cloud's reach from the origin), shrunk
