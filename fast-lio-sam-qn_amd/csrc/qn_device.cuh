@@ -52,15 +52,35 @@ struct GridView {
   int nx, ny, nz;                      // cells per axis
   int ntx, nty, ntz;                   // tiles per axis
   uint32_t n;
-  const GridDims* dims;                // device-resident numbers (null: the fields above are valid as they are)
+  const GridDims* dims;                // device-resident numbers (never null: grid_resolve reads them)
 };
-__device__ __forceinline__ GridView grid_resolve(GridView g) {
-  if (g.dims) {
-    const GridDims d = *g.dims;
-    g.ox = d.ox; g.oy = d.oy; g.oz = d.oz; g.cell = d.cell; g.inv_cell = d.inv_cell; g.eps = d.eps;
-    g.nx = d.nx; g.ny = d.ny; g.nz = d.nz; g.ntx = d.ntx; g.nty = d.nty; g.ntz = d.ntz; g.n = d.n;
-  }
+// Values that are the same in every lane but were fetched through a pointer the compiler knows nothing about (a pointer that itself came out of a device-resident
+// argument table: k_lanes) land in VECTOR registers; these put them back into scalar registers.  On a value that already lives in an SGPR they fold away.
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ __forceinline__ float uni(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
+__device__ __forceinline__ double uni(double v) { union { double d; int i[2]; } u; u.d = v; u.i[0] = __builtin_amdgcn_readfirstlane(u.i[0]); u.i[1] = __builtin_amdgcn_readfirstlane(u.i[1]); return u.d; }
+__device__ __forceinline__ GridView grid_resolve(GridView g) {      // (dims is always set: build_grid.  Unconditional on purpose - a conditional copy became a select of POINTERS
+  const GridDims d = *g.dims;                                       //  between the device numbers and a stack copy of the argument: 16 bytes of scratch in the hottest kernel)
+  g.ox = uni(d.ox); g.oy = uni(d.oy); g.oz = uni(d.oz); g.cell = uni(d.cell); g.inv_cell = uni(d.inv_cell); g.eps = uni(d.eps);
+  g.nx = uni(d.nx); g.ny = uni(d.ny); g.nz = uni(d.nz); g.ntx = uni(d.ntx); g.nty = uni(d.nty); g.ntz = uni(d.ntz); g.n = uni(d.n);
   return g;
+}
+
+// ------------------------------------------------------------------ pair as a grid dimension
+// Every kernel of the registration chain is a functor F { TB, OCC, Args, run(args, bx, nbx) }: `bx` / `nbx` stand for blockIdx.x / gridDim.x.
+// The classic launch (one registration per stream) wraps it in a __global__ of its own; the BATCHED launch is k_lanes<F>: blockIdx.y selects one
+// entry of a device-resident table - one entry per (candidate pair, cloud) - so B independent registrations ride in ONE launch with their own
+// buffers, grid sizes and state (SURVEY 7.1 step 8 "pair-as-grid-dimension"; loop_closure.cpp:116-124: the pairs share nothing).  The same
+// instruction sequence runs on the same inputs either way: the records are bit-identical to the per-context path's.
+// gridDim.x is a multiple of 8 in batched launches, so (linear workgroup id) mod 8 - the XCD a block lands on - is bx mod 8 like in a 1-D grid.
+template <class A> struct alignas(16) LaneEntry { A a; uint32_t nbx; uint32_t pad_[3]; };
+template <class F>
+__global__ void __launch_bounds__(F::TB, F::OCC) k_lanes(const LaneEntry<typename F::Args>* __restrict__ tab) {
+  const LaneEntry<typename F::Args>* e = tab + blockIdx.y;
+  const uint32_t nbx = e->nbx;
+  if (blockIdx.x >= nbx) return;
+  F::run(e->a, blockIdx.x, nbx);
 }
 
 #define QN_INF_KEY 0xFFFFFFFFFFFFFFFFull

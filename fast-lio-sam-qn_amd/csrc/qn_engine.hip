@@ -88,7 +88,11 @@ static void carve_cloud(qn_ctx* c, Slab& sl, CloudBuf& b) {
   sl.take(b.dims, sizeof(GridDims));
 }
 
-extern "C" int qn_ctx_create(int device, uint32_t max_points, qn_ctx** out) {
+static int ctx_create(int device, uint32_t max_points, hipStream_t shared_stream, qn_ctx** out);
+extern "C" int qn_ctx_create(int device, uint32_t max_points, qn_ctx** out) { return ctx_create(device, max_points, nullptr, out); }
+// shared_stream: the context is a LANE of a batch context and works on its owner's stream (no stream of its own: HIP deals streams to a handful of hardware
+// queues in creation order, and idle extra streams make working streams share queues)
+static int ctx_create(int device, uint32_t max_points, hipStream_t shared_stream, qn_ctx** out) {
   if (!out || max_points == 0) return QN_ERR_INVALID_ARG;
   *out = nullptr;
   int ndev = 0;
@@ -102,7 +106,8 @@ extern "C" int qn_ctx_create(int device, uint32_t max_points, qn_ctx** out) {
   int rc = QN_OK;
   auto fail = [&](int code) { qn_ctx_destroy(c); return code; };
   if (hipSetDevice(device) != hipSuccess) return fail(QN_ERR_NO_DEVICE);
-  if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) return fail(QN_ERR_HIP);
+  if (shared_stream) { c->stream = shared_stream; c->owns_stream = false; c->is_lane = true; }
+  else if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) return fail(QN_ERR_HIP);
 #define CA(call) if ((call) != hipSuccess) return fail(QN_ERR_HIP)
   auto carve = [&](Slab& sl) {
     carve_cloud(c, sl, c->cloud[0]);
@@ -177,6 +182,10 @@ extern "C" void qn_ctx_destroy(qn_ctx* c) {
   hipSetDevice(c->device);
   if (c->stream) hipStreamSynchronize(c->stream);
   if (c->stream2) hipStreamSynchronize(c->stream2);                     // a target may still be in preparation there (TargetScope)
+  for (qn_ctx* l : c->lanes) if (l != c) qn_ctx_destroy(l);
+  c->lanes.clear();
+  if (c->args_h) hipHostFree(c->args_h);
+  hipFree(c->args_d);
   c->prof_collect();
   hipFree(c->slab);                                                      // every per-context device buffer of the GICP path lives in it (qn_ctx_create)
   hipFree(c->q_mm_c); hipFree(c->q_mm_q); hipFree(c->q_mm_qn); hipFree(c->q_mm_L); hipFree(c->q_mm_table); hipFree(c->q_mm_table_q); hipFree(c->q_mm_pairs); hipFree(c->q_mm_cnt); hipFree(c->q_mm_vkeys); hipFree(c->q_mm_vcnt);
@@ -191,7 +200,7 @@ extern "C" void qn_ctx_destroy(qn_ctx* c) {
   hipFree(c->pg_clk); if (c->list_probe) hipFree(c->list_probe); if (c->pg_status_host) hipHostFree(c->pg_status_host);
   if (c->ev_pair) hipEventDestroy(c->ev_pair);
   if (c->stream2) { hipStreamSynchronize(c->stream2); hipStreamDestroy(c->stream2); }
-  if (c->stream) hipStreamDestroy(c->stream);
+  if (c->stream && c->owns_stream) hipStreamDestroy(c->stream);
   delete c;
 }
 
@@ -267,25 +276,39 @@ static int join_target(qn_ctx* c) {
 // K1: pack + bbox + grid numbers (on the device) -> count -> exclusive scan -> scatter.  No host round trip: the kernels read the numbers from
 // device memory (GridView::dims, grid_resolve); the table-sized scan uses the grid of the largest table and leaves early.  What the host
 // needs to know - "the cloud held non-finite coordinates" - arrives with the pinned mirror at the next synchronisation (clouds_valid).
-static int build_grid(qn_ctx* c, CloudBuf& b, const char* dsrc, uint32_t stride) {
+// (arguments of the five launches for one cloud: the classic path launches them one by one, the batched path puts the entries of every cloud of a batch into ONE launch each)
+struct GridLaunch { PackBBoxK::Args pack; uint32_t pack_nb; CellCountK::Args count; ScanLookbackK::Args scan; uint32_t scan_nb; ScatterK::Args scat; StableCellsK::Args stab; bool stable; uint32_t nb; };
+static GridLaunch prep_grid(qn_ctx* c, CloudBuf& b, const char* dsrc, uint32_t stride) {
   const uint32_t n = b.n;
-  hipStream_t s = c->stream;
   GridView& g = b.grid;
   memset(&g, 0, sizeof(g));
   g.pts = b.sorted; g.cell_start = b.cell_start; g.dbg = c->dbg_counters; g.n = n; g.dims = b.dims;
-  const uint32_t nb = (n + QN_BLOCK - 1) / QN_BLOCK;
-  const uint32_t sb_max = (c->max_cells + QN_BLOCK * QN_SCAN_ITEMS - 1) / (QN_BLOCK * QN_SCAN_ITEMS);
+  GridLaunch L;
+  L.nb = (n + QN_BLOCK - 1) / QN_BLOCK;
+  L.scan_nb = (c->max_cells + QN_BLOCK * QN_SCAN_ITEMS - 1) / (QN_BLOCK * QN_SCAN_ITEMS);
   if (((++c->build_epoch) & 0x3fffffffu) == 0u) ++c->build_epoch;     // (0 = the tag of the zero-initialised status words)
+  L.pack_nb = std::min<uint32_t>(L.nb, (uint32_t)std::min(c->bbox_blocks, QN_BBOX_MAX_BLOCKS));
+  L.pack = PackBBoxK::Args{dsrc, stride, n, b.raw, c->bbox_acc, c->max_cells, c->cell_override, b.dims, b.dims_host};
+  L.count = CellCountK::Args{b.raw, n, g, b.counts, b.cell_of_pt};
+  L.scan = ScanLookbackK::Args{b.counts, b.dims, b.cell_start, c->scan_status, c->build_epoch, n};
+  L.stable = c->stable_cells;
+  L.scat = ScatterK::Args{b.raw, n, b.cell_of_pt, b.cell_start, b.counts, L.stable ? b.sorted_tmp : b.sorted};
+  L.stab = StableCellsK::Args{b.sorted_tmp, n, b.cell_of_pt, b.cell_start, b.sorted};
+  b.has_grid = true; b.has_cov = false;
+  return L;
+}
+static int build_grid(qn_ctx* c, CloudBuf& b, const char* dsrc, uint32_t stride) {
+  hipStream_t s = c->stream;
+  const GridLaunch L = prep_grid(c, b, dsrc, stride);
   { ProfScope ps(c, QN_K_GRID_BUILD);
     // 5 launches, nothing else: the bounding-box accumulator and the cell counters clean up after themselves (the last block of the first kernel; k_scatter's
     // atomicSub hands every counter back at zero), the scan is single-pass, the numbers reach the host through the pinned mirror
-    hipLaunchKernelGGL(k_pack_bbox_dims, dim3(std::min<uint32_t>(nb, (uint32_t)std::min(c->bbox_blocks, QN_BBOX_MAX_BLOCKS))), dim3(QN_BLOCK), 0, s, dsrc, stride, n, b.raw, c->bbox_acc, c->max_cells, c->cell_override, b.dims, b.dims_host);
-    hipLaunchKernelGGL(k_cell_count, dim3(nb), dim3(QN_BLOCK), 0, s, b.raw, n, g, b.counts, b.cell_of_pt);
-    hipLaunchKernelGGL(k_scan_lookback, dim3(sb_max), dim3(QN_BLOCK), 0, s, (const uint32_t*)b.counts, (const GridDims*)b.dims, b.cell_start, c->scan_status, c->build_epoch, n);
-    hipLaunchKernelGGL(k_scatter, dim3(nb), dim3(QN_BLOCK), 0, s, b.raw, n, b.cell_of_pt, b.cell_start, b.counts, c->stable_cells ? b.sorted_tmp : b.sorted);
-    if (c->stable_cells) hipLaunchKernelGGL(k_stable_cells, dim3(nb), dim3(QN_BLOCK), 0, s, (const float4*)b.sorted_tmp, n, (const uint32_t*)b.cell_of_pt, (const uint32_t*)b.cell_start, b.sorted); }
+    hipLaunchKernelGGL(k_pack_bbox_dims, dim3(L.pack_nb), dim3(QN_BLOCK), 0, s, L.pack.in, L.pack.stride, L.pack.n, L.pack.raw, L.pack.acc, L.pack.max_cells, L.pack.cell_override, L.pack.dims_dev, L.pack.dims_host);
+    hipLaunchKernelGGL(k_cell_count, dim3(L.nb), dim3(QN_BLOCK), 0, s, L.count.pts, L.count.n, L.count.g, L.count.counts, L.count.cell_of_pt);
+    hipLaunchKernelGGL(k_scan_lookback, dim3(L.scan_nb), dim3(QN_BLOCK), 0, s, L.scan.in, L.scan.dims, L.scan.out, L.scan.status, L.scan.epoch, L.scan.total);
+    hipLaunchKernelGGL(k_scatter, dim3(L.nb), dim3(QN_BLOCK), 0, s, L.scat.pts, L.scat.n, L.scat.cell_of_pt, L.scat.cell_start, L.scat.counts, L.scat.sorted);
+    if (L.stable) hipLaunchKernelGGL(k_stable_cells, dim3(L.nb), dim3(QN_BLOCK), 0, s, L.stab.in, L.stab.n, L.stab.cell_of_pt, L.stab.cell_start, L.stab.out); }
   HIPCHK(c, hipGetLastError());
-  b.has_grid = true; b.has_cov = false;
   return QN_OK;
 }
 // after a synchronisation: did a cloud hold non-finite coordinates?  (is_dense == false clouds are not supported: the reference's KD-tree build would not survive them)
@@ -331,30 +354,48 @@ extern "C" int qn_gicp_set_source_device(qn_ctx* c, const float* xyz, uint32_t n
 extern "C" int qn_gicp_set_target_device(qn_ctx* c, const float* xyz, uint32_t n, uint32_t stride) { return set_cloud(c, QN_TARGET, xyz, n, stride, true); }
 
 // ------------------------------------------------------------------ calculateSource/TargetCovariances
-template <int KMAX>
-static void launch_knn_cov(qn_ctx* c, CloudBuf& b, int k, int32_t* kidx, float* kd2) {
-  hipStream_t s = c->stream;
+// the five launches of the histogram-selection path for one cloud (classic: one by one; batched: one entry per cloud in ONE launch each)
+struct KnnLaunch { KnnHistArgs sel; uint32_t sel_nb; KnnHistArgs lst; uint32_t lst_nb; KnnSingleK::Args single; uint32_t single_nb; KnnCovArgs tail; uint32_t tail_nb; CovFromIdxK::Args cov; uint32_t cov_nb; };
+static float knn_first_radius(const qn_ctx* c, const CloudBuf& b) {
   // first radius in cells.  A cloud of <= 65536 points is ONE round of waves (16 queries each, 4096 resident): the kernel then lasts as long as
   // its slowest wave, and a wave that has to retry with a doubled radius is 3-4x slower - a wider first radius (fewer retries) wins there
   // (30k points: 174 -> 116 us); beyond that the retries hide behind the next round of waves and the smaller radius wins (100k: 100 vs 131 us);
   // at 10k points the wider radius measured slower again (few waves, each with more candidates): 2.5 only between 16k and 64k.
-  const float r0 = -(c->margin_knn > 0.f ? c->margin_knn : (b.n > 16384u && b.n <= 65536u ? 2.5f : 2.0f));      // negative = in cells (the kernels know the cell edge, the host does not)
+  return -(c->margin_knn > 0.f ? c->margin_knn : (b.n > 16384u && b.n <= 65536u ? 2.5f : 2.0f));      // negative = in cells (the kernels know the cell edge, the host does not)
+}
+static KnnLaunch prep_knn(qn_ctx* c, CloudBuf& b, int k, int32_t* kidx, float* kd2) {
+  const float r0 = knn_first_radius(c, b);
+  uint32_t* genc = c->fb_count2 + 1;
+  KnnLaunch L;
+  L.sel_nb = (b.n + QN_KNN_BLOCK / 4 - 1) / (QN_KNN_BLOCK / 4);     // 16 queries per wave
+  L.sel = KnnHistArgs{b.grid, k, r0, c->knn_single_all ? -1 : c->knn_rounds, kidx, kd2, c->fb_list, c->fb_count2, c->big_list, genc};
+  L.lst_nb = std::min<uint32_t>((b.n + 63) / 64, 512) * (QN_BLOCK / QN_KNN_BLOCK);
+  L.lst = KnnHistArgs{b.grid, k, r0, 64, kidx, kd2, c->fb_list, c->fb_count2, c->big_list, genc};
+  // far / overflowing queries (isolated points, sparse far field): one per wave; its leftovers -> the sorted-list kernel (fb_list is free again)
+  L.single_nb = std::min<uint32_t>((b.n + 3) / 4, 2048);
+  L.single = KnnSingleK::Args{b.grid, k, kidx, kd2, c->big_list, genc, c->fb_list, c->fb_count2 + 2};
+  L.tail_nb = std::min<uint32_t>((b.n + 63) / 64, 1024);
+  L.tail = KnnCovArgs{b.grid, b.raw, k, r0, 64, b.nrm, kidx, kd2, c->fb_list, c->fb_count2 + 2};
+  L.cov_nb = (b.n + QN_BLOCK - 1) / QN_BLOCK;
+  L.cov = CovFromIdxK::Args{b.raw, b.sorted, b.n, k, kidx, b.nrm, &b == &c->cloud[0] ? c->nrm_s_sorted : (double*)nullptr, &b == &c->cloud[0] ? (TargetRec*)nullptr : c->tgt_rec, c->fb_count2};   // + the optimiser ticks' layouts
+  return L;
+}
+template <int KMAX>
+static void launch_knn_cov(qn_ctx* c, CloudBuf& b, int k, int32_t* kidx, float* kd2) {
+  hipStream_t s = c->stream;
   if (c->knn_hist) {                        // histogram selection (default); its leftovers -> hist list pass -> general sorted-list pass
-    const uint32_t nb = (b.n + QN_KNN_BLOCK / 4 - 1) / (QN_KNN_BLOCK / 4);     // 16 queries per wave
-    uint32_t* genc = c->fb_count2 + 1;
+    const KnnLaunch L = prep_knn(c, b, k, kidx, kd2);
     constexpr int HCAP = KMAX <= 24 ? 32 : 48;      // pass-2 list capacity: 32 keeps the selection kernel at 4 waves/SIMD
     { ProfScope sel(c, QN_K_KNN_SELECT);
-      hipLaunchKernelGGL(HIP_KERNEL_NAME(k_knn_hist<false, HCAP>), dim3(nb), dim3(QN_KNN_BLOCK), 0, s, b.grid, k, r0, c->knn_single_all ? -1 : c->knn_rounds, kidx, kd2, c->fb_list, c->fb_count2, c->big_list, genc); }
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(k_knn_hist<false, HCAP>), dim3(L.sel_nb), dim3(QN_KNN_BLOCK), 0, s, L.sel.g, L.sel.k, L.sel.r0, L.sel.max_rounds, L.sel.knn_idx, L.sel.knn_d2, L.sel.fb_list, L.sel.fb_count, L.sel.gen_list, L.sel.gen_count); }
     ProfScope ps(c, QN_K_KNN_COV);
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_knn_hist<true, HCAP>), dim3(std::min<uint32_t>((b.n + 63) / 64, 512) * (QN_BLOCK / QN_KNN_BLOCK)), dim3(QN_KNN_BLOCK), 0, s, b.grid, k, r0, 64, kidx, kd2, c->fb_list, c->fb_count2, c->big_list, genc);
-    // far / overflowing queries (isolated points, sparse far field): one per wave; its leftovers -> the sorted-list kernel (fb_list is free again)
-    hipLaunchKernelGGL(k_knn_single, dim3(std::min<uint32_t>((b.n + 3) / 4, 2048)), dim3(QN_BLOCK), 0, s, b.grid, k, kidx, kd2, c->big_list, genc, c->fb_list, c->fb_count2 + 2);
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_knn_cov<KMAX, true, 4>), dim3(std::min<uint32_t>((b.n + 63) / 64, 1024)), dim3(QN_BLOCK), 0, s, b.grid, b.raw, k, r0, 64, b.nrm, kidx, kd2, c->fb_list, c->fb_count2 + 2);
-    const uint32_t nbp = (b.n + QN_BLOCK - 1) / QN_BLOCK;
-    hipLaunchKernelGGL(k_cov_from_idx, dim3(nbp), dim3(QN_BLOCK), 0, s, b.raw, b.sorted, b.n, k, kidx, b.nrm,
-                       &b == &c->cloud[0] ? c->nrm_s_sorted : (double*)nullptr, &b == &c->cloud[0] ? (TargetRec*)nullptr : c->tgt_rec, c->fb_count2);   // + the optimiser ticks' layouts
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_knn_hist<true, HCAP>), dim3(L.lst_nb), dim3(QN_KNN_BLOCK), 0, s, L.lst.g, L.lst.k, L.lst.r0, L.lst.max_rounds, L.lst.knn_idx, L.lst.knn_d2, L.lst.fb_list, L.lst.fb_count, L.lst.gen_list, L.lst.gen_count);
+    hipLaunchKernelGGL(k_knn_single, dim3(L.single_nb), dim3(QN_BLOCK), 0, s, L.single.g, L.single.k, L.single.knn_idx, L.single.knn_d2, L.single.list, L.single.count, L.single.gen_list, L.single.gen_count);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_knn_cov<KMAX, true, 4>), dim3(L.tail_nb), dim3(QN_BLOCK), 0, s, L.tail.g, L.tail.raw, L.tail.k, L.tail.r0, L.tail.max_rounds, L.tail.cov, L.tail.knn_idx, L.tail.knn_d2, L.tail.fb_list, L.tail.fb_count);
+    hipLaunchKernelGGL(k_cov_from_idx, dim3(L.cov_nb), dim3(QN_BLOCK), 0, s, L.cov.raw, L.cov.sorted, L.cov.n, L.cov.k, L.cov.knn_idx, L.cov.nrm, L.cov.nrm_sorted, L.cov.rec, L.cov.list_counts);
     return;
   }
+  const float r0 = knn_first_radius(c, b);
   ProfScope ps(c, QN_K_KNN_COV);
   {                                         // sorted-list sink, 16 queries per wave x 4 candidate sub-slots (knn_hist = 0)
     const uint32_t nb = (b.n + QN_BLOCK / 4 - 1) / (QN_BLOCK / 4);
@@ -390,12 +431,12 @@ extern "C" int qn_gicp_compute_covariances(qn_ctx* c, int which) { return comput
 // tick = index of this NN pass within the align (list-pass grids shrink as the optimiser converges: the first search
 // leaves ~10-20 % of the queries to the list passes, the first tracked pass most of them after the big initial pose
 // step, later passes a handful - any grid is correct, the lists are walked wave-stride)
-static void enqueue_nn(qn_ctx* c, int mode /*0 align, 1 fitness*/, float* sqd_out, bool seeded, int tick = 0, int cond = 0) {
-  hipStream_t s = c->stream;
+// (arguments of the grid pass and the list pass of one exact 1-NN search; `seeded` searches replace the grid pass by k_nn_track)
+struct NnLaunch { NnSearchArgs grid; uint32_t grid_nb; NnSearchArgs list; uint32_t list_nb; bool group; };
+static NnLaunch prep_nn(qn_ctx* c, int mode /*0 align, 1 fitness*/, float* sqd_out, bool seeded, int tick, int cond) {
   CloudBuf &S = c->cloud[0], &T = c->cloud[1];
   const uint32_t nb = (S.n + QN_NN_BLOCK / 4 - 1) / (QN_NN_BLOCK / 4);   // grid passes: 16 queries per wave
   const uint32_t nb4 = (S.n + QN_BLOCK / 4 - 1) / (QN_BLOCK / 4);       // list passes: 4 waves per block
-  const uint32_t nbt = (S.n + QN_BLOCK - 1) / QN_BLOCK;               // tracking: one query per lane
   const double thr2 = c->params.max_corr_dist * c->params.max_corr_dist;
   GicpState* st = st_cur(c);
   uint32_t* fbc = &st->fb_count; uint32_t* bgc = &st->big_count;
@@ -413,21 +454,35 @@ static void enqueue_nn(qn_ctx* c, int mode /*0 align, 1 fitness*/, float* sqd_ou
   opt.group = c->far_group >= 0 ? c->far_group : (batch ? 4096 : 0); opt.group_min = 0;
   opt.probe = (mode == 0 && !seeded) ? c->list_probe : nullptr;
   opt.fb_small = (mode == 0 && !c->persist_batch_off) ? (uint32_t)c->list_small : 0u;      // (a batch member keeps the 16-per-wave lists: fewer wave-instructions per query, +2 % throughput)
-  if (opt.probe) (void)hipMemsetAsync(c->list_probe, 0, sizeof(unsigned long long) * 4 * 16384, s);
   NnOpt opt0; opt0.clear_ref = nullptr; opt0.cond = 0; opt0.group = 0; opt0.group_min = 0; opt0.probe = nullptr; opt0.fb_small = 0;
   c->clear_far_now = mode == 0 && !seeded ? false : c->clear_far_now;
+  const NnOpt& o = mode == 0 ? opt : opt0;
+  NnLaunch L;
+  L.grid_nb = nb; L.list_nb = fbb + (uint32_t)big_blocks; L.group = mode == 0 && opt.group > 0;
+  L.grid = NnSearchArgs{S.grid, T.grid, st, thr2, r0, mode == 0 ? c->nn_rounds : 1, c->corr, sqd_out, c->nn_idx, c->nn_ref, c->fb_list, fbc, c->big_list, bgc, 0, big_ratio, far_stats, o};
+  L.list = NnSearchArgs{S.grid, T.grid, st, thr2, r0, 64, c->corr, sqd_out, c->nn_idx, c->nn_ref, c->fb_list, fbc, c->big_list, bgc, big_blocks, big_ratio, far_stats, o};
+  return L;
+}
+#define QN_NN_ARGS(A) A.src, A.tgt, A.st, A.thr2, A.r0, A.max_rounds, A.corr, A.sqd, A.nn_idx, A.nn_ref, A.fb_list, A.fb_count, A.big_list, A.big_count, A.big_blocks, A.big_ratio, A.far_stats, A.opt
+static void enqueue_nn(qn_ctx* c, int mode /*0 align, 1 fitness*/, float* sqd_out, bool seeded, int tick = 0, int cond = 0) {
+  hipStream_t s = c->stream;
+  CloudBuf &S = c->cloud[0], &T = c->cloud[1];
+  const uint32_t nbt = (S.n + QN_BLOCK - 1) / QN_BLOCK;               // tracking: one query per lane
+  const NnLaunch L = prep_nn(c, mode, sqd_out, seeded, tick, cond);
+  if (L.grid.opt.probe) (void)hipMemsetAsync(c->list_probe, 0, sizeof(unsigned long long) * 4 * 16384, s);
+  const NnSearchArgs& G = L.grid; const NnSearchArgs& F = L.list;
   if (mode == 0) {
     { ProfScope ps(c, QN_K_NN_SEARCH);
-      if (seeded) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_nn_track<0>), dim3(nbt), dim3(QN_BLOCK), 0, s, S.grid, T.grid, T.raw, st, thr2, c->corr, sqd_out, c->nn_idx, c->nn_ref, c->fb_list, fbc, c->big_list, bgc);
-      else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_nn_search<0, false, QN_NN_BLOCK>), dim3(nb), dim3(QN_NN_BLOCK), 0, s, S.grid, T.grid, st, thr2, r0, c->nn_rounds, c->corr, sqd_out, c->nn_idx, c->nn_ref, c->fb_list, fbc, c->big_list, bgc, 0, big_ratio, far_stats, opt); }
+      if (seeded) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_nn_track<0>), dim3(nbt), dim3(QN_BLOCK), 0, s, S.grid, T.grid, T.raw, G.st, G.thr2, c->corr, sqd_out, c->nn_idx, c->nn_ref, c->fb_list, G.fb_count, c->big_list, G.big_count);
+      else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_nn_search<0, false, QN_NN_BLOCK>), dim3(L.grid_nb), dim3(QN_NN_BLOCK), 0, s, QN_NN_ARGS(G)); }
     { ProfScope ps(c, QN_K_NN_FALLBACK);
-      if (opt.group > 0) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_nn_search<0, true, QN_BLOCK, true>), dim3(fbb + big_blocks), dim3(QN_BLOCK), 0, s, S.grid, T.grid, st, thr2, r0, 64, c->corr, sqd_out, c->nn_idx, c->nn_ref, c->fb_list, fbc, c->big_list, bgc, big_blocks, big_ratio, far_stats, opt);
-      else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_nn_search<0, true, QN_BLOCK>), dim3(fbb + big_blocks), dim3(QN_BLOCK), 0, s, S.grid, T.grid, st, thr2, r0, 64, c->corr, sqd_out, c->nn_idx, c->nn_ref, c->fb_list, fbc, c->big_list, bgc, big_blocks, big_ratio, far_stats, opt); }
+      if (L.group) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_nn_search<0, true, QN_BLOCK, true>), dim3(L.list_nb), dim3(QN_BLOCK), 0, s, QN_NN_ARGS(F));
+      else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_nn_search<0, true, QN_BLOCK>), dim3(L.list_nb), dim3(QN_BLOCK), 0, s, QN_NN_ARGS(F)); }
   } else {
     ProfScope ps(c, QN_K_FITNESS);
-    if (seeded) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_nn_track<1>), dim3(nbt), dim3(QN_BLOCK), 0, s, S.grid, T.grid, T.raw, st, thr2, c->corr, sqd_out, c->nn_idx, c->nn_ref, c->fb_list, fbc, c->big_list, bgc);
-    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_nn_search<1, false, QN_NN_BLOCK>), dim3(nb), dim3(QN_NN_BLOCK), 0, s, S.grid, T.grid, st, thr2, r0, 1, c->corr, sqd_out, c->nn_idx, c->nn_ref, c->fb_list, fbc, c->big_list, bgc, 0, big_ratio, far_stats, opt0);
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_nn_search<1, true, QN_BLOCK>), dim3(fbb + big_blocks), dim3(QN_BLOCK), 0, s, S.grid, T.grid, st, thr2, r0, 64, c->corr, sqd_out, c->nn_idx, c->nn_ref, c->fb_list, fbc, c->big_list, bgc, big_blocks, big_ratio, far_stats, opt0);
+    if (seeded) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_nn_track<1>), dim3(nbt), dim3(QN_BLOCK), 0, s, S.grid, T.grid, T.raw, G.st, G.thr2, c->corr, sqd_out, c->nn_idx, c->nn_ref, c->fb_list, G.fb_count, c->big_list, G.big_count);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_nn_search<1, false, QN_NN_BLOCK>), dim3(L.grid_nb), dim3(QN_NN_BLOCK), 0, s, QN_NN_ARGS(G));
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_nn_search<1, true, QN_BLOCK>), dim3(L.list_nb), dim3(QN_BLOCK), 0, s, QN_NN_ARGS(F));
   }
 }
 // debug knob "verify_track": a fresh, unseeded search of the current pose into scratch buffers, compared query by query with what
@@ -449,19 +504,30 @@ static void enqueue_verify(qn_ctx* c, bool fused) {
 static uint32_t acc_blocks(const qn_ctx* c) { return std::min<uint32_t>((c->cloud[0].n + QN_BLOCK - 1) / QN_BLOCK, QN_ACC_MAX_BLOCKS); }
 static uint32_t tick_ppt(const qn_ctx* c) { return std::max<uint32_t>(c->tick_ppt_min, (c->cloud[0].n + c->tick_tb * QN_ACC_MAX_BLOCKS - 1) / (c->tick_tb * QN_ACC_MAX_BLOCKS)); }
 static uint32_t tick_blocks(const qn_ctx* c) { const uint32_t per = c->tick_tb * tick_ppt(c); return (c->cloud[0].n + per - 1) / per; }
-static void enqueue_accumulate(qn_ctx* c, int cond = 0) {          // partial rows of the CURRENT generation
-  ProfScope ps(c, QN_K_ACCUMULATE);
+static AccumulateK::Args prep_accumulate(qn_ctx* c, int cond) {          // partial rows of the CURRENT generation
   CloudBuf &S = c->cloud[0];
-  hipLaunchKernelGGL(k_accumulate, dim3(acc_blocks(c)), dim3(QN_BLOCK), 0, c->stream, S.raw, S.n, S.nrm, c->tgt_rec, c->corr, st_cur(c), part_cur(c), cond);
+  const AccumulateK::Args a{S.raw, S.n, S.nrm, c->tgt_rec, c->corr, st_cur(c), part_cur(c), cond};
   c->part_rows = (int)acc_blocks(c);
+  return a;
+}
+static void enqueue_accumulate(qn_ctx* c, int cond = 0) {
+  ProfScope ps(c, QN_K_ACCUMULATE);
+  const uint32_t nb = acc_blocks(c);
+  const AccumulateK::Args a = prep_accumulate(c, cond);
+  hipLaunchKernelGGL(k_accumulate, dim3(nb), dim3(QN_BLOCK), 0, c->stream, a.src_raw, a.ns, a.nrm_s, a.tgt_rec, a.corr, a.st, a.partials, a.cond);
 }
 // one controller step as its own launch: generation g -> g + 1 (k_solve)
+static SolveArgs prep_solve(qn_ctx* c, int mode, int will_produce, const LookArgs* look) {
+  LookArgs la; memset(&la, 0, sizeof(la)); if (look) la = *look;
+  const SolveArgs a{st_cur(c), st_nxt(c), part_cur(c), c->part_rows, make_cfg(c), c->trace, mode, will_produce, la};
+  c->gen++; c->part_rows = -1;                                      // consumed: whatever controller comes next (k_tick's prologue, the persistent kernel, another k_solve) must not step again
+  return a;
+}
 static void enqueue_solve(qn_ctx* c, int mode, int will_produce, const LookArgs* look = nullptr) {
   ProfScope ps(c, QN_K_SOLVE);
-  LookArgs la; memset(&la, 0, sizeof(la)); if (look) la = *look;
-  if (c->tick_tb == 256) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_solve<256>), dim3(1), dim3(256), 0, c->stream, st_cur(c), st_nxt(c), part_cur(c), c->part_rows, make_cfg(c), c->trace, mode, will_produce, la);
-  else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_solve<512>), dim3(1), dim3(512), 0, c->stream, st_cur(c), st_nxt(c), part_cur(c), c->part_rows, make_cfg(c), c->trace, mode, will_produce, la);
-  c->gen++; c->part_rows = -1;                                      // consumed: whatever controller comes next (k_tick's prologue, the persistent kernel, another k_solve) must not step again
+  const SolveArgs a = prep_solve(c, mode, will_produce, look);
+  if (c->tick_tb == 256) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_solve<256>), dim3(1), dim3(256), 0, c->stream, a.st_in, a.st_out, a.partials, a.rows, a.cfg, a.trace, a.mode, a.will_produce, a.look);
+  else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_solve<512>), dim3(1), dim3(512), 0, c->stream, a.st_in, a.st_out, a.partials, a.rows, a.cfg, a.trace, a.mode, a.will_produce, a.look);
 }
 // One "tick" of the device-side state machine = [controller step on the previous tick's partial rows] + [body under the new state].
 // Tracked regime: ONE kernel (k_tick: controller in the prologue of every block, tracked NN + accumulation, LM trial passes included).
@@ -476,8 +542,14 @@ static TickArgs tick_args(qn_ctx* c) {
   a.clk = c->clk_probe ? c->clk_probe + 8 * (c->clk_n++ % 256) : nullptr; a.clk_blk = c->clk_probe ? c->clk_probe + 8 * 256 : nullptr;
   return a;
 }
-static void enqueue_tick_fused(qn_ctx* c) {
+static FarArgs far_args(qn_ctx* c) {         // k_far behind the tick that just advanced the generation (st_cur = the state that tick published)
   CloudBuf &S = c->cloud[0], &T = c->cloud[1];
+  FarArgs f;
+  f.src = S.grid; f.tgt = T.grid; f.st = st_cur(c); f.thr2 = c->params.max_corr_dist * c->params.max_corr_dist; f.nn_idx = c->nn_idx; f.nn_ref = c->nn_ref; f.nrm_s = c->nrm_s_sorted; f.tgt_rec = c->tgt_rec; f.tgt_raw = T.raw;
+  f.cand = c->far_cand; f.cand_ref = c->far_cand_ref; f.cand_b = c->far_cand_b; f.far_req = c->far_req; f.far_rows = c->far_rows; f.far_stats = c->far_stats; f.ranked_max = c->far_ranked ? (uint32_t)QN_FAR_WORDS : 0u;
+  return f;
+}
+static void enqueue_tick_fused(qn_ctx* c) {
   TickArgs a = tick_args(c);
   { ProfScope ps(c, QN_K_GN_TICK_FUSED);
     const dim3 gr(tick_blocks(c)), bl(c->tick_tb);
@@ -489,9 +561,7 @@ static void enqueue_tick_fused(qn_ctx* c) {
   }
   c->gen++; c->part_rows = (int)tick_blocks(c);
   if (a.far_mode == 1) {                       // the tick's refresh requests, chip-wide, one query per wave; its rows follow the tick's
-    FarArgs f;
-    f.src = S.grid; f.tgt = T.grid; f.st = st_cur(c); f.thr2 = a.thr2; f.nn_idx = c->nn_idx; f.nn_ref = c->nn_ref; f.nrm_s = c->nrm_s_sorted; f.tgt_rec = c->tgt_rec; f.tgt_raw = T.raw;
-    f.cand = c->far_cand; f.cand_ref = c->far_cand_ref; f.cand_b = c->far_cand_b; f.far_req = c->far_req; f.far_rows = c->far_rows; f.far_stats = c->far_stats; f.ranked_max = c->far_ranked ? (uint32_t)QN_FAR_WORDS : 0u;
+    const FarArgs f = far_args(c);
     { ProfScope ps(c, QN_K_FAR);
       hipLaunchKernelGGL(k_far, dim3(QN_FAR_BLOCKS), dim3(QN_FAR_THREADS), 0, c->stream, f);
       hipLaunchKernelGGL(k_far_reduce, dim3(1), dim3(QN_FAR_BLOCKS), 0, c->stream, c->far_rows, part_cur(c) + (size_t)c->part_rows * QN_NPART, c->far_stats); }
@@ -806,7 +876,11 @@ extern "C" int qn_icp_alignment_device(qn_ctx* c, const float* src, uint32_t ns,
   return icp_alignment(c, src, ns, dst, nt, stride, thr, out, valid, 1);
 }
 
-// batch over several contexts (streams): one host worker thread per context, dynamic pair assignment
+// batch over several contexts (streams): one host worker thread per context, dynamic pair assignment.  A context whose batch_lanes is >= 2 (the default) takes
+// `batch_lanes` pairs at a time and registers them in lockstep, the pair as a grid dimension of every launch (qn_batch.inc); otherwise one pair at a time.
+namespace { bool batch_supported(const qn_ctx* c); int batch_ensure_lanes(qn_ctx* c);
+            int batch_register(qn_ctx* owner, const qn_pair_desc* pairs, const uint32_t* idx, uint32_t m, double thr, qn_gicp_result* results, int* valid, int* status,
+                               std::vector<const float*>& last_src, std::vector<uint64_t>& last_key); }
 extern "C" int qn_icp_alignment_batch(qn_ctx* const* ctxs, uint32_t n_ctx, const qn_pair_desc* pairs, uint32_t n_pairs, double thr,
                                       qn_gicp_result* results, int* valid, int* status) {
   if (!ctxs || n_ctx == 0 || (n_pairs && (!pairs || !results || !valid || !status))) return QN_ERR_INVALID_ARG;
@@ -816,18 +890,43 @@ extern "C" int qn_icp_alignment_batch(qn_ctx* const* ctxs, uint32_t n_ctx, const
   // add streams to the hardware queues (measured: 2290 -> 1880 registrations/s with 4 contexts), so it is switched off for the batch
   std::vector<char> saved(n_ctx);
   std::vector<char> saved_p(n_ctx);
-  for (uint32_t i = 0; i < n_ctx; i++) { saved[i] = ctxs[i]->pair_pipeline; saved_p[i] = ctxs[i]->persist_batch_off; if (n_ctx > 1) { ctxs[i]->pair_pipeline = false; ctxs[i]->persist_batch_off = true; } }
-  auto worker = [&](qn_ctx* c) {
+  std::vector<char> use_lanes(n_ctx);
+  for (uint32_t i = 0; i < n_ctx; i++) {
+    saved[i] = ctxs[i]->pair_pipeline; saved_p[i] = ctxs[i]->persist_batch_off;
+    use_lanes[i] = n_pairs > 1 && batch_supported(ctxs[i]) && batch_ensure_lanes(ctxs[i]) == QN_OK;
+    if (n_ctx > 1 || use_lanes[i]) { ctxs[i]->pair_pipeline = false; ctxs[i]->persist_batch_off = true; }
+  }
+  auto worker = [&](qn_ctx* c, bool lanes) {
+    if (lanes) {
+      (void)hipSetDevice(c->device);
+      const uint32_t B = (uint32_t)c->lanes.size();
+      // (pairs are dealt in runs of B; when the batch is smaller than the lanes of all contexts together the runs shrink so that every context gets work)
+      const uint32_t run = std::max<uint32_t>(1u, std::min<uint32_t>(B, (n_pairs + n_ctx - 1) / n_ctx));
+      std::vector<const float*> last_src(B, nullptr); std::vector<uint64_t> last_key(B, 0);
+      std::vector<uint32_t> idx(B);
+      for (;;) {
+        const uint32_t base = next.fetch_add(run);
+        if (base >= n_pairs) break;
+        const uint32_t m = std::min(run, n_pairs - base);
+        for (uint32_t l = 0; l < m; l++) idx[l] = base + l;
+        const int rc = batch_register(c, pairs, idx.data(), m, thr, results, valid, status, last_src, last_key);
+        if (rc != QN_OK) { (void)hipStreamSynchronize(c->stream); for (uint32_t l = 0; l < m; l++) status[base + l] = rc; std::fill(last_src.begin(), last_src.end(), nullptr); }
+      }
+      return;
+    }
+    const qn_pair_desc* last = nullptr;                                 // the source this context holds (within THIS call: same pointer = same cloud): the candidates of one query share it
     for (;;) {
       const uint32_t i = next.fetch_add(1);
       if (i >= n_pairs) break;
       const qn_pair_desc& p = pairs[i];
-      status[i] = icp_alignment(c, p.src, p.ns, p.dst, p.nt, p.stride_bytes, thr, &results[i], &valid[i], p.on_device ? 1 : 0);
+      const bool same = last && last->src == p.src && last->ns == p.ns && last->stride_bytes == p.stride_bytes && last->on_device == p.on_device;
+      status[i] = icp_alignment(c, p.src, p.ns, p.dst, p.nt, p.stride_bytes, thr, &results[i], &valid[i], p.on_device ? 1 : 0, same);
+      last = status[i] == QN_OK ? &p : nullptr;
     }
   };
   std::vector<std::thread> th;
-  for (uint32_t i = 1; i < n_ctx; i++) th.emplace_back(worker, ctxs[i]);
-  worker(ctxs[0]);
+  for (uint32_t i = 1; i < n_ctx; i++) th.emplace_back(worker, ctxs[i], use_lanes[i] != 0);
+  worker(ctxs[0], use_lanes[0] != 0);
   for (auto& t : th) t.join();
   for (uint32_t i = 0; i < n_ctx; i++) { ctxs[i]->pair_pipeline = saved[i] != 0; ctxs[i]->persist_batch_off = saved_p[i] != 0; }
   return QN_OK;
@@ -948,6 +1047,11 @@ extern "C" int qn_debug_set(qn_ctx* c, const char* key, double v) {
     if (c->pg_clk) (void)hipMemset(c->pg_clk, 0, 8 * (64 * 16 + 16));
     if (v == 0) { (void)hipFree(c->pg_clk); c->pg_clk = nullptr; }
   }
+  else if (k == "batch_lanes") {                                 // candidate pairs per kernel launch of the batch entry points (qn_batch.inc); < 2: one pair at a time on this context's stream
+    const int b = std::max(1, std::min((int)v, 64));
+    if (b < (int)c->lanes.size()) { if (hipStreamSynchronize(c->stream) != hipSuccess) return QN_ERR_HIP; while ((int)c->lanes.size() > std::max(b, 1)) { qn_ctx* l = c->lanes.back(); c->lanes.pop_back(); if (l != c) qn_ctx_destroy(l); } }
+    c->batch_lanes = b;
+  }
   else if (k == "batch_member") c->persist_batch_off = v != 0;      // this context registers beside others (qn_multi with in_flight > 1): no persistent launches
   else if (k == "stable_cells") c->stable_cells = v != 0;
   else if (k == "knn_hist") c->knn_hist = v != 0;
@@ -1025,7 +1129,10 @@ extern "C" int qn_debug_get(qn_ctx* c, const char* key, double* value) {
   if (k == "quatro_wall_match_ms") { *value = c->q_wall_ms[1]; return QN_OK; }
   if (k == "quatro_wall_solve_ms") { *value = c->q_wall_ms[2]; return QN_OK; }
   if (k == "extra_unseeded") { *value = c->last_extra_unseeded; return QN_OK; }          // the adaptive hand-over's decision in the latest align (ticks)
-  if (k == "persist_launches") { *value = c->persist_launches; return QN_OK; }      // aligns of this context that ran the persistent kernel
+  if (k == "persist_launches") { *value = c->persist_launches; return QN_OK; }
+  if (k == "batch_launches") { *value = (double)c->batch_launches; return QN_OK; }      // kernel launches / pairs of the batched path so far (launches per registration = the ratio)
+  if (k == "batch_pairs") { *value = (double)c->batch_pairs; return QN_OK; }
+  if (k == "batch_lanes") { *value = (double)c->batch_lanes; return QN_OK; }      // aligns of this context that ran the persistent kernel
   if (k == "feat_fallbacks") { *value = c->feat_fallbacks; return QN_OK; }      // matrix-core feature searches repeated with the VALU kernel (survivor overflow)
   if (k == "feat_survivors") { *value = c->feat_survivors; return QN_OK; }      // survivors of the latest forward search (exactly re-evaluated pairs)
   return QN_ERR_INVALID_ARG;
@@ -1060,4 +1167,5 @@ extern "C" int qn_debug_get_grid(qn_ctx* c, int which, double out[8]) {
   return QN_OK;
 }
 
+#include "qn_batch.inc"
 #include "qn_quatro_host.inc"

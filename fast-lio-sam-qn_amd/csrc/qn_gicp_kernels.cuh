@@ -49,15 +49,23 @@ __device__ __forceinline__ uint32_t xcd_block(uint32_t b, uint32_t nb) {
 }
 
 // ------------------------------------------------------------------ K1 grid build (utility kernels: qn_util_kernels.cuh)
-static __global__ void k_cell_count(const float4* __restrict__ pts, uint32_t n, GridView g, uint32_t* __restrict__ counts, uint32_t* __restrict__ cell_of_pt) {
-  g = grid_resolve(g);
-  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  float4 p = pts[i];
-  int cx = cell_coord(p.x, g.ox, g.inv_cell, g.nx), cy = cell_coord(p.y, g.oy, g.inv_cell, g.ny), cz = cell_coord(p.z, g.oz, g.inv_cell, g.nz);
-  uint32_t c = cell_key(g, cx, cy, cz);
-  cell_of_pt[i] = c;
-  atomicAdd(&counts[c], 1u);
+struct CellCountK {
+  static constexpr int TB = QN_BLOCK, OCC = 1;
+  struct Args { const float4* pts; uint32_t n; GridView g; uint32_t* counts; uint32_t* cell_of_pt; };
+  static __device__ __forceinline__ void run(const Args& a, const uint32_t bx, const uint32_t) {
+    const GridView g = grid_resolve(a.g);
+    const uint32_t i = bx * QN_BLOCK + threadIdx.x;
+    if (i >= a.n) return;
+    const float4 p = a.pts[i];
+    const int cx = cell_coord(p.x, g.ox, g.inv_cell, g.nx), cy = cell_coord(p.y, g.oy, g.inv_cell, g.ny), cz = cell_coord(p.z, g.oz, g.inv_cell, g.nz);
+    const uint32_t c = cell_key(g, cx, cy, cz);
+    a.cell_of_pt[i] = c;
+    atomicAdd(&a.counts[c], 1u);
+  }
+};
+static __global__ void __launch_bounds__(QN_BLOCK) k_cell_count(const float4* __restrict__ pts, uint32_t n, GridView g, uint32_t* __restrict__ counts, uint32_t* __restrict__ cell_of_pt) {
+  const CellCountK::Args a{pts, n, g, counts, cell_of_pt};
+  CellCountK::run(a, blockIdx.x, gridDim.x);
 }
 
 // The grid's numbers from the bounding box, on the device: cell edge ~4 points per ground-plane cell (the clouds are voxel-grid centroids sampled on
@@ -96,56 +104,66 @@ __device__ inline GridDims grid_dims_from_bbox(const int (&omn)[3], const int (&
 // kernel, no read-back in front of or behind the build.  (Accumulator words are only ever touched with agent-scope atomics: the blocks sit on different XCDs.)
 #define QN_BBOX_MAX_BLOCKS 256
 struct BBoxAcc { int mn[3], mx[3]; uint32_t nonfinite, ticket; };
+struct PackBBoxK {
+  static constexpr int TB = QN_BLOCK, OCC = 1;
+  struct Args { const char* in; uint32_t stride, n; float4* raw; BBoxAcc* acc; uint32_t max_cells; double cell_override; GridDims* dims_dev; GridDims* dims_host; };
+  static __device__ __forceinline__ void run(const Args& a, const uint32_t bx, const uint32_t nbx) {
+    __shared__ int smn[QN_BLOCK / 64][3], smx[QN_BLOCK / 64][3], sbad[QN_BLOCK / 64];
+    const char* __restrict__ in = a.in; float4* __restrict__ raw = a.raw; BBoxAcc* acc = a.acc;
+    const uint32_t n = a.n, stride = a.stride;
+    int mn[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff}, mx[3] = {(int)0x80000000, (int)0x80000000, (int)0x80000000};
+    int bad = 0;
+    for (uint32_t i = bx * QN_BLOCK + threadIdx.x; i < n; i += nbx * QN_BLOCK) {
+      const float* q = (const float*)(in + (size_t)i * stride);
+      const float4 p = make_float4(q[0], q[1], q[2], 1.0f);
+      raw[i] = p;
+      if (!(isfinite(p.x) && isfinite(p.y) && isfinite(p.z))) { bad = 1; continue; }
+      const int ox = f2ord(p.x), oy = f2ord(p.y), oz = f2ord(p.z);
+      mn[0] = min(mn[0], ox); mn[1] = min(mn[1], oy); mn[2] = min(mn[2], oz);
+      mx[0] = max(mx[0], ox); mx[1] = max(mx[1], oy); mx[2] = max(mx[2], oz);
+    }
+#pragma unroll
+    for (int d = 0; d < 3; d++) { mn[d] = wave_min_i(mn[d]); mx[d] = wave_max_i(mx[d]); }
+    bad = wave_max_i(bad);
+    const int wid = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { for (int d = 0; d < 3; d++) { smn[wid][d] = mn[d]; smx[wid][d] = mx[d]; } sbad[wid] = bad; }
+    __syncthreads();
+    __shared__ int s_last;
+    if (threadIdx.x == 0) {
+      for (int w = 1; w < QN_BLOCK / 64; w++) { for (int d = 0; d < 3; d++) { mn[d] = min(mn[d], smn[w][d]); mx[d] = max(mx[d], smx[w][d]); } bad |= sbad[w]; }
+      // the block's box goes to a slot of its own (six contended atomics per block on the same words cost more than the whole reduction: 64 blocks, 10 us);
+      // the one contended operation left is the ticket
+      BBoxAcc* mine = acc + 1 + bx;
+      for (int d = 0; d < 3; d++) { __hip_atomic_store(&mine->mn[d], mn[d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); __hip_atomic_store(&mine->mx[d], mx[d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+      __hip_atomic_store(&mine->nonfinite, (uint32_t)bad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __threadfence();
+      s_last = atomicAdd(&acc->ticket, 1u) == nbx - 1u ? 1 : 0;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    // the last block: its first wave folds the slots (one per lane, QN_BBOX_MAX_BLOCKS <= 256: four rounds at most), lane 0 derives the numbers
+    if (threadIdx.x >= 64) return;
+    __threadfence();
+    for (int d = 0; d < 3; d++) { mn[d] = 0x7fffffff; mx[d] = (int)0x80000000; }
+    int nf = 0;
+    for (uint32_t b = threadIdx.x; b < nbx; b += 64) {
+      const BBoxAcc* o = acc + 1 + b;
+      for (int d = 0; d < 3; d++) { mn[d] = min(mn[d], __hip_atomic_load(&o->mn[d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)); mx[d] = max(mx[d], __hip_atomic_load(&o->mx[d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)); }
+      nf |= (int)__hip_atomic_load(&o->nonfinite, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+#pragma unroll
+    for (int d = 0; d < 3; d++) { mn[d] = wave_min_i(mn[d]); mx[d] = wave_max_i(mx[d]); }
+    nf = wave_max_i(nf);
+    if (threadIdx.x != 0) return;
+    const GridDims g = grid_dims_from_bbox(mn, mx, nf != 0, n, a.max_cells, a.cell_override);
+    *a.dims_dev = g; *a.dims_host = g;
+    __hip_atomic_store(&acc->ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+};
 static __global__ void __launch_bounds__(QN_BLOCK) k_pack_bbox_dims(const char* __restrict__ in, uint32_t stride, uint32_t n, float4* __restrict__ raw, BBoxAcc* acc,
                                                                     uint32_t max_cells, double cell_override, GridDims* __restrict__ dims_dev, GridDims* __restrict__ dims_host) {
-  __shared__ int smn[QN_BLOCK / 64][3], smx[QN_BLOCK / 64][3], sbad[QN_BLOCK / 64];
-  int mn[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff}, mx[3] = {(int)0x80000000, (int)0x80000000, (int)0x80000000};
-  int bad = 0;
-  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-    const float* q = (const float*)(in + (size_t)i * stride);
-    const float4 p = make_float4(q[0], q[1], q[2], 1.0f);
-    raw[i] = p;
-    if (!(isfinite(p.x) && isfinite(p.y) && isfinite(p.z))) { bad = 1; continue; }
-    const int ox = f2ord(p.x), oy = f2ord(p.y), oz = f2ord(p.z);
-    mn[0] = min(mn[0], ox); mn[1] = min(mn[1], oy); mn[2] = min(mn[2], oz);
-    mx[0] = max(mx[0], ox); mx[1] = max(mx[1], oy); mx[2] = max(mx[2], oz);
-  }
-#pragma unroll
-  for (int d = 0; d < 3; d++) { mn[d] = wave_min_i(mn[d]); mx[d] = wave_max_i(mx[d]); }
-  bad = wave_max_i(bad);
-  const int wid = threadIdx.x >> 6;
-  if ((threadIdx.x & 63) == 0) { for (int d = 0; d < 3; d++) { smn[wid][d] = mn[d]; smx[wid][d] = mx[d]; } sbad[wid] = bad; }
-  __syncthreads();
-  __shared__ int s_last;
-  if (threadIdx.x == 0) {
-    for (int w = 1; w < QN_BLOCK / 64; w++) { for (int d = 0; d < 3; d++) { mn[d] = min(mn[d], smn[w][d]); mx[d] = max(mx[d], smx[w][d]); } bad |= sbad[w]; }
-    // the block's box goes to a slot of its own (six contended atomics per block on the same words cost more than the whole reduction: 64 blocks, 10 us);
-    // the one contended operation left is the ticket
-    BBoxAcc* mine = acc + 1 + blockIdx.x;
-    for (int d = 0; d < 3; d++) { __hip_atomic_store(&mine->mn[d], mn[d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); __hip_atomic_store(&mine->mx[d], mx[d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-    __hip_atomic_store(&mine->nonfinite, (uint32_t)bad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __threadfence();
-    s_last = atomicAdd(&acc->ticket, 1u) == gridDim.x - 1u ? 1 : 0;
-  }
-  __syncthreads();
-  if (!s_last) return;
-  // the last block: its first wave folds the slots (one per lane, QN_BBOX_MAX_BLOCKS <= 256: four rounds at most), lane 0 derives the numbers
-  if (threadIdx.x >= 64) return;
-  __threadfence();
-  for (int d = 0; d < 3; d++) { mn[d] = 0x7fffffff; mx[d] = (int)0x80000000; }
-  int nf = 0;
-  for (uint32_t b = threadIdx.x; b < gridDim.x; b += 64) {
-    const BBoxAcc* o = acc + 1 + b;
-    for (int d = 0; d < 3; d++) { mn[d] = min(mn[d], __hip_atomic_load(&o->mn[d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)); mx[d] = max(mx[d], __hip_atomic_load(&o->mx[d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)); }
-    nf |= (int)__hip_atomic_load(&o->nonfinite, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-#pragma unroll
-  for (int d = 0; d < 3; d++) { mn[d] = wave_min_i(mn[d]); mx[d] = wave_max_i(mx[d]); }
-  nf = wave_max_i(nf);
-  if (threadIdx.x != 0) return;
-  const GridDims g = grid_dims_from_bbox(mn, mx, nf != 0, n, max_cells, cell_override);
-  *dims_dev = g; *dims_host = g;
-  __hip_atomic_store(&acc->ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const PackBBoxK::Args a{in, stride, n, raw, acc, max_cells, cell_override, dims_dev, dims_host};
+  PackBBoxK::run(a, blockIdx.x, gridDim.x);
 }
 static __global__ void k_bbox_acc_init(BBoxAcc* acc, int count) {
   for (int i = threadIdx.x; blockIdx.x == 0 && i < count; i += blockDim.x) { BBoxAcc a; for (int d = 0; d < 3; d++) { a.mn[d] = 0x7fffffff; a.mx[d] = (int)0x80000000; } a.nonfinite = 0; a.ticket = 0; acc[i] = a; }
@@ -157,82 +175,100 @@ static __global__ void k_bbox_acc_init(BBoxAcc* acc, int count) {
 // at once.  All blocks are co-resident (<= 2048 tiles of 256 threads on 256 CUs), so a tile waiting on its predecessors cannot starve them.  out[m] = total.
 #define QN_LB_STATE_AGG 1ull
 #define QN_LB_STATE_INC 2ull
+struct ScanLookbackK {
+  static constexpr int TB = QN_BLOCK, OCC = 1;
+  struct Args { const uint32_t* in; const GridDims* dims; uint32_t* out; unsigned long long* status; uint32_t epoch, total; };
+  static __device__ __forceinline__ void run(const Args& a, const uint32_t bx, const uint32_t) {
+    __shared__ uint32_t wsum[QN_BLOCK / 64];
+    __shared__ uint32_t s_prefix;
+    const uint32_t* __restrict__ in = a.in; uint32_t* __restrict__ out = a.out; unsigned long long* status = a.status;
+    const uint32_t total = a.total;
+    const uint32_t m = uni(a.dims->ncells);
+    const uint32_t tile = bx;
+    if (tile * (uint32_t)(QN_BLOCK * QN_SCAN_ITEMS) >= m) return;
+    const uint32_t base = (tile * QN_BLOCK + threadIdx.x) * QN_SCAN_ITEMS;
+    uint32_t v[QN_SCAN_ITEMS], s = 0;
+    if (base + QN_SCAN_ITEMS <= m) {
+      const uint4* q = (const uint4*)(in + base);
+#pragma unroll
+      for (int j = 0; j < QN_SCAN_ITEMS / 4; j++) { const uint4 x = q[j]; v[4 * j] = x.x; v[4 * j + 1] = x.y; v[4 * j + 2] = x.z; v[4 * j + 3] = x.w; }
+    } else {
+#pragma unroll
+      for (int j = 0; j < QN_SCAN_ITEMS; j++) v[j] = (base + j < m) ? in[base + j] : 0u;
+    }
+#pragma unroll
+    for (int j = 0; j < QN_SCAN_ITEMS; j++) s += v[j];
+    uint32_t inc = s;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { uint32_t t = __shfl_up(inc, o); if (lane >= o) inc += t; }
+    if (lane == 63) wsum[wid] = inc;
+    __syncthreads();
+    uint32_t woff = 0, agg = 0;
+    for (int w = 0; w < QN_BLOCK / 64; w++) { if (w < wid) woff += wsum[w]; agg += wsum[w]; }
+    const unsigned long long tag = (unsigned long long)(a.epoch & 0x3fffffffu) << 34;
+    if (wid == 0) {
+      uint32_t prefix = 0;
+      if (tile == 0) {
+        if (lane == 0) __hip_atomic_store(status, tag | (QN_LB_STATE_INC << 32) | agg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      } else {
+        if (lane == 0) __hip_atomic_store(status + tile, tag | (QN_LB_STATE_AGG << 32) | agg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int look = (int)tile - 1;                                      // lane l watches tile look - l
+        for (;;) {
+          const int mine = look - lane;
+          unsigned long long x = 0;
+          if (mine >= 0) { do { x = __hip_atomic_load(status + mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } while ((x >> 34) != (tag >> 34)); }
+          const bool is_inc = mine >= 0 && ((x >> 32) & 3ull) == QN_LB_STATE_INC;
+          const unsigned long long incs = __ballot(is_inc);
+          const int first = incs ? __ffsll((long long)incs) - 1 : 64;  // nearest tile with an inclusive prefix, as a lane number
+          uint32_t part = (mine >= 0 && lane <= first) ? (uint32_t)x : 0u;
+#pragma unroll
+          for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);
+          prefix += part;
+          if (incs || look - 64 < 0) break;
+          look -= 64;
+        }
+        if (lane == 0) __hip_atomic_store(status + tile, tag | (QN_LB_STATE_INC << 32) | (prefix + agg), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      if (lane == 0) s_prefix = prefix;
+    }
+    __syncthreads();
+    uint32_t run = s_prefix + woff + inc - s;
+    if (base + QN_SCAN_ITEMS <= m) {
+      uint4* q = (uint4*)(out + base);
+#pragma unroll
+      for (int j = 0; j < QN_SCAN_ITEMS / 4; j++) { uint4 x; x.x = run; run += v[4 * j]; x.y = run; run += v[4 * j + 1]; x.z = run; run += v[4 * j + 2]; x.w = run; run += v[4 * j + 3]; q[j] = x; }
+    } else {
+#pragma unroll
+      for (int j = 0; j < QN_SCAN_ITEMS; j++) { if (base + j < m) out[base + j] = run; run += v[j]; }
+    }
+    if (base <= m && m < base + QN_SCAN_ITEMS) out[m] = total;       // (m is a multiple of the 128-cell tile: this is the thread whose first item would be index m ...)
+    if (m == (tile + 1u) * (uint32_t)(QN_BLOCK * QN_SCAN_ITEMS) && threadIdx.x == QN_BLOCK - 1) out[m] = total;      // (... or the table ends with this tile)
+  }
+};
 static __global__ void __launch_bounds__(QN_BLOCK) k_scan_lookback(const uint32_t* __restrict__ in, const GridDims* __restrict__ dims, uint32_t* __restrict__ out,
                                                                    unsigned long long* status, uint32_t epoch, uint32_t total) {
-  __shared__ uint32_t wsum[QN_BLOCK / 64];
-  __shared__ uint32_t s_prefix;
-  const uint32_t m = dims->ncells;
-  const uint32_t tile = blockIdx.x;
-  if (tile * (uint32_t)(QN_BLOCK * QN_SCAN_ITEMS) >= m) return;
-  const uint32_t base = (tile * QN_BLOCK + threadIdx.x) * QN_SCAN_ITEMS;
-  uint32_t v[QN_SCAN_ITEMS], s = 0;
-  if (base + QN_SCAN_ITEMS <= m) {
-    const uint4* q = (const uint4*)(in + base);
-#pragma unroll
-    for (int j = 0; j < QN_SCAN_ITEMS / 4; j++) { const uint4 x = q[j]; v[4 * j] = x.x; v[4 * j + 1] = x.y; v[4 * j + 2] = x.z; v[4 * j + 3] = x.w; }
-  } else {
-#pragma unroll
-    for (int j = 0; j < QN_SCAN_ITEMS; j++) v[j] = (base + j < m) ? in[base + j] : 0u;
-  }
-#pragma unroll
-  for (int j = 0; j < QN_SCAN_ITEMS; j++) s += v[j];
-  uint32_t inc = s;
-  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) { uint32_t t = __shfl_up(inc, o); if (lane >= o) inc += t; }
-  if (lane == 63) wsum[wid] = inc;
-  __syncthreads();
-  uint32_t woff = 0, agg = 0;
-  for (int w = 0; w < QN_BLOCK / 64; w++) { if (w < wid) woff += wsum[w]; agg += wsum[w]; }
-  const unsigned long long tag = (unsigned long long)(epoch & 0x3fffffffu) << 34;
-  if (wid == 0) {
-    uint32_t prefix = 0;
-    if (tile == 0) {
-      if (lane == 0) __hip_atomic_store(status, tag | (QN_LB_STATE_INC << 32) | agg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    } else {
-      if (lane == 0) __hip_atomic_store(status + tile, tag | (QN_LB_STATE_AGG << 32) | agg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      int look = (int)tile - 1;                                      // lane l watches tile look - l
-      for (;;) {
-        const int mine = look - lane;
-        unsigned long long x = 0;
-        if (mine >= 0) { do { x = __hip_atomic_load(status + mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } while ((x >> 34) != (tag >> 34)); }
-        const bool is_inc = mine >= 0 && ((x >> 32) & 3ull) == QN_LB_STATE_INC;
-        const unsigned long long incs = __ballot(is_inc);
-        const int first = incs ? __ffsll((long long)incs) - 1 : 64;  // nearest tile with an inclusive prefix, as a lane number
-        uint32_t part = (mine >= 0 && lane <= first) ? (uint32_t)x : 0u;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);
-        prefix += part;
-        if (incs || look - 64 < 0) break;
-        look -= 64;
-      }
-      if (lane == 0) __hip_atomic_store(status + tile, tag | (QN_LB_STATE_INC << 32) | (prefix + agg), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    if (lane == 0) s_prefix = prefix;
-  }
-  __syncthreads();
-  uint32_t run = s_prefix + woff + inc - s;
-  if (base + QN_SCAN_ITEMS <= m) {
-    uint4* q = (uint4*)(out + base);
-#pragma unroll
-    for (int j = 0; j < QN_SCAN_ITEMS / 4; j++) { uint4 x; x.x = run; run += v[4 * j]; x.y = run; run += v[4 * j + 1]; x.z = run; run += v[4 * j + 2]; x.w = run; run += v[4 * j + 3]; q[j] = x; }
-  } else {
-#pragma unroll
-    for (int j = 0; j < QN_SCAN_ITEMS; j++) { if (base + j < m) out[base + j] = run; run += v[j]; }
-  }
-  if (base <= m && m < base + QN_SCAN_ITEMS) out[m] = total;       // (m is a multiple of the 128-cell tile: this is the thread whose first item would be index m ...)
-  if (m == (tile + 1u) * (uint32_t)(QN_BLOCK * QN_SCAN_ITEMS) && threadIdx.x == QN_BLOCK - 1) out[m] = total;      // (... or the table ends with this tile)
+  const ScanLookbackK::Args a{in, dims, out, status, epoch, total};
+  ScanLookbackK::run(a, blockIdx.x, gridDim.x);
 }
 
-static __global__ void k_scatter(const float4* __restrict__ pts, uint32_t n, const uint32_t* __restrict__ cell_of_pt,
+struct ScatterK {
+  static constexpr int TB = QN_BLOCK, OCC = 1;
+  struct Args { const float4* pts; uint32_t n; const uint32_t* cell_of_pt; const uint32_t* cell_start; uint32_t* counts; float4* sorted; };
+  static __device__ __forceinline__ void run(const Args& a, const uint32_t bx, const uint32_t) {
+    const uint32_t i = bx * QN_BLOCK + threadIdx.x;
+    if (i >= a.n) return;
+    const uint32_t c = a.cell_of_pt[i];
+    const uint32_t slot = a.cell_start[c] + atomicSub(&a.counts[c], 1u) - 1u;
+    float4 p = a.pts[i];
+    p.w = __uint_as_float(i);
+    a.sorted[slot] = p;
+  }
+};
+static __global__ void __launch_bounds__(QN_BLOCK) k_scatter(const float4* __restrict__ pts, uint32_t n, const uint32_t* __restrict__ cell_of_pt,
                           const uint32_t* __restrict__ cell_start, uint32_t* __restrict__ counts, float4* __restrict__ sorted) {
-  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  uint32_t c = cell_of_pt[i];
-  uint32_t slot = cell_start[c] + atomicSub(&counts[c], 1u) - 1u;
-  float4 p = pts[i];
-  p.w = __uint_as_float(i);
-  sorted[slot] = p;
+  const ScatterK::Args a{pts, n, cell_of_pt, cell_start, counts, sorted};
+  ScatterK::run(a, blockIdx.x, gridDim.x);
 }
 
 // The scatter's atomics hand out the slots of a cell in arrival order: the order INSIDE a cell differs from run to run.  Searches do not care
@@ -240,17 +276,26 @@ static __global__ void k_scatter(const float4* __restrict__ pts, uint32_t n, con
 // the FPFH kernels sum neighbours in walk order: with an arbitrary order inside the cells those f64 sums - and so H, b and the pose - differed
 // in the last bits between two runs of the same registration.  This pass puts every cell's points in ascending original index (rank = number of
 // smaller indices in the cell: ~4 points per cell, one thread per point).  Cells above 256 points (degenerate clouds) keep the arrival order.
-static __global__ void k_stable_cells(const float4* __restrict__ in, uint32_t n, const uint32_t* __restrict__ cell_of_pt, const uint32_t* __restrict__ cell_start,
+struct StableCellsK {
+  static constexpr int TB = QN_BLOCK, OCC = 1;
+  struct Args { const float4* in; uint32_t n; const uint32_t* cell_of_pt; const uint32_t* cell_start; float4* out; };
+  static __device__ __forceinline__ void run(const Args& a, const uint32_t bx, const uint32_t) {
+    const float4* __restrict__ in = a.in; float4* __restrict__ out = a.out;
+    const uint32_t t = bx * QN_BLOCK + threadIdx.x;
+    if (t >= a.n) return;
+    const float4 p = in[t];
+    const uint32_t i = __float_as_uint(p.w), c = a.cell_of_pt[i];
+    const uint32_t s = a.cell_start[c], e = a.cell_start[c + 1];
+    if (e - s > 256u) { out[t] = p; return; }
+    uint32_t rank = 0;
+    for (uint32_t u = s; u < e; u++) rank += __float_as_uint(in[u].w) < i ? 1u : 0u;
+    out[s + rank] = p;
+  }
+};
+static __global__ void __launch_bounds__(QN_BLOCK) k_stable_cells(const float4* __restrict__ in, uint32_t n, const uint32_t* __restrict__ cell_of_pt, const uint32_t* __restrict__ cell_start,
                                       float4* __restrict__ out) {
-  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= n) return;
-  const float4 p = in[t];
-  const uint32_t i = __float_as_uint(p.w), c = cell_of_pt[i];
-  const uint32_t s = cell_start[c], e = cell_start[c + 1];
-  if (e - s > 256u) { out[t] = p; return; }
-  uint32_t rank = 0;
-  for (uint32_t u = s; u < e; u++) rank += __float_as_uint(in[u].w) < i ? 1u : 0u;
-  out[s + rank] = p;
+  const StableCellsK::Args a{in, n, cell_of_pt, cell_start, out};
+  StableCellsK::run(a, blockIdx.x, gridDim.x);
 }
 
 // ------------------------------------------------------------------ K2+K3 k-NN + covariance (k-NN selection: k_knn_hist below, k_knn_cov in qn_knn_kernels.cuh)
@@ -263,62 +308,73 @@ struct __attribute__((aligned(64))) TargetRec { float4 p; double n[3]; double pa
 static_assert(sizeof(TargetRec) == 64, "TargetRec is one 64-byte line");
 // Threads walk the points in cell-sorted order (a block's points are spatial neighbours, so their k-NN gathers overlap in
 // L1/L2), blocks in XCD-aware order.
+struct CovFromIdxK {
+  static constexpr int TB = QN_BLOCK, OCC = 1;
+  struct Args { const float4* raw; const float4* sorted; uint32_t n; int k; const int32_t* knn_idx; double* nrm; double* nrm_sorted; TargetRec* rec; uint32_t* list_counts; };
+  static __device__ __forceinline__ void run(const Args& a, const uint32_t bx, const uint32_t nbx) {
+    const float4* __restrict__ raw = a.raw; const int32_t* __restrict__ knn_idx = a.knn_idx;
+    double* __restrict__ nrm = a.nrm; double* __restrict__ nrm_sorted = a.nrm_sorted; TargetRec* __restrict__ rec = a.rec;
+    const int k = a.k;
+    if (bx == 0 && threadIdx.x < 4) a.list_counts[threadIdx.x] = 0u;      // the selection passes' list counters go back to zero behind their last reader (no memset in front of the next cloud)
+    const uint32_t spos = xcd_block(bx, nbx) * QN_BLOCK + threadIdx.x;
+    if (spos >= a.n) return;
+    const uint32_t i = __float_as_uint(a.sorted[spos].w);
+    const int32_t* nb = knn_idx + (size_t)i * k;
+    int found = 0;
+    double mean[3] = {0, 0, 0};
+    // neighbours four at a time: the four index loads, then the four point gathers are issued together (a loop of dependent idx -> point
+    // round trips with 1.5 waves per SIMD was the whole cost of this kernel); the sums are still formed in neighbour order
+    for (int j = 0; j < k; j += 4) {
+      int32_t u[4]; float4 q[4];
+#pragma unroll
+      for (int e = 0; e < 4; e++) u[e] = j + e < k ? nb[j + e] : -1;
+#pragma unroll
+      for (int e = 0; e < 4; e++) q[e] = raw[u[e] < 0 ? 0 : u[e]];
+#pragma unroll
+      for (int e = 0; e < 4; e++) if (u[e] >= 0) { mean[0] += (double)q[e].x; mean[1] += (double)q[e].y; mean[2] += (double)q[e].z; found++; }
+    }
+    double nv[3] = {0, 0, 0};                  // found == 0 cannot happen for a finite point (it is its own neighbour); a zero normal reads as C = I
+    // the layouts of the optimiser ticks are written here as well (nrm_sorted: source, cell-sorted order; rec: target, 64-byte records)
+    auto store = [&]() __attribute__((always_inline)) {
+#pragma unroll
+      for (int u = 0; u < 3; u++) nrm[(size_t)i * 3 + u] = nv[u];
+      if (nrm_sorted) {
+#pragma unroll
+        for (int u = 0; u < 3; u++) nrm_sorted[(size_t)spos * 3 + u] = nv[u];
+      }
+      if (rec) { TargetRec r; r.p = raw[i];
+#pragma unroll
+        for (int u = 0; u < 3; u++) { r.n[u] = nv[u]; r.pad[u] = 0; }
+        rec[i] = r; }
+    };
+    if (found == 0) { store(); return; }
+    mean[0] /= found; mean[1] /= found; mean[2] /= found;
+    double c[6] = {0, 0, 0, 0, 0, 0};
+    for (int j = 0; j < k; j += 4) {
+      int32_t u[4]; float4 q[4];
+#pragma unroll
+      for (int e = 0; e < 4; e++) u[e] = j + e < k ? nb[j + e] : -1;
+#pragma unroll
+      for (int e = 0; e < 4; e++) q[e] = raw[u[e] < 0 ? 0 : u[e]];
+#pragma unroll
+      for (int e = 0; e < 4; e++) if (u[e] >= 0) {
+        const double dx = (double)q[e].x - mean[0], dy = (double)q[e].y - mean[1], dz = (double)q[e].z - mean[2];
+        c[0] += dx * dx; c[1] += dx * dy; c[2] += dx * dz; c[3] += dy * dy; c[4] += dy * dz; c[5] += dz * dz;
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < 6; t++) c[t] /= found;
+    double w[3], V[3][3];
+    sym_eig3(c, w, V);
+    // C = V diag(1, 1, 1e-3) V^T = I - 0.999 v3 v3^T  (V orthonormal): keep v3, the eigenvector of the smallest eigenvalue
+    nv[0] = V[0][2]; nv[1] = V[1][2]; nv[2] = V[2][2];
+    store();
+  }
+};
 static __global__ void __launch_bounds__(QN_BLOCK) k_cov_from_idx(const float4* __restrict__ raw, const float4* __restrict__ sorted, uint32_t n, int k, const int32_t* __restrict__ knn_idx, double* __restrict__ nrm,
                                                                   double* __restrict__ nrm_sorted, TargetRec* __restrict__ rec, uint32_t* __restrict__ list_counts) {
-  if (blockIdx.x == 0 && threadIdx.x < 4) list_counts[threadIdx.x] = 0u;      // the selection passes' list counters go back to zero behind their last reader (no memset in front of the next cloud)
-  const uint32_t spos = xcd_block(blockIdx.x, gridDim.x) * QN_BLOCK + threadIdx.x;
-  if (spos >= n) return;
-  const uint32_t i = __float_as_uint(sorted[spos].w);
-  const int32_t* nb = knn_idx + (size_t)i * k;
-  int found = 0;
-  double mean[3] = {0, 0, 0};
-  // neighbours four at a time: the four index loads, then the four point gathers are issued together (a loop of dependent idx -> point
-  // round trips with 1.5 waves per SIMD was the whole cost of this kernel); the sums are still formed in neighbour order
-  for (int j = 0; j < k; j += 4) {
-    int32_t u[4]; float4 q[4];
-#pragma unroll
-    for (int e = 0; e < 4; e++) u[e] = j + e < k ? nb[j + e] : -1;
-#pragma unroll
-    for (int e = 0; e < 4; e++) q[e] = raw[u[e] < 0 ? 0 : u[e]];
-#pragma unroll
-    for (int e = 0; e < 4; e++) if (u[e] >= 0) { mean[0] += (double)q[e].x; mean[1] += (double)q[e].y; mean[2] += (double)q[e].z; found++; }
-  }
-  double nv[3] = {0, 0, 0};                  // found == 0 cannot happen for a finite point (it is its own neighbour); a zero normal reads as C = I
-  // the layouts of the optimiser ticks are written here as well (nrm_sorted: source, cell-sorted order; rec: target, 64-byte records)
-  auto store = [&]() __attribute__((always_inline)) {
-#pragma unroll
-    for (int u = 0; u < 3; u++) nrm[(size_t)i * 3 + u] = nv[u];
-    if (nrm_sorted) {
-#pragma unroll
-      for (int u = 0; u < 3; u++) nrm_sorted[(size_t)spos * 3 + u] = nv[u];
-    }
-    if (rec) { TargetRec r; r.p = raw[i];
-#pragma unroll
-      for (int u = 0; u < 3; u++) { r.n[u] = nv[u]; r.pad[u] = 0; }
-      rec[i] = r; }
-  };
-  if (found == 0) { store(); return; }
-  mean[0] /= found; mean[1] /= found; mean[2] /= found;
-  double c[6] = {0, 0, 0, 0, 0, 0};
-  for (int j = 0; j < k; j += 4) {
-    int32_t u[4]; float4 q[4];
-#pragma unroll
-    for (int e = 0; e < 4; e++) u[e] = j + e < k ? nb[j + e] : -1;
-#pragma unroll
-    for (int e = 0; e < 4; e++) q[e] = raw[u[e] < 0 ? 0 : u[e]];
-#pragma unroll
-    for (int e = 0; e < 4; e++) if (u[e] >= 0) {
-      const double dx = (double)q[e].x - mean[0], dy = (double)q[e].y - mean[1], dz = (double)q[e].z - mean[2];
-      c[0] += dx * dx; c[1] += dx * dy; c[2] += dx * dz; c[3] += dy * dy; c[4] += dy * dz; c[5] += dz * dz;
-    }
-  }
-#pragma unroll
-  for (int t = 0; t < 6; t++) c[t] /= found;
-  double w[3], V[3][3];
-  sym_eig3(c, w, V);
-  // C = V diag(1, 1, 1e-3) V^T = I - 0.999 v3 v3^T  (V orthonormal): keep v3, the eigenvector of the smallest eigenvalue
-  nv[0] = V[0][2]; nv[1] = V[1][2]; nv[2] = V[2][2];
-  store();
+  const CovFromIdxK::Args a{raw, sorted, n, k, knn_idx, nrm, nrm_sorted, rec, list_counts};
+  CovFromIdxK::run(a, blockIdx.x, gridDim.x);
 }
 
 // parity read-back: the 3x3 covariances the reference stores (A.1.3), rebuilt from the normals: xx xy xz yy yz zz
@@ -342,50 +398,74 @@ static __global__ void k_cov_from_normals(const double* __restrict__ nrm, uint32
 #ifndef QN_KNN_BLOCK
 #define QN_KNN_BLOCK 64
 #endif
+struct KnnHistArgs { GridView g; int k; float r0; int max_rounds; int32_t* knn_idx; float* knn_d2; uint2* fb_list; uint32_t* fb_count; uint2* gen_list; uint32_t* gen_count; };
+template <bool LIST, int HCAP>
+struct KnnHistK {
+  static constexpr int TB = QN_KNN_BLOCK, OCC = HCAP <= 32 ? 4 : 3;
+  using Args = KnnHistArgs;
+  static __device__ __forceinline__ void run(const Args& a, const uint32_t bx, const uint32_t nbx) {
+    __shared__ WaveLdsH<HCAP> lds[QN_KNN_BLOCK / 64];
+    const GridView g = grid_resolve(a.g);
+    const int k = a.k, max_rounds = a.max_rounds;
+    int32_t* __restrict__ knn_idx = a.knn_idx; float* __restrict__ knn_d2 = a.knn_d2;
+    uint2* __restrict__ fb_list = a.fb_list; uint32_t* __restrict__ fb_count = a.fb_count; uint2* __restrict__ gen_list = a.gen_list; uint32_t* __restrict__ gen_count = a.gen_count;
+    float r0 = a.r0; if (r0 < 0.f) r0 = -r0 * g.cell;              // (a negative radius is in cells: the host does not know the cell edge)
+    WaveLdsH<HCAP>* my = &lds[threadIdx.x >> 6];
+    const uint32_t nq = LIST ? uni(*fb_count) : g.n;
+    if (LIST && g.dbg && bx == 0 && threadIdx.x == 0) atomicAdd(&g.dbg[4], nq);
+    const uint32_t wave0 = (LIST ? bx : xcd_block(bx, nbx)) * (QN_KNN_BLOCK / 64) + (threadIdx.x >> 6), nwaves = nbx * (QN_KNN_BLOCK / 64);
+    for (uint32_t base = wave0 * 16; base < nq; base += nwaves * 16) {
+      const uint32_t slot = base + (threadIdx.x & 15);
+      bool active = slot < nq;
+      uint32_t t = slot; float r = r0; bool general = false;
+      if (LIST && active) { const uint2 rec = fb_list[slot]; t = rec.x; r = __uint_as_float(rec.y & 0x7fffffffu); general = (rec.y >> 31) != 0; }
+      const float4 q = active ? g.pts[t] : make_float4(0, 0, 0, 0);
+      const uint32_t i = __float_as_uint(q.w);
+      int status = 2;
+      {
+        const int st = wave_knn_hist<HCAP>(g, q.x, q.y, q.z, active && !general, r, k, max_rounds < 0 ? -max_rounds : max_rounds, my, knn_idx + (size_t)i * k, knn_d2 ? knn_d2 + (size_t)i * k : nullptr);
+        if (!general) status = st;
+      }
+      if (!active || (threadIdx.x & 63) >= 16 || status == 0) continue;
+      if (LIST) { const uint32_t fs = atomicAdd(gen_count, 1u); gen_list[fs] = make_uint2(t, __float_as_uint(r)); }
+      else if (status == 2 || r > 2.5f * r0 || max_rounds < 0 /* every leftover: launch_knn_cov */) { const uint32_t fs = atomicAdd(gen_count, 1u); gen_list[fs] = make_uint2(t, __float_as_uint(r)); }   // far or overflowing: one query per wave (k_knn_single)
+      else { const uint32_t fs = atomicAdd(fb_count, 1u); fb_list[fs] = make_uint2(t, __float_as_uint(r)); }
+    }
+  }
+};
 template <bool LIST, int HCAP>
 __global__ void __launch_bounds__(QN_KNN_BLOCK, HCAP <= 32 ? 4 : 3) k_knn_hist(GridView g, int k, float r0, int max_rounds, int32_t* __restrict__ knn_idx, float* __restrict__ knn_d2,
                                                        uint2* __restrict__ fb_list, uint32_t* __restrict__ fb_count, uint2* __restrict__ gen_list, uint32_t* __restrict__ gen_count) {
-  __shared__ WaveLdsH<HCAP> lds[QN_KNN_BLOCK / 64];
-  g = grid_resolve(g); if (r0 < 0.f) r0 = -r0 * g.cell;              // (a negative radius is in cells: the host does not know the cell edge)
-  WaveLdsH<HCAP>* my = &lds[threadIdx.x >> 6];
-  const uint32_t nq = LIST ? *fb_count : g.n;
-  if (LIST && g.dbg && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&g.dbg[4], nq);
-  const uint32_t wave0 = (LIST ? blockIdx.x : xcd_block(blockIdx.x, gridDim.x)) * (QN_KNN_BLOCK / 64) + (threadIdx.x >> 6), nwaves = gridDim.x * (QN_KNN_BLOCK / 64);
-  for (uint32_t base = wave0 * 16; base < nq; base += nwaves * 16) {
-    const uint32_t slot = base + (threadIdx.x & 15);
-    bool active = slot < nq;
-    uint32_t t = slot; float r = r0; bool general = false;
-    if (LIST && active) { const uint2 rec = fb_list[slot]; t = rec.x; r = __uint_as_float(rec.y & 0x7fffffffu); general = (rec.y >> 31) != 0; }
-    const float4 q = active ? g.pts[t] : make_float4(0, 0, 0, 0);
-    const uint32_t i = __float_as_uint(q.w);
-    int status = 2;
-    {
-      const int st = wave_knn_hist<HCAP>(g, q.x, q.y, q.z, active && !general, r, k, max_rounds < 0 ? -max_rounds : max_rounds, my, knn_idx + (size_t)i * k, knn_d2 ? knn_d2 + (size_t)i * k : nullptr);
-      if (!general) status = st;
-    }
-    if (!active || (threadIdx.x & 63) >= 16 || status == 0) continue;
-    if (LIST) { const uint32_t fs = atomicAdd(gen_count, 1u); gen_list[fs] = make_uint2(t, __float_as_uint(r)); }
-    else if (status == 2 || r > 2.5f * r0 || max_rounds < 0 /* every leftover: launch_knn_cov */) { const uint32_t fs = atomicAdd(gen_count, 1u); gen_list[fs] = make_uint2(t, __float_as_uint(r)); }   // far or overflowing: one query per wave (k_knn_single)
-    else { const uint32_t fs = atomicAdd(fb_count, 1u); fb_list[fs] = make_uint2(t, __float_as_uint(r)); }
-  }
+  const KnnHistArgs a{g, k, r0, max_rounds, knn_idx, knn_d2, fb_list, fb_count, gen_list, gen_count};
+  KnnHistK<LIST, HCAP>::run(a, blockIdx.x, gridDim.x);
 }
 
 // The far / overflowing k-NN queries, one per wave (wave_knn_single); what it cannot finish goes to the sorted-list kernel.
+struct KnnSingleK {
+  static constexpr int TB = QN_BLOCK, OCC = 1;
+  struct Args { GridView g; int k; int32_t* knn_idx; float* knn_d2; const uint2* list; const uint32_t* count; uint2* gen_list; uint32_t* gen_count; };
+  static __device__ __forceinline__ void run(const Args& a, const uint32_t bx, const uint32_t nbx) {
+    __shared__ WaveLdsH1 lds[QN_BLOCK / 64];
+    const GridView g = grid_resolve(a.g);
+    const int k = a.k;
+    int32_t* __restrict__ knn_idx = a.knn_idx; float* __restrict__ knn_d2 = a.knn_d2; const uint2* __restrict__ list = a.list; uint2* __restrict__ gen_list = a.gen_list; uint32_t* __restrict__ gen_count = a.gen_count;
+    WaveLdsH1* my = &lds[threadIdx.x >> 6];
+    const uint32_t nq = uni(*a.count);
+    if (g.dbg && bx == 0 && threadIdx.x == 0) atomicAdd(&g.dbg[8], nq);
+    const uint32_t wave0 = bx * (QN_BLOCK / 64) + (threadIdx.x >> 6), nwaves = nbx * (QN_BLOCK / 64);
+    for (uint32_t e = wave0; e < nq; e += nwaves) {
+      const uint2 rec = list[e];
+      const float4 q = g.pts[rec.x];
+      const uint32_t i = __float_as_uint(q.w);
+      const int st = wave_knn_single(g, q.x, q.y, q.z, __uint_as_float(rec.y & 0x7fffffffu), k, my, knn_idx + (size_t)i * k, knn_d2 ? knn_d2 + (size_t)i * k : nullptr);
+      if (st != 0 && (threadIdx.x & 63) == 0) { if (g.dbg) atomicAdd(&g.dbg[9], 1u); const uint32_t fs = atomicAdd(gen_count, 1u); gen_list[fs] = make_uint2(rec.x, rec.y & 0x7fffffffu); }
+    }
+  }
+};
 static __global__ void __launch_bounds__(QN_BLOCK) k_knn_single(GridView g, int k, int32_t* __restrict__ knn_idx, float* __restrict__ knn_d2,
                                                                 const uint2* __restrict__ list, const uint32_t* __restrict__ count, uint2* __restrict__ gen_list, uint32_t* __restrict__ gen_count) {
-  __shared__ WaveLdsH1 lds[QN_BLOCK / 64];
-  g = grid_resolve(g);
-  WaveLdsH1* my = &lds[threadIdx.x >> 6];
-  const uint32_t nq = *count;
-  if (g.dbg && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&g.dbg[8], nq);
-  const uint32_t wave0 = blockIdx.x * (QN_BLOCK / 64) + (threadIdx.x >> 6), nwaves = gridDim.x * (QN_BLOCK / 64);
-  for (uint32_t e = wave0; e < nq; e += nwaves) {
-    const uint2 rec = list[e];
-    const float4 q = g.pts[rec.x];
-    const uint32_t i = __float_as_uint(q.w);
-    const int st = wave_knn_single(g, q.x, q.y, q.z, __uint_as_float(rec.y & 0x7fffffffu), k, my, knn_idx + (size_t)i * k, knn_d2 ? knn_d2 + (size_t)i * k : nullptr);
-    if (st != 0 && (threadIdx.x & 63) == 0) { if (g.dbg) atomicAdd(&g.dbg[9], 1u); const uint32_t fs = atomicAdd(gen_count, 1u); gen_list[fs] = make_uint2(rec.x, rec.y & 0x7fffffffu); }
-  }
+  const KnnSingleK::Args a{g, k, knn_idx, knn_d2, list, count, gen_list, gen_count};
+  KnnSingleK::run(a, blockIdx.x, gridDim.x);
 }
 
 // ------------------------------------------------------------------ K4a nearest-neighbour search
@@ -425,24 +505,31 @@ struct NnOpt { float4* clear_ref; int cond; int group, group_min; unsigned long 
 // queries of k_nn_track with their seed radius), 16 per wave, rounds until exact.
 // In the LIST launch the last `big_blocks` blocks serve big_list instead, one query per wave (wave_search_single).
 // BLOCK = threads per block: the grid passes run one wave per block (finer refill of the CUs), the list passes four.
+struct NnSearchArgs { GridView src, tgt; const GicpState* st; double thr2; float r0; int max_rounds; int32_t* corr; float* sqd; int32_t* nn_idx; float4* nn_ref;
+                      uint2* fb_list; uint32_t* fb_count; uint2* big_list; uint32_t* big_count; int big_blocks; float big_ratio; uint32_t* far_stats; NnOpt opt; };
 template <int MODE, bool LIST, int BLOCK, bool GROUP = false>      // GROUP: the far list may be served in groups of neighbours (its own instantiation: the grouped search costs registers)
-__global__ void __launch_bounds__(BLOCK, GROUP ? 5 : 6) k_nn_search(GridView src, GridView tgt, const GicpState* __restrict__ st, double thr2, float r0, int max_rounds,
-                                                        int32_t* __restrict__ corr, float* __restrict__ sqd, int32_t* __restrict__ nn_idx, float4* __restrict__ nn_ref,
-                                                        uint2* __restrict__ fb_list, uint32_t* __restrict__ fb_count,
-                                                        uint2* __restrict__ big_list, uint32_t* __restrict__ big_count, int big_blocks, float big_ratio, uint32_t* __restrict__ far_stats, NnOpt opt) {
+struct NnSearchK {
+  static constexpr int TB = BLOCK, OCC = GROUP ? 5 : 6;
+  using Args = NnSearchArgs;
+  static __device__ __forceinline__ void run(const Args& a, const uint32_t bx, const uint32_t nbx) {
+    GridView src = a.src, tgt = a.tgt; const GicpState* __restrict__ st = a.st; const double thr2 = a.thr2; float r0 = a.r0; const int max_rounds = a.max_rounds;
+    int32_t* __restrict__ corr = a.corr; float* __restrict__ sqd = a.sqd; int32_t* __restrict__ nn_idx = a.nn_idx; float4* __restrict__ nn_ref = a.nn_ref;
+    uint2* __restrict__ fb_list = a.fb_list; uint32_t* __restrict__ fb_count = a.fb_count; uint2* __restrict__ big_list = a.big_list; uint32_t* __restrict__ big_count = a.big_count;
+    const int big_blocks = a.big_blocks; const float big_ratio = a.big_ratio; uint32_t* __restrict__ far_stats = a.far_stats; const NnOpt opt = a.opt;
+
   __shared__ WaveLds lds[BLOCK / 64];
-  if (MODE == 0 && st->phase != 0) return;
-  if (MODE == 1 && st->phase != 2) return;
-  if (opt.cond && !(st->reserved & opt.cond)) return;                // a conditional launch behind look_decide
+  if (MODE == 0 && uni(st->phase) != 0) return;
+  if (MODE == 1 && uni(st->phase) != 2) return;
+  if (opt.cond && !(uni(st->reserved) & opt.cond)) return;           // a conditional launch behind look_decide
   src = grid_resolve(src); tgt = grid_resolve(tgt); if (r0 < 0.f) r0 = -r0 * tgt.cell;
   float Tf[12];
 #pragma unroll
-  for (int j = 0; j < 12; j++) Tf[j] = (float)st->x0[j];
-  if (LIST && (int)blockIdx.x >= (int)gridDim.x - big_blocks) {            // ---- big entries: one query per wave
-    const uint32_t nbig = *big_count;
-    if (tgt.dbg && blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) atomicAdd(&tgt.dbg[7], nbig);
+  for (int j = 0; j < 12; j++) Tf[j] = uni((float)st->x0[j]);
+  if (LIST && (int)bx >= (int)nbx - big_blocks) {            // ---- big entries: one query per wave
+    const uint32_t nbig = uni(*big_count);
+    if (tgt.dbg && bx == nbx - 1 && threadIdx.x == 0) atomicAdd(&tgt.dbg[7], nbig);
     uint32_t nfar = 0;                                                     // far queries of this pass (the host hands far_stats only to the LAST unseeded pass, when the clouds are nearly aligned)
-    const uint32_t bw0 = (blockIdx.x - (gridDim.x - big_blocks)) * (BLOCK / 64) + (threadIdx.x >> 6), nbw = big_blocks * (BLOCK / 64);
+    const uint32_t bw0 = (bx - (nbx - big_blocks)) * (BLOCK / 64) + (threadIdx.x >> 6), nbw = big_blocks * (BLOCK / 64);
     // Long lists (the first unseeded ticks of a misaligned pair, the non-overlapping part of a partial overlap): a wave takes E CONSECUTIVE entries - the list keeps
     // the cell-sorted order of the queries, so they are neighbours in space - and serves the ones whose balls overlap with ONE shared scan (wave_search_far16);
     // loners still get the whole wave (wave_search_single).  Short lists stay one entry per wave: nothing to share, and every entry starts at once.
@@ -497,7 +584,8 @@ __global__ void __launch_bounds__(BLOCK, GROUP ? 5 : 6) k_nn_search(GridView src
     // A SHORT 16-per-wave list is served here as well, one entry per wave: a few hundred list waves grinding through growth rounds for all their queries were the
     // long pole of the later unseeded passes (55 us against 20).  The decision is taken from the list's actual length: a pair that is still metres off at its
     // second iteration leaves tens of thousands of leftovers there, and those need the 16-per-wave pass (435 us otherwise).
-    const uint32_t nfb1 = (opt.fb_small && *fb_count <= opt.fb_small) ? *fb_count : 0u;
+    const uint32_t nfb_all = uni(*fb_count);
+    const uint32_t nfb1 = (opt.fb_small && nfb_all <= opt.fb_small) ? nfb_all : 0u;
     for (uint32_t w = bw0; w < nbig + nfb1; w += nbw) {
       const uint2 rec = w < nbig ? big_list[w] : fb_list[w - nbig];
       const float4 p = src.pts[rec.x];
@@ -523,10 +611,10 @@ __global__ void __launch_bounds__(BLOCK, GROUP ? 5 : 6) k_nn_search(GridView src
     if (opt.probe && (threadIdx.x & 63) == 0 && bw0 < 16384u) { opt.probe[4 * bw0] = (pr_max << 32) | pr_n; opt.probe[4 * bw0 + 1] = pr_sum; opt.probe[4 * bw0 + 2] = pr_a; opt.probe[4 * bw0 + 3] = pr_b; }
     return;
   }
-  const uint32_t nq = LIST ? *fb_count : src.n;
+  const uint32_t nq = LIST ? uni(*fb_count) : src.n;
   if (LIST && opt.fb_small && nq <= opt.fb_small) return;          // (served one per wave by the other blocks of this launch)
-  if (LIST && tgt.dbg && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&tgt.dbg[5], nq);
-  const uint32_t wave0 = blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6), nwaves = (gridDim.x - (LIST ? big_blocks : 0)) * (BLOCK / 64);   // (XCD remap measured slower here: the leftover lists lose their locality)
+  if (LIST && tgt.dbg && bx == 0 && threadIdx.x == 0) atomicAdd(&tgt.dbg[5], nq);
+  const uint32_t wave0 = bx * (BLOCK / 64) + (threadIdx.x >> 6), nwaves = (nbx - (LIST ? big_blocks : 0)) * (BLOCK / 64);   // (XCD remap measured slower here: the leftover lists lose their locality)
   for (uint32_t base = wave0 * 16; base < nq; base += nwaves * 16) {
     const uint32_t slot = base + (threadIdx.x & 15);
     const bool active = slot < nq;
@@ -556,6 +644,15 @@ __global__ void __launch_bounds__(BLOCK, GROUP ? 5 : 6) k_nn_search(GridView src
       wave_append(fb_list, fb_count, mine && !done && !far, make_uint2(t, __float_as_uint(-rn)));      // continue from rn
     }
   }
+  }
+};
+template <int MODE, bool LIST, int BLOCK, bool GROUP = false>
+__global__ void __launch_bounds__(BLOCK, GROUP ? 5 : 6) k_nn_search(GridView src, GridView tgt, const GicpState* __restrict__ st, double thr2, float r0, int max_rounds,
+                                                        int32_t* __restrict__ corr, float* __restrict__ sqd, int32_t* __restrict__ nn_idx, float4* __restrict__ nn_ref,
+                                                        uint2* __restrict__ fb_list, uint32_t* __restrict__ fb_count,
+                                                        uint2* __restrict__ big_list, uint32_t* __restrict__ big_count, int big_blocks, float big_ratio, uint32_t* __restrict__ far_stats, NnOpt opt) {
+  const NnSearchArgs a{src, tgt, st, thr2, r0, max_rounds, corr, sqd, nn_idx, nn_ref, fb_list, fb_count, big_list, big_count, big_blocks, big_ratio, far_stats, opt};
+  NnSearchK<MODE, LIST, BLOCK, GROUP>::run(a, blockIdx.x, gridDim.x);
 }
 
 // ------------------------------------------------------------------ K4b / K5 accumulate
@@ -638,30 +735,41 @@ __device__ __forceinline__ void reduce_block_partials(const double acc[QN_NPART]
   }
 }
 
+struct AccumulateK {
+  static constexpr int TB = QN_BLOCK, OCC = 1;
+  struct Args { const float4* src_raw; uint32_t ns; const double* nrm_s; const TargetRec* tgt_rec; const int32_t* corr; const GicpState* st; double* partials; int cond; };
+  static __device__ __forceinline__ void run(const Args& a, const uint32_t bx, const uint32_t nbx) {
+    __shared__ double red[QN_BLOCK / 64][QN_NPART];
+    const float4* __restrict__ src_raw = a.src_raw; const double* __restrict__ nrm_s = a.nrm_s; const TargetRec* __restrict__ tgt_rec = a.tgt_rec;
+    const int32_t* __restrict__ corr = a.corr; const GicpState* __restrict__ st = a.st;
+    const uint32_t ns = a.ns;
+    const int phase = uni(st->phase);
+    if (phase == 2) return;
+    if (a.cond && !(uni(st->reserved) & a.cond)) return;               // a conditional launch behind look_decide
+    double R[3][4], T[3][4];
+#pragma unroll
+    for (int u = 0; u < 3; u++)
+#pragma unroll
+      for (int b = 0; b < 4; b++) { T[u][b] = uni(phase == 0 ? st->x0[4 * u + b] : st->xi[4 * u + b]); R[u][b] = uni(st->x0[4 * u + b]); }
+    double acc[QN_NPART];
+#pragma unroll
+    for (int t = 0; t < QN_NPART; t++) acc[t] = 0;
+    for (uint32_t i = bx * QN_BLOCK + threadIdx.x; i < ns; i += nbx * QN_BLOCK) {
+      const int j = corr[i];
+      if (j < 0) continue;
+      const TargetRec* rec = tgt_rec + j;
+      const double na[3] = {nrm_s[(size_t)i * 3], nrm_s[(size_t)i * 3 + 1], nrm_s[(size_t)i * 3 + 2]};
+      const double nb[3] = {rec->n[0], rec->n[1], rec->n[2]};
+      accumulate_point_n(R, T, src_raw[i], rec->p, na, nb, phase == 0, acc);
+    }
+    reduce_block_partials(acc, phase == 0, a.partials, red, bx);
+  }
+};
 static __global__ void __launch_bounds__(QN_BLOCK) k_accumulate(const float4* __restrict__ src_raw, uint32_t ns, const double* __restrict__ nrm_s, const TargetRec* __restrict__ tgt_rec,
                                                          const int32_t* __restrict__ corr, const GicpState* __restrict__ st,
                                                          double* __restrict__ partials, int cond) {
-  __shared__ double red[QN_BLOCK / 64][QN_NPART];
-  const int phase = st->phase;
-  if (phase == 2) return;
-  if (cond && !(st->reserved & cond)) return;                        // a conditional launch behind look_decide
-  double R[3][4], T[3][4];
-#pragma unroll
-  for (int a = 0; a < 3; a++)
-#pragma unroll
-    for (int b = 0; b < 4; b++) { T[a][b] = phase == 0 ? st->x0[4 * a + b] : st->xi[4 * a + b]; R[a][b] = st->x0[4 * a + b]; }
-  double acc[QN_NPART];
-#pragma unroll
-  for (int t = 0; t < QN_NPART; t++) acc[t] = 0;
-  for (uint32_t i = blockIdx.x * QN_BLOCK + threadIdx.x; i < ns; i += gridDim.x * QN_BLOCK) {
-    const int j = corr[i];
-    if (j < 0) continue;
-    const TargetRec* rec = tgt_rec + j;
-    const double na[3] = {nrm_s[(size_t)i * 3], nrm_s[(size_t)i * 3 + 1], nrm_s[(size_t)i * 3 + 2]};
-    const double nb[3] = {rec->n[0], rec->n[1], rec->n[2]};
-    accumulate_point_n(R, T, src_raw[i], rec->p, na, nb, phase == 0, acc);
-  }
-  reduce_block_partials(acc, phase == 0, partials, red, blockIdx.x);
+  const AccumulateK::Args a{src_raw, ns, nrm_s, tgt_rec, corr, st, partials, cond};
+  AccumulateK::run(a, blockIdx.x, gridDim.x);
 }
 
 // ------------------------------------------------------------------ K4a', temporal tracking
@@ -1074,38 +1182,59 @@ __device__ inline void look_decide(GicpState* st, ResultBlock* out, uint32_t* __
 // One controller step as its own launch (unseeded first ticks, the end of a chunk, the debug entry points): generation g -> g + 1.
 // mode 0: the LM / GN controller, if partial rows are pending under st_in.  mode 1 / 2: reduce a linearisation / an error pass only.
 // will_produce: a body that writes partial rows under the NEW state follows (so they are pending for the next controller step).
+struct SolveArgs { const GicpState* st_in; GicpState* st_out; const double* partials; int rows; GicpConfig cfg; qn_iter_trace* trace; int mode, will_produce; LookArgs look; };
 template <int NT>      // NT = the thread count of the k_tick variant in use: both run the same row reduction, bit for bit
+struct SolveK {
+  static constexpr int TB = NT, OCC = 1;
+  using Args = SolveArgs;
+  static __device__ __forceinline__ void run(const Args& a, const uint32_t, const uint32_t) {
+    __shared__ double sums[QN_NPART];
+    __shared__ double part8[QN_NPART][NT / QN_NPART + 1];
+    __shared__ GicpState sh;                       // the controller works on an LDS copy: one coalesced read, one coalesced write-back
+    __shared__ SolveWork Awork_s; SolveWork* Awork = &Awork_s;
+    static_assert(sizeof(GicpState) % 8 == 0, "GicpState is copied as 8-byte words");
+    const GicpState* __restrict__ st_in = a.st_in; GicpState* __restrict__ st_out = a.st_out;
+    const int rows = a.rows, mode = a.mode;
+    for (int i = threadIdx.x; i < (int)(sizeof(GicpState) / 8); i += NT) ((unsigned long long*)&sh)[i] = ((const unsigned long long*)st_in)[i];
+    __syncthreads();
+    const int phase = sh.phase;
+    if (mode != 0 || (sh.pending && phase != 2 && rows >= 0)) {        // rows < 0: the pending rows were consumed by an earlier stand-alone controller step
+      reduce_partial_rows<NT>(a.partials, rows, part8, sums);
+      if (threadIdx.x == 0) { const GicpConfig cfg = a.cfg; solve_controller(&sh, sums, cfg, a.trace, mode, phase, Awork); }
+    }
+    if (threadIdx.x == 0) { sh.fb_count = 0; sh.big_count = 0; sh.pending = (a.will_produce && sh.phase != 2) ? 1 : 0; }
+    if (threadIdx.x == 0 && a.look.enabled) look_decide(&sh, a.look.out, a.look.far_stats, a.look.sdims, a.look.tdims, a.look.allow_extra);
+    __syncthreads();
+    for (int i = threadIdx.x; i < (int)(sizeof(GicpState) / 8); i += NT) ((unsigned long long*)st_out)[i] = ((const unsigned long long*)&sh)[i];
+  }
+};
+template <int NT>
 static __global__ void __launch_bounds__(NT) k_solve(const GicpState* __restrict__ st_in, GicpState* __restrict__ st_out, const double* __restrict__ partials, int rows,
                                                                    GicpConfig cfg, qn_iter_trace* trace, int mode, int will_produce, LookArgs look) {
-  __shared__ double sums[QN_NPART];
-  __shared__ double part8[QN_NPART][NT / QN_NPART + 1];
-  __shared__ GicpState sh;                       // the controller works on an LDS copy: one coalesced read, one coalesced write-back
-  __shared__ SolveWork Awork_s; SolveWork* Awork = &Awork_s;
-  static_assert(sizeof(GicpState) % 8 == 0, "GicpState is copied as 8-byte words");
-  for (int i = threadIdx.x; i < (int)(sizeof(GicpState) / 8); i += NT) ((unsigned long long*)&sh)[i] = ((const unsigned long long*)st_in)[i];
-  __syncthreads();
-  const int phase = sh.phase;
-  if (mode != 0 || (sh.pending && phase != 2 && rows >= 0)) {        // rows < 0: the pending rows were consumed by an earlier stand-alone controller step
-    reduce_partial_rows<NT>(partials, rows, part8, sums);
-    if (threadIdx.x == 0) solve_controller(&sh, sums, cfg, trace, mode, phase, Awork);
-  }
-  if (threadIdx.x == 0) { sh.fb_count = 0; sh.big_count = 0; sh.pending = (will_produce && sh.phase != 2) ? 1 : 0; }
-  if (threadIdx.x == 0 && look.enabled) look_decide(&sh, look.out, look.far_stats, look.sdims, look.tdims, look.allow_extra);
-  __syncthreads();
-  for (int i = threadIdx.x; i < (int)(sizeof(GicpState) / 8); i += NT) ((unsigned long long*)st_out)[i] = ((const unsigned long long*)&sh)[i];
+  const SolveArgs a{st_in, st_out, partials, rows, cfg, trace, mode, will_produce, look};
+  SolveK<NT>::run(a, blockIdx.x, gridDim.x);
 }
 
-static __global__ void k_init_state(GicpState* st, const float* __restrict__ guess /* 16 or null */, int has_guess, int phase, uint32_t* __restrict__ far_stats /* 4 words or null: zeroed */) {
-  if (blockIdx.x != 0) return;
-  const int i = threadIdx.x;                                         // one wave: lane i writes element i of every array
-  if (i < 16) { const double v = has_guess ? (double)guess[i] : ((i % 5 == 0) ? 1.0 : 0.0); st->x0[i] = v; st->xi[i] = v; st->delta[i] = (i % 5 == 0) ? 1.0 : 0.0; }
-  if (i < 36) { st->H[i] = 0; st->final_H[i] = (i % 7 == 0) ? 1.0 : 0.0; }
-  if (i < 6) { st->b[i] = 0; st->d[i] = 0; }
-  if (i >= 60 && far_stats) far_stats[i - 60] = 0u;
-  if (i != 0) return;
-  st->y0 = st->yi = st->den = 0; st->lambda = -1.0; st->nu = 2.0; st->fitness = 0;
-  st->outer = st->inner = 0; st->phase = phase; st->converged = 0; st->lm_failed = 0; st->fb_count = 0; st->big_count = 0; st->trace_len = 0;
-  st->pending = phase != 2 ? 1 : 0; st->reserved = 0;      // the first tick's body writes partial rows under this state
+struct InitStateK {
+  static constexpr int TB = 64, OCC = 1;
+  struct Args { GicpState* st; const float* guess /* 16 or null */; int has_guess, phase; uint32_t* far_stats /* 4 words or null: zeroed */; };
+  static __device__ __forceinline__ void run(const Args& a, const uint32_t bx, const uint32_t) {
+    if (bx != 0) return;
+    GicpState* st = a.st; const float* __restrict__ guess = a.guess; const int phase = a.phase;
+    const int i = threadIdx.x;                                         // one wave: lane i writes element i of every array
+    if (i < 16) { const double v = a.has_guess ? (double)guess[i] : ((i % 5 == 0) ? 1.0 : 0.0); st->x0[i] = v; st->xi[i] = v; st->delta[i] = (i % 5 == 0) ? 1.0 : 0.0; }
+    if (i < 36) { st->H[i] = 0; st->final_H[i] = (i % 7 == 0) ? 1.0 : 0.0; }
+    if (i < 6) { st->b[i] = 0; st->d[i] = 0; }
+    if (i >= 60 && a.far_stats) a.far_stats[i - 60] = 0u;
+    if (i != 0) return;
+    st->y0 = st->yi = st->den = 0; st->lambda = -1.0; st->nu = 2.0; st->fitness = 0;
+    st->outer = st->inner = 0; st->phase = phase; st->converged = 0; st->lm_failed = 0; st->fb_count = 0; st->big_count = 0; st->trace_len = 0;
+    st->pending = phase != 2 ? 1 : 0; st->reserved = 0;      // the first tick's body writes partial rows under this state
+  }
+};
+static __global__ void __launch_bounds__(64) k_init_state(GicpState* st, const float* __restrict__ guess, int has_guess, int phase, uint32_t* __restrict__ far_stats) {
+  const InitStateK::Args a{st, guess, has_guess, phase, far_stats};
+  InitStateK::run(a, blockIdx.x, gridDim.x);
 }
 static __global__ void k_set_pose(GicpState* st, const double* __restrict__ T, int which /*0 x0, 1 xi, 2 neither*/, int phase) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
@@ -1161,18 +1290,27 @@ static __global__ void k_transform_cloud(const float4* __restrict__ in, uint32_t
 }
 
 
-static __global__ void k_finalize(const GicpState* __restrict__ st, ResultBlock* out, uint32_t* __restrict__ far_stats) {   // out lives in pinned host memory
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  out->far_requests = far_stats ? far_stats[1] : 0u; out->far_misses = far_stats ? far_stats[0] : 0u; out->far_queries = far_stats ? far_stats[3] : 0u;
-  // [1]: requests of the last tick k_far served; [0]: misses counted since (mode 2); [3]: far queries of the chunk's last unseeded pass
-  if (far_stats) { far_stats[0] = 0u; far_stats[1] = 0u; far_stats[3] = 0u; }
-  for (int i = 0; i < 16; i++) { out->r.T64[i] = st->x0[i]; out->r.T[i] = (float)st->x0[i]; }
-  for (int i = 0; i < 36; i++) out->r.H[i] = st->final_H[i];
-  out->r.fitness = st->fitness; out->r.iterations = st->outer; out->r.converged = st->converged; out->r.lm_failed = st->lm_failed; out->r.reserved = 0;
-  out->phase = st->phase; out->trace_len = st->trace_len;
-  double mr = 0, mt = 0;
-  for (int a = 0; a < 3; a++) { for (int b = 0; b < 3; b++) mr = fmax(mr, fabs(st->delta[4 * a + b] - (a == b ? 1.0 : 0.0))); mt = fmax(mt, fabs(st->delta[4 * a + 3])); }
-  out->step_dt = mt; out->step_dr = mr;
+struct FinalizeK {
+  static constexpr int TB = 64, OCC = 1;
+  struct Args { const GicpState* st; ResultBlock* out /* pinned host memory */; uint32_t* far_stats; };
+  static __device__ __forceinline__ void run(const Args& a, const uint32_t bx, const uint32_t) {
+    if (threadIdx.x != 0 || bx != 0) return;
+    const GicpState* __restrict__ st = a.st; ResultBlock* out = a.out; uint32_t* __restrict__ far_stats = a.far_stats;
+    out->far_requests = far_stats ? far_stats[1] : 0u; out->far_misses = far_stats ? far_stats[0] : 0u; out->far_queries = far_stats ? far_stats[3] : 0u;
+    // [1]: requests of the last tick k_far served; [0]: misses counted since (mode 2); [3]: far queries of the chunk's last unseeded pass
+    if (far_stats) { far_stats[0] = 0u; far_stats[1] = 0u; far_stats[3] = 0u; }
+    for (int i = 0; i < 16; i++) { out->r.T64[i] = st->x0[i]; out->r.T[i] = (float)st->x0[i]; }
+    for (int i = 0; i < 36; i++) out->r.H[i] = st->final_H[i];
+    out->r.fitness = st->fitness; out->r.iterations = st->outer; out->r.converged = st->converged; out->r.lm_failed = st->lm_failed; out->r.reserved = 0;
+    out->phase = st->phase; out->trace_len = st->trace_len;
+    double mr = 0, mt = 0;
+    for (int u = 0; u < 3; u++) { for (int b = 0; b < 3; b++) mr = fmax(mr, fabs(st->delta[4 * u + b] - (u == b ? 1.0 : 0.0))); mt = fmax(mt, fabs(st->delta[4 * u + 3])); }
+    out->step_dt = mt; out->step_dr = mr;
+  }
+};
+static __global__ void __launch_bounds__(64) k_finalize(const GicpState* __restrict__ st, ResultBlock* out, uint32_t* __restrict__ far_stats) {   // out lives in pinned host memory
+  const FinalizeK::Args a{st, out, far_stats};
+  FinalizeK::run(a, blockIdx.x, gridDim.x);
 }
 
 

@@ -4,7 +4,7 @@
 #if !defined(QN_INST_GROUP) || QN_INST_GROUP < 1
 #error "compile with -DQN_INST_GROUP=<1..QN_NUM_INST_GROUPS>"
 #endif
-#if QN_INST_GROUP == 1 || QN_INST_GROUP == 10
+#if QN_INST_GROUP == 1 || QN_INST_GROUP == 10 || QN_INST_GROUP == 11
 #include "qn_instances.h"
 #else
 #include "qn_instances_knn.h"

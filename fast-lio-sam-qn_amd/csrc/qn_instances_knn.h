@@ -6,7 +6,7 @@
 #ifndef QN_INST_GROUP
 #define QN_INST_GROUP 0
 #endif
-#define QN_NUM_INST_GROUPS 10
+#define QN_NUM_INST_GROUPS 11
 
 #if QN_INST_GROUP == 2
 #define QN_G2 template
@@ -56,6 +56,10 @@ QN_G2 __global__ void k_knn_cov<16, true, 4> QN_KNN_COV_ARGS;
 QN_G3 __global__ void k_knn_cov<20, true, 4> QN_KNN_COV_ARGS;
 QN_G4 __global__ void k_knn_cov<24, true, 4> QN_KNN_COV_ARGS;
 QN_G5 __global__ void k_knn_cov<32, true, 4> QN_KNN_COV_ARGS;
+QN_G2 __global__ void k_lanes<KnnCovK<16, true, 4>>(const LaneEntry<KnnCovArgs>*);      // batched forms of the exact tail (k_lanes: blockIdx.y = one cloud of one candidate pair)
+QN_G3 __global__ void k_lanes<KnnCovK<20, true, 4>>(const LaneEntry<KnnCovArgs>*);
+QN_G4 __global__ void k_lanes<KnnCovK<24, true, 4>>(const LaneEntry<KnnCovArgs>*);
+QN_G5 __global__ void k_lanes<KnnCovK<32, true, 4>>(const LaneEntry<KnnCovArgs>*);
 QN_G6 __global__ void k_knn_cov<16, false, 4> QN_KNN_COV_ARGS;
 QN_G7 __global__ void k_knn_cov<20, false, 4> QN_KNN_COV_ARGS;
 QN_G8 __global__ void k_knn_cov<24, false, 4> QN_KNN_COV_ARGS;

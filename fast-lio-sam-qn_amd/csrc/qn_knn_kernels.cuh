@@ -26,16 +26,22 @@ __device__ __forceinline__ void store_knn(const BestK<KMAX>& sink, int32_t* __re
 // One kernel body for both passes.  LIST = false: query t = global query slot, radius margin * cell, two
 // rounds, leftovers appended to fb_list with the radius to continue from.  LIST = true: the queries are
 // the fb_list entries of the first pass (16 per wave, wave-stride), rounds until exact.
+struct KnnCovArgs { GridView g; const float4* raw; int k; float r0; int max_rounds; double* cov; int32_t* knn_idx; float* knn_d2; uint2* fb_list; uint32_t* fb_count; };
 template <int KMAX, bool LIST, int S>
-__global__ void __launch_bounds__(QN_BLOCK, 3) k_knn_cov(GridView g, const float4* __restrict__ raw, int k, float r0, int max_rounds,
-                                                      double* __restrict__ cov, int32_t* __restrict__ knn_idx, float* __restrict__ knn_d2,
-                                                      uint2* __restrict__ fb_list, uint32_t* __restrict__ fb_count) {
+struct KnnCovK {
+  static constexpr int TB = QN_BLOCK, OCC = 3;
+  using Args = KnnCovArgs;
+  static __device__ __forceinline__ void run(const Args& a, const uint32_t bx, const uint32_t nbx) {
+    const GridView g = grid_resolve(a.g);
+    const int k = a.k, max_rounds = a.max_rounds; float r0 = a.r0;
+    int32_t* __restrict__ knn_idx = a.knn_idx; float* __restrict__ knn_d2 = a.knn_d2; uint2* __restrict__ fb_list = a.fb_list; uint32_t* __restrict__ fb_count = a.fb_count;
+
   __shared__ WaveLdsK lds[QN_BLOCK / 64];
-  g = grid_resolve(g); if (r0 < 0.f) r0 = -r0 * g.cell;              // (a negative radius is in cells)
+  if (r0 < 0.f) r0 = -r0 * g.cell;              // (a negative radius is in cells)
   WaveLdsK* my = &lds[threadIdx.x >> 6];
-  const uint32_t nq = LIST ? *fb_count : g.n;
-  if (LIST && g.dbg && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&g.dbg[4], nq);
-  const uint32_t wave0 = blockIdx.x * (QN_BLOCK / 64) + (threadIdx.x >> 6), nwaves = gridDim.x * (QN_BLOCK / 64);
+  const uint32_t nq = LIST ? uni(*fb_count) : g.n;
+  if (LIST && g.dbg && bx == 0 && threadIdx.x == 0) atomicAdd(&g.dbg[4], nq);
+  const uint32_t wave0 = bx * (QN_BLOCK / 64) + (threadIdx.x >> 6), nwaves = nbx * (QN_BLOCK / 64);
   constexpr uint32_t QPW = 64 / S;                                          // queries per wave
   for (uint32_t base = wave0 * QPW; base < nq; base += nwaves * QPW) {      // (non-LIST grids cover nq in one trip)
     const uint32_t slot = base + (threadIdx.x & (QPW - 1));
@@ -54,6 +60,14 @@ __global__ void __launch_bounds__(QN_BLOCK, 3) k_knn_cov(GridView g, const float
       fb_list[fs] = make_uint2(t, __float_as_uint(r));
     }
   }
+  }
+};
+template <int KMAX, bool LIST, int S>
+__global__ void __launch_bounds__(QN_BLOCK, 3) k_knn_cov(GridView g, const float4* __restrict__ raw, int k, float r0, int max_rounds,
+                                                      double* __restrict__ cov, int32_t* __restrict__ knn_idx, float* __restrict__ knn_d2,
+                                                      uint2* __restrict__ fb_list, uint32_t* __restrict__ fb_count) {
+  const KnnCovArgs a{g, raw, k, r0, max_rounds, cov, knn_idx, knn_d2, fb_list, fb_count};
+  KnnCovK<KMAX, LIST, S>::run(a, blockIdx.x, gridDim.x);
 }
 
 }  // namespace qn

@@ -129,6 +129,11 @@ extern "C" int qn_multi_set_params(qn_multi* m, const qn_gicp_params* p) {
   return QN_OK;
 }
 
+extern "C" int qn_multi_debug_set(qn_multi* m, const char* key, double value) {      // a developer knob (qn_debug_set) on every context, e.g. "batch_lanes"
+  if (!m || !key) return QN_ERR_INVALID_ARG;
+  for (auto& v : m->ctx) for (qn_ctx* c : v) { const int rc = qn_debug_set(c, key, value); if (rc != QN_OK) return rc; }
+  return QN_OK;
+}
 extern "C" int qn_multi_gpu_count(const qn_multi* m) { return m ? m->n_gpus : 0; }
 extern "C" int qn_multi_get_timing(const qn_multi* m, double* per_gpu_ms, double* gather_ms) {
   if (!m || !per_gpu_ms || !gather_ms) return QN_ERR_INVALID_ARG;
@@ -154,43 +159,32 @@ extern "C" int qn_multi_align_best(qn_multi* m, const qn_pair_desc* pairs, uint3
   // ---- the data path: independent registrations, no collective
   std::vector<std::vector<qn_pair_record>> mine(N, std::vector<qn_pair_record>(per));
   for (int g = 0; g < N; g++) for (uint32_t l = 0; l < per; l++) { qn_pair_record& r = mine[g][l]; memset(&r, 0, sizeof(r)); r.pair_id = -1; r.status = QN_ERR_EMPTY_CLOUD; r.fitness = DBL_MAX; }
-  std::vector<std::atomic<uint32_t>> next(N);
-  for (auto& a : next) a.store(0);
-  auto worker = [&](int g, qn_ctx* c) {
-    const float* last_src = nullptr; uint32_t last_ns = 0, last_stride = 0; int last_dev = -1;      // the source this context holds (within THIS call: same pointer = same cloud)
-    for (;;) {
-      const uint32_t l = next[g].fetch_add(1);
-      const uint64_t i = (uint64_t)g + (uint64_t)l * N;
-      if (l >= per || i >= n_pairs) break;
-      const qn_pair_desc& p = pairs[i];
-      qn_gicp_result res; int valid = 0;
-      int st;
-      if (last_src == p.src && last_ns == p.ns && last_stride == p.stride_bytes && last_dev == p.on_device)      // candidates of one query: the source is prepared once per context
-        st = qn_icp_alignment_same_source(c, p.dst, p.nt, p.stride_bytes, p.on_device, score_thr, &res, &valid);
-      else
-        st = p.on_device ? qn_icp_alignment_device(c, p.src, p.ns, p.dst, p.nt, p.stride_bytes, score_thr, &res, &valid)
-                         : qn_icp_alignment(c, p.src, p.ns, p.dst, p.nt, p.stride_bytes, score_thr, &res, &valid);
-      if (st == QN_OK) { last_src = p.src; last_ns = p.ns; last_stride = p.stride_bytes; last_dev = p.on_device; } else last_src = nullptr;
-      qn_pair_record& r = mine[g][l];
-      r.pair_id = (int32_t)i; r.status = st; r.valid = (st == QN_OK && valid) ? 1 : 0; r.converged = st == QN_OK ? res.converged : 0;
-      r.iterations = st == QN_OK ? res.iterations : 0; r.fitness = st == QN_OK ? res.fitness : DBL_MAX;
-      if (st == QN_OK) memcpy(r.T, res.T, sizeof(r.T)); else for (int k = 0; k < 16; k++) r.T[k] = (k % 5 == 0) ? 1.f : 0.f;
-    }
-  };
+  // each GPU's pairs go through qn_icp_alignment_batch on that GPU's `in_flight` contexts: every context registers runs of pairs in lockstep, the pair as a
+  // grid dimension of every kernel launch (qn_gicp_align_batch); candidates that share their source buffer share its grid and covariances per lane
   using clk = std::chrono::steady_clock;
   const clk::time_point t_start = clk::now();
-  std::vector<std::atomic<long long>> t_end(N);
-  for (auto& a : t_end) a.store(0);
-  auto timed_worker = [&](int g, qn_ctx* c) {
-    worker(g, c);
-    const long long ns = std::chrono::duration_cast<std::chrono::nanoseconds>(clk::now() - t_start).count();
-    long long prev = t_end[g].load(); while (prev < ns && !t_end[g].compare_exchange_weak(prev, ns)) {}
+  std::vector<long long> t_end(N, 0);
+  std::vector<int> gpu_rc(N, QN_OK);
+  auto gpu_worker = [&](int g) {
+    std::vector<qn_pair_desc> mp; std::vector<uint32_t> ids;
+    for (uint32_t l = 0; l < per; l++) { const uint64_t i = (uint64_t)g + (uint64_t)l * N; if (i < n_pairs) { mp.push_back(pairs[i]); ids.push_back((uint32_t)i); } }
+    std::vector<qn_gicp_result> res(mp.size()); std::vector<int> val(mp.size(), 0), st(mp.size(), QN_ERR_HIP);
+    if (!mp.empty()) gpu_rc[g] = qn_icp_alignment_batch(m->ctx[g].data(), (uint32_t)m->ctx[g].size(), mp.data(), (uint32_t)mp.size(), score_thr, res.data(), val.data(), st.data());
+    for (size_t l = 0; l < mp.size(); l++) {
+      qn_pair_record& r = mine[g][l];
+      const int s_ = gpu_rc[g] == QN_OK ? st[l] : gpu_rc[g];
+      r.pair_id = (int32_t)ids[l]; r.status = s_; r.valid = (s_ == QN_OK && val[l]) ? 1 : 0; r.converged = s_ == QN_OK ? res[l].converged : 0;
+      r.iterations = s_ == QN_OK ? res[l].iterations : 0; r.fitness = s_ == QN_OK ? res[l].fitness : DBL_MAX;
+      if (s_ == QN_OK) memcpy(r.T, res[l].T, sizeof(r.T)); else for (int k = 0; k < 16; k++) r.T[k] = (k % 5 == 0) ? 1.f : 0.f;
+    }
+    t_end[g] = std::chrono::duration_cast<std::chrono::nanoseconds>(clk::now() - t_start).count();
   };
   std::vector<std::thread> th;
-  for (int g = 0; g < N; g++) for (int s = 0; s < m->in_flight; s++) th.emplace_back(timed_worker, g, m->ctx[g][s]);
+  for (int g = 1; g < N; g++) th.emplace_back(gpu_worker, g);
+  gpu_worker(0);
   for (auto& t : th) t.join();
   m->gpu_ms.assign(N, 0.0);
-  for (int g = 0; g < N; g++) m->gpu_ms[g] = 1e-6 * (double)t_end[g].load();
+  for (int g = 0; g < N; g++) m->gpu_ms[g] = 1e-6 * (double)t_end[g];
   const clk::time_point t_gather = clk::now();
   // ---- the one exchange step: gather the record tables (N x per x 96 bytes: latency-bound, ring or tree does not matter at this size)
   // A failure after the first asynchronous operation must not return while copies out of `mine` (pageable host memory) may still be staging:

@@ -457,8 +457,13 @@ __device__ __forceinline__ void tick_point(const TickArgs& a, const float (&Tf)[
 // PROBE = true: the developer variant with device-clock stamps (knob clk_probe); the production instantiations carry none of it.
 union WaveScratch { WaveLds w; double red[7 * 64]; };
 static_assert(sizeof(WaveLds) >= 7 * 64 * sizeof(double), "the transpose buffer aliases the wave's search scratch");
-template <int TB, int OCC, int MODE, bool PROBE>
-__global__ void __launch_bounds__(TB, OCC) k_tick(TickArgs a) {
+template <int TB_, int OCC_, int MODE, bool PROBE>
+struct TickK {
+  static constexpr int TB = TB_, OCC = OCC_;
+  using Args = TickArgs;
+  static __device__ __forceinline__ void run(const TickArgs& a_in, const uint32_t bx, const uint32_t nbx_) {
+    TickArgs a = a_in;
+
   __shared__ WaveScratch sc[TB / 64];
   __shared__ double wsum[TB / 64][QN_NPART];
   __shared__ GicpState sh;
@@ -467,15 +472,15 @@ __global__ void __launch_bounds__(TB, OCC) k_tick(TickArgs a) {
   __shared__ SolveWork Awork_s; SolveWork* Awork = &Awork_s;
   static_assert(sizeof(GicpState) % 8 == 0, "GicpState is copied as 8-byte words");
   const int tid = threadIdx.x;
-  const uint32_t nblk = gridDim.x;
+  const uint32_t nblk = nbx_;
   a.src = grid_resolve(a.src); a.tgt = grid_resolve(a.tgt);
-  const bool probe = PROBE && a.clk != nullptr && blockIdx.x == 0 && threadIdx.x == 0;
+  const bool probe = PROBE && a.clk != nullptr && bx == 0 && threadIdx.x == 0;
   if (PROBE) {
     if (probe) a.clk[0] = wall_clock64();
     if (threadIdx.x == 0) atomicMax(&a.clk[7], ~wall_clock64());       // earliest block start (as a max of the complement)
-    if (MODE == 0 && threadIdx.x == 0) { a.clk_blk[8 * blockIdx.x] = wall_clock64(); a.clk_blk[8 * blockIdx.x + 4] = 0; a.clk_blk[8 * blockIdx.x + 5] = 0; a.clk_blk[8 * blockIdx.x + 6] = 0; }
+    if (MODE == 0 && threadIdx.x == 0) { a.clk_blk[8 * bx] = wall_clock64(); a.clk_blk[8 * bx + 4] = 0; a.clk_blk[8 * bx + 5] = 0; a.clk_blk[8 * bx + 6] = 0; }
   }
-  const uint32_t lblk = xcd_block(blockIdx.x, nblk);               // XCD x works on one contiguous eighth of the cell-sorted source
+  const uint32_t lblk = xcd_block(bx, nblk);               // XCD x works on one contiguous eighth of the cell-sorted source
   // ---- pose-independent loads of this thread's first point, in flight during the prologue
   uint32_t t = (lblk * a.ppt) * TB + tid;
   bool valid = t < a.src.n;
@@ -494,14 +499,14 @@ __global__ void __launch_bounds__(TB, OCC) k_tick(TickArgs a) {
   reduce_partial_rows<TB>(a.part_in, a.rows_in, part8, sums);        // (rows of a state that is not pending are summed and ignored: rows_in is what matters)
   if (probe) a.clk[1] = wall_clock64();
   const int pending = sh.pending, phase_in = sh.phase;
-  if (pending && phase_in != 2 && a.rows_in >= 0 && tid == 0) solve_controller(&sh, sums, a.cfg, blockIdx.x == 0 ? a.trace : nullptr, 0, phase_in, Awork);      // (rows_in < 0: already consumed by a stand-alone k_solve)
+  if (pending && phase_in != 2 && a.rows_in >= 0 && tid == 0) solve_controller(&sh, sums, a.cfg, bx == 0 ? a.trace : nullptr, 0, phase_in, Awork);      // (rows_in < 0: already consumed by a stand-alone k_solve)
   if (PROBE) {
     if (probe) a.clk[2] = wall_clock64();
-    if (MODE == 0 && threadIdx.x == 0) a.clk_blk[8 * blockIdx.x + 1] = wall_clock64();
+    if (MODE == 0 && threadIdx.x == 0) a.clk_blk[8 * bx + 1] = wall_clock64();
   }
   if (tid == 0) { sh.fb_count = 0; sh.big_count = 0; sh.pending = (MODE == 0 && sh.phase != 2) ? 1 : 0; }
   __syncthreads();
-  if (blockIdx.x == 0) for (int i = tid; i < (int)(sizeof(GicpState) / 8); i += TB) ((unsigned long long*)a.st_out)[i] = ((const unsigned long long*)&sh)[i];
+  if (bx == 0) for (int i = tid; i < (int)(sizeof(GicpState) / 8); i += TB) ((unsigned long long*)a.st_out)[i] = ((const unsigned long long*)&sh)[i];
   const int phase = sh.phase;
   if (MODE == 0 ? phase == 2 : phase != 2) return;
   const bool lin = MODE == 1 || phase == 0;
@@ -530,13 +535,21 @@ __global__ void __launch_bounds__(TB, OCC) k_tick(TickArgs a) {
   if (PROBE) {
     if (probe) a.clk[5] = wall_clock64();
     if (threadIdx.x == 0) atomicMax(&a.clk[6], wall_clock64());        // latest block end
-    if (MODE == 0 && threadIdx.x == 0) a.clk_blk[8 * blockIdx.x + 3] = wall_clock64();
+    if (MODE == 0 && threadIdx.x == 0) a.clk_blk[8 * bx + 3] = wall_clock64();
   }
-}
+  }
+};
+template <int TB, int OCC, int MODE, bool PROBE>
+__global__ void __launch_bounds__(TB, OCC) k_tick(TickArgs a) { TickK<TB, OCC, MODE, PROBE>::run(a, blockIdx.x, gridDim.x); }
 
 // result block of an align(): state + fitness = (sum of the block sums, fixed order) / (points with a neighbour), written to pinned host memory
-static __global__ void k_finalize_fit(const GicpState* __restrict__ st, ResultBlock* out, uint32_t* __restrict__ far_stats,
-                                      const double* __restrict__ fit_psum, const uint32_t* __restrict__ fit_pcnt, int nblk) {
+struct FinalizeFitK {
+  static constexpr int TB = 64, OCC = 1;
+  struct Args { const GicpState* st; ResultBlock* out; uint32_t* far_stats; const double* fit_psum; const uint32_t* fit_pcnt; int nblk; };
+  static __device__ __forceinline__ void run(const Args& a, const uint32_t, const uint32_t) {
+    const GicpState* __restrict__ st = a.st; ResultBlock* out = a.out; uint32_t* __restrict__ far_stats = a.far_stats;
+    const double* __restrict__ fit_psum = a.fit_psum; const uint32_t* __restrict__ fit_pcnt = a.fit_pcnt; const int nblk = a.nblk;
+
   const int lane = threadIdx.x;                                     // one wave
   double s = 0; uint32_t c = 0;
   if (st->phase == 2) {
@@ -553,6 +566,12 @@ static __global__ void k_finalize_fit(const GicpState* __restrict__ st, ResultBl
   out->phase = st->phase; out->trace_len = st->trace_len;
   out->far_requests = far_stats ? far_stats[1] : 0u; out->far_misses = far_stats ? far_stats[0] : 0u; out->far_queries = far_stats ? far_stats[3] : 0u;
   if (far_stats) { far_stats[0] = 0u; far_stats[1] = 0u; far_stats[3] = 0u; }
+  }
+};
+static __global__ void __launch_bounds__(64) k_finalize_fit(const GicpState* __restrict__ st, ResultBlock* out, uint32_t* __restrict__ far_stats,
+                                      const double* __restrict__ fit_psum, const uint32_t* __restrict__ fit_pcnt, int nblk) {
+  const FinalizeFitK::Args a{st, out, far_stats, fit_psum, fit_pcnt, nblk};
+  FinalizeFitK::run(a, blockIdx.x, gridDim.x);
 }
 
 // k_far: the refresh requests of the tick that just ran (bits in far_req), one query per WAVE, chip-wide.  Chunks of 64 source positions
@@ -573,7 +592,12 @@ struct FarArgs {
   uint32_t ranked_max;                 // request words up to which the requests are ranked globally (QN_FAR_WORDS; 0 = word-per-block distribution: clouds beyond 262144 points, and the test of that path)
   uint32_t* far_stats;
 };
-static __global__ void __launch_bounds__(QN_FAR_THREADS) k_far(FarArgs a) {
+struct FarK {
+  static constexpr int TB = QN_FAR_THREADS, OCC = 1;
+  using Args = FarArgs;
+  static __device__ __forceinline__ void run(const FarArgs& a_in, const uint32_t bx, const uint32_t) {
+    FarArgs a = a_in;
+
   __shared__ WaveLdsH1 lds[QN_FAR_THREADS / 64];
   __shared__ double wsum[QN_FAR_THREADS / 64][QN_NPART];
   __shared__ uint32_t wpre[QN_FAR_WORDS];                           // exclusive popcount prefix of the request words
@@ -581,18 +605,18 @@ static __global__ void __launch_bounds__(QN_FAR_THREADS) k_far(FarArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   constexpr int NW = QN_FAR_THREADS / 64;
   a.src = grid_resolve(a.src); a.tgt = grid_resolve(a.tgt);
-  const int phase = a.st->phase;
+  const int phase = uni(a.st->phase);
   double acc[QN_NPART];
 #pragma unroll
   for (int u = 0; u < QN_NPART; u++) acc[u] = 0;
-  if (phase == 0 && a.st->pending) {
+  if (phase == 0 && uni(a.st->pending)) {
     float Tf[12]; double X0[3][4];
 #pragma unroll
-    for (int j = 0; j < 12; j++) Tf[j] = (float)a.st->x0[j];
+    for (int j = 0; j < 12; j++) Tf[j] = uni((float)a.st->x0[j]);
 #pragma unroll
     for (int r = 0; r < 3; r++)
 #pragma unroll
-      for (int c = 0; c < 4; c++) X0[r][c] = a.st->x0[4 * r + c];
+      for (int c = 0; c < 4; c++) X0[r][c] = uni(a.st->x0[4 * r + c]);
     const uint32_t nchunks = (a.src.n + 63u) >> 6;
     // Work distribution.  The requests are bits in far_req (one word per 64 consecutive source positions) and they are CLUSTERED: the part of the source that has
     // no counterpart in the target is one stretch of the cell-sorted order.  Handing words to blocks (the first version) left most of the chip idle while a few
@@ -600,7 +624,7 @@ static __global__ void __launch_bounds__(QN_FAR_THREADS) k_far(FarArgs a) {
     // goes to wave e mod (all waves of the launch): balanced, and still a fixed assignment - the sums below are formed in a reproducible order.
     const bool ranked = nchunks <= min((uint32_t)QN_FAR_WORDS, a.ranked_max);
     uint32_t total_req = 0;
-    if (ranked && a.far_stats[0] != 0u) {                            // ([0]: the requests the tick counted - none: nothing to rank, nothing to serve)
+    if (ranked && uni(a.far_stats[0]) != 0u) {                            // ([0]: the requests the tick counted - none: nothing to rank, nothing to serve)
       for (uint32_t w = tid; w < nchunks; w += QN_FAR_THREADS) wpre[w] = (uint32_t)__popcll(a.far_req[w]);
       __syncthreads();
       // exclusive prefix over nchunks <= QN_FAR_WORDS values: thread i owns the run [i * PER, (i + 1) * PER)
@@ -619,10 +643,10 @@ static __global__ void __launch_bounds__(QN_FAR_THREADS) k_far(FarArgs a) {
       for (uint32_t u = 0; u < PER; u++) { const uint32_t w = tid * PER + u; if (w < nchunks) wpre[w] = base; base += loc[u]; }
       __syncthreads();
     }
-    const uint32_t gw = blockIdx.x * NW + wid, ngw = QN_FAR_BLOCKS * NW;
+    const uint32_t gw = bx * NW + wid, ngw = QN_FAR_BLOCKS * NW;
     uint32_t seen = 0;                                              // requests of this block so far (block-uniform; the unranked path)
     uint32_t e = gw;                                                  // ranked path: this wave's next request
-    uint32_t ch = ranked ? 0u : blockIdx.x;
+    uint32_t ch = ranked ? 0u : bx;
     unsigned long long word = 0;
     for (;;) {
       uint32_t t;
@@ -701,9 +725,16 @@ static __global__ void __launch_bounds__(QN_FAR_THREADS) k_far(FarArgs a) {
   __syncthreads();
   if (tid < QN_NPART) { double v = 0;
 #pragma unroll
-    for (int w = 0; w < NW; w++) v += wsum[w][tid]; a.far_rows[(size_t)blockIdx.x * QN_NPART + tid] = v; }
-}
-static __global__ void __launch_bounds__(QN_FAR_BLOCKS) k_far_reduce(const double* __restrict__ far_rows, double* __restrict__ part_row, uint32_t* __restrict__ far_stats) {
+    for (int w = 0; w < NW; w++) v += wsum[w][tid]; a.far_rows[(size_t)bx * QN_NPART + tid] = v; }
+  }
+};
+static __global__ void __launch_bounds__(QN_FAR_THREADS) k_far(FarArgs a) { FarK::run(a, blockIdx.x, gridDim.x); }
+struct FarReduceK {
+  static constexpr int TB = QN_FAR_BLOCKS, OCC = 1;
+  struct Args { const double* far_rows; double* part_row; uint32_t* far_stats; };
+  static __device__ __forceinline__ void run(const Args& a, const uint32_t, const uint32_t) {
+    const double* __restrict__ far_rows = a.far_rows; double* __restrict__ part_row = a.part_row; uint32_t* __restrict__ far_stats = a.far_stats;
+
   __shared__ double sh[QN_FAR_BLOCKS / 32][QN_NPART];
   const int tid = threadIdx.x, c = tid % 32, seg = tid / 32;          // 16 segments of 32 rows; threads c >= 28 idle
   if (tid == 0) { far_stats[1] = far_stats[0]; far_stats[0] = 0u; }   // [1] = requests of the tick just served (here, not in k_far: every block of k_far reads [0] when it starts)
@@ -718,6 +749,11 @@ static __global__ void __launch_bounds__(QN_FAR_BLOCKS) k_far_reduce(const doubl
   }
   __syncthreads();
   if (tid < QN_NPART) { double v = 0; for (int s = 0; s < QN_FAR_BLOCKS / 32; s++) v += sh[s][tid]; part_row[tid] = v; }
+  }
+};
+static __global__ void __launch_bounds__(QN_FAR_BLOCKS) k_far_reduce(const double* __restrict__ far_rows, double* __restrict__ part_row, uint32_t* __restrict__ far_stats) {
+  const FarReduceK::Args a{far_rows, part_row, far_stats};
+  FarReduceK::run(a, blockIdx.x, gridDim.x);
 }
 
 }  // namespace qn

@@ -14,7 +14,7 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fP
          "-Wno-unused-result", "-Wno-unused-value", "-Wno-pass-failed", "-I" + os.path.join(ROOT, "include")]
 
 
-N_INST_GROUPS = 10     # = QN_NUM_INST_GROUPS in csrc/qn_instances.h
+N_INST_GROUPS = 11     # = QN_NUM_INST_GROUPS in csrc/qn_instances.h
 
 
 def sources():

@@ -474,6 +474,24 @@ def icp_alignment_batch(contexts, pairs, score_thr=1.5):
     return results, list(valid), list(status)
 
 
+def gicp_align_batch(ctx, pairs, score_thr=1.5):
+    """qn_gicp_align_batch: the same batch on ONE context, the pair as a grid dimension of every kernel launch (`batch_lanes` pairs in lockstep).
+    pairs / return value as icp_alignment_batch."""
+    n = len(pairs)
+    descs = (PairDesc * n)(); keep = []
+    for i, (s, ns, d, nt, stride, dev) in enumerate(pairs):
+        if not dev:
+            s = np.ascontiguousarray(s, dtype=np.float32); d = np.ascontiguousarray(d, dtype=np.float32); keep += [s, d]
+            descs[i] = PairDesc(s.ctypes.data, ns, d.ctypes.data, nt, stride, 0)
+        else:
+            descs[i] = PairDesc(s, ns, d, nt, stride, 1)
+    results = (GicpResult * n)(); valid = (C.c_int * n)(); status = (C.c_int * n)()
+    st = lib().qn_gicp_align_batch(ctx.h, descs, C.c_uint32(n), C.c_double(score_thr), results, valid, status)
+    if st != QN_OK:
+        raise EngineError(st, lib().qn_status_str(st).decode() + ": " + lib().qn_last_error(ctx.h).decode())
+    return results, list(valid), list(status)
+
+
 class PairRecord(C.Structure):
     _fields_ = [("pair_id", C.c_int32), ("status", C.c_int32), ("valid", C.c_int32), ("converged", C.c_int32), ("iterations", C.c_int32),
                 ("reserved", C.c_int32), ("fitness", C.c_double), ("T", C.c_float * 16)]
@@ -508,6 +526,9 @@ class MultiGpu:
 
     def set_params(self, p):
         self._check(self._l.qn_multi_set_params(self.h, C.byref(p)))
+
+    def debug_set(self, key, value):
+        self._check(self._l.qn_multi_debug_set(self.h, key.encode(), C.c_double(value)))
 
     def timing(self):
         """(per-GPU ms [n_gpus], gather ms) of the latest align_best"""

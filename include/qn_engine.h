@@ -146,6 +146,12 @@ typedef struct {
 } qn_pair_desc;
 int  qn_icp_alignment_batch(qn_ctx* const* ctxs, uint32_t n_ctx, const qn_pair_desc* pairs, uint32_t n_pairs, double score_thr,
                             qn_gicp_result* results, int* valid, int* status);
+/* The same batch on ONE context with the PAIR AS A GRID DIMENSION (SURVEY.md 8b qn_gicp_align_batch; 7.1 step 8): the pairs are registered `lanes` at a
+ * time (default 8; qn_debug_set(ctx, "batch_lanes", B)) in lockstep - every kernel of the chain is launched once for all of them, blockIdx.y selecting the
+ * pair's entry of a device-resident argument table - on the context's one stream.  Each pair is an independent icpAlignment (loop_closure.cpp:110-136) with the
+ * context's parameters; consecutive pairs of a lane that name the same source buffer share its grid and covariances (the candidates of one query).
+ * Records are bit-identical to qn_icp_alignment_batch's one-pair-per-stream path.  qn_icp_alignment_batch itself uses this per context.          */
+int  qn_gicp_align_batch(qn_ctx*, const qn_pair_desc* pairs, uint32_t n_pairs, double score_thr, qn_gicp_result* results, int* valid, int* status);
 
 /* ---- candidate pairs sharded over the GPUs of one node (BASELINE "batch of 64 candidate keyframe pairs sharded
  * across 8 MI355X, RCCL gather of best loop").  The reference registers ONE candidate per timer tick
@@ -169,6 +175,7 @@ void qn_multi_destroy(qn_multi*);
 const char* qn_multi_last_error(const qn_multi*);    /* NULL argument: why the last qn_multi_init on this thread failed */
 int  qn_multi_gpu_count(const qn_multi*);
 int  qn_multi_set_params(qn_multi*, const qn_gicp_params*);            /* loop_closure.cpp:9-16, on every context */
+int  qn_multi_debug_set(qn_multi*, const char* key, double value);     /* qn_debug_set on every context (e.g. "batch_lanes": pairs per kernel launch of each context) */
 /* host wall clock of the latest qn_multi_align_best: per GPU from the call's start to its last pair's end [n_gpus], and the gather step */
 int  qn_multi_get_timing(const qn_multi*, double* per_gpu_ms, double* gather_ms);
 /* pairs[i].src/dst: host buffers, or (on_device) buffers resident on GPU device_ids[i mod n_gpus].  records (optional, n_pairs
