@@ -48,6 +48,7 @@ struct qn_ctx {
   qn::GicpState* state = nullptr;       // [2], double buffered: generation g in state[g & 1] (qn_gicp_kernels.cuh)
   uint32_t gen = 0; int part_rows = 0;  // current generation; rows of the partial buffer written under it
   double* partials = nullptr;           // [2][QN_ACC_MAX_BLOCKS][28]
+  uint32_t* tail_ticket = nullptr;      // the last-block ticket of the controller tail (controller_tail, qn_gicp_kernels.cuh)
   double* fit_psum = nullptr; uint32_t* fit_pcnt = nullptr;
   qn_iter_trace* trace = nullptr; uint32_t trace_len = 0;
   int32_t* corr = nullptr; int32_t* nn_idx = nullptr; int32_t* knn_idx = nullptr; float4* nn_ref = nullptr; double* nrm_s_sorted = nullptr; qn::TargetRec* tgt_rec = nullptr; float* sqd = nullptr; float* sqd_fit = nullptr;
@@ -95,7 +96,7 @@ struct qn_ctx {
   int tick_occ = 4;                     // k_tick variant: waves per SIMD the register budget allows (4 = 128 VGPRs: other streams' kernels keep half of the register file)
   // persistent align kernel (qn_persist.cuh): granule buffers, give-up status, epoch counter; `persist` = knob, `persist_batch_off` = this context works in a batch
   unsigned long long* pg_rows = nullptr; unsigned long long* pg_bc = nullptr; unsigned long long* pg_fit = nullptr; uint32_t* pg_status = nullptr; uint32_t* pg_status_host = nullptr;
-  unsigned long long* pg_clk = nullptr; uint32_t pg_epoch = 0; bool prof_persist = false, persist = true, persist_batch_off = false; uint32_t persist_launches = 0;
+  unsigned long long* pg_clk = nullptr; uint32_t pg_epoch = 0; bool prof_persist = false, persist = true, persist_batch_off = false, persist_fits = true; int persist_resident_blocks = 0; uint32_t persist_launches = 0, persist_gave_up = 0; unsigned long long persist_timeout = 25000000ull;
   uint32_t* dbg_counters = nullptr;
   unsigned long long* clk_probe = nullptr; uint32_t clk_n = 0;   // developer probe: device-clock stamps of k_tick
   // verify_track (debug): scratch of the fresh search every tracked pass is compared with

@@ -152,6 +152,7 @@ static int ctx_create(int device, uint32_t max_points, hipStream_t shared_stream
     sl.take(c->pg_bc, sizeof(unsigned long long) * 64);
     sl.take(c->pg_fit, sizeof(unsigned long long) * (QN_PERSIST_MAX_BLOCKS + 1) * 4);
     sl.take(c->pg_status, 4 * sizeof(uint32_t));
+    sl.take(c->tail_ticket, 4 * sizeof(uint32_t));
   };
   { Slab dry; carve(dry);                                             // pass 1: the size; pass 2: the pointers
     Slab sl; sl.cap = (dry.off + ((size_t)2 << 20) - 1) & ~(((size_t)2 << 20) - 1);
@@ -166,6 +167,7 @@ static int ctx_create(int device, uint32_t max_points, hipStream_t shared_stream
   CA(hipMemsetAsync(c->pg_bc, 0, sizeof(unsigned long long) * 64, c->stream));
   CA(hipMemsetAsync(c->pg_fit, 0, sizeof(unsigned long long) * (QN_PERSIST_MAX_BLOCKS + 1) * 4, c->stream));
   CA(hipMemsetAsync(c->pg_status, 0, 4 * sizeof(uint32_t), c->stream));
+  CA(hipMemsetAsync(c->tail_ticket, 0, 4 * sizeof(uint32_t), c->stream));      // the last-block ticket of the controller tail: handed back at zero by every launch that uses it
   CA(hipMemsetAsync(c->state, 0, 2 * sizeof(GicpState), c->stream));
   hipLaunchKernelGGL(k_bbox_acc_init, dim3(1), dim3(256), 0, c->stream, c->bbox_acc, 2 * (QN_BBOX_MAX_BLOCKS + 1));
   CA(hipMemsetAsync(c->fb_count2, 0, 4 * sizeof(uint32_t), c->stream)); CA(hipMemsetAsync(c->fb_count2b, 0, 4 * sizeof(uint32_t), c->stream));      // the k-NN list counters: every covariance stage hands them back at zero (k_cov_from_idx)
@@ -173,6 +175,13 @@ static int ctx_create(int device, uint32_t max_points, hipStream_t shared_stream
   for (int w = 0; w < 2; w++) CA(hipMemsetAsync(c->cloud[w].counts, 0, sizeof(uint32_t) * ((size_t)c->max_cells + 1), c->stream));      // the cell counters are handed back at zero by every build (k_scatter)
   CA(hipStreamSynchronize(c->stream));
 #undef CA
+  { // the persistent align kernel needs all of its blocks resident at once (up to QN_PERSIST_MAX_BLOCKS + 1 blocks of 512 threads): on a smaller or compute-partitioned
+    // device it would only spin until its time-out - measured here once per context, not assumed
+    int per_cu = 0; hipDeviceProp_t prop;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(&k_align_persist<QN_PERSIST_TB, false>), QN_PERSIST_TB, 0) != hipSuccess || hipGetDeviceProperties(&prop, device) != hipSuccess) { (void)hipGetLastError(); per_cu = 0; prop.multiProcessorCount = 0; }
+    c->persist_resident_blocks = per_cu * prop.multiProcessorCount;
+    c->persist_fits = c->persist_resident_blocks >= QN_PERSIST_MAX_BLOCKS + 1;
+  }
   *out = c;
   return QN_OK;
 }
@@ -504,17 +513,25 @@ static void enqueue_verify(qn_ctx* c, bool fused) {
 static uint32_t acc_blocks(const qn_ctx* c) { return std::min<uint32_t>((c->cloud[0].n + QN_BLOCK - 1) / QN_BLOCK, QN_ACC_MAX_BLOCKS); }
 static uint32_t tick_ppt(const qn_ctx* c) { return std::max<uint32_t>(c->tick_ppt_min, (c->cloud[0].n + c->tick_tb * QN_ACC_MAX_BLOCKS - 1) / (c->tick_tb * QN_ACC_MAX_BLOCKS)); }
 static uint32_t tick_blocks(const qn_ctx* c) { const uint32_t per = c->tick_tb * tick_ppt(c); return (c->cloud[0].n + per - 1) / per; }
-static AccumulateK::Args prep_accumulate(qn_ctx* c, int cond) {          // partial rows of the CURRENT generation
+// The controller step of a producer launch (controller_tail): generation g -> g + 1 inside the launch that wrote the rows.
+static TailArgs tail_args(qn_ctx* c, int enabled, int rows, const LookArgs* look = nullptr) {
+  TailArgs t; memset(&t, 0, sizeof(t));
+  t.st_in = st_cur(c); t.st_out = st_nxt(c); t.cfg = make_cfg(c); t.trace = c->trace; t.ticket = c->tail_ticket; t.enabled = enabled; t.rows = rows;
+  if (look) t.look = *look;
+  return t;
+}
+// tail = true: an optimiser tick - the launch's last block runs the controller and the generation advances; false: the rows stay for a stand-alone k_solve (debug entry points)
+static AccumulateK::Args prep_accumulate(qn_ctx* c, int cond, bool tail, const LookArgs* look = nullptr) {
   CloudBuf &S = c->cloud[0];
-  const AccumulateK::Args a{S.raw, S.n, S.nrm, c->tgt_rec, c->corr, st_cur(c), part_cur(c), cond};
-  c->part_rows = (int)acc_blocks(c);
+  const AccumulateK::Args a{S.raw, S.n, S.nrm, c->tgt_rec, c->corr, st_cur(c), part_cur(c), cond, tail_args(c, tail ? 1 : 0, (int)acc_blocks(c), look)};
+  if (tail) { c->gen++; c->part_rows = -1; } else c->part_rows = (int)acc_blocks(c);
   return a;
 }
-static void enqueue_accumulate(qn_ctx* c, int cond = 0) {
+static void enqueue_accumulate(qn_ctx* c, int cond, bool tail, const LookArgs* look = nullptr) {
   ProfScope ps(c, QN_K_ACCUMULATE);
   const uint32_t nb = acc_blocks(c);
-  const AccumulateK::Args a = prep_accumulate(c, cond);
-  hipLaunchKernelGGL(k_accumulate, dim3(nb), dim3(QN_BLOCK), 0, c->stream, a.src_raw, a.ns, a.nrm_s, a.tgt_rec, a.corr, a.st, a.partials, a.cond);
+  const AccumulateK::Args a = prep_accumulate(c, cond, tail, look);
+  hipLaunchKernelGGL(k_accumulate, dim3(nb), dim3(QN_BLOCK), 0, c->stream, a);
 }
 // one controller step as its own launch: generation g -> g + 1 (k_solve)
 static SolveArgs prep_solve(qn_ctx* c, int mode, int will_produce, const LookArgs* look) {
@@ -531,13 +548,15 @@ static void enqueue_solve(qn_ctx* c, int mode, int will_produce, const LookArgs*
 }
 // One "tick" of the device-side state machine = [controller step on the previous tick's partial rows] + [body under the new state].
 // Tracked regime: ONE kernel (k_tick: controller in the prologue of every block, tracked NN + accumulation, LM trial passes included).
-static TickArgs tick_args(qn_ctx* c) {
+// mode 0: an optimiser tick (its last block steps the controller unless the far-query refresh kernels follow); mode 1: the closing pass (nothing to step)
+static TickArgs tick_args(qn_ctx* c, int mode = 0) {
   CloudBuf &S = c->cloud[0], &T = c->cloud[1];
   TickArgs a;
-  a.src = S.grid; a.tgt = T.grid; a.st_in = st_cur(c); a.st_out = st_nxt(c); a.part_in = part_cur(c); a.part_out = part_nxt(c); a.rows_in = c->part_rows;
-  a.cfg = make_cfg(c); a.trace = c->trace; a.thr2 = c->params.max_corr_dist * c->params.max_corr_dist;
+  a.src = S.grid; a.tgt = T.grid; a.part_out = part_cur(c);
+  a.thr2 = c->params.max_corr_dist * c->params.max_corr_dist;
   a.nn_idx = c->nn_idx; a.nn_ref = c->nn_ref; a.nrm_s = c->nrm_s_sorted; a.tgt_rec = c->tgt_rec; a.ppt = tick_ppt(c);
   a.far_mode = c->far_enabled ? c->far_mode : 0; a.tgt_raw = T.raw; a.cand = c->far_cand; a.cand_ref = c->far_cand_ref; a.cand_b = c->far_cand_b; a.far_req = c->far_req; a.far_stats = c->far_stats;
+  a.tail = tail_args(c, (mode == 0 && a.far_mode != 1) ? 1 : 0, (int)tick_blocks(c));
   a.aligned = c->aligned; a.fit_psum = c->fit_psum; a.fit_pcnt = c->fit_pcnt;
   a.clk = c->clk_probe ? c->clk_probe + 8 * (c->clk_n++ % 256) : nullptr; a.clk_blk = c->clk_probe ? c->clk_probe + 8 * 256 : nullptr;
   return a;
@@ -549,6 +568,9 @@ static FarArgs far_args(qn_ctx* c) {         // k_far behind the tick that just 
   f.cand = c->far_cand; f.cand_ref = c->far_cand_ref; f.cand_b = c->far_cand_b; f.far_req = c->far_req; f.far_rows = c->far_rows; f.far_stats = c->far_stats; f.ranked_max = c->far_ranked ? (uint32_t)QN_FAR_WORDS : 0u;
   return f;
 }
+static FarReduceK::Args far_reduce_args(qn_ctx* c) {      // behind k_far: the side table -> one more row, then the controller step the tick left to it
+  return FarReduceK::Args{c->far_rows, part_cur(c), (int)tick_blocks(c), c->far_stats, tail_args(c, 1, (int)tick_blocks(c) + 1)};
+}
 static void enqueue_tick_fused(qn_ctx* c) {
   TickArgs a = tick_args(c);
   { ProfScope ps(c, QN_K_GN_TICK_FUSED);
@@ -559,43 +581,39 @@ static void enqueue_tick_fused(qn_ctx* c) {
     else { if (c->tick_occ >= 4) QN_TICK_LAUNCH(512, 4, false); else if (c->tick_occ == 3) QN_TICK_LAUNCH(512, 3, false); else QN_TICK_LAUNCH(512, 2, false); }
 #undef QN_TICK_LAUNCH
   }
-  c->gen++; c->part_rows = (int)tick_blocks(c);
-  if (a.far_mode == 1) {                       // the tick's refresh requests, chip-wide, one query per wave; its rows follow the tick's
+  if (a.far_mode == 1) {                       // the tick's refresh requests, chip-wide, one query per wave; its row follows the tick's, then the controller step
     const FarArgs f = far_args(c);
     { ProfScope ps(c, QN_K_FAR);
       hipLaunchKernelGGL(k_far, dim3(QN_FAR_BLOCKS), dim3(QN_FAR_THREADS), 0, c->stream, f);
-      hipLaunchKernelGGL(k_far_reduce, dim3(1), dim3(QN_FAR_BLOCKS), 0, c->stream, c->far_rows, part_cur(c) + (size_t)c->part_rows * QN_NPART, c->far_stats); }
-    c->part_rows += 1;
+      hipLaunchKernelGGL(k_far_reduce, dim3(1), dim3(QN_FAR_BLOCKS), 0, c->stream, far_reduce_args(c)); }
   }
-  if (c->verify_track) enqueue_verify(c, true);
+  if (c->verify_track) enqueue_verify(c, true);         // (before the generation advances: st_cur is still the state - the pose - the tick's body used)
+  c->gen++; c->part_rows = -1;
 }
 // Unseeded regime (the first outer iterations, while the pose still moves by more than a few cells): controller launch, grid search +
 // list passes, accumulation.  `first`: the very first tick of an align has nothing to consume.
-static void enqueue_tick(qn_ctx* c, bool seeded, int tick_no, bool first) {
+static void enqueue_tick(qn_ctx* c, bool seeded, int tick_no, const LookArgs* look = nullptr) {
   const int per_outer = c->params.optimizer == QN_OPT_LM ? 2 : 1, tick = tick_no / per_outer;      // tick = outer iteration (list-pass grid sizes)
   if (tick_no < c->unseeded_until) seeded = false;
   if (seeded && c->fused_ticks) { enqueue_tick_fused(c); return; }
-  if (!first) enqueue_solve(c, 0, 1);
   enqueue_nn(c, 0, c->sqd, seeded, tick);
   if (c->verify_track && seeded) enqueue_verify(c, false);
-  enqueue_accumulate(c);
+  enqueue_accumulate(c, 0, true, look);                              // + the controller step (and, behind the chunk's last unseeded tick of a lone forced run, the hand-over decision)
 }
 // The closing pass of align(): the last controller step + (once the state machine is done) fitness sweep + output cloud in ONE launch
 // (k_tick<.., 1>) and the result block (k_finalize_fit).  `tracked`: the neighbours of the last tick seed the sweep; without them
 // (no iteration ran, or the fused path is switched off) the unfused sequence runs: controller, search + list pass, two reductions, transform.
 static void enqueue_epilogue(qn_ctx* c, double max_range, bool tracked) {
   if (tracked && c->fused_ticks && c->fused_final) {
-    TickArgs a = tick_args(c);
+    TickArgs a = tick_args(c, 1);
     { ProfScope ps(c, QN_K_FITNESS);
       const dim3 gr(tick_blocks(c)), bl(c->tick_tb);
       if (c->tick_tb == 256) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_tick<256, 4, 1, false>), gr, bl, 0, c->stream, a);
       else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_tick<512, 4, 1, false>), gr, bl, 0, c->stream, a); }
-    c->gen++; c->part_rows = 0;
     hipLaunchKernelGGL(k_finalize_fit, dim3(1), dim3(64), 0, c->stream, st_cur(c), c->result_host, c->far_stats, c->fit_psum, c->fit_pcnt, (int)tick_blocks(c));
     return;
   }
-  enqueue_solve(c, 0, 0);                                       // the controller step that consumes the chunk's last partial rows
-  GicpState* st = st_cur(c);
+  GicpState* st = st_cur(c);                                    // (already stepped by the controller tail of the chunk's last tick)
   enqueue_nn(c, 1, c->sqd_fit, tracked, 1);
   { ProfScope ps(c, QN_K_FITNESS);
     hipLaunchKernelGGL(k_fitness_partial, dim3(QN_FIT_BLOCKS), dim3(QN_BLOCK), 0, c->stream, c->sqd_fit, c->cloud[0].n, max_range, st, c->fit_psum, c->fit_pcnt, 1);
@@ -610,14 +628,29 @@ static void enqueue_epilogue(qn_ctx* c, double max_range, bool tracked) {
 // other contexts, the profiling / verification / probe modes and the far-query refresh regime (k_far between the ticks) keep the k_tick chain.
 static std::atomic<int> g_aligns_in_flight{0};
 static uint32_t persist_ppt(const qn_ctx* c) { const uint32_t cap = QN_PERSIST_TB * QN_PERSIST_MAX_BLOCKS; return (c->cloud[0].n + cap - 1) / cap; }
+// (clouds beyond QN_PERSIST_TB x QN_PERSIST_MAX_BLOCKS points keep the chain: with more than one point per lane the persistent kernel's tracking records would live in memory, where
+//  its top-2 form - nn_ref.w bounds the THIRD-nearest point - is not what k_tick reads; persist_fits: the launch's nblk + 1 blocks are all resident on this device, measured at context creation)
 static bool persist_usable(const qn_ctx* c, bool alone) {
-  return c->persist && !c->persist_batch_off && alone && c->fused_ticks && c->fused_final && (!c->prof_on || c->prof_persist) && !c->verify_track && !c->clk_probe && c->tick_tb == QN_PERSIST_TB &&
+  return c->persist && c->persist_fits && persist_ppt(c) == 1 && !c->persist_batch_off && alone && c->fused_ticks && c->fused_final && (!c->prof_on || c->prof_persist) && !c->verify_track && !c->clk_probe && c->tick_tb == QN_PERSIST_TB &&
          (!c->far_enabled || c->far_mode == 2) && c->pg_rows != nullptr;
 }
-static int launch_persist(qn_ctx* c, uint32_t max_ticks, int cond = 0, int rows_if_extra = 0) {
+// A persistent launch that gave up (bounded spins: the reducer or a worker waited longer than `persist_timeout` - another tenant holds CUs, a partitioned device ...) leaves
+// its row buffers in an unknown state and tracking records in its own top-2 form: re-arm the buffers; the caller then runs the whole align again on the k_tick chain
+// (the reference would just be slow there, loop_closure.cpp:124 - never a lost loop closure).
+static const int QN_INTERNAL_RETRY = -100;
+static int persist_recover(qn_ctx* c) {
+  hipStream_t s = c->stream;
+  HIPCHK(c, hipMemsetAsync(c->pg_rows, 0xFF, sizeof(unsigned long long) * 3 * QN_PERSIST_ROWS * QN_PERSIST_RSTRIDE, s));
+  HIPCHK(c, hipMemsetAsync(c->pg_status, 0, 4 * sizeof(uint32_t), s));
+  HIPCHK(c, hipStreamSynchronize(s));
+  char buf[200]; snprintf(buf, sizeof(buf), "align: the persistent kernel gave up (code %u after %u ticks: 1 rows, 2 tick budget, 3 closing sums, 4 pose) - the registration was re-run on the k_tick chain", c->pg_status_host[0], c->pg_status_host[1]);
+  c->last_error = buf; c->persist_gave_up++;
+  return QN_OK;
+}
+static int launch_persist(qn_ctx* c, uint32_t max_ticks, int cond = 0) {
   PersistArgs A;
-  A.t = tick_args(c);
-  A.cond = cond; A.rows_if_extra = rows_if_extra; A.status_host = c->pg_status_host;
+  A.t = tick_args(c);                                                // (tail.st_in: the state the chain left, already stepped; tail.st_out: where the reducer leaves the final state)
+  A.cond = cond; A.status_host = c->pg_status_host;
   A.t.ppt = persist_ppt(c); A.t.clk = nullptr; A.t.clk_blk = nullptr;
   A.t.far_mode = c->far_enabled ? 2 : 0;
   const uint32_t per = QN_PERSIST_TB * A.t.ppt;
@@ -629,7 +662,7 @@ static int launch_persist(qn_ctx* c, uint32_t max_ticks, int cond = 0, int rows_
   }
   A.rows_g = c->pg_rows; A.bc_g = c->pg_bc; A.fit_g = c->pg_fit; A.status = c->pg_status; A.result = c->result_host;
   A.epoch0 = c->pg_epoch; A.max_ticks = max_ticks; c->pg_epoch += max_ticks + 8;
-  A.timeout = 25000000ull;                                           // 0.25 s of the 100 MHz wall clock: three orders of magnitude above any legitimate wait
+  A.timeout = c->persist_timeout;                                    // per spin, 100 MHz wall clock; default 0.25 s: three orders of magnitude above any legitimate wait
   c->pg_status_host[0] = 0xffffffffu; c->pg_status_host[1] = 0;      // (the reducer overwrites it when it leaves)
   { ProfScope ps(c, QN_K_ALIGN_PERSIST);
     A.clk = c->pg_clk;
@@ -649,7 +682,8 @@ static int ready(qn_ctx* c) {
 static int gicp_align(qn_ctx* c, const float guess[16], qn_gicp_result* out, bool alone);
 extern "C" int qn_gicp_align(qn_ctx* c, const float guess[16], qn_gicp_result* out) {
   const bool alone = g_aligns_in_flight.fetch_add(1) == 0;           // (a heuristic for the persistent launch only: correctness never depends on it)
-  const int rc = gicp_align(c, guess, out, alone);
+  int rc = gicp_align(c, guess, out, alone);
+  if (rc == QN_INTERNAL_RETRY) rc = gicp_align(c, guess, out, false);      // (alone = false: no persistent launch this time)
   g_aligns_in_flight.fetch_sub(1);
   return rc;
 }
@@ -697,45 +731,39 @@ static int gicp_align(qn_ctx* c, const float guess[16], qn_gicp_result* out, boo
   c->unseeded_until = adaptive ? chunk : fixed_unseeded;           // ticks below this index search unseeded (enqueue_tick)
   bool seeded = false; int tick_no = 0;   // the first linearisation runs the full grid search; every later NN pass tracks from it
   for (;;) {
-    for (int t = 0; t < chunk; t++) {
-      c->count_far_now = first_chunk && (t / per_outer == (chunk - 1) / per_outer);      // far-query statistics: the chunk's last unseeded linearisation
-      enqueue_tick(c, seeded, tick_no, tick_no == 0 || c->part_rows < 0); tick_no++; seeded = true;
-    }
-    c->count_far_now = false;
-    const bool look = adaptive && first_chunk && ticks_left > chunk;      // the adaptive look: the controller step behind the chunk's last tick, then the state
-    // A registration that is alone on the GPU takes the look ON THE DEVICE (look_decide): the conditional third unseeded iteration and the persistent launch are enqueued
-    // behind it and read its flags - no host round trip between the unseeded ticks and the tracked regime (it cost 15-30 us of a 0.6 ms align).  If the flags
-    // say "not the persistent kernel" (many far neighbours: the k_far regime), that launch returns at once and the chain goes on from the host below.
-    const bool dev_look = look && c->device_look && tick_no > 0;
+    const bool look = adaptive && first_chunk && ticks_left > chunk;      // the adaptive look: the state behind the chunk's last tick (its controller tail has stepped it)
+    // A registration that is alone on the GPU takes the look ON THE DEVICE (look_decide, at the end of that controller tail): the conditional third unseeded iteration and
+    // the persistent launch are enqueued behind it and read its flags - no host round trip between the unseeded ticks and the tracked regime (it cost 15-30 us of a
+    // 0.6 ms align).  If the flags say "not the persistent kernel" (many far neighbours: the k_far regime), that launch returns at once and the chain goes on from the host below.
+    const bool dev_look = look && c->device_look && chunk > 0;
     const bool with_persist = dev_look && persist_usable(c, alone);   // (a batch member takes the same look - its third unseeded iteration is conditional too - and carries on with the chain)
-    bool declined = false;
-    if (look && !dev_look) enqueue_solve(c, 0, 1);
+    LookArgs la; memset(&la, 0, sizeof(la));
     if (dev_look) {
-      LookArgs la; la.out = c->result_host; la.far_stats = c->far_stats; la.sdims = c->cloud[0].dims; la.tdims = c->cloud[1].dims; la.enabled = 1;
+      la.out = c->result_host; la.far_stats = c->far_stats; la.sdims = c->cloud[0].dims; la.tdims = c->cloud[1].dims; la.enabled = 1;
       la.allow_extra = std::min(ticks_left - chunk - 1, per_outer) > 0 ? 1 : 0;
       c->result_host->look = 0;
-      enqueue_solve(c, 0, 1, &la);                                   // the controller step behind the chunk's last tick, and the decision at its end
+    }
+    for (int t = 0; t < chunk; t++) {
+      c->count_far_now = first_chunk && (t / per_outer == (chunk - 1) / per_outer);      // far-query statistics: the chunk's last unseeded linearisation
+      enqueue_tick(c, seeded, tick_no, (dev_look && t == chunk - 1) ? &la : nullptr); tick_no++; seeded = true;
+    }
+    c->count_far_now = false;
+    bool declined = false;
+    if (dev_look) {
       c->unseeded_until = tick_no + 1;
       enqueue_nn(c, 0, c->sqd, false, tick_no / per_outer, QN_LOOK_EXTRA);
-      enqueue_accumulate(c, QN_LOOK_EXTRA);
-      const int rows_if_extra = c->part_rows;
-      c->part_rows = -1;                                            // (the kernel picks rows_if_extra instead when the extra iteration ran)
-      if (with_persist && (rc = launch_persist(c, (uint32_t)(budget - chunk) + 2u, QN_LOOK_GO, rows_if_extra)) != QN_OK) return rc;
+      enqueue_accumulate(c, QN_LOOK_EXTRA, true);                   // (flag not set: the launch hands the state on unchanged)
+      if (with_persist && (rc = launch_persist(c, (uint32_t)(budget - chunk) + 2u, QN_LOOK_GO)) != QN_OK) return rc;
       HIPCHK(c, hipGetLastError());
       HIPCHK(c, hipStreamSynchronize(s));
       if ((rc = clouds_valid(c)) != QN_OK) return rc;
       const int extra = (c->result_host->look & QN_LOOK_EXTRA) ? per_outer : 0;
       c->last_extra_unseeded = extra;
       if (with_persist && c->result_host->phase == 2) break;        // the whole registration ran behind the look
-      if (with_persist && c->pg_status_host[0] != 5u) {
-        (void)hipMemsetAsync(c->pg_rows, 0xFF, sizeof(unsigned long long) * 3 * QN_PERSIST_ROWS * QN_PERSIST_RSTRIDE, s); (void)hipMemsetAsync(c->pg_status, 0, 4 * sizeof(uint32_t), s); (void)hipStreamSynchronize(s);
-        char buf[160]; snprintf(buf, sizeof(buf), "align: the persistent kernel gave up (code %u after %u ticks: 1 rows, 2 tick budget, 3 closing sums, 4 pose)", c->pg_status_host[0], c->pg_status_host[1]);
-        c->last_error = buf; return QN_ERR_HIP;
-      }
+      if (with_persist && c->pg_status_host[0] != 5u) { if ((rc = persist_recover(c)) != QN_OK) return rc; return QN_INTERNAL_RETRY; }      // gave up: the whole align again, on the chain
       // declined: the state is the one the look (and the extra iteration, if it ran) left - carry on with the chain
       declined = true;
-      if (with_persist) { c->gen--; c->persist_launches--; }        // (the declined launch wrote no state)
-      c->part_rows = extra ? rows_if_extra : -1;
+      if (with_persist) { c->gen--; c->persist_launches--; }        // (the launch wrote no state)
       tick_no += extra; budget -= extra; ticks_left -= extra;
       c->unseeded_until = tick_no;
     } else {
@@ -779,7 +807,7 @@ static int gicp_align(qn_ctx* c, const float guess[16], qn_gicp_result* out, boo
       extra = std::min(extra * per_outer, std::max(0, std::min(ticks_left - 1, per_outer)));
       if (!(moved == moved)) extra = 0;
       c->unseeded_until = tick_no + extra;
-      for (int t = 0; t < extra; t++) { enqueue_tick(c, seeded, tick_no, c->part_rows < 0); tick_no++; }
+      for (int t = 0; t < extra; t++) { enqueue_tick(c, seeded, tick_no); tick_no++; }
       budget -= extra; ticks_left -= extra;
       if (exact_ticks) chunk = c->far_mode == 1 ? std::min(ticks_left, c->far_chunk) : ticks_left;
       c->last_extra_unseeded = extra;
@@ -788,12 +816,9 @@ static int gicp_align(qn_ctx* c, const float guess[16], qn_gicp_result* out, boo
       if ((rc = launch_persist(c, (uint32_t)budget + 2u)) != QN_OK) return rc;
       HIPCHK(c, hipGetLastError());
       HIPCHK(c, hipStreamSynchronize(s));
-      if (c->result_host->phase != 2) {
-        (void)hipMemsetAsync(c->pg_rows, 0xFF, sizeof(unsigned long long) * 3 * QN_PERSIST_ROWS * QN_PERSIST_RSTRIDE, s); (void)hipMemsetAsync(c->pg_status, 0, 4 * sizeof(uint32_t), s); (void)hipStreamSynchronize(s);      // a launch that gave up leaves its row buffers in an unknown state
-        char buf[160]; snprintf(buf, sizeof(buf), "align: the persistent kernel gave up (code %u after %u ticks: 1 rows, 2 tick budget, 3 closing sums, 4 pose)", c->pg_status_host[0], c->pg_status_host[1]);
-        c->last_error = buf; return QN_ERR_HIP;
-      }
-      break;
+      if (c->result_host->phase == 2) break;
+      if ((rc = persist_recover(c)) != QN_OK) return rc;            // gave up: the whole align again, on the chain
+      return QN_INTERNAL_RETRY;
     }
     first_chunk = false;
   }
@@ -985,7 +1010,7 @@ extern "C" int qn_gicp_linearize(qn_ctx* c, const double T[16], double H[36], do
   hipStream_t s = c->stream;
   HIPCHK(c, hipMemcpyAsync(c->pose_tmp, T, sizeof(double) * 16, hipMemcpyHostToDevice, s));
   hipLaunchKernelGGL(k_set_pose, dim3(1), dim3(64), 0, s, st_cur(c), c->pose_tmp, 0, 0);
-  enqueue_nn(c, 0, c->sqd, false); enqueue_accumulate(c); enqueue_solve(c, 1, 0);
+  enqueue_nn(c, 0, c->sqd, false); enqueue_accumulate(c, 0, false); enqueue_solve(c, 1, 0);
   GicpState* hs = (GicpState*)malloc(sizeof(GicpState));
   hipError_t e = hipMemcpyAsync(hs, st_cur(c), sizeof(GicpState), hipMemcpyDeviceToHost, s);
   if (e == hipSuccess && corr_out) e = hipMemcpyAsync(corr_out, c->corr, sizeof(int32_t) * c->cloud[0].n, hipMemcpyDeviceToHost, s);
@@ -1006,7 +1031,7 @@ extern "C" int qn_gicp_compute_error(qn_ctx* c, const double T[16], double* err)
   hipStream_t s = c->stream;
   HIPCHK(c, hipMemcpyAsync(c->pose_tmp, T, sizeof(double) * 16, hipMemcpyHostToDevice, s));
   hipLaunchKernelGGL(k_set_pose, dim3(1), dim3(64), 0, s, st_cur(c), c->pose_tmp, 1, 1);
-  enqueue_accumulate(c); enqueue_solve(c, 2, 0);
+  enqueue_accumulate(c, 0, false); enqueue_solve(c, 2, 0);
   HIPCHK(c, hipMemcpyAsync(c->scalar_host, &st_cur(c)->yi, sizeof(double), hipMemcpyDeviceToHost, s));
   HIPCHK(c, hipStreamSynchronize(s));
   *err = c->scalar_host[0];
@@ -1041,6 +1066,7 @@ extern "C" int qn_debug_set(qn_ctx* c, const char* key, double v) {
   else if (k == "batch_look") c->batch_look = v != 0;
   else if (k == "pair_pipeline") c->pair_pipeline = v != 0;
   else if (k == "persist") c->persist = v != 0;
+  else if (k == "persist_timeout") c->persist_timeout = v < 1 ? 1ull : (unsigned long long)v;      // 100 MHz ticks a spin of the persistent kernel may last (tests force a give-up with a tiny value)
   else if (k == "prof_persist") c->prof_persist = v != 0;      // profiling (qn_prof_enable) normally times the k_tick chain; 1: let the persistent kernel run and time it as its own family
   else if (k == "persist_probe") {                              // developer probe: wall-clock stamps inside k_align_persist (qn_debug_get_persist_clk)
     if (v != 0 && !c->pg_clk) { if (hipMalloc(&c->pg_clk, 8 * (64 * 16 + 16)) != hipSuccess) return QN_ERR_HIP; }
@@ -1130,6 +1156,9 @@ extern "C" int qn_debug_get(qn_ctx* c, const char* key, double* value) {
   if (k == "quatro_wall_solve_ms") { *value = c->q_wall_ms[2]; return QN_OK; }
   if (k == "extra_unseeded") { *value = c->last_extra_unseeded; return QN_OK; }          // the adaptive hand-over's decision in the latest align (ticks)
   if (k == "persist_launches") { *value = c->persist_launches; return QN_OK; }
+  if (k == "persist_gave_up") { *value = c->persist_gave_up; return QN_OK; }      // persistent launches that gave up and were re-run on the k_tick chain
+  if (k == "persist_fits") { *value = c->persist_fits ? 1 : 0; return QN_OK; }
+  if (k == "persist_resident_blocks") { *value = c->persist_resident_blocks; return QN_OK; }
   if (k == "batch_launches") { *value = (double)c->batch_launches; return QN_OK; }      // kernel launches / pairs of the batched path so far (launches per registration = the ratio)
   if (k == "batch_pairs") { *value = (double)c->batch_pairs; return QN_OK; }
   if (k == "batch_lanes") { *value = (double)c->batch_lanes; return QN_OK; }      // aligns of this context that ran the persistent kernel

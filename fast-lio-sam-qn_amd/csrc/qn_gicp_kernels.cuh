@@ -716,8 +716,17 @@ __device__ __forceinline__ void accumulate_point_n(const double (*Rx)[4], const 
   }
 }
 
+// Rows that another block of the SAME launch reads (the last block to finish runs the controller: controller_tail) leave their block as agent-scope write-through
+// stores and are read with agent-scope loads - the per-XCD L2s are never asked to be coherent (the hand-off of the persistent kernel, qn_persist.cuh).
+typedef __attribute__((address_space(1))) unsigned long long qn_gu64;
+__device__ __forceinline__ void pr_store(unsigned long long* p, unsigned long long bits) { __hip_atomic_store((qn_gu64*)p, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ unsigned long long pr_load(const unsigned long long* p) { return __hip_atomic_load((qn_gu64*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void row_store(double* p, double v, const bool coherent) {
+  if (coherent) pr_store((unsigned long long*)p, (unsigned long long)__double_as_longlong(v)); else *p = v;
+}
+
 // block-level reduction of the 28 per-thread sums (DPP row sums + 2 cross-row shuffles per wave, then the 4 waves in order)
-__device__ __forceinline__ void reduce_block_partials(const double acc[QN_NPART], const bool lin, double* __restrict__ partials, double (*red)[QN_NPART], const uint32_t blk) {
+__device__ __forceinline__ void reduce_block_partials(const double acc[QN_NPART], const bool lin, double* __restrict__ partials, double (*red)[QN_NPART], const uint32_t blk, const bool coherent = false) {
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   if (lin) {
 #pragma unroll
@@ -731,46 +740,11 @@ __device__ __forceinline__ void reduce_block_partials(const double acc[QN_NPART]
     double s = 0;
 #pragma unroll
     for (int w = 0; w < QN_BLOCK / 64; w++) s += red[w][threadIdx.x];
-    partials[(size_t)blk * QN_NPART + threadIdx.x] = s;   // blk = LOGICAL block: the reduction tree does not depend on the block order
+    row_store(&partials[(size_t)blk * QN_NPART + threadIdx.x], s, coherent);   // blk = LOGICAL block: the reduction tree does not depend on the block order
   }
 }
 
-struct AccumulateK {
-  static constexpr int TB = QN_BLOCK, OCC = 1;
-  struct Args { const float4* src_raw; uint32_t ns; const double* nrm_s; const TargetRec* tgt_rec; const int32_t* corr; const GicpState* st; double* partials; int cond; };
-  static __device__ __forceinline__ void run(const Args& a, const uint32_t bx, const uint32_t nbx) {
-    __shared__ double red[QN_BLOCK / 64][QN_NPART];
-    const float4* __restrict__ src_raw = a.src_raw; const double* __restrict__ nrm_s = a.nrm_s; const TargetRec* __restrict__ tgt_rec = a.tgt_rec;
-    const int32_t* __restrict__ corr = a.corr; const GicpState* __restrict__ st = a.st;
-    const uint32_t ns = a.ns;
-    const int phase = uni(st->phase);
-    if (phase == 2) return;
-    if (a.cond && !(uni(st->reserved) & a.cond)) return;               // a conditional launch behind look_decide
-    double R[3][4], T[3][4];
-#pragma unroll
-    for (int u = 0; u < 3; u++)
-#pragma unroll
-      for (int b = 0; b < 4; b++) { T[u][b] = uni(phase == 0 ? st->x0[4 * u + b] : st->xi[4 * u + b]); R[u][b] = uni(st->x0[4 * u + b]); }
-    double acc[QN_NPART];
-#pragma unroll
-    for (int t = 0; t < QN_NPART; t++) acc[t] = 0;
-    for (uint32_t i = bx * QN_BLOCK + threadIdx.x; i < ns; i += nbx * QN_BLOCK) {
-      const int j = corr[i];
-      if (j < 0) continue;
-      const TargetRec* rec = tgt_rec + j;
-      const double na[3] = {nrm_s[(size_t)i * 3], nrm_s[(size_t)i * 3 + 1], nrm_s[(size_t)i * 3 + 2]};
-      const double nb[3] = {rec->n[0], rec->n[1], rec->n[2]};
-      accumulate_point_n(R, T, src_raw[i], rec->p, na, nb, phase == 0, acc);
-    }
-    reduce_block_partials(acc, phase == 0, a.partials, red, bx);
-  }
-};
-static __global__ void __launch_bounds__(QN_BLOCK) k_accumulate(const float4* __restrict__ src_raw, uint32_t ns, const double* __restrict__ nrm_s, const TargetRec* __restrict__ tgt_rec,
-                                                         const int32_t* __restrict__ corr, const GicpState* __restrict__ st,
-                                                         double* __restrict__ partials, int cond) {
-  const AccumulateK::Args a{src_raw, ns, nrm_s, tgt_rec, corr, st, partials, cond};
-  AccumulateK::run(a, blockIdx.x, gridDim.x);
-}
+// (AccumulateK / k_accumulate: below the controller, whose step the last block of the launch may run - controller_tail)
 
 // ------------------------------------------------------------------ K4a', temporal tracking
 // Iterations after the first (and the fitness pass) start from the previous iteration's nearest
@@ -1121,32 +1095,40 @@ __device__ inline void solve_controller(GicpState* st, const double* sums, const
 }
 
 
-// Deterministic sum of `rows` partial rows (28 f64 each) by a block of NT threads: SEGS = NT / 28 strided sub-sums per component
-// (thread (s, c) adds rows s, s + SEGS, ... in order; a wave reads whole rows: coalesced 224-byte runs), combined in a fixed order.
-// The loads of up to 32 rows per thread are issued back to back (ONE memory round trip for <= 32 SEGS rows - the rows sit in
-// L2 / MALL, ~1 us away - instead of one per small batch).  Every caller (the prologue of k_tick in every block, k_solve) runs the same
-// instantiation and gets the same bits.  Ends with a __syncthreads(); sums[] is valid for every thread afterwards.
+// Deterministic sum of `rows` partial rows (28 f64 each): QN_ROW_SEGS = 18 strided sub-sums per component (sub-sum (s, c) adds rows s, s + 18, ... in order; a wave
+// reads whole rows: coalesced 224-byte runs), combined in a fixed order.  A block of 512 threads gives every (s, c) pair a thread of its own, a block of 256
+// threads takes two pairs per thread - the ORDER of the additions is the same for every block size, so every caller (the controller tail of k_tick / k_accumulate /
+// k_far_reduce, k_solve, the persistent kernel's reducer) gets the same bits.  The loads of up to 32 rows per sub-sum are issued back to back (ONE memory round
+// trip - the rows sit in L2 / MALL, ~1 us away).  COHERENT: the rows were written by other blocks of THIS launch (row_store) - agent-scope loads.
+// Ends with a __syncthreads(); sums[] is valid for every thread afterwards.
 #define QN_ROWS_BATCH 32
-template <int NT>
-__device__ __forceinline__ void reduce_partial_rows(const double* __restrict__ part, const int rows, double (*part_s)[NT / QN_NPART + 1], double* sums) {
-  constexpr int SEGS = NT / QN_NPART;
+#define QN_ROW_SEGS 18
+template <int NT, bool COHERENT>
+__device__ __forceinline__ void reduce_rows(const double* __restrict__ part, const int rows, double (*part_s)[QN_ROW_SEGS + 1], double* sums) {
+  constexpr int PER = NT / QN_NPART;                                  // (s, c) pairs one pass of the block covers: 18 at 512 threads, 9 at 256
+  static_assert(PER >= 1 && QN_ROW_SEGS % PER == 0, "block size must tile the 18 segments");
   const int tid = threadIdx.x;
-  if (tid < QN_NPART * SEGS) {
-    const int s = tid / QN_NPART, c = tid - s * QN_NPART;
-    double a = 0;
-    for (int r0 = s; r0 < rows; r0 += SEGS * QN_ROWS_BATCH) {
-      double v[QN_ROWS_BATCH];
+  if (tid < QN_NPART * PER) {
+    const int s0 = tid / QN_NPART, c = tid - s0 * QN_NPART;
+    for (int s = s0; s < QN_ROW_SEGS; s += PER) {
+      double a = 0;
+      for (int r0 = s; r0 < rows; r0 += QN_ROW_SEGS * QN_ROWS_BATCH) {
+        double v[QN_ROWS_BATCH];
 #pragma unroll
-      for (int u = 0; u < QN_ROWS_BATCH; u++) { const int r = r0 + SEGS * u; v[u] = r < rows ? part[(size_t)r * QN_NPART + c] : 0.0; }
+        for (int u = 0; u < QN_ROWS_BATCH; u++) {
+          const int r = r0 + QN_ROW_SEGS * u;
+          v[u] = r < rows ? (COHERENT ? __longlong_as_double((long long)pr_load((const unsigned long long*)(part + (size_t)r * QN_NPART + c))) : part[(size_t)r * QN_NPART + c]) : 0.0;
+        }
 #pragma unroll
-      for (int u = 0; u < QN_ROWS_BATCH; u++) a += v[u];
+        for (int u = 0; u < QN_ROWS_BATCH; u++) a += v[u];
+      }
+      part_s[c][s] = a;
     }
-    part_s[c][s] = a;
   }
   __syncthreads();
   if (tid < QN_NPART) { double v = 0;
 #pragma unroll
-    for (int s = 0; s < SEGS; s++) v += part_s[tid][s]; sums[tid] = v; }
+    for (int s = 0; s < QN_ROW_SEGS; s++) v += part_s[tid][s]; sums[tid] = v; }
   __syncthreads();
 }
 
@@ -1179,6 +1161,40 @@ __device__ inline void look_decide(GicpState* st, ResultBlock* out, uint32_t* __
   st->reserved = flags; out->look = (uint32_t)flags | 0x100u;        // (0x100: "a device look ran")
 }
 
+// The controller step at the TAIL of the launch that produced the partial rows (round 4; before: in the prologue of the NEXT launch, run redundantly by every one
+// of its blocks after each had re-read every row - 196 x 196 x 224 B and 196 one-lane f64 solves per tick).  Every block stores its row (row_store, write-through),
+// waits for the stores' acknowledgement and takes a ticket; the block that draws the last ticket reads the state the launch ran under, sums the rows in the fixed
+// order of reduce_rows, runs the LM / GN controller and writes the NEXT state: generation g -> g + 1 inside the producer.  The following launch starts from one
+// 300-byte state.  Same controller code, same order of additions as k_solve and the persistent kernel's reducer => the same bits.
+struct TailArgs { const GicpState* st_in; GicpState* st_out; GicpConfig cfg; qn_iter_trace* trace; uint32_t* ticket; int enabled; int rows; LookArgs look; };      // rows: partial rows of the launch
+struct TailLds { GicpState sh; double part[QN_NPART][QN_ROW_SEGS + 1]; double sums[QN_NPART]; SolveWork work; int last; };
+template <int NT>
+__device__ __forceinline__ void controller_tail(const TailArgs& t, const double* __restrict__ rows, const uint32_t nblk, TailLds* L) {
+  const int tid = threadIdx.x;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                   // this block's row (stored by its first wave, which also takes the ticket) has been acknowledged
+  if (tid == 0) L->last = __hip_atomic_fetch_add(t.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nblk - 1u ? 1 : 0;
+  __syncthreads();
+  if (!L->last) return;
+  if (tid == 0) __hip_atomic_store(t.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (nobody else touches it any more: every other block has drawn)
+  static_assert(sizeof(GicpState) % 8 == 0, "GicpState is copied as 8-byte words");
+  for (int i = tid; i < (int)(sizeof(GicpState) / 8); i += NT) ((unsigned long long*)&L->sh)[i] = ((const unsigned long long*)t.st_in)[i];
+  reduce_rows<NT, true>(rows, t.rows, L->part, L->sums);
+  if (tid == 0) {
+    const int phase = L->sh.phase;
+    if (L->sh.pending && phase != 2) { const GicpConfig cfg = t.cfg; solve_controller(&L->sh, L->sums, cfg, t.trace, 0, phase, &L->work); }
+    L->sh.fb_count = 0; L->sh.big_count = 0; L->sh.pending = L->sh.phase != 2 ? 1 : 0;      // the next launch's body writes rows under the new state
+    if (t.look.enabled) look_decide(&L->sh, t.look.out, t.look.far_stats, t.look.sdims, t.look.tdims, t.look.allow_extra);
+  }
+  __syncthreads();
+  for (int i = tid; i < (int)(sizeof(GicpState) / 8); i += NT) ((unsigned long long*)t.st_out)[i] = ((const unsigned long long*)&L->sh)[i];
+}
+// a launch that leaves early (state machine done, or a conditional launch whose flag is not set) hands the state on unchanged: the host advances the generation regardless
+template <int NT>
+__device__ __forceinline__ void state_pass_through(const TailArgs& t, const uint32_t bx) {
+  if (bx != 0) return;
+  for (int i = threadIdx.x; i < (int)(sizeof(GicpState) / 8); i += NT) ((unsigned long long*)t.st_out)[i] = ((const unsigned long long*)t.st_in)[i];
+}
+
 // One controller step as its own launch (unseeded first ticks, the end of a chunk, the debug entry points): generation g -> g + 1.
 // mode 0: the LM / GN controller, if partial rows are pending under st_in.  mode 1 / 2: reduce a linearisation / an error pass only.
 // will_produce: a body that writes partial rows under the NEW state follows (so they are pending for the next controller step).
@@ -1189,7 +1205,7 @@ struct SolveK {
   using Args = SolveArgs;
   static __device__ __forceinline__ void run(const Args& a, const uint32_t, const uint32_t) {
     __shared__ double sums[QN_NPART];
-    __shared__ double part8[QN_NPART][NT / QN_NPART + 1];
+    __shared__ double part8[QN_NPART][QN_ROW_SEGS + 1];
     __shared__ GicpState sh;                       // the controller works on an LDS copy: one coalesced read, one coalesced write-back
     __shared__ SolveWork Awork_s; SolveWork* Awork = &Awork_s;
     static_assert(sizeof(GicpState) % 8 == 0, "GicpState is copied as 8-byte words");
@@ -1199,7 +1215,7 @@ struct SolveK {
     __syncthreads();
     const int phase = sh.phase;
     if (mode != 0 || (sh.pending && phase != 2 && rows >= 0)) {        // rows < 0: the pending rows were consumed by an earlier stand-alone controller step
-      reduce_partial_rows<NT>(a.partials, rows, part8, sums);
+      reduce_rows<NT, false>(a.partials, rows, part8, sums);
       if (threadIdx.x == 0) { const GicpConfig cfg = a.cfg; solve_controller(&sh, sums, cfg, a.trace, mode, phase, Awork); }
     }
     if (threadIdx.x == 0) { sh.fb_count = 0; sh.big_count = 0; sh.pending = (a.will_produce && sh.phase != 2) ? 1 : 0; }
@@ -1214,6 +1230,41 @@ static __global__ void __launch_bounds__(NT) k_solve(const GicpState* __restrict
   const SolveArgs a{st_in, st_out, partials, rows, cfg, trace, mode, will_produce, look};
   SolveK<NT>::run(a, blockIdx.x, gridDim.x);
 }
+
+// ------------------------------------------------------------------ K4b / K5 accumulate (+ the controller step in the launch's last block)
+struct AccumulateK {
+  static constexpr int TB = QN_BLOCK, OCC = 1;
+  struct Args { const float4* src_raw; uint32_t ns; const double* nrm_s; const TargetRec* tgt_rec; const int32_t* corr; const GicpState* st; double* partials; int cond; TailArgs tail; };
+  static __device__ __forceinline__ void run(const Args& a, const uint32_t bx, const uint32_t nbx) {
+    __shared__ double red[QN_BLOCK / 64][QN_NPART];
+    __shared__ TailLds tl;
+    const float4* __restrict__ src_raw = a.src_raw; const double* __restrict__ nrm_s = a.nrm_s; const TargetRec* __restrict__ tgt_rec = a.tgt_rec;
+    const int32_t* __restrict__ corr = a.corr; const GicpState* __restrict__ st = a.st;
+    const uint32_t ns = a.ns;
+    const int phase = uni(st->phase);
+    const bool skip = phase == 2 || (a.cond && !(uni(st->reserved) & a.cond));      // done, or a conditional launch behind look_decide whose flag is not set
+    if (skip) { if (a.tail.enabled) state_pass_through<QN_BLOCK>(a.tail, bx); return; }
+    double R[3][4], T[3][4];
+#pragma unroll
+    for (int u = 0; u < 3; u++)
+#pragma unroll
+      for (int b = 0; b < 4; b++) { T[u][b] = uni(phase == 0 ? st->x0[4 * u + b] : st->xi[4 * u + b]); R[u][b] = uni(st->x0[4 * u + b]); }
+    double acc[QN_NPART];
+#pragma unroll
+    for (int t = 0; t < QN_NPART; t++) acc[t] = 0;
+    for (uint32_t i = bx * QN_BLOCK + threadIdx.x; i < ns; i += nbx * QN_BLOCK) {
+      const int j = corr[i];
+      if (j < 0) continue;
+      const TargetRec* rec = tgt_rec + j;
+      const double na[3] = {nrm_s[(size_t)i * 3], nrm_s[(size_t)i * 3 + 1], nrm_s[(size_t)i * 3 + 2]};
+      const double nb[3] = {rec->n[0], rec->n[1], rec->n[2]};
+      accumulate_point_n(R, T, src_raw[i], rec->p, na, nb, phase == 0, acc);
+    }
+    reduce_block_partials(acc, phase == 0, a.partials, red, bx, a.tail.enabled != 0);
+    if (a.tail.enabled) controller_tail<QN_BLOCK>(a.tail, a.partials, nbx, &tl);
+  }
+};
+static __global__ void __launch_bounds__(QN_BLOCK) k_accumulate(AccumulateK::Args a) { AccumulateK::run(a, blockIdx.x, gridDim.x); }
 
 struct InitStateK {
   static constexpr int TB = 64, OCC = 1;

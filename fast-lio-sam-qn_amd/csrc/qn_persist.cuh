@@ -9,7 +9,7 @@
 //
 //   worker, tick g:   poll the pose granules tagged g + 1  ->  tick_point (tracked exact 1-NN + the 28 sums; LM trial passes alike)
 //                     ->  publish the block's row: 28 f64 into buffer (g + 1) % 3, whose slots read "not arrived" (a signalling-NaN sentinel) until then
-//   reducer, tick g:  spin on the nblk rows of buffer g % 3 until no slot holds the sentinel (tick 0: the partial rows the unseeded ticks left, plain loads), put the
+//   reducer, tick g:  spin on the nblk rows of buffer g % 3 until no slot holds the sentinel (tick 0: nothing to gather - the state the chain left is already stepped), put the
 //                     previous buffer back to "not arrived"  ->  fixed-order sum,
 //                     LM / GN controller (solve_controller: the same code, the same order of additions as k_tick's prologue, so both paths
 //                     give the same bits)  ->  publish x0, xi, phase as granules tagged g + 1
@@ -26,7 +26,6 @@
 
 namespace qn {
 
-typedef __attribute__((address_space(1))) unsigned long long qn_gu64;
 #define QN_PERSIST_TB 512
 #define QN_PERSIST_MAX_BLOCKS 240          // worker blocks (+ 1 reducer): every block needs a CU of its own (256 on the chip)
 #define QN_PERSIST_BC 49                   // pose granules: x0[12] and xi[12] (two each), phase
@@ -35,7 +34,7 @@ typedef __attribute__((address_space(1))) unsigned long long qn_gu64;
 #define QN_PERSIST_SENTINEL 0xFFFFFFFFFFFFFFFFull      // "row value not arrived": a NaN pattern no f64 sum of finite terms can produce (arithmetic yields the canonical quiet NaN) - and all bytes equal, so hipMemset can write it
 
 struct PersistArgs {
-  TickArgs t;                              // st_in: the state the unseeded ticks left (its pending rows in part_in / rows_in); st_out: the final state
+  TickArgs t;                              // t.tail.st_in: the state the unseeded ticks left (already stepped by their controller tail: nothing pending); t.tail.st_out: the final state
   unsigned long long* rows_g;              // [3][QN_PERSIST_ROWS][32] partial rows as raw f64 bits, buffer = tick % 3; a slot holds QN_PERSIST_SENTINEL until its value lands
   unsigned long long* bc_g;                // [64] pose granules
   unsigned long long* fit_g;               // [nblk][4] closing pass: sum lo, sum hi, count
@@ -45,7 +44,6 @@ struct PersistArgs {
   unsigned long long timeout;              // wall_clock64 units (100 MHz) a spin may last
   uint32_t* status_host;                   // pinned mirror of `status`, written by the reducer when it leaves (no memset in front of, no copy behind the launch)
   int cond;                                // != 0: launched behind look_decide without a host look - go ahead only if the state's QN_LOOK_GO flag is set
-  int rows_if_extra;                       // cond: the partial rows the conditional unseeded iteration leaves (QN_LOOK_EXTRA set), else rows_in = -1
   unsigned long long* clk;                 // developer probe (PROBE = true): [tick < 64][16] wall-clock stamps: 0 rows complete, 1 sums, 2 controller, 3 pose published (reducer);
                                            // 4 pose seen, 5 body done, 6 row published (worker block 0); 8..10 the same for the last worker block; [64 * 16] = launch start
 };
@@ -56,8 +54,7 @@ __device__ __forceinline__ void pg_store(unsigned long long* p, uint32_t epoch, 
 __device__ __forceinline__ unsigned long long pg_load(const unsigned long long* p) {
   return __hip_atomic_load((qn_gu64*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-__device__ __forceinline__ void pr_store(unsigned long long* p, unsigned long long bits) { __hip_atomic_store((qn_gu64*)p, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ unsigned long long pr_load(const unsigned long long* p) { return __hip_atomic_load((qn_gu64*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// (pr_store / pr_load: qn_gicp_kernels.cuh - the controller tail of the chain kernels hands its rows over the same way)
 // 16-byte write-through store (agent scope): a row leaves its block as ONE instruction of 16 lanes (8-byte sc1 stores are one fabric write each and took
 // 4 us to be acknowledged with 196 blocks storing 28 of them at once).  Each 8-byte half is read on its own by the reducer: no tearing inside a half.
 __device__ __forceinline__ void pr_store16(unsigned long long* p, unsigned long long lo, unsigned long long hi) {
@@ -80,7 +77,8 @@ __global__ void __launch_bounds__(TB, TB / 256) k_align_persist(PersistArgs A) {
   __shared__ WaveScratch sc[TB / 64];
   __shared__ double wsum[TB / 64][QN_NPART];
   __shared__ GicpState sh;                                           // reducer: the optimiser state; workers use bc below
-  __shared__ double part8[QN_NPART][TB / QN_NPART + 1];
+  __shared__ double part8[QN_NPART][QN_ROW_SEGS + 1];
+  static_assert(TB / QN_NPART == QN_ROW_SEGS, "the reducer's thread -> (segment, component) map is reduce_rows' at 512 threads");
   __shared__ double sums[QN_NPART];
   __shared__ SolveWork Awork_s;
   __shared__ double bc_x0[16], bc_xi[16];
@@ -88,9 +86,8 @@ __global__ void __launch_bounds__(TB, TB / 256) k_align_persist(PersistArgs A) {
   __shared__ unsigned long long tie_list[TB / 64][QN_HCAP1]; __shared__ uint32_t tie_cnt[TB / 64];
   A.t.src = grid_resolve(A.t.src); A.t.tgt = grid_resolve(A.t.tgt);
   if (A.cond) {                                                      // behind look_decide: its flags decide (uniform over the launch: the state is not written before the reducer's last step)
-    const int flags = A.t.st_in->reserved;
+    const int flags = A.t.tail.st_in->reserved;
     if (!(flags & QN_LOOK_GO)) { if (blockIdx.x == A.nblk && threadIdx.x == 0) { A.status_host[0] = 5u; A.status_host[1] = 0u; } return; }      // declined: nothing touched
-    A.t.rows_in = (flags & QN_LOOK_EXTRA) ? A.rows_if_extra : -1;
   }
   const TickArgs& a = A.t;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -100,18 +97,18 @@ __global__ void __launch_bounds__(TB, TB / 256) k_align_persist(PersistArgs A) {
 
   if (blockIdx.x == nblk) {
     // ------------------------------------------------------------------ the reducer block
-    constexpr int SEGS = TB / QN_NPART;                              // = reduce_partial_rows<TB>'s partition: thread (s, c) sums rows s, s + SEGS, ...
+    constexpr int SEGS = TB / QN_NPART;                              // = reduce_rows' partition (QN_ROW_SEGS at TB = 512): thread (s, c) sums rows s, s + SEGS, ...
     constexpr int UMAX = (QN_PERSIST_MAX_BLOCKS + SEGS - 1) / SEGS;
     const int rs = tid / QN_NPART, rc = tid - rs * QN_NPART;
     const bool rthread = tid < QN_NPART * SEGS;
-    for (int i = tid; i < (int)(sizeof(GicpState) / 8); i += TB) ((unsigned long long*)&sh)[i] = ((const unsigned long long*)a.st_in)[i];
+    for (int i = tid; i < (int)(sizeof(GicpState) / 8); i += TB) ((unsigned long long*)&sh)[i] = ((const unsigned long long*)a.tail.st_in)[i];
     if (tid == 0) { bc_fail = 0; bc_phase = 0; }
     // (all three row buffers read "not arrived" at this point: the context memsets them once, and every launch puts back what it dirtied - below)
     __syncthreads();
     uint32_t g = 0;
     for (;; g++) {
-      if (g == 0) reduce_partial_rows<TB>(a.part_in, a.rows_in, part8, sums);
-      else {
+      const unsigned long long t_tick = wall_clock64();                // (the time-out bounds ONE wait, not the launch: a long legitimate run - LM with many rejected trials - is not a hang)
+      if (g > 0) {                                                     // (tick 0: the state the chain left is already stepped - its rows were consumed by the controller tail of the launch that wrote them)
         // the rows the workers wrote under pose g: buffer g % 3.  The data IS the flag: a slot holds the sentinel until its value lands.  Every thread
         // spins on its own slots (no block barrier per pass); arrived values stay in registers, only the missing ones are asked for again.
         unsigned long long* buf = A.rows_g + (size_t)(g % 3u) * QN_PERSIST_ROWS * QN_PERSIST_RSTRIDE;
@@ -129,7 +126,7 @@ __global__ void __launch_bounds__(TB, TB / 256) k_align_persist(PersistArgs A) {
           for (int u = 0; u < UMAX; u++) if ((need >> u) & 1u) x[u] = pr_load(buf + (size_t)(rs + SEGS * u) * QN_PERSIST_RSTRIDE + rc);
 #pragma unroll
           for (int u = 0; u < UMAX; u++) if (((need >> u) & 1u) && x[u] != QN_PERSIST_SENTINEL) { v[u] = __longlong_as_double((long long)x[u]); need &= ~(1u << u); }
-          if ((spins & 255u) == 255u && pg_expired(t_start, A.timeout, A.status, 1u)) { bc_fail = 1; break; }
+          if ((spins & 255u) == 255u && pg_expired(t_tick, A.timeout, A.status, 1u)) { bc_fail = 1; break; }
         }
         if (PROBE && tid == 0 && g < 64) A.clk[16 * g + 7] = wall_clock64();
         // consumed: the buffer of the PREVIOUS tick goes back to "not arrived" (it is written again under pose g + 2, which this block publishes only after
@@ -141,7 +138,7 @@ __global__ void __launch_bounds__(TB, TB / 256) k_align_persist(PersistArgs A) {
         }
         if (rthread) { double acc = 0;
 #pragma unroll
-          for (int u = 0; u < UMAX; u++) acc += v[u];                // rows s, s + SEGS, ... in order; the rows beyond nblk add +0.0 like reduce_partial_rows
+          for (int u = 0; u < UMAX; u++) acc += v[u];                // rows s, s + SEGS, ... in order; the rows beyond nblk add +0.0 like reduce_rows
           part8[rc][rs] = acc; }
         __syncthreads();
         if (PROBE && tid == 0 && g < 64) A.clk[16 * g + 0] = wall_clock64();
@@ -154,7 +151,7 @@ __global__ void __launch_bounds__(TB, TB / 256) k_align_persist(PersistArgs A) {
         if (tid == 0 && !bc_fail) {
           if (PROBE && g < 64) A.clk[16 * g + 1] = wall_clock64();
           const int phase_in = sh.phase;
-          if (sh.pending && phase_in != 2 && (g > 0 || a.rows_in >= 0)) solve_controller(&sh, sums, a.cfg, a.trace, 0, phase_in, &Awork_s);      // (rows_in < 0: the launch starts behind a stand-alone controller step)
+          if (sh.pending && phase_in != 2 && g > 0) solve_controller(&sh, sums, a.tail.cfg, a.tail.trace, 0, phase_in, &Awork_s);
           sh.fb_count = 0; sh.big_count = 0; sh.pending = sh.phase != 2 ? 1 : 0;
           if (g + 1 >= A.max_ticks && sh.phase != 2) { atomicCAS(A.status, 0u, 2u); bc_fail = 1; }
           bc_phase = sh.phase;
@@ -185,6 +182,7 @@ __global__ void __launch_bounds__(TB, TB / 256) k_align_persist(PersistArgs A) {
     }
     // ---- closing: fold the workers' (sum, count) like k_finalize_fit (lane L adds blocks 8 L .. 8 L + 7, then the wave sum), write the result and the state
     const uint32_t epf = A.epoch0 + g + 1;
+    const unsigned long long t_close = wall_clock64();
     if (tid < 64) {
       double s = 0; uint32_t cn = 0;
       unsigned long long done = 0;
@@ -201,7 +199,7 @@ __global__ void __launch_bounds__(TB, TB / 256) k_align_persist(PersistArgs A) {
             pv[u] = __longlong_as_double((long long)((hi << 32) | (lo & 0xffffffffull))); pc[u] = (uint32_t)cc; done |= 1ull << u; }
         }
         if (__all(done == 0xffull)) break;
-        if (__any(lane == 0 && pg_expired(t_start, A.timeout, A.status, 3u))) { fail = true; break; }
+        if (__any(lane == 0 && pg_expired(t_close, A.timeout, A.status, 3u))) { fail = true; break; }
         __builtin_amdgcn_s_sleep(1);
       }
 #pragma unroll
@@ -227,7 +225,7 @@ __global__ void __launch_bounds__(TB, TB / 256) k_align_persist(PersistArgs A) {
       }
     }
     __syncthreads();
-    for (int i = tid; i < (int)(sizeof(GicpState) / 8); i += TB) ((unsigned long long*)a.st_out)[i] = ((const unsigned long long*)&sh)[i];
+    for (int i = tid; i < (int)(sizeof(GicpState) / 8); i += TB) ((unsigned long long*)a.tail.st_out)[i] = ((const unsigned long long*)&sh)[i];
     return;
   }
 
@@ -249,10 +247,11 @@ __global__ void __launch_bounds__(TB, TB / 256) k_align_persist(PersistArgs A) {
     __syncthreads();                                                 // (the previous tick's readers of bc_* and wsum are done)
     if (tid < 64) {                                                  // ONE wave polls: lanes 0..48 hold one granule each
       unsigned long long x = 0; bool fail = false; uint32_t spins = 0;
+      const unsigned long long t_wait = wall_clock64();
       for (;;) {
         if (lane < QN_PERSIST_BC) x = pg_load(A.bc_g + lane);
         if (__all(lane >= QN_PERSIST_BC || (uint32_t)(x >> 32) == ep)) break;
-        if ((++spins & 255u) == 0u && __any(lane == 0 && pg_expired(t_start, A.timeout, A.status, 4u))) { fail = true; break; }
+        if ((++spins & 255u) == 0u && __any(lane == 0 && pg_expired(t_wait, A.timeout, A.status, 4u))) { fail = true; break; }
       }
       const uint32_t lo = (uint32_t)x, hi = (uint32_t)__shfl_down(x, 1);   // lane 2 i: low word of value i, lane 2 i + 1: its high word
       if (lane < 48 && !(lane & 1)) { const double d = __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo)); if (lane < 24) bc_x0[lane >> 1] = d; else bc_xi[(lane - 24) >> 1] = d; }

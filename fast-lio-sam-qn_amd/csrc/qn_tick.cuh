@@ -24,11 +24,9 @@ namespace qn {
 
 struct TickArgs {
   GridView src, tgt;
-  const GicpState* st_in; GicpState* st_out;
-  const double* part_in; double* part_out;
-  int rows_in;                         // rows of part_in written by the previous producer (read only when st_in->pending); < 0: a stand-alone controller step consumed them already
-  GicpConfig cfg;
-  qn_iter_trace* trace;
+  TailArgs tail;                       // tail.st_in: the state this launch runs under; tail.st_out / cfg / trace / ticket: the controller step its last block runs (enabled = 0: rows left
+                                       // for k_far_reduce - the far-query refresh adds a row first - or, MODE 1, nothing to step).  The persistent kernel reads st_in / st_out / cfg / trace from here too.
+  double* part_out;                    // this launch's partial rows (one per block)
   double thr2;
   int32_t* nn_idx; float4* nn_ref;
   const double* nrm_s;                 // [n][3] source normals, cell-sorted order
@@ -466,11 +464,7 @@ struct TickK {
 
   __shared__ WaveScratch sc[TB / 64];
   __shared__ double wsum[TB / 64][QN_NPART];
-  __shared__ GicpState sh;
-  __shared__ double part8[QN_NPART][TB / QN_NPART + 1];
-  __shared__ double sums[QN_NPART];
-  __shared__ SolveWork Awork_s; SolveWork* Awork = &Awork_s;
-  static_assert(sizeof(GicpState) % 8 == 0, "GicpState is copied as 8-byte words");
+  __shared__ TailLds tl;                                            // the state this launch runs under; in the last block: the controller's workspace and the next state
   const int tid = threadIdx.x;
   const uint32_t nblk = nbx_;
   a.src = grid_resolve(a.src); a.tgt = grid_resolve(a.tgt);
@@ -493,26 +487,20 @@ struct TickK {
   if (valid && (uint32_t)j0s < a.tgt.n) { const TargetRec* r = a.tgt_rec + j0s; rec0.p = r->p; rec0.n[0] = r->n[0]; rec0.n[1] = r->n[1]; rec0.n[2] = r->n[2]; }
   Top2 no_t2; no_t2.j1 = -1; no_t2.p1 = make_float4(0, 0, 0, 0);     // (the chain keeps no runner-up: its tracking record is re-read from memory every tick)
 
-  // ---- prologue: consume the pending partial rows, run the controller, publish the state.  The state words and the partial rows are
-  // requested back to back with the point loads above: one memory round trip in front of the controller.
-  for (int i = tid; i < (int)(sizeof(GicpState) / 8); i += TB) ((unsigned long long*)&sh)[i] = ((const unsigned long long*)a.st_in)[i];
-  reduce_partial_rows<TB>(a.part_in, a.rows_in, part8, sums);        // (rows of a state that is not pending are summed and ignored: rows_in is what matters)
-  if (probe) a.clk[1] = wall_clock64();
-  const int pending = sh.pending, phase_in = sh.phase;
-  if (pending && phase_in != 2 && a.rows_in >= 0 && tid == 0) solve_controller(&sh, sums, a.cfg, bx == 0 ? a.trace : nullptr, 0, phase_in, Awork);      // (rows_in < 0: already consumed by a stand-alone k_solve)
+  // ---- the state this launch runs under: written by the controller tail of the previous launch (or by k_init_state / k_solve).  ONE 300-byte read, requested back
+  // to back with the point loads above - no row reduction, no controller in front of the body any more (controller_tail).
+  for (int i = tid; i < (int)(sizeof(GicpState) / 8); i += TB) ((unsigned long long*)&tl.sh)[i] = ((const unsigned long long*)a.tail.st_in)[i];
+  __syncthreads();
   if (PROBE) {
-    if (probe) a.clk[2] = wall_clock64();
+    if (probe) { a.clk[1] = wall_clock64(); a.clk[2] = a.clk[1]; }
     if (MODE == 0 && threadIdx.x == 0) a.clk_blk[8 * bx + 1] = wall_clock64();
   }
-  if (tid == 0) { sh.fb_count = 0; sh.big_count = 0; sh.pending = (MODE == 0 && sh.phase != 2) ? 1 : 0; }
-  __syncthreads();
-  if (bx == 0) for (int i = tid; i < (int)(sizeof(GicpState) / 8); i += TB) ((unsigned long long*)a.st_out)[i] = ((const unsigned long long*)&sh)[i];
-  const int phase = sh.phase;
-  if (MODE == 0 ? phase == 2 : phase != 2) return;
+  const int phase = tl.sh.phase;
+  if (MODE == 0 ? phase == 2 : phase != 2) { if (MODE == 0 && a.tail.enabled) state_pass_through<TB>(a.tail, bx); return; }      // ticks past convergence / a closing pass before it: nothing to do
   const bool lin = MODE == 1 || phase == 0;
   float Tf[12];
 #pragma unroll
-  for (int j = 0; j < 12; j++) Tf[j] = (float)sh.x0[j];
+  for (int j = 0; j < 12; j++) Tf[j] = (float)tl.sh.x0[j];
   for (uint32_t it = 0; it < a.ppt; it++) {
     if (it > 0) {                                                  // (only clouds beyond 131072 points)
       t = (lblk * a.ppt + it) * TB + tid; valid = t < a.src.n;
@@ -522,7 +510,7 @@ struct TickK {
       if (valid) { na[0] = a.nrm_s[(size_t)t * 3]; na[1] = a.nrm_s[(size_t)t * 3 + 1]; na[2] = a.nrm_s[(size_t)t * 3 + 2]; }
       if (valid && (uint32_t)j0s < a.tgt.n) { const TargetRec* r = a.tgt_rec + j0s; rec0.p = r->p; rec0.n[0] = r->n[0]; rec0.n[1] = r->n[1]; rec0.n[2] = r->n[2]; }
     }
-    tick_point<MODE, PROBE, false>(a, Tf, sh.x0, sh.xi, lin, it == 0, t, valid, p, j0s, ref, na, rec0, no_t2, &sc[tid >> 6].w, sc[tid >> 6].red, wsum[tid >> 6], nullptr, nullptr, probe);
+    tick_point<MODE, PROBE, false>(a, Tf, tl.sh.x0, tl.sh.xi, lin, it == 0, t, valid, p, j0s, ref, na, rec0, no_t2, &sc[tid >> 6].w, sc[tid >> 6].red, wsum[tid >> 6], nullptr, nullptr, probe);
   }
   __syncthreads();
   if (MODE == 1) {
@@ -531,12 +519,14 @@ struct TickK {
   }
   if (tid < QN_NPART) { double v = 0;
 #pragma unroll
-    for (int w = 0; w < TB / 64; w++) v += wsum[w][tid]; a.part_out[(size_t)lblk * QN_NPART + tid] = v; }
+    for (int w = 0; w < TB / 64; w++) v += wsum[w][tid]; row_store(&a.part_out[(size_t)lblk * QN_NPART + tid], v, a.tail.enabled != 0); }
   if (PROBE) {
     if (probe) a.clk[5] = wall_clock64();
     if (threadIdx.x == 0) atomicMax(&a.clk[6], wall_clock64());        // latest block end
     if (MODE == 0 && threadIdx.x == 0) a.clk_blk[8 * bx + 3] = wall_clock64();
   }
+  // ---- the controller step on this launch's rows, by the last block to get here (far_mode 1: k_far adds a row first - k_far_reduce runs the step)
+  if (a.tail.enabled) controller_tail<TB>(a.tail, a.part_out, nblk, &tl);
   }
 };
 template <int TB, int OCC, int MODE, bool PROBE>
@@ -729,31 +719,41 @@ struct FarK {
   }
 };
 static __global__ void __launch_bounds__(QN_FAR_THREADS) k_far(FarArgs a) { FarK::run(a, blockIdx.x, gridDim.x); }
-struct FarReduceK {
+struct FarReduceK {      // folds k_far's side table into ONE more partial row behind the tick's, then runs the controller step on all of them (the tick left it to this launch)
   static constexpr int TB = QN_FAR_BLOCKS, OCC = 1;
-  struct Args { const double* far_rows; double* part_row; uint32_t* far_stats; };
+  struct Args { const double* far_rows; double* part; int rows; uint32_t* far_stats; TailArgs tail; };      // part: the tick's row buffer, rows: the rows the tick wrote
   static __device__ __forceinline__ void run(const Args& a, const uint32_t, const uint32_t) {
-    const double* __restrict__ far_rows = a.far_rows; double* __restrict__ part_row = a.part_row; uint32_t* __restrict__ far_stats = a.far_stats;
-
-  __shared__ double sh[QN_FAR_BLOCKS / 32][QN_NPART];
-  const int tid = threadIdx.x, c = tid % 32, seg = tid / 32;          // 16 segments of 32 rows; threads c >= 28 idle
-  if (tid == 0) { far_stats[1] = far_stats[0]; far_stats[0] = 0u; }   // [1] = requests of the tick just served (here, not in k_far: every block of k_far reads [0] when it starts)
-  if (c < QN_NPART) {
-    double v[32];
+    __shared__ double sh[QN_FAR_BLOCKS / 32][QN_NPART];
+    __shared__ TailLds tl;
+    const double* __restrict__ far_rows = a.far_rows; double* part_row = a.part + (size_t)a.rows * QN_NPART; uint32_t* __restrict__ far_stats = a.far_stats;
+    const int tid = threadIdx.x, c = tid % 32, seg = tid / 32;          // 16 segments of 32 rows; threads c >= 28 idle
+    if (tid == 0) { far_stats[1] = far_stats[0]; far_stats[0] = 0u; }   // [1] = requests of the tick just served (here, not in k_far: every block of k_far reads [0] when it starts)
+    if (c < QN_NPART) {
+      double v[32];
 #pragma unroll
-    for (int u = 0; u < 32; u++) v[u] = far_rows[(size_t)(seg * 32 + u) * QN_NPART + c];       // 32 loads in flight
-    double a = 0;
+      for (int u = 0; u < 32; u++) v[u] = far_rows[(size_t)(seg * 32 + u) * QN_NPART + c];       // 32 loads in flight
+      double acc = 0;
 #pragma unroll
-    for (int u = 0; u < 32; u++) a += v[u];
-    sh[seg][c] = a;
-  }
-  __syncthreads();
-  if (tid < QN_NPART) { double v = 0; for (int s = 0; s < QN_FAR_BLOCKS / 32; s++) v += sh[s][tid]; part_row[tid] = v; }
+      for (int u = 0; u < 32; u++) acc += v[u];
+      sh[seg][c] = acc;
+    }
+    __syncthreads();
+    if (tid < QN_NPART) { double v = 0; for (int s2 = 0; s2 < QN_FAR_BLOCKS / 32; s2++) v += sh[s2][tid]; row_store(&part_row[tid], v, true); }
+    if (!a.tail.enabled) return;
+    // the controller step over the tick's rows + this one (single block: it is its own "last block"; the row above is read back with the same agent-scope loads)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int i = tid; i < (int)(sizeof(GicpState) / 8); i += TB) ((unsigned long long*)&tl.sh)[i] = ((const unsigned long long*)a.tail.st_in)[i];
+    reduce_rows<TB, true>(a.part, a.rows + 1, tl.part, tl.sums);
+    if (tid == 0) {
+      const int phase = tl.sh.phase;
+      if (tl.sh.pending && phase != 2) { const GicpConfig cfg = a.tail.cfg; solve_controller(&tl.sh, tl.sums, cfg, a.tail.trace, 0, phase, &tl.work); }
+      tl.sh.fb_count = 0; tl.sh.big_count = 0; tl.sh.pending = tl.sh.phase != 2 ? 1 : 0;
+    }
+    __syncthreads();
+    for (int i = tid; i < (int)(sizeof(GicpState) / 8); i += TB) ((unsigned long long*)a.tail.st_out)[i] = ((const unsigned long long*)&tl.sh)[i];
   }
 };
-static __global__ void __launch_bounds__(QN_FAR_BLOCKS) k_far_reduce(const double* __restrict__ far_rows, double* __restrict__ part_row, uint32_t* __restrict__ far_stats) {
-  const FarReduceK::Args a{far_rows, part_row, far_stats};
-  FarReduceK::run(a, blockIdx.x, gridDim.x);
-}
+static __global__ void __launch_bounds__(QN_FAR_BLOCKS) k_far_reduce(FarReduceK::Args a) { FarReduceK::run(a, blockIdx.x, gridDim.x); }
 
 }  // namespace qn
