@@ -107,6 +107,57 @@ def roofline_leg(ctx, register, ms_step, align_ms, nprof=4):
     return roofline
 
 
+def batched_roofline_leg(engine, ctx, pairs, lanes, rounds=3):
+    """The path `value` runs: qn_gicp_align_batch on ONE context, `lanes` registrations per kernel launch (k_lanes<F>, the pair as a grid dimension).  hipEvents around every
+    batched launch on the context's own stream (qn_prof_*; a family's `launches` count the registrations a launch carried, so total / launches = the per-registration share of a launch);
+    measured with nothing else on the GPU, so the durations are the kernels' own."""
+    descs = [(pairs[j % len(pairs)][0].data_ptr(), N_PTS, pairs[j % len(pairs)][1].data_ptr(), N_PTS, 12, 1) for j in range(lanes)]
+    engine.gicp_align_batch(ctx, descs)
+    ctx.prof_reset(); ctx.prof_enable(True)
+    for _ in range(rounds):
+        _, _, st = engine.gicp_align_batch(ctx, descs)
+        assert all(x == 0 for x in st), st
+    ctx.synchronize(); ctx.prof_enable(False)
+    stats = ctx.prof_stats(); nreg = rounds * lanes
+    fam_ms = {k: v[0] / nreg for k, v in stats.items() if v[1] > 0}             # ms per registration (amortised over the lanes)
+    fam_avg = {k: v[0] / v[1] for k, v in stats.items() if v[1] > 0}            # ms per registration-launch = batched launch duration / lanes
+    ab = algorithmic_bytes()
+    single_k = {"knn_select": ("k_lanes<KnnHistK<false, 32>>", N_PTS * (16 + 16 * K_COV)),
+                "gn_tick_fused": ("k_lanes<TickK<512, 4, 0, false>>", ab["gn_iteration"]),
+                "nn_search": ("k_lanes<NnSearchK<0, false, 256>>", ab["gn_iteration"]),
+                "nn_fallback": ("k_lanes<NnSearchK<0, true, 256, true>>", ab["gn_iteration"]),
+                "accumulate": ("k_lanes<AccumulateK>", ab["gn_iteration"])}
+    dom = max((k for k in fam_ms if k in single_k), key=fam_ms.get)
+    dom_kernel, per_launch_bytes = single_k[dom]
+    pmc_all = None
+    pmc_path = os.path.join(ROOT, "profiles", "pmc_latest.json")
+    if os.path.exists(pmc_path):
+        try:
+            pmc_all = json.load(open(pmc_path))
+        except Exception:
+            pmc_all = None
+    def traffic_of(k):
+        e = (pmc_all or {}).get("batched", {}).get(k) if isinstance(pmc_all, dict) else None
+        return e.get("hbm_bytes_per_registration_launch") if isinstance(e, dict) else None
+    kernels = {k: {"kernel": single_k[k][0], "avg_launch_ms_per_registration": round(fam_avg[k], 6), "avg_batched_launch_ms": round(fam_avg[k] * lanes, 5),
+                   "launches_per_registration": round(stats[k][1] / nreg, 2), "algorithmic_bytes_per_registration_launch": single_k[k][1],
+                   "achieved_GBs": round(single_k[k][1] / (fam_avg[k] * 1e-3) / 1e9, 2), "frac": round(single_k[k][1] / (fam_avg[k] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                   "traffic": traffic_of(k)} for k in single_k if k in fam_avg}
+    achieved = per_launch_bytes / (fam_avg[dom] * 1e-3) / 1e9
+    total_ms = sum(fam_ms.values())
+    return {"bound": "hbm", "kernel": dom_kernel, "family": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
+            "traffic": traffic_of(dom),
+            "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the same batched workload (tools/gpu_round.sh <tag> pmc -> profiles/pmc_latest.json); null = not collected for this state",
+            "stale_from": (pmc_all or {}).get("_meta", {}).get("tag") if isinstance(pmc_all, dict) else None,
+            "lanes": lanes, "registrations_profiled": nreg,
+            "avg_batched_launch_ms": round(fam_avg[dom] * lanes, 5), "avg_launch_ms_per_registration": round(fam_avg[dom], 6), "algorithmic_bytes_per_launch": per_launch_bytes * lanes,
+            "family_ms_per_registration": {k: round(v, 4) for k, v in fam_ms.items()}, "kernel_ms_per_registration_one_context": round(total_ms, 4),
+            "kernels": kernels,
+            "path": "qn_gicp_align_batch on one context alone on the GPU: hipEvents around every k_lanes launch on the context's stream; every feature of the measured path is on "
+                    "(the batched path has no second stream and no persistent kernel to switch off)",
+            "note": "working set of a batch (lanes x ~30 MB) is MALL/L2 resident: nominal HBM yardstick (SURVEY 8d); the engine is VALU-issue / latency bound - see valu_issue"}
+
+
 def spawn_ranks(args):
     """plain `python bench.py --gpus N`: start the N ranks (one process per GPU) and relay rank 0's JSON line."""
     n = args.gpus
@@ -215,11 +266,12 @@ def latency_legs(engine, synth, pairs, args, world, ctx=None, p80=None):
         g.bind(); r = register(0)
         Tg = np.array(r.T64).reshape(4, 4)
         dtp = float(np.abs(Tg - ro["T"]).max()); dt_m, dr_rad = synth.pose_error(Tg, ro["T"])
+        out_oracle = (ro["T"].tolist(), float(ro["fitness"]), int(ro["iterations"]))
         parity = {"pair": 0, "max_abs_T_diff": dtp, "dt_m": dt_m, "dr_rad": dr_rad, "iterations": [int(r.iterations), int(ro["iterations"])],
                   "score_rel_diff": abs(r.fitness - ro["fitness"]) / max(ro["fitness"], 1e-300), "ok": bool(dtp <= 1e-9 and r.iterations == ro["iterations"])}
     else:
-        dtp, parity = None, None
-    out = {"single": single, "host": host, "align": align, "roofline": roofline, "cpu": cpu, "dtp": dtp, "parity": parity,
+        dtp, parity, out_oracle = None, None, (None, None, None)
+    out = {"oracle_T": out_oracle[0], "oracle_fitness": out_oracle[1], "oracle_iterations": out_oracle[2], "single": single, "host": host, "align": align, "roofline": roofline, "cpu": cpu, "dtp": dtp, "parity": parity,
            "persistent_align_launches": int(ctx.debug_get("persist_launches")), "alone_in_process": bool(own)}
     if p80:
         # ---- SURVEY 8d's generator case (80 % overlap), one registration at a time: percentiles over 8 distinct pairs + kernel-family breakdown
@@ -329,6 +381,7 @@ def single_process(args, engine, synth, json_fd):
     for g in range(n):
         torch.cuda.synchronize(g)
     mg = engine.MultiGpu(n, N_PTS + 1024, in_flight=max(1, args.in_flight))
+    mg.debug_set("batch_lanes", max(1, args.lanes))
     gg = engine.GicpParams(); engine.lib().qn_gicp_default_params(__import__("ctypes").byref(gg))
     gg.k_correspondences, gg.max_iterations, gg.max_corr_dist, gg.optimizer, gg.force_iterations = K_COV, GN_ITERS, 52.5, 1, GN_ITERS
     mg.set_params(gg)
@@ -391,7 +444,9 @@ def main():
     ap.add_argument("--no-quatro", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="only the headline measurement (profiling runs)")
     ap.add_argument("--pairs", type=int, default=8, help="distinct synthetic pairs (scenes) per rank, cycled over the steps (>= 2 x in-flight)")
-    ap.add_argument("--in-flight", type=int, default=4, help="candidate pairs registered concurrently per GPU (one context = one hipStream each)")
+    ap.add_argument("--in-flight", type=int, default=3, help="contexts (= hipStreams) per GPU; each registers `--lanes` candidate pairs per kernel launch")
+    ap.add_argument("--lanes", type=int, default=8, help="candidate pairs per kernel launch of a context (qn_gicp_align_batch: the pair as a grid dimension); 1 = the classic one-registration-per-stream chain")
+    ap.add_argument("--repeats", type=int, default=5, help="extra timed repeats of the --steps block for the spread of `value` (reported in config.value_repeats)")
     ap.add_argument("--shift", type=float, default=None, help="developer: scene-window shift of the synthetic pairs in metres (default: the generator's 5 m = ~96 %% overlap; 24 = 80 %%)")
     ap.add_argument("--batch-pairs", type=int, default=64, help="BASELINE configs[3]: candidate pairs of one query, sharded over the ranks")
     ap.add_argument("--single-process", action="store_true", help="ONE process drives all --gpus N devices through qn_multi_init(N) / qn_multi_align_best (ncclCommInitAll + grouped ncclAllGather inside the C-ABI): the path a C++ host like the reference's single process would call")
@@ -436,6 +491,8 @@ def main():
     # `in_flight` contexts (= hipStreams) per GPU: the candidate pairs of a loop-closure query are independent
     # registrations (BASELINE "batch of candidate keyframe pairs"), several are kept in flight to fill the chip
     ctxs = [engine.Context(N_PTS + 1024, device=local) for _ in range(max(1, args.in_flight))]
+    for cx in ctxs:
+        cx.debug_set("batch_lanes", max(1, args.lanes))
     gs = []
     for cx in ctxs:
         gg = engine.NanoGICP(cx)
@@ -488,7 +545,8 @@ def main():
         return min((a.tolist() for a in allrec), key=lambda a: (a[2], a[0]))
 
     if args.warmup > 0:
-        batch(args.warmup)
+        batch(max(args.warmup, 4 * len(ctxs) * max(1, args.lanes)))      # (at least four full runs of lanes per context: the lane sub-contexts are created on first use, and the
+                                                                       #  first launches of every kernel variant load its code object - multi-millisecond hiccups in the first few batches)
     if dist is not None:          # untimed: bring up the communicator's channels (RCCL connects lazily on the first collective)
         gather_best([0.0] * 19)
         dist.all_reduce(torch.zeros(1, dtype=torch.float64, device=cdev), op=dist.ReduceOp.MAX)
@@ -508,6 +566,14 @@ def main():
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
+    # ---- spread of `value`: the same --steps block, `repeats` more times (a 60 ms timed region cannot resolve a few per cent on its own)
+    rep_vals = []
+    for _ in range(max(0, args.repeats)):
+        barrier(); tr = time.perf_counter(); _, _, st_r = batch(args.steps); barrier(); wr = time.perf_counter() - tr
+        assert all(x == 0 for x in st_r), st_r
+        if dist is not None:
+            tmax = torch.tensor([wr], dtype=torch.float64, device=cdev); dist.all_reduce(tmax, op=dist.ReduceOp.MAX); wr = float(tmax.item())
+        rep_vals.append(world * args.steps / wr)
 
     # ---- BASELINE configs[3], literally: ONE query with `batch_pairs` (64) DISTINCT candidate pairs, pair i -> rank i mod N, each rank
     # through qn_multi_align_best (its GPU, `in_flight` streams, the RCCL gather of its record table inside the C-ABI), then the
@@ -526,6 +592,7 @@ def main():
                 t = (t @ R.T + torch.tensor([0.05 * v, -0.03 * v, 0.0], dtype=torch.float32, device=t.device)).contiguous()
             bpairs.append((s, t))
         mg = engine.MultiGpu(1, N_PTS + 1024, in_flight=len(ctxs), device_ids=[local])
+        mg.debug_set("batch_lanes", max(1, args.lanes))
         mg.set_params(g.p)
         descs = [(s.data_ptr(), N_PTS, t.data_ptr(), N_PTS, 12, 1) for s, t in bpairs]
         mg.align_best(descs[:min(len(descs), 4)])                     # untimed warm-up of the new contexts
@@ -596,8 +663,32 @@ def main():
     if rank == 0:
         ms_step = 1e3 * elapsed / args.steps
         L = lat_legs if lat_legs is not None else latency_legs(engine, synth, pairs, args, world, ctx, p80=p80)
-        single, host, align, roofline, cpu, dtp, parity = L["single"], L["host"], L["align"], L["roofline"], L["cpu"], L["dtp"], L["parity"]
-        align_ms = align["median"]; roofline["whole_registration"] = whole_registration(ms_step)
+        single, host, align, chain_roofline, cpu, dtp, parity = L["single"], L["host"], L["align"], L["roofline"], L["cpu"], L["dtp"], L["parity"]
+        align_ms = align["median"]
+        # ---- the roofline object describes the path `value` ran: the batched launches (one context alone on the GPU, hipEvents on its stream); the classic chain's leg
+        # (one registration per stream, what the latency figures time) rides along as `single_stream_chain`
+        if max(1, args.lanes) >= 2:
+            roofline = batched_roofline_leg(engine, ctx, pairs, max(1, args.lanes))
+            roofline["single_stream_chain"] = chain_roofline
+        else:
+            roofline = chain_roofline
+        roofline["whole_registration"] = whole_registration(ms_step)
+        vb_path = os.path.join(ROOT, "profiles", "valu_budget_latest.json")
+        if os.path.exists(vb_path):      # what the engine is actually bound by: VALU issue slots (SQ_ACTIVE_INST_VALU per kernel x launches per registration; tools/gpu_sq.sh + tools/valu_budget.py)
+            try:
+                vb = json.load(open(vb_path)); qc = float(vb["quad_cycles_per_registration"])
+                chip_us = qc * 4.0 / (1024 * float(vb.get("clock_ghz", 2.1)) * 1e3)
+                roofline["valu_issue"] = {"quad_cycles_per_registration": qc, "us_of_a_fully_issuing_chip": round(chip_us, 1), "frac_of_issue_slots": round(chip_us / (ms_step * 1e3), 4),
+                                          "source": vb.get("source"), "note": "1024 SIMDs x one wave64 VALU instruction per 4 cycles; frac = that time / the measured step time of this run"}
+            except Exception as ex:
+                roofline["valu_issue"] = {"error": repr(ex)}
+        # parity of the BATCHED path on the headline workload: the timed batch's own record of pair 0 against the oracle (the classic path's check is `parity`)
+        if parity is not None and L.get("oracle_T") is not None:
+            Tb = np.array(results[0].T64).reshape(4, 4); To = np.array(L["oracle_T"])
+            dtb = float(np.abs(Tb - To).max())
+            parity["batched_path"] = {"pair": 0, "max_abs_T_diff": dtb, "iterations": int(results[0].iterations), "score_rel_diff": abs(results[0].fitness - L["oracle_fitness"]) / max(L["oracle_fitness"], 1e-300),
+                                      "ok": bool(dtb <= 1e-9 and results[0].iterations == L["oracle_iterations"])}
+            parity["ok"] = bool(parity["ok"] and parity["batched_path"]["ok"])
 
         extras = {"latency_legs": {"alone_in_process": L["alone_in_process"], "persistent_align_launches": L["persistent_align_launches"],
                                    "note": "ms_per_registration_single_stream, ..._from_host_buffers, ms_per_align, overlap80 single-stream, reference_operating_point and quatro are one-registration-at-a-time figures "
@@ -644,11 +735,16 @@ def main():
                "dtype": "f32 search / f64 accumulate", "data": "synthetic",
                "config": {"workload": "Nano-GICP icpAlignment, synthetic 100k x 100k street-scene pairs, k=20 covariances, 20 forced GN iterations (BASELINE configs[1])",
                           "points": N_PTS, "k": K_COV, "gn_iterations": GN_ITERS, "sharding": "pair i -> rank i mod N, all_gather of best record",
-                          "in_flight": len(ctxs), "distinct_pairs_per_rank": len(pairs),
+                          "in_flight": len(ctxs), "lanes": max(1, args.lanes), "distinct_pairs_per_rank": len(pairs),
+                          "launch_structure": "%d contexts (streams) x %d candidate pairs per kernel launch (qn_gicp_align_batch: k_lanes<F>, blockIdx.y = pair); launches per registration %.2f" % (len(ctxs), max(1, args.lanes), ctx.debug_get("batch_launches") / max(1.0, ctx.debug_get("batch_pairs"))),
+                          "value_repeats": {"values": [round(v, 1) for v in rep_vals], "median": round(float(np.median(rep_vals)), 1) if rep_vals else None,
+                                            "min": round(min(rep_vals), 1) if rep_vals else None, "max": round(max(rep_vals), 1) if rep_vals else None,
+                                            "note": "the same --steps block timed `repeats` more times after the reported region"},
                           "ms_per_registration_single_stream": single["median"], "ms_per_registration_single_stream_stats": single,
                           "ms_per_registration_from_host_buffers": host["median"], "ms_per_registration_from_host_buffers_stats": host,
                           "ms_per_align": align_ms, "ms_per_align_stats": align, "winner_pair": int(winner[0]), "winner_score": winner[2],
                           "max_abs_T_diff_vs_oracle": dtp, "parity_vs_oracle": parity, "batch64": batch64, "quatro": quatro, **extras},
+               "value_overlap80": (extras.get("overlap80") or {}).get("registrations_per_s"),
                "roofline": roofline, "cpu_baseline": cpu}
         os.write(json_fd, (json.dumps(out) + "\n").encode())
         if parity is not None and not parity["ok"]:

@@ -20,7 +20,7 @@ struct CloudBuf {                       // one point cloud, resident in HBM
   qn::GridDims* dims_host = nullptr;    // pinned mirror, copied behind every grid build: valid after the next synchronisation of the stream that built the grid
 };
 
-struct ProfSpan { int family; hipEvent_t a, b; };
+struct ProfSpan { int family; hipEvent_t a, b; int count; };      // count: registrations a batched launch (k_lanes) carried - the family's `launches` are counted per registration
 
 struct qn_ctx {
   int device = 0;
@@ -108,5 +108,5 @@ struct qn_ctx {
   std::string last_error;
 
   void set_error(const char* what, hipError_t e, int line);
-  void prof_begin(int family); void prof_end(); void prof_collect();
+  void prof_begin(int family, int count = 1); void prof_end(); void prof_collect();
 };

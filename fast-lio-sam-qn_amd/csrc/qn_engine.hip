@@ -26,9 +26,9 @@ void qn_ctx::set_error(const char* what, hipError_t e, int line) {
 }
 
 // ------------------------------------------------------------------ profiling (bench roofline leg)
-void qn_ctx::prof_begin(int family) {
+void qn_ctx::prof_begin(int family, int count) {
   if (!prof_on) return;
-  ProfSpan sp; sp.family = family;
+  ProfSpan sp; sp.family = family; sp.count = count;
   if (hipEventCreate(&sp.a) != hipSuccess || hipEventCreate(&sp.b) != hipSuccess) return;
   hipEventRecord(sp.a, stream);
   spans.push_back(sp);
@@ -39,7 +39,7 @@ void qn_ctx::prof_end() {
 }
 void qn_ctx::prof_collect() {
   for (auto& sp : spans) {
-    float ms = 0; if (hipEventSynchronize(sp.b) == hipSuccess && hipEventElapsedTime(&ms, sp.a, sp.b) == hipSuccess) { stats[sp.family].total_ms += ms; stats[sp.family].launches += 1; }
+    float ms = 0; if (hipEventSynchronize(sp.b) == hipSuccess && hipEventElapsedTime(&ms, sp.a, sp.b) == hipSuccess) { stats[sp.family].total_ms += ms; stats[sp.family].launches += sp.count; }
     hipEventDestroy(sp.a); hipEventDestroy(sp.b);
   }
   spans.clear();
@@ -287,7 +287,7 @@ static int join_target(qn_ctx* c) {
 // needs to know - "the cloud held non-finite coordinates" - arrives with the pinned mirror at the next synchronisation (clouds_valid).
 // (arguments of the five launches for one cloud: the classic path launches them one by one, the batched path puts the entries of every cloud of a batch into ONE launch each)
 struct GridLaunch { PackBBoxK::Args pack; uint32_t pack_nb; CellCountK::Args count; ScanLookbackK::Args scan; uint32_t scan_nb; ScatterK::Args scat; StableCellsK::Args stab; bool stable; uint32_t nb; };
-static GridLaunch prep_grid(qn_ctx* c, CloudBuf& b, const char* dsrc, uint32_t stride) {
+static GridLaunch prep_grid(qn_ctx* c, CloudBuf& b, const char* dsrc, uint32_t stride, bool lanes = false) {
   const uint32_t n = b.n;
   GridView& g = b.grid;
   memset(&g, 0, sizeof(g));
@@ -296,7 +296,8 @@ static GridLaunch prep_grid(qn_ctx* c, CloudBuf& b, const char* dsrc, uint32_t s
   L.nb = (n + QN_BLOCK - 1) / QN_BLOCK;
   L.scan_nb = (c->max_cells + QN_BLOCK * QN_SCAN_ITEMS - 1) / (QN_BLOCK * QN_SCAN_ITEMS);
   if (((++c->build_epoch) & 0x3fffffffu) == 0u) ++c->build_epoch;     // (0 = the tag of the zero-initialised status words)
-  L.pack_nb = std::min<uint32_t>(L.nb, (uint32_t)std::min(c->bbox_blocks, QN_BBOX_MAX_BLOCKS));
+  // (a lone build wants few blocks - one contended ticket each; in a batched launch the clouds run side by side and the pack pass is bandwidth: all the slots)
+  L.pack_nb = std::min<uint32_t>(L.nb, (uint32_t)std::min(lanes ? QN_BBOX_MAX_BLOCKS : c->bbox_blocks, QN_BBOX_MAX_BLOCKS));
   L.pack = PackBBoxK::Args{dsrc, stride, n, b.raw, c->bbox_acc, c->max_cells, c->cell_override, b.dims, b.dims_host};
   L.count = CellCountK::Args{b.raw, n, g, b.counts, b.cell_of_pt};
   L.scan = ScanLookbackK::Args{b.counts, b.dims, b.cell_start, c->scan_status, c->build_epoch, n};
@@ -372,18 +373,20 @@ static float knn_first_radius(const qn_ctx* c, const CloudBuf& b) {
   // at 10k points the wider radius measured slower again (few waves, each with more candidates): 2.5 only between 16k and 64k.
   return -(c->margin_knn > 0.f ? c->margin_knn : (b.n > 16384u && b.n <= 65536u ? 2.5f : 2.0f));      // negative = in cells (the kernels know the cell edge, the host does not)
 }
-static KnnLaunch prep_knn(qn_ctx* c, CloudBuf& b, int k, int32_t* kidx, float* kd2) {
+// lanes: the launch carries many clouds (k_lanes) - the list passes, which serve a handful of leftovers per cloud with wave-stride loops, get small grids
+// (an empty block still costs the dispatcher ~4 ns: 2048 of them x 16 clouds were 140 us per launch)
+static KnnLaunch prep_knn(qn_ctx* c, CloudBuf& b, int k, int32_t* kidx, float* kd2, bool lanes = false) {
   const float r0 = knn_first_radius(c, b);
   uint32_t* genc = c->fb_count2 + 1;
   KnnLaunch L;
   L.sel_nb = (b.n + QN_KNN_BLOCK / 4 - 1) / (QN_KNN_BLOCK / 4);     // 16 queries per wave
   L.sel = KnnHistArgs{b.grid, k, r0, c->knn_single_all ? -1 : c->knn_rounds, kidx, kd2, c->fb_list, c->fb_count2, c->big_list, genc};
-  L.lst_nb = std::min<uint32_t>((b.n + 63) / 64, 512) * (QN_BLOCK / QN_KNN_BLOCK);
+  L.lst_nb = std::min<uint32_t>((b.n + 63) / 64, lanes ? 96 : 512) * (QN_BLOCK / QN_KNN_BLOCK);
   L.lst = KnnHistArgs{b.grid, k, r0, 64, kidx, kd2, c->fb_list, c->fb_count2, c->big_list, genc};
   // far / overflowing queries (isolated points, sparse far field): one per wave; its leftovers -> the sorted-list kernel (fb_list is free again)
-  L.single_nb = std::min<uint32_t>((b.n + 3) / 4, 2048);
+  L.single_nb = std::min<uint32_t>((b.n + 3) / 4, lanes ? 128 : 2048);
   L.single = KnnSingleK::Args{b.grid, k, kidx, kd2, c->big_list, genc, c->fb_list, c->fb_count2 + 2};
-  L.tail_nb = std::min<uint32_t>((b.n + 63) / 64, 1024);
+  L.tail_nb = std::min<uint32_t>((b.n + 63) / 64, lanes ? 64 : 1024);
   L.tail = KnnCovArgs{b.grid, b.raw, k, r0, 64, b.nrm, kidx, kd2, c->fb_list, c->fb_count2 + 2};
   L.cov_nb = (b.n + QN_BLOCK - 1) / QN_BLOCK;
   L.cov = CovFromIdxK::Args{b.raw, b.sorted, b.n, k, kidx, b.nrm, &b == &c->cloud[0] ? c->nrm_s_sorted : (double*)nullptr, &b == &c->cloud[0] ? (TargetRec*)nullptr : c->tgt_rec, c->fb_count2};   // + the optimiser ticks' layouts
@@ -451,7 +454,7 @@ static NnLaunch prep_nn(qn_ctx* c, int mode /*0 align, 1 fitness*/, float* sqd_o
   uint32_t* fbc = &st->fb_count; uint32_t* bgc = &st->big_count;
   uint32_t* far_stats = (mode == 0 && !seeded && c->count_far_now) ? c->far_stats : nullptr;      // the LAST unseeded pass before the host's look (the clouds are best aligned then)
   const bool wide = tick <= 2 || (mode == 0 && !seeded);                                              // every unseeded pass of an align leaves thousands of queries to the lists, whatever its index
-  const int big_blocks = wide ? c->big_blocks0 : 1024;                                                // waves with one far query each (idle blocks exit at once)
+  int big_blocks = wide ? c->big_blocks0 : 1024;                                                      // waves with one far query each (idle blocks exit at once)
   const uint32_t fbb = std::min<uint32_t>(nb4, wide ? (uint32_t)c->fb_blocks0 : 256u);                           // list pass: wave-stride over the leftovers
   const float r0 = -(tick == 0 && mode == 0 && c->margin_nn_t0 > 0.f ? c->margin_nn_t0 : c->margin_nn);      // negative = in cells
   const float big_ratio = c->big_ratio;
@@ -461,6 +464,8 @@ static NnLaunch prep_nn(qn_ctx* c, int mode /*0 align, 1 fitness*/, float* sqd_o
   // wave starts them all at once, and the leaner kernel keeps 6 blocks per CU (ms_per_align 0.552 against 0.570 / 0.609 with the grouped variant)
   const bool batch = c->persist_batch_off;
   opt.group = c->far_group >= 0 ? c->far_group : (batch ? 4096 : 0); opt.group_min = 0;
+  // (a grouped far list is served ceil(length / group) entries per wave: `group` waves are all it can use - same entry -> wave assignment, three quarters fewer empty blocks)
+  if (mode == 0 && opt.group > 0) big_blocks = std::min(big_blocks, std::max(64, (opt.group + QN_BLOCK / 64 - 1) / (QN_BLOCK / 64)));
   opt.probe = (mode == 0 && !seeded) ? c->list_probe : nullptr;
   opt.fb_small = (mode == 0 && !c->persist_batch_off) ? (uint32_t)c->list_small : 0u;      // (a batch member keeps the 16-per-wave lists: fewer wave-instructions per query, +2 % throughput)
   NnOpt opt0; opt0.clear_ref = nullptr; opt0.cond = 0; opt0.group = 0; opt0.group_min = 0; opt0.probe = nullptr; opt0.fb_small = 0;
