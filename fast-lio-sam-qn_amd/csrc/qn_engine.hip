@@ -444,7 +444,7 @@ extern "C" int qn_gicp_compute_covariances(qn_ctx* c, int which) { return comput
 // leaves ~10-20 % of the queries to the list passes, the first tracked pass most of them after the big initial pose
 // step, later passes a handful - any grid is correct, the lists are walked wave-stride)
 // (arguments of the grid pass and the list pass of one exact 1-NN search; `seeded` searches replace the grid pass by k_nn_track)
-struct NnLaunch { NnSearchArgs grid; uint32_t grid_nb; NnSearchArgs list; uint32_t list_nb; bool group; };
+struct NnLaunch { NnSearchArgs grid; uint32_t grid_nb; NnSearchArgs list; uint32_t list_nb; bool group; bool lane; };      // lane: the first pass runs one query per lane (NnLaneK)
 static NnLaunch prep_nn(qn_ctx* c, int mode /*0 align, 1 fitness*/, float* sqd_out, bool seeded, int tick, int cond) {
   CloudBuf &S = c->cloud[0], &T = c->cloud[1];
   const uint32_t nb = (S.n + QN_NN_BLOCK / 4 - 1) / (QN_NN_BLOCK / 4);   // grid passes: 16 queries per wave
@@ -472,7 +472,8 @@ static NnLaunch prep_nn(qn_ctx* c, int mode /*0 align, 1 fitness*/, float* sqd_o
   c->clear_far_now = mode == 0 && !seeded ? false : c->clear_far_now;
   const NnOpt& o = mode == 0 ? opt : opt0;
   NnLaunch L;
-  L.grid_nb = nb; L.list_nb = fbb + (uint32_t)big_blocks; L.group = mode == 0 && opt.group > 0;
+  L.lane = c->nn_lane && mode == 0 && !seeded;
+  L.grid_nb = L.lane ? (S.n + 255u) / 256u : nb; L.list_nb = fbb + (uint32_t)big_blocks; L.group = mode == 0 && opt.group > 0;
   L.grid = NnSearchArgs{S.grid, T.grid, st, thr2, r0, mode == 0 ? c->nn_rounds : 1, c->corr, sqd_out, c->nn_idx, c->nn_ref, c->fb_list, fbc, c->big_list, bgc, 0, big_ratio, far_stats, o};
   L.list = NnSearchArgs{S.grid, T.grid, st, thr2, r0, 64, c->corr, sqd_out, c->nn_idx, c->nn_ref, c->fb_list, fbc, c->big_list, bgc, big_blocks, big_ratio, far_stats, o};
   return L;
@@ -488,6 +489,7 @@ static void enqueue_nn(qn_ctx* c, int mode /*0 align, 1 fitness*/, float* sqd_ou
   if (mode == 0) {
     { ProfScope ps(c, QN_K_NN_SEARCH);
       if (seeded) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_nn_track<0>), dim3(nbt), dim3(QN_BLOCK), 0, s, S.grid, T.grid, T.raw, G.st, G.thr2, c->corr, sqd_out, c->nn_idx, c->nn_ref, c->fb_list, G.fb_count, c->big_list, G.big_count);
+      else if (L.lane) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_nn_lane<0>), dim3(L.grid_nb), dim3(256), 0, s, G);
       else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_nn_search<0, false, QN_NN_BLOCK>), dim3(L.grid_nb), dim3(QN_NN_BLOCK), 0, s, QN_NN_ARGS(G)); }
     { ProfScope ps(c, QN_K_NN_FALLBACK);
       if (L.group) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_nn_search<0, true, QN_BLOCK, true>), dim3(L.list_nb), dim3(QN_BLOCK), 0, s, QN_NN_ARGS(F));
@@ -1087,6 +1089,7 @@ extern "C" int qn_debug_set(qn_ctx* c, const char* key, double v) {
   else if (k == "stable_cells") c->stable_cells = v != 0;
   else if (k == "knn_hist") c->knn_hist = v != 0;
   else if (k == "nn_rounds") c->nn_rounds = v < 1 ? 1 : (int)v;
+  else if (k == "nn_lane") c->nn_lane = v != 0;                  // first (unseeded) 1-NN pass one query per lane (NnLaneK) instead of the cooperative 16-per-wave search
   else if (k == "track_from_tick") c->track_from_tick = v < 1 ? 1 : (int)v;
   else if (k == "single_from_tick") c->single_from_tick = v < 1 ? 1 : (int)v;
   else if (k == "fused_from_tick") c->fused_from_tick = v < 1 ? 1 : (int)v;

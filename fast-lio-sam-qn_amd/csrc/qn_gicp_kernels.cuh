@@ -744,6 +744,93 @@ __device__ __forceinline__ void reduce_block_partials(const double acc[QN_NPART]
   }
 }
 
+// ------------------------------------------------------------------ K4a'' first (unseeded) pass, one query per LANE
+// The unseeded passes of an align start with ONE round at radius r0 = one cell (margin_nn): the query's ball box is 3 x 3 x 3 cells, i.e. <= 9 (y, z) rows of <= 2
+// segments each (a row crosses a tile boundary at most once), ~40-60 candidates.  The cooperative search (wave_search: 16 queries per wave, cluster boxes, one dense
+// candidate stream staged through LDS) spends ~80 wave-instructions per query on that machinery; here every lane walks ITS OWN box - segment bounds of a whole
+// pass fetched in one go, candidates two at a time - for ~15-20 per query, four times fewer waves and no LDS.  Neighbouring lanes are neighbours in space (cell-sorted
+// order), so their rows are the same cache lines and their trip counts agree.  Same certificate as wave_search (best distance < distance to the nearest box face
+// with unseen cells behind it), same radius rule and the same routing of the leftovers (far -> one-per-wave list, near -> 16-per-wave list); results are exact
+// either way, so everything downstream sees the same correspondences (tests: test_knn_bit_exact's 1-NN side, test_linearize_and_error, the oracle parity sweeps).
+#define QN_LANE_ROWS 9
+template <int MODE>
+struct NnLaneK {
+  static constexpr int TB = 256, OCC = 6;
+  using Args = NnSearchArgs;
+  static __device__ __forceinline__ void run(const Args& a, const uint32_t bx, const uint32_t) {
+    const GicpState* __restrict__ st = a.st; const NnOpt opt = a.opt;
+    if (MODE == 0 && uni(st->phase) != 0) return;
+    if (MODE == 1 && uni(st->phase) != 2) return;
+    if (opt.cond && !(uni(st->reserved) & opt.cond)) return;           // a conditional launch behind look_decide
+    const GridView src = grid_resolve(a.src), tgt = grid_resolve(a.tgt);
+    float r0 = a.r0; if (r0 < 0.f) r0 = -r0 * tgt.cell;
+    float Tf[12];
+#pragma unroll
+    for (int j = 0; j < 12; j++) Tf[j] = uni((float)st->x0[j]);
+    const uint32_t t = bx * TB + threadIdx.x;
+    const bool active = t < src.n;
+    const float4 p = active ? src.pts[t] : make_float4(0, 0, 0, 0);
+    float qx, qy, qz; xform_query<MODE>(Tf, p.x, p.y, p.z, qx, qy, qz);
+    if (MODE == 0 && opt.clear_ref && active) opt.clear_ref[t] = make_float4(0.f, 0.f, 0.f, 0.f);      // no far-candidate list yet (w = 0)
+    float r = r0;
+    const int x0 = cell_coord(qx - r, tgt.ox, tgt.inv_cell, tgt.nx), x1 = cell_coord(qx + r, tgt.ox, tgt.inv_cell, tgt.nx);
+    const int y0 = cell_coord(qy - r, tgt.oy, tgt.inv_cell, tgt.ny), y1 = cell_coord(qy + r, tgt.oy, tgt.inv_cell, tgt.ny);
+    const int z0 = cell_coord(qz - r, tgt.oz, tgt.inv_cell, tgt.nz), z1 = cell_coord(qz + r, tgt.oz, tgt.inv_cell, tgt.nz);
+    const int tx0 = x0 >> 3, ntr = (x1 >> 3) - tx0 + 1, nyr = y1 - y0 + 1, nrow = nyr * (z1 - z0 + 1);
+    const bool scan = active && nrow <= QN_LANE_ROWS && ntr <= 2;       // (a wider first radius - knob margin_nn - may not fit: such a query goes to the lists unscanned, with its radius)
+    Best1 sink; sink.init();
+    const float4* __restrict__ pts = tgt.pts; const uint32_t* __restrict__ cs = tgt.cell_start;
+#pragma unroll 1
+    for (int part = 0; part < 2; part++) {
+      if (!__any(scan && part < ntr)) break;
+      uint32_t s[QN_LANE_ROWS], e[QN_LANE_ROWS];
+#pragma unroll
+      for (int rr = 0; rr < QN_LANE_ROWS; rr++) {
+        s[rr] = 0; e[rr] = 0;
+        if (scan && part < ntr && rr < nrow) {
+          int qz_, ry_; divmod_small(rr, nyr, qz_, ry_);
+          const int tx = tx0 + part, xa = max(x0, tx << 3), xb = min(x1, (tx << 3) + 7);
+          const uint32_t k0 = cell_key(tgt, xa, y0 + ry_, z0 + qz_);
+          s[rr] = cs[k0]; e[rr] = cs[k0 + (uint32_t)(xb - xa) + 1u];
+        }
+      }
+#pragma unroll
+      for (int rr = 0; rr < QN_LANE_ROWS; rr++) {
+        for (uint32_t u = s[rr]; u < e[rr]; u += 2) {                    // two candidates per trip, both loads in flight
+          const bool two = u + 1 < e[rr];
+          const float4 c0 = pts[u], c1 = pts[two ? u + 1 : u];
+          sink.consider(true, sqdist(qx, qy, qz, c0.x, c0.y, c0.z), __float_as_uint(c0.w));
+          sink.consider(two, sqdist(qx, qy, qz, c1.x, c1.y, c1.z), __float_as_uint(c1.w));
+        }
+      }
+    }
+    // certification: nearest face of the scanned box that has unseen cells behind it (wave_search's rule, on the query's own box)
+    const float INF = __int_as_float(0x7f800000);
+    bool certified = false; float d_unseen = INF;
+    if (scan) {
+      float d = INF;
+      if (x0 > 0) d = fminf(d, qx - (tgt.ox + x0 * tgt.cell));
+      if (x1 < tgt.nx - 1) d = fminf(d, (tgt.ox + (x1 + 1) * tgt.cell) - qx);
+      if (y0 > 0) d = fminf(d, qy - (tgt.oy + y0 * tgt.cell));
+      if (y1 < tgt.ny - 1) d = fminf(d, (tgt.oy + (y1 + 1) * tgt.cell) - qy);
+      if (z0 > 0) d = fminf(d, qz - (tgt.oz + z0 * tgt.cell));
+      if (z1 < tgt.nz - 1) d = fminf(d, (tgt.oz + (z1 + 1) * tgt.cell) - qz);
+      if (d == INF || !(r == r)) { certified = true; d_unseen = INF; }      // the whole grid was scanned (or a non-finite query: nothing to find)
+      else { d -= tgt.eps; d_unseen = d; certified = d > 0.f && sink.full() && sink.worst_d2() < d * d; }
+      if (!certified) r = sink.full() ? fmaxf(sqrtf(sink.worst_d2()) * 1.000001f + tgt.eps, r + tgt.eps) : 2.f * r + tgt.cell;      // the radius the list pass continues from
+    }
+    if (active && certified) {
+      store_nn<MODE>(sink.key, __float_as_uint(p.w), t, a.thr2, a.corr, a.sqd, a.nn_idx);
+      if (MODE == 0) a.nn_ref[t] = make_float4(qx, qy, qz, fminf(sqrtf(sink.second), d_unseen));      // bound-pruning reference: where this query was scanned and how far away every other point is at least
+    }
+    const bool far = r > a.big_ratio * r0;
+    wave_append(a.big_list, a.big_count, active && !certified && far, make_uint2(t, __float_as_uint(-r)));     // far: one query per wave
+    wave_append(a.fb_list, a.fb_count, active && !certified && !far, make_uint2(t, __float_as_uint(-r)));      // continue from r
+  }
+};
+template <int MODE>
+__global__ void __launch_bounds__(256, 6) k_nn_lane(NnSearchArgs a) { NnLaneK<MODE>::run(a, blockIdx.x, gridDim.x); }
+
 // (AccumulateK / k_accumulate: below the controller, whose step the last block of the launch may run - controller_tail)
 
 // ------------------------------------------------------------------ K4a', temporal tracking
