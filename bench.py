@@ -356,6 +356,14 @@ def latency_legs(engine, synth, pairs, args, world, ctx=None, p80=None):
                                     "note": "screening GEMM on v_mfma_f32_32x32x16_f16: K = 112 (f16 hi/lo split of 33 bins + bound terms), full pass + 1/4 sampled pass, forward search only "
                                             "(Ns x Nt); time = BOTH searches + de-duplication + operand images + exact stage, so the fraction is a lower bound. effective_f32_TF = 2*33*Ns*Nt / time"},
                      "host_wall_ms": host_wall}
+                if npts == 30000 and not args.no_cpu_baseline:
+                    # spot check of BASELINE configs[2] against the CPU oracle (quatro<>::align, loop_closure.cpp:144): same validity, the SAME correspondence set, pose within 1e-4 m / rad
+                    from oracle import oracle as orc
+                    rq = q.align(qs, qt, debug=True); oq = orc.quatro_align(qs, qt)
+                    dtq, drq = synth.pose_error(rq["T"], oq["T"])
+                    e["parity_vs_oracle"] = {"valid": [bool(rq["valid"]), bool(oq["valid"])], "correspondences": [int(len(rq["corres"])), int(len(oq["corres"]))],
+                                             "same_correspondences": bool(np.array_equal(rq["corres"], oq["corres"])), "dt_m": dtq, "dr_rad": drq,
+                                             "ok": bool(rq["valid"] == oq["valid"] and np.array_equal(rq["corres"], oq["corres"]) and dtq <= 1e-4 and drq <= 1e-4)}
                 quatro["%dk" % (npts // 1000)] = e
         except Exception as ex:
             quatro = {"error": repr(ex)}
@@ -749,6 +757,9 @@ def main():
         os.write(json_fd, (json.dumps(out) + "\n").encode())
         if parity is not None and not parity["ok"]:
             raise SystemExit("bench.py: the benched workload does NOT match the oracle: %r" % (parity,))
+        qpar = ((quatro or {}).get("30k") or {}).get("parity_vs_oracle") if isinstance(quatro, dict) else None
+        if qpar is not None and not qpar["ok"]:
+            raise SystemExit("bench.py: the Quatro stage (configs[2]) does NOT match the oracle: %r" % (qpar,))
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

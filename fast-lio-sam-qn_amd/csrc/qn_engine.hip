@@ -10,6 +10,7 @@
 #include <vector>
 #include <atomic>
 #include <thread>
+#include <chrono>
 #include "qn_instances.h"      // heavy template kernels: declared here, compiled in qn_inst.hip (one TU per group)
 #include "qn_context.h"
 
@@ -213,13 +214,14 @@ extern "C" void qn_ctx_destroy(qn_ctx* c) {
   delete c;
 }
 
+static int clouds_valid(qn_ctx* c);
 extern "C" void* qn_ctx_stream(qn_ctx* c) { return c ? (void*)c->stream : nullptr; }
 extern "C" int qn_ctx_synchronize(qn_ctx* c) {
   if (!c) return QN_ERR_INVALID_ARG;
   HIPCHK(c, hipStreamSynchronize(c->stream));
   if (c->stream2) HIPCHK(c, hipStreamSynchronize(c->stream2));          // a target still being prepared (TargetScope)
   c->prof_collect();
-  return QN_OK;
+  return clouds_valid(c);                                              // (every synchronising entry point reports a cloud with non-finite coordinates: the setters do not wait for the GPU)
 }
 
 extern "C" int qn_gicp_set_params(qn_ctx* c, const qn_gicp_params* p) {
@@ -1027,7 +1029,7 @@ extern "C" int qn_gicp_linearize(qn_ctx* c, const double T[16], double H[36], do
   memcpy(H, hs->H, sizeof(double) * 36); memcpy(b6, hs->b, sizeof(double) * 6); *err = hs->y0;
   free(hs);
   c->prof_collect();
-  return QN_OK;
+  return clouds_valid(c);
 }
 
 extern "C" int qn_gicp_compute_error(qn_ctx* c, const double T[16], double* err) {
@@ -1085,6 +1087,7 @@ extern "C" int qn_debug_set(qn_ctx* c, const char* key, double v) {
     if (b < (int)c->lanes.size()) { if (hipStreamSynchronize(c->stream) != hipSuccess) return QN_ERR_HIP; while ((int)c->lanes.size() > std::max(b, 1)) { qn_ctx* l = c->lanes.back(); c->lanes.pop_back(); if (l != c) qn_ctx_destroy(l); } }
     c->batch_lanes = b;
   }
+  else if (k == "batch_trace") c->batch_trace = v != 0;           // developer: host timeline of every batched segment on stderr
   else if (k == "batch_member") c->persist_batch_off = v != 0;      // this context registers beside others (qn_multi with in_flight > 1): no persistent launches
   else if (k == "stable_cells") c->stable_cells = v != 0;
   else if (k == "knn_hist") c->knn_hist = v != 0;

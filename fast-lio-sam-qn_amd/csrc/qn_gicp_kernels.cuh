@@ -796,11 +796,13 @@ struct NnLaneK {
       }
 #pragma unroll
       for (int rr = 0; rr < QN_LANE_ROWS; rr++) {
-        for (uint32_t u = s[rr]; u < e[rr]; u += 2) {                    // two candidates per trip, both loads in flight
-          const bool two = u + 1 < e[rr];
-          const float4 c0 = pts[u], c1 = pts[two ? u + 1 : u];
+        for (uint32_t u = s[rr]; u < e[rr]; u += 4) {                    // four candidates per trip, all four loads in flight (a row is 3 cells: one trip, rarely two)
+          const uint32_t last = e[rr] - 1u;
+          const float4 c0 = pts[u], c1 = pts[min(u + 1u, last)], c2 = pts[min(u + 2u, last)], c3 = pts[min(u + 3u, last)];
           sink.consider(true, sqdist(qx, qy, qz, c0.x, c0.y, c0.z), __float_as_uint(c0.w));
-          sink.consider(two, sqdist(qx, qy, qz, c1.x, c1.y, c1.z), __float_as_uint(c1.w));
+          sink.consider(u + 1u <= last, sqdist(qx, qy, qz, c1.x, c1.y, c1.z), __float_as_uint(c1.w));
+          sink.consider(u + 2u <= last, sqdist(qx, qy, qz, c2.x, c2.y, c2.z), __float_as_uint(c2.w));
+          sink.consider(u + 3u <= last, sqdist(qx, qy, qz, c3.x, c3.y, c3.z), __float_as_uint(c3.w));
         }
       }
     }

@@ -79,6 +79,8 @@ def test_quatro_align_parity_fullsize(eng, oracle, pair_id, n):
         assert common >= 0.9 * len(oa["corres"]), (common, len(oa["corres"]))
         assert dt <= 0.3 and dr <= np.radians(2.0), (dt, dr)
     print("  coarse stage vs the oracle's own descriptors: branch %s, |dT| = %.2e m / %.2e rad; oracle matcher on %d x %d descriptors: %.1f s" % ("STRICT" if strict else "LOOSE (an SPFH bin differs)", dt, dr, len(src), len(tgt), t_match))
+    if not strict:      # visible in a -q run: the loose bar was met, the strict one could not be applied (recorded as an expected failure, not as a pass)
+        pytest.xfail("LOOSE branch: %d SPFH row(s) differ from the oracle's by a bin edge; coarse pose within %.2e m / %.2e rad" % (max(rp["spfh_rows_off"] for rp in rep), dt, dr))
 
 
 def test_advanced_matching_parity_30k(eng, oracle):
