@@ -553,8 +553,13 @@ def main():
         return min((a.tolist() for a in allrec), key=lambda a: (a[2], a[0]))
 
     if args.warmup > 0:
-        batch(max(args.warmup, 4 * len(ctxs) * max(1, args.lanes)))      # (at least four full runs of lanes per context: the lane sub-contexts are created on first use, and the
-                                                                       #  first launches of every kernel variant load its code object - multi-millisecond hiccups in the first few batches)
+        # untimed warm-up: at least `--warmup` registrations, at least four full runs of lanes per context (the lane sub-contexts are created on first use, and the first
+        # launches of every kernel variant load its code object - multi-millisecond hiccups in the first few batches), and at least 0.25 s of sustained work (after the
+        # seconds of CPU-side scene generation above the device sits in a low power state; a 30 ms warm-up left the first timed region 10 % slow)
+        tw = time.perf_counter()
+        batch(max(args.warmup, 4 * len(ctxs) * max(1, args.lanes)))
+        while time.perf_counter() - tw < 0.25:
+            batch(2 * len(ctxs) * max(1, args.lanes))
     if dist is not None:          # untimed: bring up the communicator's channels (RCCL connects lazily on the first collective)
         gather_best([0.0] * 19)
         dist.all_reduce(torch.zeros(1, dtype=torch.float64, device=cdev), op=dist.ReduceOp.MAX)
