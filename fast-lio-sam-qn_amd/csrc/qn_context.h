@@ -76,7 +76,7 @@ struct qn_ctx {
   float big_ratio = 2.5f;               // first-search leftovers whose next radius exceeds big_ratio * r0 go one-per-wave
   bool fused_ticks = true;              // GN ticks >= 3: tracking + leftovers + accumulation in one kernel
   int nn_rounds = 1;                    // rounds of an unseeded NN search before a query goes to the list pass
-  bool nn_lane = true;                  // the first pass of an unseeded search runs one query per lane over its own 3 x 3 x 3 cell box (NnLaneK)
+  int nn_lane = -1;                     // the first pass of an unseeded search runs one query per lane over its own 3 x 3 x 3 cell box (NnLaneK): -1 = batch members only, 0 = never, 1 = always
   int track_from_tick = 3;              // NN passes before this tick search unseeded (ball around the query) instead of tracking the previous neighbour
   int fused_from_tick = 3;
   int unseeded_until = 3; bool count_far_now = false; int last_extra_unseeded = 0;   // per align: ticks below this index search unseeded; far-query statistics of this pass; the adaptive decision (debug read-back)

@@ -474,7 +474,9 @@ static NnLaunch prep_nn(qn_ctx* c, int mode /*0 align, 1 fitness*/, float* sqd_o
   c->clear_far_now = mode == 0 && !seeded ? false : c->clear_far_now;
   const NnOpt& o = mode == 0 ? opt : opt0;
   NnLaunch L;
-  L.lane = c->nn_lane && mode == 0 && !seeded;
+  // one query per lane for batch members (throughput: a quarter of the waves, a fifth of the instructions); a LONE registration keeps the cooperative pass - its 1563
+  // one-per-lane waves are a single latency-bound round (48 us against 36-41)
+  L.lane = (c->nn_lane > 0 || (c->nn_lane < 0 && c->persist_batch_off)) && mode == 0 && !seeded;
   L.grid_nb = L.lane ? (S.n + 255u) / 256u : nb; L.list_nb = fbb + (uint32_t)big_blocks; L.group = mode == 0 && opt.group > 0;
   L.grid = NnSearchArgs{S.grid, T.grid, st, thr2, r0, mode == 0 ? c->nn_rounds : 1, c->corr, sqd_out, c->nn_idx, c->nn_ref, c->fb_list, fbc, c->big_list, bgc, 0, big_ratio, far_stats, o};
   L.list = NnSearchArgs{S.grid, T.grid, st, thr2, r0, 64, c->corr, sqd_out, c->nn_idx, c->nn_ref, c->fb_list, fbc, c->big_list, bgc, big_blocks, big_ratio, far_stats, o};
@@ -1092,7 +1094,7 @@ extern "C" int qn_debug_set(qn_ctx* c, const char* key, double v) {
   else if (k == "stable_cells") c->stable_cells = v != 0;
   else if (k == "knn_hist") c->knn_hist = v != 0;
   else if (k == "nn_rounds") c->nn_rounds = v < 1 ? 1 : (int)v;
-  else if (k == "nn_lane") c->nn_lane = v != 0;                  // first (unseeded) 1-NN pass one query per lane (NnLaneK) instead of the cooperative 16-per-wave search
+  else if (k == "nn_lane") c->nn_lane = v < 0 ? -1 : (v != 0 ? 1 : 0);                  // first (unseeded) 1-NN pass one query per lane (NnLaneK) instead of the cooperative 16-per-wave search
   else if (k == "track_from_tick") c->track_from_tick = v < 1 ? 1 : (int)v;
   else if (k == "single_from_tick") c->single_from_tick = v < 1 ? 1 : (int)v;
   else if (k == "fused_from_tick") c->fused_from_tick = v < 1 ? 1 : (int)v;

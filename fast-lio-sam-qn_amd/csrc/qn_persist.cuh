@@ -81,7 +81,7 @@ __global__ void __launch_bounds__(TB, TB / 256) k_align_persist(PersistArgs A) {
   static_assert(TB / QN_NPART == QN_ROW_SEGS, "the reducer's thread -> (segment, component) map is reduce_rows' at 512 threads");
   __shared__ double sums[QN_NPART];
   __shared__ SolveWork Awork_s;
-  __shared__ double bc_x0[16], bc_xi[16];
+  __shared__ double bc_x0[16], bc_xi[16], bc_G[9];
   __shared__ int bc_phase, bc_fail;
   __shared__ unsigned long long tie_list[TB / 64][QN_HCAP1]; __shared__ uint32_t tie_cnt[TB / 64];
   A.t.src = grid_resolve(A.t.src); A.t.tgt = grid_resolve(A.t.tgt);
@@ -257,6 +257,8 @@ __global__ void __launch_bounds__(TB, TB / 256) k_align_persist(PersistArgs A) {
       if (lane < 48 && !(lane & 1)) { const double d = __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo)); if (lane < 24) bc_x0[lane >> 1] = d; else bc_xi[(lane - 24) >> 1] = d; }
       if (lane == 48) bc_phase = (int)lo;
       if (lane == 0 && fail) bc_fail = 1;
+      wave_lds_fence();
+      pose_gram(bc_x0, bc_G, lane);                                   // R R^T of the new pose (emit_point reads the poses and this from LDS)
     }
     __syncthreads();
     if (bc_fail || bc_phase == 3) return;
@@ -273,7 +275,7 @@ __global__ void __launch_bounds__(TB, TB / 256) k_align_persist(PersistArgs A) {
           p = valid ? a.src.pts[t] : make_float4(0, 0, 0, 0); j0s = valid ? a.nn_idx[t] : -1; ref = valid ? a.nn_ref[t] : make_float4(0, 0, 0, 0); t2.j1 = -1;
           if (valid && (uint32_t)j0s < a.tgt.n) { const TargetRec* r = a.tgt_rec + j0s; rec0.p = r->p; rec0.n[0] = r->n[0]; rec0.n[1] = r->n[1]; rec0.n[2] = r->n[2]; }
         }
-        tick_point<1, false, true>(a, Tf, bc_x0, bc_xi, true, it == 0, t, valid, p, j0s, ref, na, rec0, t2, &sc[tid >> 6].w, sc[tid >> 6].red, wsum[tid >> 6], tie_list[tid >> 6], &tie_cnt[tid >> 6], false);
+        tick_point<1, false, true>(a, Tf, bc_x0, bc_xi, bc_G, true, it == 0, t, valid, p, j0s, ref, na, rec0, t2, &sc[tid >> 6].w, sc[tid >> 6].red, wsum[tid >> 6], tie_list[tid >> 6], &tie_cnt[tid >> 6], false);
       }
       __syncthreads();
       if (tid == 0) { double sv = 0, cv = 0; for (int w = 0; w < TB / 64; w++) { sv += wsum[w][0]; cv += wsum[w][1]; }
@@ -288,7 +290,7 @@ __global__ void __launch_bounds__(TB, TB / 256) k_align_persist(PersistArgs A) {
         if (valid) { na[0] = a.nrm_s[(size_t)t * 3]; na[1] = a.nrm_s[(size_t)t * 3 + 1]; na[2] = a.nrm_s[(size_t)t * 3 + 2]; }
         if (valid && (uint32_t)j0s < a.tgt.n) { const TargetRec* r = a.tgt_rec + j0s; rec0.p = r->p; rec0.n[0] = r->n[0]; rec0.n[1] = r->n[1]; rec0.n[2] = r->n[2]; }
       }
-      tick_point<0, false, true>(a, Tf, bc_x0, bc_xi, lin, it == 0, t, valid, p, j0s, ref, na, rec0, t2, &sc[tid >> 6].w, sc[tid >> 6].red, wsum[tid >> 6], tie_list[tid >> 6], &tie_cnt[tid >> 6], false);
+      tick_point<0, false, true>(a, Tf, bc_x0, bc_xi, bc_G, lin, it == 0, t, valid, p, j0s, ref, na, rec0, t2, &sc[tid >> 6].w, sc[tid >> 6].red, wsum[tid >> 6], tie_list[tid >> 6], &tie_cnt[tid >> 6], false);
     }
     __syncthreads();
     if (PROBE && tid == 0 && pslot >= 0 && g < 64) A.clk[16 * g + pslot + 1] = wall_clock64();

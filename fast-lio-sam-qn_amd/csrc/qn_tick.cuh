@@ -90,14 +90,21 @@ __device__ __forceinline__ void fold7(const double g[7], const int G, const bool
   wave_lds_fence();
 }
 
+// G = R R^T of the pose in LDS (9 threads; the caller puts a barrier behind it): accumulate_point_n's expression, entry by entry
+__device__ __forceinline__ void pose_gram(const double* __restrict__ sx0, double* __restrict__ sG, const int t) {
+  if (t < 9) { const int a = t / 3, b = t - 3 * a; sG[t] = sx0[4 * a] * sx0[4 * b] + sx0[4 * a + 1] * sx0[4 * b + 1] + sx0[4 * a + 2] * sx0[4 * b + 2]; }
+}
 // One correspondence's contribution to the 28 sums (accumulate_point_n's arithmetic, term for term), produced SEVEN values at a time
 // and folded across the wave at once: a lane never holds the 28 f64 accumulators (56 VGPRs) next to the matrices they are made of,
 // which is what pushed this kernel to 240 VGPRs.  have = false: the lane contributes zeros.
-__device__ __forceinline__ void emit_point(const bool have, const bool lin, const bool first, const double (*Rx)[4], const double (*Tx)[4], const float4 pa, const float4 pb,
+__device__ __forceinline__ void emit_point(const bool have, const bool lin, const bool first, const double* __restrict__ sRx, const double* __restrict__ sTx, const double* __restrict__ sG, const float4 pa, const float4 pb,
                                            const double na[3], const double nb[3], double* __restrict__ wbuf, double* __restrict__ wrow) {
+  // sRx / sTx: the 3 x 4 poses (row-major, stride 4) in LDS - Rx rotates the source normal (x0), Tx is the pose the residual is evaluated at (x0; xi in an LM trial pass);
+  // sG = Rx Rx^T, formed once per block with the expression below.  Read where they are used (broadcast ds_read_b64): a lane never holds a pose in registers - the 24 to
+  // 48 VGPRs that cost were what this kernel spilled at its 128-register budget.
   double m[3];
 #pragma unroll
-  for (int a = 0; a < 3; a++) m[a] = Rx[a][0] * na[0] + Rx[a][1] * na[1] + Rx[a][2] * na[2];
+  for (int a = 0; a < 3; a++) m[a] = sRx[4 * a] * na[0] + sRx[4 * a + 1] * na[1] + sRx[4 * a + 2] * na[2];
   // R C_A R^T = R R^T - 0.999 m m^T.  R R^T is I to rounding for every pose the optimiser builds from the identity guess of
   // loop_closure.cpp:124, but NOT for a caller's f32 guess with a rotation (pcl::Registration::align(output, guess)): its rows are
   // orthonormal to 6e-8 only, the reference multiplies with the matrix as it is, and the difference is 1e-7 of the cost.
@@ -105,15 +112,12 @@ __device__ __forceinline__ void emit_point(const bool have, const bool lin, cons
 #pragma unroll
   for (int a = 0; a < 3; a++)
 #pragma unroll
-    for (int b = 0; b < 3; b++) {
-      const double g = Rx[a][0] * Rx[b][0] + Rx[a][1] * Rx[b][1] + Rx[a][2] * Rx[b][2];
-      rcr.m[a][b] = ((a == b ? 1.0 : 0.0) - 0.999 * nb[a] * nb[b]) + (g - 0.999 * m[a] * m[b]);
-    }
+    for (int b = 0; b < 3; b++) rcr.m[a][b] = ((a == b ? 1.0 : 0.0) - 0.999 * nb[a] * nb[b]) + (sG[3 * a + b] - 0.999 * m[a] * m[b]);
   const M3 M = m3_inverse(rcr);
   const double mA[3] = {(double)pa.x, (double)pa.y, (double)pa.z};
   double tA[3], e[3], Me[3];
 #pragma unroll
-  for (int r = 0; r < 3; r++) tA[r] = Tx[r][0] * mA[0] + Tx[r][1] * mA[1] + Tx[r][2] * mA[2] + Tx[r][3];
+  for (int r = 0; r < 3; r++) tA[r] = sTx[4 * r] * mA[0] + sTx[4 * r + 1] * mA[1] + sTx[4 * r + 2] * mA[2] + sTx[4 * r + 3];
   e[0] = (double)pb.x - tA[0]; e[1] = (double)pb.y - tA[1]; e[2] = (double)pb.z - tA[2];
 #pragma unroll
   for (int r = 0; r < 3; r++) Me[r] = M.m[r][0] * e[0] + M.m[r][1] * e[1] + M.m[r][2] * e[2];
@@ -213,9 +217,10 @@ struct Top2 { int32_t j1; float4 p1; };                                // j1 = -
 // sx0 / sxi: the f64 poses in LDS (fetched only where the sums are formed: the search and the accumulation are the two register-hungry parts, their live
 // ranges are kept apart).  wl / red: the wave's search scratch and the transpose buffer that aliases it; wrow: the wave's row of the block's 28 sums.
 // Must be called convergently by the whole wave.  PROBE: developer clock stamps (compiled out of the production kernels).
-template <int MODE, bool PROBE, bool TOP2>
-__device__ __forceinline__ void tick_point(const TickArgs& a, const float (&Tf)[12], const double* __restrict__ sx0, const double* __restrict__ sxi, const bool lin, const bool first,
-                                           const uint32_t t, const bool valid, const float4 p, int32_t& j0s, float4& ref, const double (&na)[3], TargetRec& rec0, Top2& t2,
+// NA_LATE: the source normal is fetched here, right before the sums are formed (k_tick: six registers fewer across the search); the persistent kernel hands it over preloaded
+template <int MODE, bool PROBE, bool TOP2, bool NA_LATE = false>
+__device__ __forceinline__ void tick_point(const TickArgs& a, const float (&Tf)[12], const double* __restrict__ sx0, const double* __restrict__ sxi, const double* __restrict__ sG, const bool lin, const bool first,
+                                           const uint32_t t, const bool valid, const float4 p, int32_t& j0s, float4& ref, const double (&na_in)[3], TargetRec& rec0, Top2& t2,
                                            WaveLds* __restrict__ wl, double* __restrict__ red, double* __restrict__ wrow, unsigned long long* __restrict__ wlist, uint32_t* __restrict__ wcnt, const bool probe) {
   const int tid = threadIdx.x, lane = tid & 63;
   const float INF = __int_as_float(0x7f800000);
@@ -226,13 +231,10 @@ __device__ __forceinline__ void tick_point(const TickArgs& a, const float (&Tf)[
   if (!lin) {                                                    // LM trial error: cached correspondence, gate as at the linearisation
     bool have = false;
     if (valid && finite_q && j0 < a.tgt.n) have = (double)sqdist(qx, qy, qz, rec0.p.x, rec0.p.y, rec0.p.z) < a.thr2;
-    double X0[3][4], Xi[3][4];
-#pragma unroll
-    for (int r = 0; r < 3; r++)
-#pragma unroll
-      for (int c = 0; c < 4; c++) { X0[r][c] = sx0[4 * r + c]; Xi[r][c] = sxi[4 * r + c]; }
+    double na[3] = {na_in[0], na_in[1], na_in[2]};
+    if (NA_LATE && valid) { na[0] = a.nrm_s[(size_t)t * 3]; na[1] = a.nrm_s[(size_t)t * 3 + 1]; na[2] = a.nrm_s[(size_t)t * 3 + 2]; }
     wave_lds_fence();
-    emit_point(have, false, first, X0, Xi, make_float4(p.x, p.y, p.z, 1.f), rec0.p, na, rec0.n, red, wrow);
+    emit_point(have, false, first, sx0, sxi, sG, make_float4(p.x, p.y, p.z, 1.f), rec0.p, na, rec0.n, red, wrow);
     return;
   }
   // ---- phase 0: tracked exact 1-NN (k_nn_track's logic: bound pruning, small in-lane rescan, cooperative big-ball search)
@@ -425,8 +427,8 @@ __device__ __forceinline__ void tick_point(const TickArgs& a, const float (&Tf)[
         t2.j1 = j0s; t2.p1 = rec0.p;
       }
     }
+    if (jn != j0s) a.nn_idx[t] = jn;                               // (only a CHANGED neighbour goes to memory: a converging align re-proves nearly every neighbour, and 100k unconditional stores per tick were a third of the kernel's write traffic)
     j0s = jn;                                                      // (the tracking record also stays in the caller's registers: the persistent kernel never re-reads it)
-    a.nn_idx[t] = j0s;
     if (rescanned) { ref = make_float4(qx, qy, qz, fminf(sqrtf(TOP2 && key2 != QN_INF_KEY ? third : second), d_unseen)); a.nn_ref[t] = ref; }
     if (best != QN_INF_KEY) {
       const uint32_t j = key_idx(best);                              // rec0 always is the record of j0s (gated out or not)
@@ -438,13 +440,10 @@ __device__ __forceinline__ void tick_point(const TickArgs& a, const float (&Tf)[
     if (probe) a.clk[4] = wall_clock64();
     if (MODE == 0 && threadIdx.x == 0) a.clk_blk[8 * blockIdx.x + 2] = wall_clock64();
   }
-  double X0[3][4];
-#pragma unroll
-  for (int r = 0; r < 3; r++)
-#pragma unroll
-    for (int c = 0; c < 4; c++) X0[r][c] = sx0[4 * r + c];
+  double na[3] = {na_in[0], na_in[1], na_in[2]};
+  if (NA_LATE && valid) { na[0] = a.nrm_s[(size_t)t * 3]; na[1] = a.nrm_s[(size_t)t * 3 + 1]; na[2] = a.nrm_s[(size_t)t * 3 + 2]; }
   wave_lds_fence();                                              // the wave's search scratch becomes its transpose buffer
-  emit_point(have, true, first, X0, X0, make_float4(p.x, p.y, p.z, 1.f), rec0.p, na, rec0.n, red, wrow);
+  emit_point(have, true, first, sx0, sx0, sG, make_float4(p.x, p.y, p.z, 1.f), rec0.p, na, rec0.n, red, wrow);
 }
 
 // MODE 0: an optimiser tick.  MODE 1: the closing pass of align() in ONE kernel - the last controller step in the prologue, then (only
@@ -465,6 +464,7 @@ struct TickK {
   __shared__ WaveScratch sc[TB / 64];
   __shared__ double wsum[TB / 64][QN_NPART];
   __shared__ TailLds tl;                                            // the state this launch runs under; in the last block: the controller's workspace and the next state
+  __shared__ double sG[9];                                          // R R^T of the pose (emit_point)
   const int tid = threadIdx.x;
   const uint32_t nblk = nbx_;
   a.src = grid_resolve(a.src); a.tgt = grid_resolve(a.tgt);
@@ -481,8 +481,7 @@ struct TickK {
   float4 p = valid ? a.src.pts[t] : make_float4(0, 0, 0, 0);
   int32_t j0s = valid ? a.nn_idx[t] : -1;
   float4 ref = valid ? a.nn_ref[t] : make_float4(0, 0, 0, 0);
-  double na[3] = {0, 0, 0};
-  if (valid) { na[0] = a.nrm_s[(size_t)t * 3]; na[1] = a.nrm_s[(size_t)t * 3 + 1]; na[2] = a.nrm_s[(size_t)t * 3 + 2]; }
+  const double na[3] = {0, 0, 0};                                   // (fetched inside tick_point: NA_LATE)
   TargetRec rec0; rec0.p = make_float4(0, 0, 0, 0); rec0.n[0] = rec0.n[1] = rec0.n[2] = 0;
   if (valid && (uint32_t)j0s < a.tgt.n) { const TargetRec* r = a.tgt_rec + j0s; rec0.p = r->p; rec0.n[0] = r->n[0]; rec0.n[1] = r->n[1]; rec0.n[2] = r->n[2]; }
   Top2 no_t2; no_t2.j1 = -1; no_t2.p1 = make_float4(0, 0, 0, 0);     // (the chain keeps no runner-up: its tracking record is re-read from memory every tick)
@@ -501,16 +500,17 @@ struct TickK {
   float Tf[12];
 #pragma unroll
   for (int j = 0; j < 12; j++) Tf[j] = (float)tl.sh.x0[j];
+  pose_gram(tl.sh.x0, sG, tid);
+  __syncthreads();
   for (uint32_t it = 0; it < a.ppt; it++) {
     if (it > 0) {                                                  // (only clouds beyond 131072 points)
       t = (lblk * a.ppt + it) * TB + tid; valid = t < a.src.n;
       p = valid ? a.src.pts[t] : make_float4(0, 0, 0, 0);
       j0s = valid ? a.nn_idx[t] : -1;
       ref = valid ? a.nn_ref[t] : make_float4(0, 0, 0, 0);
-      if (valid) { na[0] = a.nrm_s[(size_t)t * 3]; na[1] = a.nrm_s[(size_t)t * 3 + 1]; na[2] = a.nrm_s[(size_t)t * 3 + 2]; }
       if (valid && (uint32_t)j0s < a.tgt.n) { const TargetRec* r = a.tgt_rec + j0s; rec0.p = r->p; rec0.n[0] = r->n[0]; rec0.n[1] = r->n[1]; rec0.n[2] = r->n[2]; }
     }
-    tick_point<MODE, PROBE, false>(a, Tf, tl.sh.x0, tl.sh.xi, lin, it == 0, t, valid, p, j0s, ref, na, rec0, no_t2, &sc[tid >> 6].w, sc[tid >> 6].red, wsum[tid >> 6], nullptr, nullptr, probe);
+    tick_point<MODE, PROBE, false, true>(a, Tf, tl.sh.x0, tl.sh.xi, sG, lin, it == 0, t, valid, p, j0s, ref, na, rec0, no_t2, &sc[tid >> 6].w, sc[tid >> 6].red, wsum[tid >> 6], nullptr, nullptr, probe);
   }
   __syncthreads();
   if (MODE == 1) {
