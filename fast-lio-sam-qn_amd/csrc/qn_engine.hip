@@ -465,7 +465,7 @@ static NnLaunch prep_nn(qn_ctx* c, int mode /*0 align, 1 fitness*/, float* sqd_o
   // registrations/s; the aligned-scene headline is unchanged); a lone registration wants latency - its lists fit a few rounds of resident waves, one entry per
   // wave starts them all at once, and the leaner kernel keeps 6 blocks per CU (ms_per_align 0.552 against 0.570 / 0.609 with the grouped variant)
   const bool batch = c->persist_batch_off;
-  opt.group = c->far_group >= 0 ? c->far_group : (batch ? 4096 : 0); opt.group_min = 0;
+  opt.group = c->far_group >= 0 ? c->far_group : (batch ? 2048 : 0); opt.group_min = 0;      // (round 4, batched launches: 2048 - up to 16 neighbours per shared scan - measured +3 % over 4096; 8192 and up lose)
   // (a grouped far list is served ceil(length / group) entries per wave: `group` waves are all it can use - same entry -> wave assignment, three quarters fewer empty blocks)
   if (mode == 0 && opt.group > 0) big_blocks = std::min(big_blocks, std::max(64, (opt.group + QN_BLOCK / 64 - 1) / (QN_BLOCK / 64)));
   opt.probe = (mode == 0 && !seeded) ? c->list_probe : nullptr;
