@@ -389,7 +389,7 @@ def single_process(args, engine, synth, json_fd):
     for g in range(n):
         torch.cuda.synchronize(g)
     mg = engine.MultiGpu(n, N_PTS + 1024, in_flight=max(1, args.in_flight))
-    mg.debug_set("batch_lanes", max(1, args.lanes))
+    mg.debug_set("batch_lanes", max(1, args.lanes)); mg.debug_set("batch_share_source", 0)
     gg = engine.GicpParams(); engine.lib().qn_gicp_default_params(__import__("ctypes").byref(gg))
     gg.k_correspondences, gg.max_iterations, gg.max_corr_dist, gg.optimizer, gg.force_iterations = K_COV, GN_ITERS, 52.5, 1, GN_ITERS
     mg.set_params(gg)
@@ -501,6 +501,7 @@ def main():
     ctxs = [engine.Context(N_PTS + 1024, device=local) for _ in range(max(1, args.in_flight))]
     for cx in ctxs:
         cx.debug_set("batch_lanes", max(1, args.lanes))
+        cx.debug_set("batch_share_source", 0)       # a step is a FULL icpAlignment: every registration rebuilds its source (loop_closure.cpp:120-121) - the 8 scenes cycle over the lanes and would otherwise meet their own source again
     gs = []
     for cx in ctxs:
         gg = engine.NanoGICP(cx)
@@ -606,6 +607,7 @@ def main():
             bpairs.append((s, t))
         mg = engine.MultiGpu(1, N_PTS + 1024, in_flight=len(ctxs), device_ids=[local])
         mg.debug_set("batch_lanes", max(1, args.lanes))
+        mg.debug_set("batch_share_source", 0)       # 64 DISTINCT pairs: no shared source preparation (the re-posed variants reuse a scene's source buffer)
         mg.set_params(g.p)
         descs = [(s.data_ptr(), N_PTS, t.data_ptr(), N_PTS, 12, 1) for s, t in bpairs]
         mg.align_best(descs[:min(len(descs), 4)])                     # untimed warm-up of the new contexts
@@ -659,6 +661,7 @@ def main():
             R = torch.tensor([[ca, -sa, 0.0], [sa, ca, 0.0], [0.0, 0.0, 1.0]], dtype=torch.float32, device=t0_.device)
             stg.append((t0_ @ R.T + torch.tensor([0.02 * v, -0.01 * v, 0.0], dtype=torch.float32, device=t0_.device)).contiguous())
         sdescs = [(s0.data_ptr(), N_PTS, t.data_ptr(), N_PTS, 12, 1) for t in stg]
+        mg.debug_set("batch_share_source", 1)       # here the shared source IS the workload
         mg.align_best(sdescs[:min(len(sdescs), 4)])
         barrier()
         tb = time.perf_counter()

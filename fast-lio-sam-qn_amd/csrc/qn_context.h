@@ -28,7 +28,7 @@ struct qn_ctx {
   hipStream_t stream = nullptr; bool owns_stream = true;      // (the lanes of a batch context work on their owner's stream)
   // pair-as-grid-dimension batches (qn_gicp_align_batch, qn_batch.inc): lane 0 is this context, lanes 1 .. are sub-contexts with buffers of their own;
   // every kernel of the chain is launched ONCE for all lanes (k_lanes<F>) with its per-lane arguments in a device-resident table (args_d, staged in args_h)
-  std::vector<qn_ctx*> lanes; int batch_lanes = 8; char* args_h = nullptr; char* args_d = nullptr; size_t args_cap = 0; uint64_t batch_launches = 0, batch_pairs = 0; bool is_lane = false, batch_trace = false;
+  std::vector<qn_ctx*> lanes; int batch_lanes = 8; char* args_h = nullptr; char* args_d = nullptr; size_t args_cap = 0; uint64_t batch_launches = 0, batch_pairs = 0; bool is_lane = false, batch_trace = false, batch_share_source = true;      // batch_share_source: pairs of one batch call that name the same source buffer share its grid and covariances (the candidates of ONE query); off = every pair rebuilds its source like loop_closure.cpp:120-121
   void* slab = nullptr;                 // ONE device allocation behind every per-context buffer of the GICP path (qn_ctx_create)
   qn_gicp_params params{};
   CloudBuf cloud[2];

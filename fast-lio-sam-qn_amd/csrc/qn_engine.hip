@@ -955,7 +955,7 @@ extern "C" int qn_icp_alignment_batch(qn_ctx* const* ctxs, uint32_t n_ctx, const
       const uint32_t i = next.fetch_add(1);
       if (i >= n_pairs) break;
       const qn_pair_desc& p = pairs[i];
-      const bool same = last && last->src == p.src && last->ns == p.ns && last->stride_bytes == p.stride_bytes && last->on_device == p.on_device;
+      const bool same = c->batch_share_source && last && last->src == p.src && last->ns == p.ns && last->stride_bytes == p.stride_bytes && last->on_device == p.on_device;
       status[i] = icp_alignment(c, p.src, p.ns, p.dst, p.nt, p.stride_bytes, thr, &results[i], &valid[i], p.on_device ? 1 : 0, same);
       last = status[i] == QN_OK ? &p : nullptr;
     }
@@ -1089,6 +1089,7 @@ extern "C" int qn_debug_set(qn_ctx* c, const char* key, double v) {
     if (b < (int)c->lanes.size()) { if (hipStreamSynchronize(c->stream) != hipSuccess) return QN_ERR_HIP; while ((int)c->lanes.size() > std::max(b, 1)) { qn_ctx* l = c->lanes.back(); c->lanes.pop_back(); if (l != c) qn_ctx_destroy(l); } }
     c->batch_lanes = b;
   }
+  else if (k == "batch_share_source") c->batch_share_source = v != 0;      // batch entry points: pairs that name the same source buffer share its preparation (default on: the candidates of one query)
   else if (k == "batch_trace") c->batch_trace = v != 0;           // developer: host timeline of every batched segment on stderr
   else if (k == "batch_member") c->persist_batch_off = v != 0;      // this context registers beside others (qn_multi with in_flight > 1): no persistent launches
   else if (k == "stable_cells") c->stable_cells = v != 0;

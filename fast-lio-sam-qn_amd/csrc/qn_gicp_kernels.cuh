@@ -136,15 +136,14 @@ struct PackBBoxK {
       BBoxAcc* mine = acc + 1 + bx;
       for (int d = 0; d < 3; d++) { __hip_atomic_store(&mine->mn[d], mn[d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); __hip_atomic_store(&mine->mx[d], mx[d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
       __hip_atomic_store(&mine->nonfinite, (uint32_t)bad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __threadfence();
-      s_last = atomicAdd(&acc->ticket, 1u) == nbx - 1u ? 1 : 0;
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                   // the slot's write-through stores are acknowledged before the ticket is drawn (no L2-wide fence: 4096 of them per batched launch were most of its time)
+      s_last = __hip_atomic_fetch_add(&acc->ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nbx - 1u ? 1 : 0;
     }
     __syncthreads();
     if (!s_last) return;
     // the last block: its first wave folds the slots (one per lane, QN_BBOX_MAX_BLOCKS <= 256: four rounds at most), lane 0 derives the numbers
     if (threadIdx.x >= 64) return;
-    __threadfence();
-    for (int d = 0; d < 3; d++) { mn[d] = 0x7fffffff; mx[d] = (int)0x80000000; }
+    for (int d = 0; d < 3; d++) { mn[d] = 0x7fffffff; mx[d] = (int)0x80000000; }      // (the slots are read with agent-scope loads below)
     int nf = 0;
     for (uint32_t b = threadIdx.x; b < nbx; b += 64) {
       const BBoxAcc* o = acc + 1 + b;
@@ -308,6 +307,7 @@ struct __attribute__((aligned(64))) TargetRec { float4 p; double n[3]; double pa
 static_assert(sizeof(TargetRec) == 64, "TargetRec is one 64-byte line");
 // Threads walk the points in cell-sorted order (a block's points are spatial neighbours, so their k-NN gathers overlap in
 // L1/L2), blocks in XCD-aware order.
+#define QN_COV_BATCH 10
 struct CovFromIdxK {
   static constexpr int TB = QN_BLOCK, OCC = 1;
   struct Args { const float4* raw; const float4* sorted; uint32_t n; int k; const int32_t* knn_idx; double* nrm; double* nrm_sorted; TargetRec* rec; uint32_t* list_counts; };
@@ -322,16 +322,16 @@ struct CovFromIdxK {
     const int32_t* nb = knn_idx + (size_t)i * k;
     int found = 0;
     double mean[3] = {0, 0, 0};
-    // neighbours four at a time: the four index loads, then the four point gathers are issued together (a loop of dependent idx -> point
-    // round trips with 1.5 waves per SIMD was the whole cost of this kernel); the sums are still formed in neighbour order
-    for (int j = 0; j < k; j += 4) {
-      int32_t u[4]; float4 q[4];
+    // neighbours QN_COV_BATCH (10) at a time: the index loads, then the point gathers are issued together (a loop of dependent idx -> point
+    // round trips was the whole cost of this kernel: 4 per batch = 10 round trips at k = 20, 10 per batch = 4); the sums are still formed in neighbour order
+    for (int j = 0; j < k; j += QN_COV_BATCH) {
+      int32_t u[QN_COV_BATCH]; float4 q[QN_COV_BATCH];
 #pragma unroll
-      for (int e = 0; e < 4; e++) u[e] = j + e < k ? nb[j + e] : -1;
+      for (int e = 0; e < QN_COV_BATCH; e++) u[e] = j + e < k ? nb[j + e] : -1;
 #pragma unroll
-      for (int e = 0; e < 4; e++) q[e] = raw[u[e] < 0 ? 0 : u[e]];
+      for (int e = 0; e < QN_COV_BATCH; e++) q[e] = raw[u[e] < 0 ? 0 : u[e]];
 #pragma unroll
-      for (int e = 0; e < 4; e++) if (u[e] >= 0) { mean[0] += (double)q[e].x; mean[1] += (double)q[e].y; mean[2] += (double)q[e].z; found++; }
+      for (int e = 0; e < QN_COV_BATCH; e++) if (u[e] >= 0) { mean[0] += (double)q[e].x; mean[1] += (double)q[e].y; mean[2] += (double)q[e].z; found++; }
     }
     double nv[3] = {0, 0, 0};                  // found == 0 cannot happen for a finite point (it is its own neighbour); a zero normal reads as C = I
     // the layouts of the optimiser ticks are written here as well (nrm_sorted: source, cell-sorted order; rec: target, 64-byte records)
@@ -350,14 +350,14 @@ struct CovFromIdxK {
     if (found == 0) { store(); return; }
     mean[0] /= found; mean[1] /= found; mean[2] /= found;
     double c[6] = {0, 0, 0, 0, 0, 0};
-    for (int j = 0; j < k; j += 4) {
-      int32_t u[4]; float4 q[4];
+    for (int j = 0; j < k; j += QN_COV_BATCH) {
+      int32_t u[QN_COV_BATCH]; float4 q[QN_COV_BATCH];
 #pragma unroll
-      for (int e = 0; e < 4; e++) u[e] = j + e < k ? nb[j + e] : -1;
+      for (int e = 0; e < QN_COV_BATCH; e++) u[e] = j + e < k ? nb[j + e] : -1;
 #pragma unroll
-      for (int e = 0; e < 4; e++) q[e] = raw[u[e] < 0 ? 0 : u[e]];
+      for (int e = 0; e < QN_COV_BATCH; e++) q[e] = raw[u[e] < 0 ? 0 : u[e]];
 #pragma unroll
-      for (int e = 0; e < 4; e++) if (u[e] >= 0) {
+      for (int e = 0; e < QN_COV_BATCH; e++) if (u[e] >= 0) {
         const double dx = (double)q[e].x - mean[0], dy = (double)q[e].y - mean[1], dz = (double)q[e].z - mean[2];
         c[0] += dx * dx; c[1] += dx * dy; c[2] += dx * dz; c[3] += dy * dy; c[4] += dy * dz; c[5] += dz * dz;
       }

@@ -20,7 +20,7 @@ out = {}
 for nctx, lanes in cfgs:
     ctxs = [engine.Context(N + 1024) for _ in range(nctx)]
     for cx in ctxs:
-        cx.debug_set("batch_lanes", lanes)
+        cx.debug_set("batch_lanes", lanes); cx.debug_set("batch_share_source", 0)      # every registration rebuilds its source (8 distinct pairs cycling over 8 lanes would otherwise meet their own source again)
         g = engine.NanoGICP(cx); g.setCorrespondenceRandomness(20); g.setMaximumIterations(20); g.setMaxCorrespondenceDistance(52.5); g.setOptimizer("gn"); g.setForceIterations(20); g.bind()
     def batch(n):
         d = [(pairs[j % 8][0].data_ptr(), N, pairs[j % 8][1].data_ptr(), N, 12, 1) for j in range(n)]

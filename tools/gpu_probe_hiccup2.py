@@ -14,7 +14,7 @@ torch.cuda.synchronize()
 nctx, lanes = 3, 8
 ctxs = [engine.Context(N + 1024) for _ in range(nctx)]
 for cx in ctxs:
-    cx.debug_set("batch_lanes", lanes)
+    cx.debug_set("batch_lanes", lanes); cx.debug_set("batch_share_source", 0)
     g = engine.NanoGICP(cx); g.setCorrespondenceRandomness(20); g.setMaximumIterations(20); g.setMaxCorrespondenceDistance(52.5); g.setOptimizer("gn"); g.setForceIterations(20); g.bind()
 def batch(n):
     d = [(pairs[j % 8][0].data_ptr(), N, pairs[j % 8][1].data_ptr(), N, 12, 1) for j in range(n)]
