@@ -308,6 +308,7 @@ static_assert(sizeof(TargetRec) == 64, "TargetRec is one 64-byte line");
 // Threads walk the points in cell-sorted order (a block's points are spatial neighbours, so their k-NN gathers overlap in
 // L1/L2), blocks in XCD-aware order.
 #define QN_COV_BATCH 10
+#define QN_COV_REG 20
 struct CovFromIdxK {
   static constexpr int TB = QN_BLOCK, OCC = 1;
   struct Args { const float4* raw; const float4* sorted; uint32_t n; int k; const int32_t* knn_idx; double* nrm; double* nrm_sorted; TargetRec* rec; uint32_t* list_counts; };
@@ -322,17 +323,6 @@ struct CovFromIdxK {
     const int32_t* nb = knn_idx + (size_t)i * k;
     int found = 0;
     double mean[3] = {0, 0, 0};
-    // neighbours QN_COV_BATCH (10) at a time: the index loads, then the point gathers are issued together (a loop of dependent idx -> point
-    // round trips was the whole cost of this kernel: 4 per batch = 10 round trips at k = 20, 10 per batch = 4); the sums are still formed in neighbour order
-    for (int j = 0; j < k; j += QN_COV_BATCH) {
-      int32_t u[QN_COV_BATCH]; float4 q[QN_COV_BATCH];
-#pragma unroll
-      for (int e = 0; e < QN_COV_BATCH; e++) u[e] = j + e < k ? nb[j + e] : -1;
-#pragma unroll
-      for (int e = 0; e < QN_COV_BATCH; e++) q[e] = raw[u[e] < 0 ? 0 : u[e]];
-#pragma unroll
-      for (int e = 0; e < QN_COV_BATCH; e++) if (u[e] >= 0) { mean[0] += (double)q[e].x; mean[1] += (double)q[e].y; mean[2] += (double)q[e].z; found++; }
-    }
     double nv[3] = {0, 0, 0};                  // found == 0 cannot happen for a finite point (it is its own neighbour); a zero normal reads as C = I
     // the layouts of the optimiser ticks are written here as well (nrm_sorted: source, cell-sorted order; rec: target, 64-byte records)
     auto store = [&]() __attribute__((always_inline)) {
@@ -347,9 +337,38 @@ struct CovFromIdxK {
         for (int u = 0; u < 3; u++) { r.n[u] = nv[u]; r.pad[u] = 0; }
         rec[i] = r; }
     };
+    double c[6] = {0, 0, 0, 0, 0, 0};
+    if (k <= QN_COV_REG) {
+      // k <= 20 (the reference's 15, the bench's 20): every neighbour is gathered ONCE and kept in registers for both sweeps (the kernel is bound by its scattered
+      // 64-byte line fetches - 2 x k per point - not by arithmetic: one gather pass instead of two); sums in neighbour order, as below
+      int32_t u[QN_COV_REG]; float4 q[QN_COV_REG];
+#pragma unroll
+      for (int e = 0; e < QN_COV_REG; e++) u[e] = e < k ? nb[e] : -1;
+#pragma unroll
+      for (int e = 0; e < QN_COV_REG; e++) q[e] = raw[u[e] < 0 ? 0 : u[e]];
+#pragma unroll
+      for (int e = 0; e < QN_COV_REG; e++) if (u[e] >= 0) { mean[0] += (double)q[e].x; mean[1] += (double)q[e].y; mean[2] += (double)q[e].z; found++; }
+      if (found == 0) { store(); return; }
+      mean[0] /= found; mean[1] /= found; mean[2] /= found;
+#pragma unroll
+      for (int e = 0; e < QN_COV_REG; e++) if (u[e] >= 0) {
+        const double dx = (double)q[e].x - mean[0], dy = (double)q[e].y - mean[1], dz = (double)q[e].z - mean[2];
+        c[0] += dx * dx; c[1] += dx * dy; c[2] += dx * dz; c[3] += dy * dy; c[4] += dy * dz; c[5] += dz * dz;
+      }
+    } else {
+    // neighbours QN_COV_BATCH (10) at a time: the index loads, then the point gathers are issued together (a loop of dependent idx -> point
+    // round trips was the whole cost of this kernel: 4 per batch = 10 round trips at k = 20, 10 per batch = 4); the sums are still formed in neighbour order
+    for (int j = 0; j < k; j += QN_COV_BATCH) {
+      int32_t u[QN_COV_BATCH]; float4 q[QN_COV_BATCH];
+#pragma unroll
+      for (int e = 0; e < QN_COV_BATCH; e++) u[e] = j + e < k ? nb[j + e] : -1;
+#pragma unroll
+      for (int e = 0; e < QN_COV_BATCH; e++) q[e] = raw[u[e] < 0 ? 0 : u[e]];
+#pragma unroll
+      for (int e = 0; e < QN_COV_BATCH; e++) if (u[e] >= 0) { mean[0] += (double)q[e].x; mean[1] += (double)q[e].y; mean[2] += (double)q[e].z; found++; }
+    }
     if (found == 0) { store(); return; }
     mean[0] /= found; mean[1] /= found; mean[2] /= found;
-    double c[6] = {0, 0, 0, 0, 0, 0};
     for (int j = 0; j < k; j += QN_COV_BATCH) {
       int32_t u[QN_COV_BATCH]; float4 q[QN_COV_BATCH];
 #pragma unroll
@@ -361,6 +380,7 @@ struct CovFromIdxK {
         const double dx = (double)q[e].x - mean[0], dy = (double)q[e].y - mean[1], dz = (double)q[e].z - mean[2];
         c[0] += dx * dx; c[1] += dx * dy; c[2] += dx * dz; c[3] += dy * dy; c[4] += dy * dz; c[5] += dz * dz;
       }
+    }
     }
 #pragma unroll
     for (int t = 0; t < 6; t++) c[t] /= found;
