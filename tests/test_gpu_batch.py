@@ -147,3 +147,39 @@ def test_multi_stream_batch_uses_the_lanes():
     assert sum(c.debug_get("batch_pairs") for c in ctxs) == 11
     for c in ctxs:
         c.close()
+
+
+def test_batch_lm_with_partial_overlap_lanes():
+    """the reference's optimiser (LM, real stopping rule) on a mix of aligned and 80 %-overlap pairs: lanes stop at different iterations AND sit in different far-query regimes"""
+    from qn_amd import engine
+    clouds = [synth.make_pair(870 + i, 20000 + 2000 * i, shift=(24.0 if i % 2 == 0 else None))[:2] for i in range(5)]
+    p = params(engine)
+    ref = classic(engine, 30000, p, host_pairs(clouds))
+    got, _, _ = batched(engine, 30000, p, host_pairs(clouds), lanes=4)
+    for i, (g, r) in enumerate(zip(got, ref)):
+        assert g == r, "pair %d differs from the classic path" % i
+
+
+def test_batch_strided_clouds_capacity_and_context_reuse():
+    """pcl::PointXYZI-like strides (32 B, and a fat 48-byte point type), a pair beyond the context's capacity (QN_ERR_CAPACITY for that pair only), and the same context used for
+    classic calls and several batches in turn (lanes are reused; a classic call in between must not disturb them)"""
+    from qn_amd import engine
+    clouds = [synth.make_pair(880 + i, 4000 + 300 * i, extent=36.0)[:2] for i in range(4)]
+    p = params(engine)
+    ref = classic(engine, 6024, p, host_pairs(clouds))
+
+    def strided(a, stride_floats):
+        out = np.full((len(a), stride_floats), 7.25, np.float32); out[:, :3] = a
+        return out
+    ctx = engine.Context(6024); ctx.debug_set("batch_lanes", 3); set_params(engine, ctx, p)
+    for stride_floats in (8, 12):
+        pr = [(strided(s, stride_floats), len(s), strided(t, stride_floats), len(t), 4 * stride_floats, 0) for s, t in clouds]
+        res, val, st = engine.gicp_align_batch(ctx, pr, score_thr=1.5)
+        assert [rec(r, v, s) for r, v, s in zip(res, val, st)] == ref, "stride %d bytes" % (4 * stride_floats)
+        one = engine.icp_alignment(ctx, *clouds[1])                                     # a classic call on the batch context in between
+        assert one["iterations"] == ref[1][2] and one["score"] == ref[1][5]
+    big = synth.make_pair(889, 7000, extent=36.0)[:2]
+    res, val, st = engine.gicp_align_batch(ctx, host_pairs([clouds[0], big, clouds[2]]), score_thr=1.5)
+    assert st[1] == engine.QN_ERR_CAPACITY and val[1] == 0
+    assert rec(res[0], val[0], st[0]) == ref[0] and rec(res[2], val[2], st[2]) == ref[2]
+    ctx.close()
