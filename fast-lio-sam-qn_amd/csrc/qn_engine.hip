@@ -921,7 +921,7 @@ extern "C" int qn_icp_alignment_batch(qn_ctx* const* ctxs, uint32_t n_ctx, const
                                       qn_gicp_result* results, int* valid, int* status) {
   if (!ctxs || n_ctx == 0 || (n_pairs && (!pairs || !results || !valid || !status))) return QN_ERR_INVALID_ARG;
   for (uint32_t i = 0; i < n_ctx; i++) if (!ctxs[i]) return QN_ERR_INVALID_ARG;
-  std::atomic<uint32_t> next{0};
+  std::atomic<uint32_t> next{0}, final_share{0};
   // several registrations in flight already fill the chip: the two-stream pair pipeline of a single registration (icp_alignment) would only
   // add streams to the hardware queues (measured: 2290 -> 1880 registrations/s with 4 contexts), so it is switched off for the batch
   std::vector<char> saved(n_ctx);
@@ -936,14 +936,24 @@ extern "C" int qn_icp_alignment_batch(qn_ctx* const* ctxs, uint32_t n_ctx, const
     if (lanes) {
       (void)hipSetDevice(c->device);
       const uint32_t B = (uint32_t)c->lanes.size();
-      // (pairs are dealt in runs of B; when the batch is smaller than the lanes of all contexts together the runs shrink so that every context gets work)
-      const uint32_t run = std::max<uint32_t>(1u, std::min<uint32_t>(B, (n_pairs + n_ctx - 1) / n_ctx));
+      // (pairs are dealt in runs of B; towards the end of the batch - and when the batch is smaller than the lanes of all contexts together - the runs shrink to an n-th of
+      //  what is left, so that the contexts finish together instead of one of them registering the last full run alone)
       std::vector<const float*> last_src(B, nullptr); std::vector<uint64_t> last_key(B, 0);
       std::vector<uint32_t> idx(B);
       for (;;) {
-        const uint32_t base = next.fetch_add(run);
+        uint32_t base = next.load(), m = 0;
+        for (;;) {
+          if (base >= n_pairs) break;
+          const uint32_t rem = n_pairs - base;
+          if (rem > n_ctx * B) m = B;
+          else {                                                        // the last round: what is left, in n_ctx equal shares (fixed by the first context that gets here)
+            uint32_t q = final_share.load();
+            if (q == 0) { uint32_t want = std::min<uint32_t>(B, std::max<uint32_t>(1u, (rem + n_ctx - 1) / n_ctx)); if (final_share.compare_exchange_strong(q, want)) q = want; }
+            m = std::min(q, rem);
+          }
+          if (next.compare_exchange_weak(base, base + m)) break;
+        }
         if (base >= n_pairs) break;
-        const uint32_t m = std::min(run, n_pairs - base);
         for (uint32_t l = 0; l < m; l++) idx[l] = base + l;
         const int rc = batch_register(c, pairs, idx.data(), m, thr, results, valid, status, last_src, last_key);
         if (rc != QN_OK) { (void)hipStreamSynchronize(c->stream); for (uint32_t l = 0; l < m; l++) status[base + l] = rc; std::fill(last_src.begin(), last_src.end(), nullptr); }
