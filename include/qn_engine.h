@@ -149,7 +149,8 @@ int  qn_icp_alignment_batch(qn_ctx* const* ctxs, uint32_t n_ctx, const qn_pair_d
 /* The same batch on ONE context with the PAIR AS A GRID DIMENSION (SURVEY.md 8b qn_gicp_align_batch; 7.1 step 8): the pairs are registered `lanes` at a
  * time (default 8; qn_debug_set(ctx, "batch_lanes", B)) in lockstep - every kernel of the chain is launched once for all of them, blockIdx.y selecting the
  * pair's entry of a device-resident argument table - on the context's one stream.  Each pair is an independent icpAlignment (loop_closure.cpp:110-136) with the
- * context's parameters; consecutive pairs of a lane that name the same source buffer share its grid and covariances (the candidates of one query).
+ * context's parameters; pairs of ONE call that name the same source buffer (pointer, size, stride) share one preparation of it - grid and covariances - the way the
+ * candidates of one loop-closure query share the query cloud (qn_debug_set(ctx, "batch_share_source", 0): every pair rebuilds its source like loop_closure.cpp:120-121).
  * Records are bit-identical to qn_icp_alignment_batch's one-pair-per-stream path.  qn_icp_alignment_batch itself uses this per context.          */
 int  qn_gicp_align_batch(qn_ctx*, const qn_pair_desc* pairs, uint32_t n_pairs, double score_thr, qn_gicp_result* results, int* valid, int* status);
 
