@@ -440,9 +440,40 @@ __device__ __forceinline__ void divmod_small(int n, int d, int& q, int& r) {
 // Step (4): the points of all cluster boxes as one dense candidate stream.  fn(cp, in_tile, ccid) is called once per
 // step by all 64 lanes; the S sub-slots see S consecutive candidates (cp = point, .w = original index bits; in_tile =
 // the slot holds a real candidate; ccid = the cluster whose box the candidate came from).  Returns the stream length.
+// (the chunk loop of stream_clusters: the `total` candidates of the segment table that sits in lds->seg_excl / seg_start / seg_cid)
 template <int S, class Fn>
-__device__ __forceinline__ uint32_t stream_clusters(const GridView& g, WaveLds* lds, int ncl, uint32_t nseg_all, Fn&& fn) {
+__device__ __forceinline__ void stream_chunks(const GridView& g, WaveLds* lds, const uint32_t total, Fn&& fn) {
   const int lane = threadIdx.x & 63;
+  const float INF = __int_as_float(0x7f800000);
+  for (uint32_t cb = 0; cb < total; cb += 64) {
+    const uint32_t slot = cb + lane;
+    int j = 0;
+#pragma unroll
+    for (int step = 32; step > 0; step >>= 1) { const int t = j + step; if (t < 64 && lds->seg_excl[t] <= slot) j = t; }
+    const uint32_t cnt = min(64u, total - cb);
+    wave_lds_fence();
+    // empty slots belong to no cluster and sit infinitely far away: the `ccid == cid` test of the scorers rejects them, and so does every distance test
+    lds->tile[lane] = slot < total ? g.pts[lds->seg_start[j] + (slot - lds->seg_excl[j])] : make_float4(INF, INF, INF, 0.f);
+    lds->tile_cid[lane] = slot < total ? lds->seg_cid[j] : 0xffffffffu;
+    wave_lds_fence();
+    // S candidates per step (one per sub-slot), 4 steps per trip with the four ds_read_b128 issued BEFORE any scoring: with
+    // the read inside a predicated body every step paid the LDS latency in full (read -> wait -> score -> branch).
+    const uint32_t sub_off = (uint32_t)(S == 1 ? 0 : lane / (64 / S));
+    for (uint32_t c = 0; c < cnt; c += 4 * S) {
+      float4 cp[4]; uint32_t cc[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) { const uint32_t ci = (c + (uint32_t)(S * u) + sub_off) & 63u; cp[u] = lds->tile[ci]; cc[u] = lds->tile_cid[ci]; }
+#pragma unroll
+      for (int u = 0; u < 4; u++) fn(cp[u], true, cc[u]);
+    }
+  }
+}
+// REUSE: the caller streams the SAME clusters a second time (the two passes of the histogram selection): when all segments fit one table (nseg_all <= 64) the
+// table of the first walk is still in LDS - `reuse_total` is what that walk returned - and the cell_start gather, the divisions and the scan are skipped.
+template <int S, bool REUSE = false, class Fn>
+__device__ __forceinline__ uint32_t stream_clusters(const GridView& g, WaveLds* lds, int ncl, uint32_t nseg_all, Fn&& fn, const uint32_t reuse_total = 0) {
+  const int lane = threadIdx.x & 63;
+  if (REUSE && nseg_all <= 64u) { stream_chunks<S>(g, lds, reuse_total, fn); return reuse_total; }
   uint32_t ncand = 0;
   for (uint32_t sb = 0; sb < nseg_all; sb += 64) {
     const uint32_t sidx = sb + lane;
@@ -477,28 +508,7 @@ __device__ __forceinline__ uint32_t stream_clusters(const GridView& g, WaveLds* 
     wave_lds_fence();
     lds->seg_excl[lane] = incl - len; lds->seg_start[lane] = s; lds->seg_cid[lane] = scid;
     wave_lds_fence();
-    for (uint32_t cb = 0; cb < total; cb += 64) {
-      const uint32_t slot = cb + lane;
-      int j = 0;
-#pragma unroll
-      for (int step = 32; step > 0; step >>= 1) { const int t = j + step; if (t < 64 && lds->seg_excl[t] <= slot) j = t; }
-      const uint32_t cnt = min(64u, total - cb);
-      wave_lds_fence();
-      if (slot < total) lds->tile[lane] = g.pts[lds->seg_start[j] + (slot - lds->seg_excl[j])];
-      lds->tile_cid[lane] = slot < total ? lds->seg_cid[j] : 0xffffffffu;   // empty slots belong to no cluster: the `ccid == cid` test of the scorers rejects them
-      wave_lds_fence();
-      // S candidates per step (one per sub-slot), 4 steps per trip with the four ds_read_b128 issued BEFORE any scoring: with
-      // the read inside a predicated body every step paid the LDS latency in full (read -> wait -> score -> branch).
-      // Slots past the chunk's end hold stale points with cluster id ~0 (tile[ci & 63] is always in bounds).
-      const uint32_t sub_off = (uint32_t)(S == 1 ? 0 : lane / (64 / S));
-      for (uint32_t c = 0; c < cnt; c += 4 * S) {
-        float4 cp[4]; uint32_t cc[4];
-#pragma unroll
-        for (int u = 0; u < 4; u++) { const uint32_t ci = (c + (uint32_t)(S * u) + sub_off) & 63u; cp[u] = lds->tile[ci]; cc[u] = lds->tile_cid[ci]; }
-#pragma unroll
-        for (int u = 0; u < 4; u++) fn(cp[u], true, cc[u]);
-      }
-    }
+    stream_chunks<S>(g, lds, total, fn);
     ncand += total;
   }
   return ncand;

@@ -2,6 +2,7 @@
 // loop_closure.cpp:121,123).  Separate from qn_device.cuh so that tuning it does not rebuild the sorted-list k-NN units.
 #pragma once
 #include "qn_device.cuh"
+#include <type_traits>
 
 namespace qn {
 
@@ -23,9 +24,10 @@ namespace qn {
 template <int HCAP>
 struct WaveLdsH {
   WaveLds s;
-  union {
+  union alignas(16) {
     uint32_t hist[16][QN_HW];                     // 64 bins + 4 reject columns (one per sub-slot) + 1: rows start in different banks
     unsigned long long list[16][HCAP + 1];
+    uint4 zero_[(16 * QN_HW + 3) / 4];             // (the histogram is cleared with 16-byte stores)
   } u;
   uint32_t cnt[16];
   uint32_t kth[16];
@@ -50,16 +52,25 @@ __device__ __forceinline__ int wave_knn_hist(const GridView& g, float qx, float 
     uint32_t cid; int ncl; uint32_t nseg_all;
     build_clusters<4>(g, lds, todo, cx, cy, cz, qx, qy, qz, r, cid, ncl, nseg_all);
     // ---- pass 1: histogram
-    { uint32_t* hz = &L->u.hist[0][0];
-      for (int e = lane; e < 16 * QN_HW; e += 64) hz[e] = 0; }
+    { uint4* hz = (uint4*)&L->u.hist[0][0];                                      // (16-byte stores, unrolled: the word-by-word loop was 200 instructions per round)
+#pragma unroll
+      for (int e = 0; e < (16 * QN_HW + 3) / 4; e += 64) if (e + lane < (16 * QN_HW + 3) / 4) hz[e + lane] = make_uint4(0u, 0u, 0u, 0u); }
     wave_lds_fence();
     const int base = (int)(__float_as_uint(4.f * r * r) >> 20) - (QN_HB - 2);      // bin QN_HB-2 ends at (2 r)^2, bin QN_HB-1 = beyond (not counted)
-    const uint32_t ncand = stream_clusters<4>(g, lds, ncl, nseg_all, [&](const float4& cp, bool in_tile, uint32_t ccid) __attribute__((always_inline)) {
-      const uint32_t bits = __float_as_uint(sqdist(qx, qy, qz, cp.x, cp.y, cp.z));
-      const int bin = max((int)(bits >> 20) - base, 0);
-      const bool ok = mine && in_tile && ccid == cid && bin < QN_HB - 1;
-      atomicAdd(&L->u.hist[qs][ok ? bin : QN_HB + sub], 1u);                      // branch-free: rejected candidates land in the sub-slot's reject column
-    });
+    // (ONE cluster - 94 % of the rounds: neighbours in the sorted order - needs no cluster test: every real candidate is everybody's, and the empty slots of the last
+    //  chunk sit at infinity, beyond every bin)
+    const bool one_cluster = ncl == 1;
+    auto bin_of = [&](const float4& cp) __attribute__((always_inline)) { return max((int)(__float_as_uint(sqdist(qx, qy, qz, cp.x, cp.y, cp.z)) >> 20) - base, 0); };
+    const uint32_t ncand = one_cluster
+      ? stream_clusters<4>(g, lds, ncl, nseg_all, [&](const float4& cp, bool, uint32_t) __attribute__((always_inline)) {
+          const int bin = bin_of(cp);
+          atomicAdd(&L->u.hist[qs][(mine && bin < QN_HB - 1) ? bin : QN_HB + sub], 1u);
+        })
+      : stream_clusters<4>(g, lds, ncl, nseg_all, [&](const float4& cp, bool in_tile, uint32_t ccid) __attribute__((always_inline)) {
+          const int bin = bin_of(cp);
+          const bool ok = mine && in_tile && ccid == cid && bin < QN_HB - 1;
+          atomicAdd(&L->u.hist[qs][ok ? bin : QN_HB + sub], 1u);                      // branch-free: rejected candidates land in the sub-slot's reject column
+        });
     wave_lds_fence();
     // ---- tau: sub-slot s sums bins [16 s, 16 s + 16), then looks for the crossing in its own range
     uint32_t hv[16], mysum = 0;
@@ -78,13 +89,16 @@ __device__ __forceinline__ int wave_knn_hist(const GridView& g, float qx, float 
     wave_lds_fence();
     // ---- pass 2: collect the candidates below tau
     const bool collect = mine && enough;
-    stream_clusters<4>(g, lds, ncl, nseg_all, [&](const float4& cp, bool in_tile, uint32_t ccid) __attribute__((always_inline)) {
+    auto collect_one = [&](const float4& cp) __attribute__((always_inline)) {
       const float d2 = sqdist(qx, qy, qz, cp.x, cp.y, cp.z);
-      if (collect && in_tile && ccid == cid && __float_as_uint(d2) < tau_bits) {
+      if (collect && __float_as_uint(d2) < tau_bits) {
         const uint32_t pos = atomicAdd(&L->cnt[qs], 1u);
         if (pos < HCAP) L->u.list[qs][pos] = pack_key(d2, __float_as_uint(cp.w));
       }
-    });
+    };
+    // (the segment table of pass 1 is still in LDS when it fits one: `ncand`)
+    if (one_cluster) stream_clusters<4, true>(g, lds, ncl, nseg_all, [&](const float4& cp, bool, uint32_t) __attribute__((always_inline)) { collect_one(cp); }, ncand);
+    else stream_clusters<4, true>(g, lds, ncl, nseg_all, [&](const float4& cp, bool in_tile, uint32_t ccid) __attribute__((always_inline)) { if (in_tile && ccid == cid) collect_one(cp); }, ncand);
     wave_lds_fence();
     const uint32_t P = L->cnt[qs];
     const bool ok = collect && P <= HCAP;                                        // (P >= k by construction)
@@ -93,23 +107,24 @@ __device__ __forceinline__ int wave_knn_hist(const GridView& g, float qx, float 
     unsigned long long own[HCAP / 4]; int rank[HCAP / 4];
 #pragma unroll
     for (int j = 0; j < HCAP / 4; j++) { own[j] = (ok && (uint32_t)(sub + 4 * j) < P) ? L->u.list[qs][sub + 4 * j] : QN_INF_KEY; rank[j] = 0; }
-    // 4 list entries per step, all four LDS reads issued before the compares (the entry -> compare chain was latency-bound)
-    for (int f = 0; f < maxP; f += 4) {
-      unsigned long long kf[4];
+    // 4 list entries per step, all four LDS reads issued before the compares (the entry -> compare chain was latency-bound); NJ = own entries a lane can hold for
+    // the longest list of the wave (the usual case - k + a few entries, <= 24 - has no own[6], own[7]): one loop per width, chosen once
+    auto rank_pass = [&](auto NJ) __attribute__((always_inline)) {
+      for (int f = 0; f < maxP; f += 4) {
+        unsigned long long kf[4];
 #pragma unroll
-      for (int u = 0; u < 4; u++) kf[u] = L->u.list[qs][min(f + u, HCAP)];
+        for (int u = 0; u < 4; u++) kf[u] = L->u.list[qs][min(f + u, HCAP)];
 #pragma unroll
-      for (int u = 0; u < 4; u++) {
-        const unsigned long long kv = (ok && (uint32_t)(f + u) < P) ? kf[u] : QN_INF_KEY;
-        if (HCAP > 32 && maxP > 32) {
+        for (int u = 0; u < 4; u++) {
+          const unsigned long long kv = (ok && (uint32_t)(f + u) < P) ? kf[u] : QN_INF_KEY;
 #pragma unroll
-          for (int j = 0; j < HCAP / 4; j++) rank[j] += kv < own[j] ? 1 : 0;
-        } else {
-#pragma unroll
-          for (int j = 0; j < 8; j++) rank[j] += kv < own[j] ? 1 : 0;
+          for (int j = 0; j < decltype(NJ)::value; j++) rank[j] += kv < own[j] ? 1 : 0;
         }
       }
-    }
+    };
+    if (HCAP > 32 && maxP > 32) rank_pass(std::integral_constant<int, HCAP / 4>());
+    else if (maxP > 24) rank_pass(std::integral_constant<int, 8>());
+    else rank_pass(std::integral_constant<int, 6>());
 #pragma unroll
     for (int j = 0; j < HCAP / 4; j++) if (own[j] != QN_INF_KEY && rank[j] == k - 1) L->kth[qs] = (uint32_t)(own[j] >> 32);
     wave_lds_fence();
