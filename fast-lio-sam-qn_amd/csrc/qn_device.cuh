@@ -101,9 +101,15 @@ __device__ __forceinline__ uint32_t key_idx(unsigned long long k) { return (uint
 
 // plain f32 mul/add in source order (the library is compiled -ffp-contract=off): the oracle's
 // `dx*dx + dy*dy + dz*dz` bit for bit.
+// (x, y as ONE packed-f32 pair: v_pk_add_f32 / v_pk_mul_f32 do the two lanes' IEEE operations in one issue slot - same roundings, same sum order (dx^2 + dy^2) + dz^2,
+//  six instructions instead of eight in every candidate loop of the engine)
+typedef float qn_f2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ float sqdist(float qx, float qy, float qz, float px, float py, float pz) {
-  float dx = qx - px, dy = qy - py, dz = qz - pz;
-  return dx * dx + dy * dy + dz * dz;
+  const qn_f2 q = {qx, qy}, p = {px, py};
+  const qn_f2 d = q - p;
+  const qn_f2 d2 = d * d;
+  const float dz = qz - pz;
+  return (d2.x + d2.y) + dz * dz;
 }
 
 __device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
