@@ -61,10 +61,13 @@ __device__ __forceinline__ int wave_knn_hist(const GridView& g, float qx, float 
     //  chunk sit at infinity, beyond every bin)
     const bool one_cluster = ncl == 1;
     auto bin_of = [&](const float4& cp) __attribute__((always_inline)) { return max((int)(__float_as_uint(sqdist(qx, qy, qz, cp.x, cp.y, cp.z)) >> 20) - base, 0); };
+    // (one cluster: the bin index clamped into [0, QN_HB - 1] IS the column - column QN_HB - 1 collects what lies beyond (2 r)^2 and is left out of the sums below;
+    //  lanes without an open query get a base that sends everything there)
+    const int base1 = mine ? base : -(1 << 28);
     const uint32_t ncand = one_cluster
       ? stream_clusters<4>(g, lds, ncl, nseg_all, [&](const float4& cp, bool, uint32_t) __attribute__((always_inline)) {
-          const int bin = bin_of(cp);
-          atomicAdd(&L->u.hist[qs][(mine && bin < QN_HB - 1) ? bin : QN_HB + sub], 1u);
+          const int bin = min(max((int)(__float_as_uint(sqdist(qx, qy, qz, cp.x, cp.y, cp.z)) >> 20) - base1, 0), QN_HB - 1);
+          atomicAdd(&L->u.hist[qs][bin], 1u);
         })
       : stream_clusters<4>(g, lds, ncl, nseg_all, [&](const float4& cp, bool in_tile, uint32_t ccid) __attribute__((always_inline)) {
           const int bin = bin_of(cp);
@@ -75,7 +78,7 @@ __device__ __forceinline__ int wave_knn_hist(const GridView& g, float qx, float 
     // ---- tau: sub-slot s sums bins [16 s, 16 s + 16), then looks for the crossing in its own range
     uint32_t hv[16], mysum = 0;
 #pragma unroll
-    for (int j = 0; j < 16; j++) { hv[j] = L->u.hist[qs][sub * 16 + j]; mysum += hv[j]; }
+    for (int j = 0; j < 16; j++) { hv[j] = L->u.hist[qs][sub * 16 + j]; if (j == 15 && sub == 3) hv[j] = 0u; mysum += hv[j]; }      // (column QN_HB - 1: beyond (2 r)^2, not counted)
     const uint32_t s0 = __shfl(mysum, qs), s1 = __shfl(mysum, qs + 16), s2 = __shfl(mysum, qs + 32), s3 = __shfl(mysum, qs + 48);
     uint32_t run = (sub > 0 ? s0 : 0u) + (sub > 1 ? s1 : 0u) + (sub > 2 ? s2 : 0u);
     const bool enough = s0 + s1 + s2 + s3 >= (uint32_t)k;
