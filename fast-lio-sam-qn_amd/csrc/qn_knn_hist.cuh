@@ -89,6 +89,11 @@ __device__ __forceinline__ int wave_knn_hist(const GridView& g, float qx, float 
     const uint32_t tau_bits = (uint32_t)(base + cross + 1) << 20;                  // d2 bit patterns below this pass
     wave_lds_fence();                                                               // hist is dead: the list shares its storage
     if (lane < 16) { L->cnt[lane] = 0; L->kth[lane] = 0x7f800000u; }
+    { uint4* lz = (uint4*)&L->u.list[0][0];                                       // every list slot starts as the infinite key: what pass 2 does not fill never counts below
+      constexpr int NZ = (int)(sizeof(L->u.list) / 16);
+      static_assert(sizeof(L->u.list) % 16 == 0, "list rows are cleared with 16-byte stores");
+#pragma unroll
+      for (int e = 0; e < NZ; e += 64) if (e + lane < NZ) lz[e + lane] = make_uint4(0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu); }
     wave_lds_fence();
     // ---- pass 2: collect the candidates below tau
     const bool collect = mine && enough;
@@ -109,7 +114,7 @@ __device__ __forceinline__ int wave_knn_hist(const GridView& g, float qx, float 
     const int maxP = wave_max_i(ok ? (int)P : 0);
     unsigned long long own[HCAP / 4]; int rank[HCAP / 4];
 #pragma unroll
-    for (int j = 0; j < HCAP / 4; j++) { own[j] = (ok && (uint32_t)(sub + 4 * j) < P) ? L->u.list[qs][sub + 4 * j] : QN_INF_KEY; rank[j] = 0; }
+    for (int j = 0; j < HCAP / 4; j++) { own[j] = L->u.list[qs][sub + 4 * j]; rank[j] = 0; }      // (infinite beyond P; an overflowed list - !ok - is ranked for nothing: its query takes status 2)
     // 4 list entries per step, all four LDS reads issued before the compares (the entry -> compare chain was latency-bound); NJ = own entries a lane can hold for
     // the longest list of the wave (the usual case - k + a few entries, <= 24 - has no own[6], own[7]): one loop per width, chosen once
     auto rank_pass = [&](auto NJ) __attribute__((always_inline)) {
@@ -119,9 +124,8 @@ __device__ __forceinline__ int wave_knn_hist(const GridView& g, float qx, float 
         for (int u = 0; u < 4; u++) kf[u] = L->u.list[qs][min(f + u, HCAP)];
 #pragma unroll
         for (int u = 0; u < 4; u++) {
-          const unsigned long long kv = (ok && (uint32_t)(f + u) < P) ? kf[u] : QN_INF_KEY;
 #pragma unroll
-          for (int j = 0; j < decltype(NJ)::value; j++) rank[j] += kv < own[j] ? 1 : 0;
+          for (int j = 0; j < decltype(NJ)::value; j++) rank[j] += kf[u] < own[j] ? 1 : 0;
         }
       }
     };
