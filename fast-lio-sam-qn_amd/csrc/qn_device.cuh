@@ -193,13 +193,16 @@ struct WaveLdsK {
 struct Best1 {                         // 1-NN, plus the squared distance of the runner-up (for bound pruning)
   unsigned long long key;
   float second;                        // smallest d2 among scanned points other than `key`'s point
-  __device__ __forceinline__ void init() { key = QN_INF_KEY; second = __int_as_float(0x7f800000); }
+  float bd;                            // key's d2 as a float (+inf while there is no key): best <= second always, so a new point's d2 updates the runner-up as the MEDIAN of the three
+  __device__ __forceinline__ void init() { key = QN_INF_KEY; second = __int_as_float(0x7f800000); bd = __int_as_float(0x7f800000); }
+  // UNIQUE: the caller never shows a point twice (every scan of the engine: one pass over disjoint segments per round) - the `same point again` test is dropped
+  template <bool UNIQUE = false>
   __device__ __forceinline__ void consider(bool on, float d2, uint32_t idx) {
     const unsigned long long k = pack_key(d2, idx);                   // branch-free (selects): no exec-mask region for the scheduler to sink loads into
-    const bool lt = on && k < key;
-    const bool mid = on && !lt && k != key && d2 < second;
-    const float s_lt = key != QN_INF_KEY ? key_d2(key) : second;
-    second = lt ? s_lt : (mid ? d2 : second);
+    const bool lt = on && k < key;                                     // (ties in d2: the lower index wins the key, the runner-up distance is that d2 either way)
+    const float d2e = (on && (UNIQUE || k != key)) ? d2 : __int_as_float(0x7f800000);
+    second = __builtin_amdgcn_fmed3f(bd, second, d2e);                // d2 < best: the old best; best <= d2 < second: d2; else unchanged
+    bd = lt ? d2 : bd;
     key = lt ? k : key;
   }
   template <int S>
@@ -212,9 +215,9 @@ struct Best1 {                         // 1-NN, plus the squared distance of the
     if (key == QN_INF_KEY) c = __int_as_float(0x7f800000);
     if (S == 4) c = fminf(c, __shfl_xor(c, 16));
     c = fminf(c, __shfl_xor(c, 32));
-    if (on) { key = b; second = c; }
+    if (on) { key = b; second = c; bd = b != QN_INF_KEY ? key_d2(b) : __int_as_float(0x7f800000); }
   }
-  __device__ __forceinline__ void reset() { key = QN_INF_KEY; second = __int_as_float(0x7f800000); }
+  __device__ __forceinline__ void reset() { init(); }
   __device__ __forceinline__ bool full() const { return key != QN_INF_KEY; }
   __device__ __forceinline__ float worst_d2() const { return key_d2(key); }
   __device__ __forceinline__ int found() const { return key != QN_INF_KEY ? 1 : 0; }

@@ -819,10 +819,10 @@ struct NnLaneK {
         for (uint32_t u = s[rr]; u < e[rr]; u += 4) {                    // four candidates per trip, all four loads in flight (a row is 3 cells: one trip, rarely two)
           const uint32_t last = e[rr] - 1u;
           const float4 c0 = pts[u], c1 = pts[min(u + 1u, last)], c2 = pts[min(u + 2u, last)], c3 = pts[min(u + 3u, last)];
-          sink.consider(true, sqdist(qx, qy, qz, c0.x, c0.y, c0.z), __float_as_uint(c0.w));
-          sink.consider(u + 1u <= last, sqdist(qx, qy, qz, c1.x, c1.y, c1.z), __float_as_uint(c1.w));
-          sink.consider(u + 2u <= last, sqdist(qx, qy, qz, c2.x, c2.y, c2.z), __float_as_uint(c2.w));
-          sink.consider(u + 3u <= last, sqdist(qx, qy, qz, c3.x, c3.y, c3.z), __float_as_uint(c3.w));
+          sink.consider<true>(true, sqdist(qx, qy, qz, c0.x, c0.y, c0.z), __float_as_uint(c0.w));
+          sink.consider<true>(u + 1u <= last, sqdist(qx, qy, qz, c1.x, c1.y, c1.z), __float_as_uint(c1.w));
+          sink.consider<true>(u + 2u <= last, sqdist(qx, qy, qz, c2.x, c2.y, c2.z), __float_as_uint(c2.w));
+          sink.consider<true>(u + 3u <= last, sqdist(qx, qy, qz, c3.x, c3.y, c3.z), __float_as_uint(c3.w));
         }
       }
     }
