@@ -382,6 +382,7 @@ static KnnLaunch prep_knn(qn_ctx* c, CloudBuf& b, int k, int32_t* kidx, float* k
   uint32_t* genc = c->fb_count2 + 1;
   KnnLaunch L;
   L.sel_nb = (b.n + QN_KNN_BLOCK / 4 - 1) / (QN_KNN_BLOCK / 4);     // 16 queries per wave
+  if (lanes && c->knn_trips > 1) L.sel_nb = (L.sel_nb + (uint32_t)c->knn_trips - 1) / (uint32_t)c->knn_trips;      // batched launches: a wave serves several groups of 16 (its prologue - table entry, grid numbers - is a twentieth of a group's work)
   L.sel = KnnHistArgs{b.grid, k, r0, c->knn_single_all ? -1 : c->knn_rounds, kidx, kd2, c->fb_list, c->fb_count2, c->big_list, genc};
   L.lst_nb = std::min<uint32_t>((b.n + 63) / 64, lanes ? 96 : 512) * (QN_BLOCK / QN_KNN_BLOCK);
   L.lst = KnnHistArgs{b.grid, k, r0, 64, kidx, kd2, c->fb_list, c->fb_count2, c->big_list, genc};
@@ -1110,6 +1111,7 @@ extern "C" int qn_debug_set(qn_ctx* c, const char* key, double v) {
   else if (k == "single_from_tick") c->single_from_tick = v < 1 ? 1 : (int)v;
   else if (k == "fused_from_tick") c->fused_from_tick = v < 1 ? 1 : (int)v;
   else if (k == "knn_rounds") c->knn_rounds = v < 1 ? 1 : (int)v;
+  else if (k == "knn_trips") c->knn_trips = v < 1 ? 1 : (int)v;
   else if (k == "fused_ticks") c->fused_ticks = v != 0;
   else if (k == "big_ratio") c->big_ratio = (float)v;
   else if (k == "margin_nn_cap") c->margin_nn_cap = (int)v;
