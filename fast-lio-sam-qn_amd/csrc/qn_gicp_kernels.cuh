@@ -796,23 +796,32 @@ struct NnLaneK {
     const int x0 = cell_coord(qx - r, tgt.ox, tgt.inv_cell, tgt.nx), x1 = cell_coord(qx + r, tgt.ox, tgt.inv_cell, tgt.nx);
     const int y0 = cell_coord(qy - r, tgt.oy, tgt.inv_cell, tgt.ny), y1 = cell_coord(qy + r, tgt.oy, tgt.inv_cell, tgt.ny);
     const int z0 = cell_coord(qz - r, tgt.oz, tgt.inv_cell, tgt.nz), z1 = cell_coord(qz + r, tgt.oz, tgt.inv_cell, tgt.nz);
-    const int tx0 = x0 >> 3, ntr = (x1 >> 3) - tx0 + 1, nyr = y1 - y0 + 1, nrow = nyr * (z1 - z0 + 1);
-    const bool scan = active && nrow <= QN_LANE_ROWS && ntr <= 2;       // (a wider first radius - knob margin_nn - may not fit: such a query goes to the lists unscanned, with its radius)
+    const int tx0 = x0 >> 3, ntr = (x1 >> 3) - tx0 + 1, nyr = y1 - y0 + 1, nzr = z1 - z0 + 1;
+    const bool scan = active && nyr <= 3 && nzr <= 3 && ntr <= 2;       // (a wider first radius - knob margin_nn - may not fit: such a query goes to the lists unscanned, with its radius)
     Best1 sink; sink.init();
     const float4* __restrict__ pts = tgt.pts; const uint32_t* __restrict__ cs = tgt.cell_start;
+    // cell_key(x, y, z) = (tile << 7) | (z & 3) << 5 | (y & 3) << 3 | (x & 7) with tile = ((z >> 2) nty + (y >> 2)) ntx + (x >> 3): the z, y and x parts occupy disjoint bits and the
+    // tile parts add, so a row's key is ONE three-operand add of per-axis terms formed once (the generic per-row form - a division, the key, two 64-bit addresses - was a fifth of the kernel)
+    const uint32_t tile_zy = (uint32_t)tgt.nty * (uint32_t)tgt.ntx;
+    uint32_t kz[3], ky[3];
+#pragma unroll
+    for (int d = 0; d < 3; d++) {
+      const int z = z0 + d, y = y0 + d;
+      kz[d] = (((uint32_t)(z >> 2) * tile_zy) << 7) | ((uint32_t)(z & 3) << 5);
+      ky[d] = (((uint32_t)(y >> 2) * (uint32_t)tgt.ntx) << 7) | ((uint32_t)(y & 3) << 3);
+    }
 #pragma unroll 1
     for (int part = 0; part < 2; part++) {
       if (!__any(scan && part < ntr)) break;
+      const int tx = tx0 + part, xa = max(x0, tx << 3), xb = min(x1, (tx << 3) + 7);
+      const uint32_t kx = ((uint32_t)tx << 7) | (uint32_t)(xa & 7), xlen = (uint32_t)(xb - xa) + 1u;
+      const bool pv = scan && part < ntr;
       uint32_t s[QN_LANE_ROWS], e[QN_LANE_ROWS];
 #pragma unroll
       for (int rr = 0; rr < QN_LANE_ROWS; rr++) {
+        const int dz = rr / 3, dy = rr % 3;                              // (compile-time: the rows of a 3 x 3 box, those beyond the query's own box empty)
         s[rr] = 0; e[rr] = 0;
-        if (scan && part < ntr && rr < nrow) {
-          int qz_, ry_; divmod_small(rr, nyr, qz_, ry_);
-          const int tx = tx0 + part, xa = max(x0, tx << 3), xb = min(x1, (tx << 3) + 7);
-          const uint32_t k0 = cell_key(tgt, xa, y0 + ry_, z0 + qz_);
-          s[rr] = cs[k0]; e[rr] = cs[k0 + (uint32_t)(xb - xa) + 1u];
-        }
+        if (pv && dy < nyr && dz < nzr) { const uint32_t k0 = kz[dz] + ky[dy] + kx; s[rr] = cs[k0]; e[rr] = cs[k0 + xlen]; }
       }
 #pragma unroll
       for (int rr = 0; rr < QN_LANE_ROWS; rr++) {
