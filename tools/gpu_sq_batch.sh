@@ -7,7 +7,7 @@ STEPS=16; LANES=8
 i=0
 for SET in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU" "SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_SMEM" "SQ_WAIT_INST_LDS SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS"; do
   i=$((i+1))
-  timeout 300 rocprofv3 --kernel-trace --output-format csv --pmc $SET -d $OUT/p$i -o p -- python tools/gpu_batch_sweep.py $STEPS 1x$LANES > /dev/null 2> $OUT/p$i.err; echo "pass $i exit $?"
+  timeout 300 rocprofv3 --kernel-trace --output-format csv --pmc $SET -d $OUT/p$i -o p -- python tools/gpu_batch_sweep.py $STEPS 1x$LANES ${QN_SWEEP_SHIFT:--} > /dev/null 2> $OUT/p$i.err; echo "pass $i exit $?"
   find $OUT/p$i -name '*counter_collection.csv' -exec cp {} $OUT/sq_pass$i.csv \;
   rm -rf $OUT/p$i
 done
