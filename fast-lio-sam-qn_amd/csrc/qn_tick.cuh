@@ -113,12 +113,20 @@ __device__ __forceinline__ void emit_point(const bool have, const bool lin, cons
   for (int a = 0; a < 3; a++)
 #pragma unroll
     for (int b = 0; b < 3; b++) rcr.m[a][b] = ((a == b ? 1.0 : 0.0) - 0.999 * nb[a] * nb[b]) + (sG[3 * a + b] - 0.999 * m[a] * m[b]);
-  const M3 M = m3_inverse(rcr);
+  M3 M = m3_inverse(rcr);
+  // a lane without a correspondence contributes zeros: every one of the 28 values is linear in M, so M = 0 (and a finite residual: the neighbour record of such a lane may
+  // be anything) zeroes them all - 21 selects instead of two per value
+#pragma unroll
+  for (int a = 0; a < 3; a++)
+#pragma unroll
+    for (int b = 0; b < 3; b++) M.m[a][b] = have ? M.m[a][b] : 0.0;
   const double mA[3] = {(double)pa.x, (double)pa.y, (double)pa.z};
   double tA[3], e[3], Me[3];
 #pragma unroll
   for (int r = 0; r < 3; r++) tA[r] = sTx[4 * r] * mA[0] + sTx[4 * r + 1] * mA[1] + sTx[4 * r + 2] * mA[2] + sTx[4 * r + 3];
-  e[0] = (double)pb.x - tA[0]; e[1] = (double)pb.y - tA[1]; e[2] = (double)pb.z - tA[2];
+#pragma unroll
+  for (int r = 0; r < 3; r++) tA[r] = have ? tA[r] : 0.0;                           // (a non-finite pose: 0 x NaN must not reach the sums of a lane that has nothing to add)
+  e[0] = (double)(have ? pb.x : 0.f) - tA[0]; e[1] = (double)(have ? pb.y : 0.f) - tA[1]; e[2] = (double)(have ? pb.z : 0.f) - tA[2];
 #pragma unroll
   for (int r = 0; r < 3; r++) Me[r] = M.m[r][0] * e[0] + M.m[r][1] * e[1] + M.m[r][2] * e[2];
   const double x = tA[0], y = tA[1], z = tA[2];
@@ -130,20 +138,14 @@ __device__ __forceinline__ void emit_point(const bool have, const bool lin, cons
     g[0] = z * MS[1][0] + (-y) * MS[2][0]; g[1] = z * MS[1][1] + (-y) * MS[2][1]; g[2] = z * MS[1][2] + (-y) * MS[2][2];
     g[3] = z * (-M.m[1][0]) + (-y) * (-M.m[2][0]); g[4] = z * (-M.m[1][1]) + (-y) * (-M.m[2][1]); g[5] = z * (-M.m[1][2]) + (-y) * (-M.m[2][2]);
     g[6] = (-z) * MS[0][1] + x * MS[2][1];
-#pragma unroll
-    for (int u = 0; u < 7; u++) g[u] = have ? g[u] : 0.0;
     fold7(g, 0, first, wbuf, wrow);
     g[0] = (-z) * MS[0][2] + x * MS[2][2];
     g[1] = (-z) * (-M.m[0][0]) + x * (-M.m[2][0]); g[2] = (-z) * (-M.m[0][1]) + x * (-M.m[2][1]); g[3] = (-z) * (-M.m[0][2]) + x * (-M.m[2][2]);
     g[4] = y * MS[0][2] + (-x) * MS[1][2];
     g[5] = y * (-M.m[0][0]) + (-x) * (-M.m[1][0]); g[6] = y * (-M.m[0][1]) + (-x) * (-M.m[1][1]);
-#pragma unroll
-    for (int u = 0; u < 7; u++) g[u] = have ? g[u] : 0.0;
     fold7(g, 1, first, wbuf, wrow);
     g[0] = y * (-M.m[0][2]) + (-x) * (-M.m[1][2]);
     g[1] = M.m[0][0]; g[2] = M.m[0][1]; g[3] = M.m[0][2]; g[4] = M.m[1][1]; g[5] = M.m[1][2]; g[6] = M.m[2][2];
-#pragma unroll
-    for (int u = 0; u < 7; u++) g[u] = have ? g[u] : 0.0;
     fold7(g, 2, first, wbuf, wrow);
     g[0] = z * Me[1] + (-y) * Me[2]; g[1] = (-z) * Me[0] + x * Me[2]; g[2] = y * Me[0] + (-x) * Me[1];
     g[3] = -Me[0]; g[4] = -Me[1]; g[5] = -Me[2];
@@ -153,8 +155,6 @@ __device__ __forceinline__ void emit_point(const bool have, const bool lin, cons
     for (int u = 0; u < 6; u++) g[u] = 0.0;
   }
   g[6] = e[0] * Me[0] + e[1] * Me[1] + e[2] * Me[2];
-#pragma unroll
-  for (int u = 0; u < 7; u++) g[u] = have ? g[u] : 0.0;
   fold7(g, 3, first, wbuf, wrow);
 }
 
