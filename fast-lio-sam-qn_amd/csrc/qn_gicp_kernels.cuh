@@ -699,9 +699,10 @@ __device__ __forceinline__ void accumulate_point_n(const double (*Rx)[4], const 
 #pragma unroll
   for (int a = 0; a < 3; a++)
 #pragma unroll
-    for (int b = 0; b < 3; b++) {
+    for (int b = a; b < 3; b++) {      // the upper triangle, mirrored: the sum of two symmetric matrices, formed once per pair (a, b) - its inverse then has three cofactors less to form
       const double g = Rx[a][0] * Rx[b][0] + Rx[a][1] * Rx[b][1] + Rx[a][2] * Rx[b][2];
       rcr.m[a][b] = ((a == b ? 1.0 : 0.0) - 0.999 * nb[a] * nb[b]) + (g - 0.999 * m[a] * m[b]);
+      rcr.m[b][a] = rcr.m[a][b];
     }
   const M3 M = m3_inverse(rcr);
   const double mA[3] = {(double)pa.x, (double)pa.y, (double)pa.z};

@@ -112,7 +112,7 @@ __device__ __forceinline__ void emit_point(const bool have, const bool lin, cons
 #pragma unroll
   for (int a = 0; a < 3; a++)
 #pragma unroll
-    for (int b = 0; b < 3; b++) rcr.m[a][b] = ((a == b ? 1.0 : 0.0) - 0.999 * nb[a] * nb[b]) + (sG[3 * a + b] - 0.999 * m[a] * m[b]);
+    for (int b = a; b < 3; b++) { rcr.m[a][b] = ((a == b ? 1.0 : 0.0) - 0.999 * nb[a] * nb[b]) + (sG[3 * a + b] - 0.999 * m[a] * m[b]); rcr.m[b][a] = rcr.m[a][b]; }      // (upper triangle, mirrored: accumulate_point_n)
   M3 M = m3_inverse(rcr);
   // a lane without a correspondence contributes zeros: every one of the 28 values is linear in M, so M = 0 (and a finite residual: the neighbour record of such a lane may
   // be anything) zeroes them all - 21 selects instead of two per value
