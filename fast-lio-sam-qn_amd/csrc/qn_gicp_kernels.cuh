@@ -722,13 +722,15 @@ __device__ __forceinline__ void accumulate_point_n(const double (*Rx)[4], const 
     // upper J^T M J, row-major over (r, c >= r):  rows 0..2 = skew(tA)^T [MS | -M], rows 3..5 = M
     // row 0: J[:,0] = (0, z, -y)
     acc[0] += z * MS[1][0] + (-y) * MS[2][0]; acc[1] += z * MS[1][1] + (-y) * MS[2][1]; acc[2] += z * MS[1][2] + (-y) * MS[2][2];
-    acc[3] += z * (-M.m[1][0]) + (-y) * (-M.m[2][0]); acc[4] += z * (-M.m[1][1]) + (-y) * (-M.m[2][1]); acc[5] += z * (-M.m[1][2]) + (-y) * (-M.m[2][2]);
+    // (the rotation-translation block -skew(tA)^T M is minus the TRANSPOSE of MS: M is symmetric bit for bit - the inverse of a mirrored matrix - so z (-M10) + (-y)(-M20)
+    //  and -(M01 z + M02 (-y)) are the same products and the same rounded sum: nine entries without a multiplication)
+    acc[3] += -MS[0][0]; acc[4] += -MS[1][0]; acc[5] += -MS[2][0];
     // row 1: J[:,1] = (-z, 0, x)
     acc[6] += (-z) * MS[0][1] + x * MS[2][1]; acc[7] += (-z) * MS[0][2] + x * MS[2][2];
-    acc[8] += (-z) * (-M.m[0][0]) + x * (-M.m[2][0]); acc[9] += (-z) * (-M.m[0][1]) + x * (-M.m[2][1]); acc[10] += (-z) * (-M.m[0][2]) + x * (-M.m[2][2]);
+    acc[8] += -MS[0][1]; acc[9] += -MS[1][1]; acc[10] += -MS[2][1];
     // row 2: J[:,2] = (y, -x, 0)
     acc[11] += y * MS[0][2] + (-x) * MS[1][2];
-    acc[12] += y * (-M.m[0][0]) + (-x) * (-M.m[1][0]); acc[13] += y * (-M.m[0][1]) + (-x) * (-M.m[1][1]); acc[14] += y * (-M.m[0][2]) + (-x) * (-M.m[1][2]);
+    acc[12] += -MS[0][2]; acc[13] += -MS[1][2]; acc[14] += -MS[2][2];
     // rows 3..5: (-I)^T (-M) = M
     acc[15] += M.m[0][0]; acc[16] += M.m[0][1]; acc[17] += M.m[0][2]; acc[18] += M.m[1][1]; acc[19] += M.m[1][2]; acc[20] += M.m[2][2];
     // J^T M e

@@ -136,15 +136,15 @@ __device__ __forceinline__ void emit_point(const bool have, const bool lin, cons
 #pragma unroll
     for (int r = 0; r < 3; r++) { MS[r][0] = M.m[r][1] * z + M.m[r][2] * (-y); MS[r][1] = M.m[r][0] * (-z) + M.m[r][2] * x; MS[r][2] = M.m[r][0] * y + M.m[r][1] * (-x); }
     g[0] = z * MS[1][0] + (-y) * MS[2][0]; g[1] = z * MS[1][1] + (-y) * MS[2][1]; g[2] = z * MS[1][2] + (-y) * MS[2][2];
-    g[3] = z * (-M.m[1][0]) + (-y) * (-M.m[2][0]); g[4] = z * (-M.m[1][1]) + (-y) * (-M.m[2][1]); g[5] = z * (-M.m[1][2]) + (-y) * (-M.m[2][2]);
+    g[3] = -MS[0][0]; g[4] = -MS[1][0]; g[5] = -MS[2][0];                     // (-skew(tA)^T M = -MS^T, bit for bit: M is symmetric - accumulate_point_n)
     g[6] = (-z) * MS[0][1] + x * MS[2][1];
     fold7(g, 0, first, wbuf, wrow);
     g[0] = (-z) * MS[0][2] + x * MS[2][2];
-    g[1] = (-z) * (-M.m[0][0]) + x * (-M.m[2][0]); g[2] = (-z) * (-M.m[0][1]) + x * (-M.m[2][1]); g[3] = (-z) * (-M.m[0][2]) + x * (-M.m[2][2]);
+    g[1] = -MS[0][1]; g[2] = -MS[1][1]; g[3] = -MS[2][1];
     g[4] = y * MS[0][2] + (-x) * MS[1][2];
-    g[5] = y * (-M.m[0][0]) + (-x) * (-M.m[1][0]); g[6] = y * (-M.m[0][1]) + (-x) * (-M.m[1][1]);
+    g[5] = -MS[0][2]; g[6] = -MS[1][2];
     fold7(g, 1, first, wbuf, wrow);
-    g[0] = y * (-M.m[0][2]) + (-x) * (-M.m[1][2]);
+    g[0] = -MS[2][2];
     g[1] = M.m[0][0]; g[2] = M.m[0][1]; g[3] = M.m[0][2]; g[4] = M.m[1][1]; g[5] = M.m[1][2]; g[6] = M.m[2][2];
     fold7(g, 2, first, wbuf, wrow);
     g[0] = z * Me[1] + (-y) * Me[2]; g[1] = (-z) * Me[0] + x * Me[2]; g[2] = y * Me[0] + (-x) * Me[1];
