@@ -1105,13 +1105,11 @@ __device__ inline bool d_is_converged(const double delta[16], const GicpConfig& 
 }
 
 __device__ __forceinline__ void d_propose(GicpState* st, double lambda, SolveWork* A) {      // d = LDLT(H + lambda I).solve(-b); delta; xi = delta * x0
-  double Hl[36], rhs[6], dl[6], x0l[16];
+  double Hl[36], rhs[6], dl[6];
 #pragma unroll
   for (int i = 0; i < 36; i++) Hl[i] = st->H[i];
 #pragma unroll
   for (int i = 0; i < 6; i++) rhs[i] = -st->b[i];
-#pragma unroll
-  for (int i = 0; i < 16; i++) x0l[i] = st->x0[i];
   if (!d_ldlt_solve6_fast(Hl, lambda, rhs, dl)) {
 #pragma unroll
     for (int i = 0; i < 6; i++) A->rhs[i] = rhs[i];
@@ -1130,6 +1128,9 @@ __device__ __forceinline__ void d_propose(GicpState* st, double lambda, SolveWor
     delta[4 * a + 3] = dl[3 + a];
   }
   delta[15] = 1.0;
+  double x0l[16];                                                      // (fetched here, not next to H: 36 + 16 f64 live at once were what the kernels that carry this step spilled)
+#pragma unroll
+  for (int i = 0; i < 16; i++) x0l[i] = st->x0[i];
   d_iso_mul(delta, x0l, xi);
 #pragma unroll
   for (int i = 0; i < 6; i++) st->d[i] = dl[i];

@@ -150,9 +150,23 @@ __device__ __forceinline__ void emit_point(const bool have, const bool lin, cons
     g[0] = z * Me[1] + (-y) * Me[2]; g[1] = (-z) * Me[0] + x * Me[2]; g[2] = y * Me[0] + (-x) * Me[1];
     g[3] = -Me[0]; g[4] = -Me[1]; g[5] = -Me[2];
   } else {
-    if (first && (threadIdx.x & 63) < 21) wrow[threadIdx.x & 63] = 0.0;
+    // an LM trial pass: the cost alone.  Component 6 of the last group through the same slots and the same order of additions as fold7 (the cost of a linearisation pass and
+    // of a trial pass are compared by the controller), the other 27 sums of the row are zero - no seven-wide fold of six zeros (a zero f64 pair kept alive across the whole
+    // kernel for it was this kernel's last spill)
+    const int lane = threadIdx.x & 63, c8 = lane >> 3, s8 = lane & 7;
+    double zero = 0.0; asm volatile("" : "+v"(zero));                   // (materialised HERE: hoisted out of the per-point loop the constant was kept alive - in scratch - across the search)
+    if (first && lane < 27) wrow[lane] = zero;
+    wbuf[6 * 64 + lane] = e[0] * Me[0] + e[1] * Me[1] + e[2] * Me[2];
+    wave_lds_fence();
+    double v = zero;
+    if (c8 == 6) {
 #pragma unroll
-    for (int u = 0; u < 6; u++) g[u] = 0.0;
+      for (int u = 0; u < 8; u++) v += wbuf[6 * 64 + u * 8 + s8];
+    }
+    v = dpp_xor_add(v, 0); v = dpp_xor_add(v, 1); v = dpp_xor_add(v, 2);
+    if (c8 == 6 && s8 == 0) wrow[27] = first ? v : wrow[27] + v;
+    wave_lds_fence();
+    return;
   }
   g[6] = e[0] * Me[0] + e[1] * Me[1] + e[2] * Me[2];
   fold7(g, 3, first, wbuf, wrow);
@@ -231,7 +245,7 @@ __device__ __forceinline__ void tick_point(const TickArgs& a, const float (&Tf)[
   if (!lin) {                                                    // LM trial error: cached correspondence, gate as at the linearisation
     bool have = false;
     if (valid && finite_q && j0 < a.tgt.n) have = (double)sqdist(qx, qy, qz, rec0.p.x, rec0.p.y, rec0.p.z) < a.thr2;
-    double na[3] = {na_in[0], na_in[1], na_in[2]};
+    double na[3] = {NA_LATE ? 0.0 : na_in[0], NA_LATE ? 0.0 : na_in[1], NA_LATE ? 0.0 : na_in[2]};      // (NA_LATE: the caller's placeholder is never read - a literal here, not a value kept alive across the search)
     if (NA_LATE && valid) { na[0] = a.nrm_s[(size_t)t * 3]; na[1] = a.nrm_s[(size_t)t * 3 + 1]; na[2] = a.nrm_s[(size_t)t * 3 + 2]; }
     wave_lds_fence();
     emit_point(have, false, first, sx0, sxi, sG, make_float4(p.x, p.y, p.z, 1.f), rec0.p, na, rec0.n, red, wrow);
@@ -440,7 +454,7 @@ __device__ __forceinline__ void tick_point(const TickArgs& a, const float (&Tf)[
     if (probe) a.clk[4] = wall_clock64();
     if (MODE == 0 && threadIdx.x == 0) a.clk_blk[8 * blockIdx.x + 2] = wall_clock64();
   }
-  double na[3] = {na_in[0], na_in[1], na_in[2]};
+  double na[3] = {NA_LATE ? 0.0 : na_in[0], NA_LATE ? 0.0 : na_in[1], NA_LATE ? 0.0 : na_in[2]};
   if (NA_LATE && valid) { na[0] = a.nrm_s[(size_t)t * 3]; na[1] = a.nrm_s[(size_t)t * 3 + 1]; na[2] = a.nrm_s[(size_t)t * 3 + 2]; }
   wave_lds_fence();                                              // the wave's search scratch becomes its transpose buffer
   emit_point(have, true, first, sx0, sx0, sG, make_float4(p.x, p.y, p.z, 1.f), rec0.p, na, rec0.n, red, wrow);
