@@ -633,12 +633,12 @@ __device__ __forceinline__ float cap_face_dist(const CapBox& c, float f, int axi
 // one look-up and contribute no candidates).  Same certification and growth rule as wave_search.
 struct SingleStats { uint32_t rounds, cand, segs; float r_first, r_last; };      // developer probe (list_probe): what one search did
 __device__ __forceinline__ void wave_search_single(const GridView& g, float qx, float qy, float qz, float r, const float r_cap,
-                                                   unsigned long long& best_out, float& second_out, float& d_unseen, WaveLds* lds, SingleStats* stats = nullptr) {
+                                                   unsigned long long& best_out, float& second_out, float& d_unseen, WaveLds* lds, SingleStats& st_out, const bool stats) {      // (stats: by reference + flag - a conditional POINTER to the caller's struct made it a stack object: scratch in a kernel of the chain)
   const int lane = threadIdx.x & 63;
   const float INF = __int_as_float(0x7f800000);
   const CapBox cap = cap_of(g, qx, qy, qz);
   if (cap.S > 0.f) r = fminf(fmaxf(r, sqrtf(cap.S) + g.cell), fmaxf(r_cap, r));   // nothing is closer than the grid box itself: do not spend rounds below that
-  if (stats) { stats->rounds = 0; stats->cand = 0; stats->segs = 0; stats->r_first = r; }
+  if (stats) { st_out.rounds = 0; st_out.cand = 0; st_out.segs = 0; st_out.r_first = r; }
   // Growth rounds scan SHELLS: a tile-mode round scans whole tiles, so once the tiles within r (box distance <= r^2, the inclusion rule below) are done, the next
   // round only needs the tiles between the two radii and the running best / runner-up carry over - the scanned set after any round is exactly the set a fresh
   // scan of that round's ball would visit, each point once.  (Row-mode rounds - small boxes, partial tiles - start afresh.)
@@ -686,7 +686,7 @@ __device__ __forceinline__ void wave_search_single(const GridView& g, float qx, 
       const uint32_t total = rflu(__shfl(incl, 63));
       if (total == 0) continue;
       if (g.dbg && lane == 0) atomicAdd(&g.dbg[11], total);          // developer counter: candidates scanned
-      if (stats) stats->cand += total;
+      if (stats) st_out.cand += total;
       wave_lds_fence();
       lds->seg_excl[lane] = incl - len; lds->seg_start[lane] = s;
       wave_lds_fence();
@@ -705,7 +705,7 @@ __device__ __forceinline__ void wave_search_single(const GridView& g, float qx, 
       }
     }
     if (g.dbg && lane == 0) { atomicAdd(&g.dbg[10], 1u); atomicAdd(&g.dbg[12], (uint32_t)nseg); if (round == 0) atomicAdd(&g.dbg[13], 1u); }      // developer counters: rounds, enumerated segments, entries
-    if (stats) { stats->rounds++; stats->segs += (uint32_t)nseg; stats->r_last = r; }
+    if (stats) { st_out.rounds++; st_out.segs += (uint32_t)nseg; st_out.r_last = r; }
     if (tile_mode) { done2 = in2; ptx0 = tx0; ptx1 = tx0 + ntr - 1; pty0 = ty0; pty1 = ty0 + ntyr - 1; ptz0 = z0 >> 2; ptz1 = z1 >> 2; }
     const unsigned long long b = wave_min_u64(best);
     float c = (best == b) ? second : key_d2(best);
@@ -729,6 +729,12 @@ __device__ __forceinline__ void wave_search_single(const GridView& g, float qx, 
     r = (b != QN_INF_KEY) ? fmaxf(sqrtf(key_d2(b)) * 1.000001f + g.eps, r + g.eps) : (r > 6.f * g.cell ? r + (2.f + round) * g.cell : 2.f * r + g.cell);   // far away: grow by cells, not by factors (the cap's width grows with sqrt(r^2 - o^2))
     r = fminf(r, r_cap);
   }
+}
+
+__device__ __forceinline__ void wave_search_single(const GridView& g, float qx, float qy, float qz, float r, const float r_cap,
+                                                   unsigned long long& best_out, float& second_out, float& d_unseen, WaveLds* lds) {
+  SingleStats none;
+  wave_search_single(g, qx, qy, qz, r, r_cap, best_out, second_out, d_unseen, lds, none, false);
 }
 
 // ------------------------------------------------------------------ far queries that are neighbours: up to 16 per wave, ONE shared candidate stream

@@ -506,6 +506,9 @@ __device__ __forceinline__ void xform_query(const float Tf[12], float x, float y
 
 // corr / sqd are indexed by the ORIGINAL source index i (API order); the tracking state (nn_idx, nn_ref) by the source's
 // cell-sorted position t, the order every NN kernel walks the queries in - coalesced.
+// The indices a search stores under are known before it starts; the compiler then forms the five 64-bit store addresses up front and carries them - ten VGPRs - across the
+// whole search (they were what the list kernels spilled).  late(): the value is opaque until this point, so the addresses are formed where they are used.
+__device__ __forceinline__ uint32_t late(uint32_t v) { asm volatile("" : "+v"(v)); return v; }
 template <int MODE>
 __device__ __forceinline__ void store_nn(unsigned long long key, uint32_t i, uint32_t t, double thr2, int32_t* __restrict__ corr, float* __restrict__ sqd, int32_t* __restrict__ nn_idx) {
   const float d2 = key_d2(key);
@@ -542,9 +545,11 @@ struct NnSearchK {
   if (MODE == 1 && uni(st->phase) != 2) return;
   if (opt.cond && !(uni(st->reserved) & opt.cond)) return;           // a conditional launch behind look_decide
   src = grid_resolve(src); tgt = grid_resolve(tgt); if (r0 < 0.f) r0 = -r0 * tgt.cell;
-  float Tf[12];
-#pragma unroll
-  for (int j = 0; j < 12; j++) Tf[j] = uni((float)st->x0[j]);
+  // the f32 pose lives in LDS and is read where a query is transformed (broadcast reads): as twelve loop-invariant values it competed with ~90 other uniform numbers for the
+  // scalar registers, lost, and was kept in VECTOR registers across the searches - spilled to scratch there
+  __shared__ float sTf[12];
+  if (threadIdx.x < 12) sTf[threadIdx.x] = (float)st->x0[threadIdx.x];
+  __syncthreads();
   if (LIST && (int)bx >= (int)nbx - big_blocks) {            // ---- big entries: one query per wave
     const uint32_t nbig = uni(*big_count);
     if (tgt.dbg && bx == nbx - 1 && threadIdx.x == 0) atomicAdd(&tgt.dbg[7], nbig);
@@ -563,7 +568,10 @@ struct NnSearchK {
         const bool active = (uint32_t)qs < E && slot < nbig;
         const uint2 rec = active ? big_list[slot] : make_uint2(0u, 0u);
         const float4 p = active ? src.pts[rec.x] : make_float4(0.f, 0.f, 0.f, 0.f);
-        float qx, qy, qz; xform_query<MODE>(Tf, p.x, p.y, p.z, qx, qy, qz);
+        float qx, qy, qz; { float Tf[12];
+#pragma unroll
+          for (int j = 0; j < 12; j++) Tf[j] = sTf[j];
+          xform_query<MODE>(Tf, p.x, p.y, p.z, qx, qy, qz); }
         const float v = __uint_as_float(rec.y);
         const float r = v > 0.f ? v * 1.1f + 0.5f * tgt.cell : -v;
         const bool finite_q = (qx - qx == 0.f) && (qy - qy == 0.f) && (qz - qz == 0.f) && (r - r == 0.f);
@@ -587,10 +595,11 @@ struct NnSearchK {
           todo &= ~mm;
         }
         if (active && lane < 16) {
-          store_nn<MODE>(key, __float_as_uint(p.w), rec.x, thr2, corr, sqd, nn_idx);
+          const uint32_t tl = late(rec.x);
+          store_nn<MODE>(key, late(__float_as_uint(p.w)), tl, thr2, corr, sqd, nn_idx);
           // (the bound every OTHER target point respects is the canonical one here - the neighbour's own distance - not the scan's runner-up / unseen radius: those
           //  depend on which entries shared a scan, i.e. on the order the list was appended in, and the tracked ticks' regime decisions must not)
-          if (MODE == 0) nn_ref[rec.x] = make_float4(qx, qy, qz, key != QN_INF_KEY ? sqrtf(key_d2(key)) : INF);
+          if (MODE == 0) nn_ref[tl] = make_float4(qx, qy, qz, key != QN_INF_KEY ? sqrtf(key_d2(key)) : INF);
         }
         if (far_stats && MODE == 0) {
           const unsigned long long fm = __ballot(active && lane < 16 && key != QN_INF_KEY && key_d2(key) > 36.f * tgt.cell * tgt.cell);
@@ -609,7 +618,10 @@ struct NnSearchK {
     for (uint32_t w = bw0; w < nbig + nfb1; w += nbw) {
       const uint2 rec = w < nbig ? big_list[w] : fb_list[w - nbig];
       const float4 p = src.pts[rec.x];
-      float qx, qy, qz; xform_query<MODE>(Tf, p.x, p.y, p.z, qx, qy, qz);
+      float qx, qy, qz; { float Tf[12];
+#pragma unroll
+          for (int j = 0; j < 12; j++) Tf[j] = sTf[j];
+          xform_query<MODE>(Tf, p.x, p.y, p.z, qx, qy, qz); }
       const float v = __uint_as_float(rec.y);
       // v > 0: tight seed (the query barely moved since its last scan): scan a little wider than the bound so that the
       // following iterations can prove the neighbour unchanged; v < 0: unseeded, continue from |v|
@@ -617,13 +629,14 @@ struct NnSearchK {
       unsigned long long key; float second, d_unseen;
       const unsigned long long pt0 = opt.probe ? wall_clock64() : 0ull;
       SingleStats sst;
-      wave_search_single(tgt, qx, qy, qz, r, __int_as_float(0x7f800000), key, second, d_unseen, &lds[threadIdx.x >> 6], opt.probe ? &sst : nullptr);
+      wave_search_single(tgt, qx, qy, qz, r, __int_as_float(0x7f800000), key, second, d_unseen, &lds[threadIdx.x >> 6], sst, opt.probe != nullptr);
       if (opt.probe) { const unsigned long long dt = wall_clock64() - pt0; pr_sum += dt; pr_n++;
         if (dt > pr_max) { pr_max = dt; pr_a = ((unsigned long long)sst.rounds << 48) | ((unsigned long long)min(sst.segs, 0xffffffu) << 24) | (unsigned long long)min(sst.cand, 0xffffffu);
           pr_b = ((unsigned long long)__float_as_uint(sst.r_first) << 32) | __float_as_uint(key != QN_INF_KEY ? sqrtf(key_d2(key)) : -1.f); } }
       if ((threadIdx.x & 63) == 0) {
-        store_nn<MODE>(key, __float_as_uint(p.w), rec.x, thr2, corr, sqd, nn_idx);
-        if (MODE == 0) nn_ref[rec.x] = make_float4(qx, qy, qz, fminf(sqrtf(second), d_unseen));
+        const uint32_t tl = late(rec.x);
+        store_nn<MODE>(key, late(__float_as_uint(p.w)), tl, thr2, corr, sqd, nn_idx);
+        if (MODE == 0) nn_ref[tl] = make_float4(qx, qy, qz, fminf(sqrtf(second), d_unseen));
         if (key != QN_INF_KEY && key_d2(key) > 36.f * tgt.cell * tgt.cell) nfar++;        // neighbour beyond 6 cells (QN_FAR_RMIN_CELLS)
       }
     }
@@ -645,7 +658,10 @@ struct NnSearchK {
       if (v < 0.f) r = -v; else { r_cap = v; r = fminf(v, r0); }   // seeded (possibly loose after a big pose step): start small, never beyond the bound
     }
     const float4 p = active ? src.pts[t] : make_float4(0, 0, 0, 0);
-    float qx, qy, qz; xform_query<MODE>(Tf, p.x, p.y, p.z, qx, qy, qz);
+    float qx, qy, qz; { float Tf[12];
+#pragma unroll
+          for (int j = 0; j < 12; j++) Tf[j] = sTf[j];
+          xform_query<MODE>(Tf, p.x, p.y, p.z, qx, qy, qz); }
     Best1 sink; sink.init();
     float d_unseen;
     const bool cert = wave_search<4>(tgt, qx, qy, qz, active, r, r_cap, max_rounds, sink, &lds[threadIdx.x >> 6], d_unseen);
@@ -653,9 +669,10 @@ struct NnSearchK {
     const bool done = cert || LIST;
     if (!LIST && MODE == 0 && opt.clear_ref && mine) opt.clear_ref[t] = make_float4(0.f, 0.f, 0.f, 0.f);      // no far-candidate list yet (w = 0)
     if (mine && done) {
-      store_nn<MODE>(sink.key, __float_as_uint(p.w), t, thr2, corr, sqd, nn_idx);
+      const uint32_t tl = late(t);
+      store_nn<MODE>(sink.key, late(__float_as_uint(p.w)), tl, thr2, corr, sqd, nn_idx);
       // bound-pruning reference: where this query was scanned and how far away every other point is at least
-      if (MODE == 0) nn_ref[t] = make_float4(qx, qy, qz, fminf(sqrtf(sink.second), d_unseen));
+      if (MODE == 0) nn_ref[tl] = make_float4(qx, qy, qz, fminf(sqrtf(sink.second), d_unseen));
     }
     if (!LIST) {
       const float rn = r;
