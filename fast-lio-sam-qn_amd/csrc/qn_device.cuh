@@ -239,8 +239,9 @@ struct BestK {
   int k, cnt;
   __device__ __forceinline__ void reset() {
     w = QN_INF_KEY; cnt = 0;
+    int kk = k; asm volatile("" : "+s"(kk));                           // (opaque here: as loop invariants the KMAX initial keys were kept alive - in scratch - across the searches between two resets)
 #pragma unroll
-    for (int j = 0; j < KMAX; j++) a[j] = (j < KMAX - k) ? 0ull : QN_INF_KEY;
+    for (int j = 0; j < KMAX; j++) a[j] = (j < KMAX - kk) ? 0ull : QN_INF_KEY;
   }
   __device__ __forceinline__ void init(int k_, unsigned long long (*pend_)[64], uint32_t* dbg_ = nullptr) {
     k = k_; pend = pend_; dbg = dbg_; reset();
