@@ -1037,7 +1037,7 @@ __device__ inline void d_so3_exp(const double om[3], double R[3][3]) {
 // registration; returns false when a pivot is not strictly positive so the caller can take the
 // pivoted path (semi-definite systems: too few correspondences).  Same solution as the pivoted
 // factorisation up to rounding.
-__device__ __forceinline__ bool d_ldlt_solve6_fast(const double Ain[36], double diag_add, const double rhs[6], double x[6]) {
+__device__ __forceinline__ bool d_ldlt_solve6_fast(const double Ain[36], double diag_add, double rhs[6], double x[6], const double* b) {      // rhs = -b, fetched AFTER the factorisation (it is not needed before: six f64 less across it)
   double A[6][6];
 #pragma unroll
   for (int i = 0; i < 6; i++)
@@ -1061,6 +1061,8 @@ __device__ __forceinline__ bool d_ldlt_solve6_fast(const double Ain[36], double 
   }
   double y[6];
 #pragma unroll
+  for (int i = 0; i < 6; i++) rhs[i] = -b[i];
+#pragma unroll
   for (int i = 0; i < 6; i++) { double s = rhs[i];
 #pragma unroll
     for (int j = 0; j < i; j++) s -= A[i][j] * y[j]; y[i] = s; }
@@ -1078,7 +1080,12 @@ __device__ __forceinline__ bool d_ldlt_solve6_fast(const double Ain[36], double 
 struct SolveWork { double A[6][6]; double l[6], y[6], z[6], rhs[6]; int perm[6]; int pad[2]; };
 __device__ inline void d_ldlt_solve6(const double Ain[36], double diag_add, double x[6] /* LDS */, SolveWork* w /* LDS; w->rhs set by the caller */) {
   double (*A)[6] = w->A; int* perm = w->perm; double* l = w->l; double* y = w->y; double* z = w->z;
-  for (int i = 0; i < 6; i++) { perm[i] = i; for (int j = 0; j < 6; j++) A[i][j] = Ain[6 * i + j] + (i == j ? diag_add : 0.0); }
+#pragma unroll 1
+  for (int i = 0; i < 6; i++) {                                        // (row by row, not unrolled: unrolled, the 36 entries were all in flight at once - the spill of the kernels that carry this step)
+    perm[i] = i;
+#pragma unroll
+    for (int j = 0; j < 6; j++) A[i][j] = Ain[6 * i + j] + (i == j ? diag_add : 0.0);
+  }
   for (int k = 0; k < 6; k++) {
     int piv = k; double best = fabs(A[k][k]);
     for (int i = k + 1; i < 6; i++) if (fabs(A[i][i]) > best) { best = fabs(A[i][i]); piv = i; }
@@ -1124,10 +1131,10 @@ __device__ inline bool d_is_converged(const double delta[16], const GicpConfig& 
 __device__ __forceinline__ void d_propose(GicpState* st, double lambda, SolveWork* A) {      // d = LDLT(H + lambda I).solve(-b); delta; xi = delta * x0
   double Hl[36], rhs[6], dl[6];
 #pragma unroll
-  for (int i = 0; i < 36; i++) Hl[i] = st->H[i];
+  for (int i = 0; i < 6; i++)
 #pragma unroll
-  for (int i = 0; i < 6; i++) rhs[i] = -st->b[i];
-  if (!d_ldlt_solve6_fast(Hl, lambda, rhs, dl)) {
+    for (int j = 0; j < 6; j++) Hl[6 * i + j] = j <= i ? st->H[6 * i + j] : 0.0;      // (the fast factorisation reads the lower triangle only)
+  if (!d_ldlt_solve6_fast(Hl, lambda, rhs, dl, st->b)) {
 #pragma unroll
     for (int i = 0; i < 6; i++) A->rhs[i] = rhs[i];
     d_ldlt_solve6(st->H, lambda, st->d, A);
@@ -1371,39 +1378,7 @@ static __global__ void __launch_bounds__(NT) k_solve(const GicpState* __restrict
 }
 
 // ------------------------------------------------------------------ K4b / K5 accumulate (+ the controller step in the launch's last block)
-struct AccumulateK {
-  static constexpr int TB = QN_BLOCK, OCC = 1;
-  struct Args { const float4* src_raw; uint32_t ns; const double* nrm_s; const TargetRec* tgt_rec; const int32_t* corr; const GicpState* st; double* partials; int cond; TailArgs tail; };
-  static __device__ __forceinline__ void run(const Args& a, const uint32_t bx, const uint32_t nbx) {
-    __shared__ double red[QN_BLOCK / 64][QN_NPART];
-    __shared__ TailLds tl;
-    const float4* __restrict__ src_raw = a.src_raw; const double* __restrict__ nrm_s = a.nrm_s; const TargetRec* __restrict__ tgt_rec = a.tgt_rec;
-    const int32_t* __restrict__ corr = a.corr; const GicpState* __restrict__ st = a.st;
-    const uint32_t ns = a.ns;
-    const int phase = uni(st->phase);
-    const bool skip = phase == 2 || (a.cond && !(uni(st->reserved) & a.cond));      // done, or a conditional launch behind look_decide whose flag is not set
-    if (skip) { if (a.tail.enabled) state_pass_through<QN_BLOCK>(a.tail, bx); return; }
-    double R[3][4], T[3][4];
-#pragma unroll
-    for (int u = 0; u < 3; u++)
-#pragma unroll
-      for (int b = 0; b < 4; b++) { T[u][b] = uni(phase == 0 ? st->x0[4 * u + b] : st->xi[4 * u + b]); R[u][b] = uni(st->x0[4 * u + b]); }
-    double acc[QN_NPART];
-#pragma unroll
-    for (int t = 0; t < QN_NPART; t++) acc[t] = 0;
-    for (uint32_t i = bx * QN_BLOCK + threadIdx.x; i < ns; i += nbx * QN_BLOCK) {
-      const int j = corr[i];
-      if (j < 0) continue;
-      const TargetRec* rec = tgt_rec + j;
-      const double na[3] = {nrm_s[(size_t)i * 3], nrm_s[(size_t)i * 3 + 1], nrm_s[(size_t)i * 3 + 2]};
-      const double nb[3] = {rec->n[0], rec->n[1], rec->n[2]};
-      accumulate_point_n(R, T, src_raw[i], rec->p, na, nb, phase == 0, acc);
-    }
-    reduce_block_partials(acc, phase == 0, a.partials, red, bx, a.tail.enabled != 0);
-    if (a.tail.enabled) controller_tail<QN_BLOCK>(a.tail, a.partials, nbx, &tl);
-  }
-};
-static __global__ void __launch_bounds__(QN_BLOCK) k_accumulate(AccumulateK::Args a) { AccumulateK::run(a, blockIdx.x, gridDim.x); }
+// (AccumulateK / k_accumulate: qn_tick.cuh - the unseeded ticks' sums are formed by emit_point like the tracked ticks')
 
 struct InitStateK {
   static constexpr int TB = 64, OCC = 1;

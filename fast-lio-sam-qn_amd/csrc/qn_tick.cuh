@@ -543,6 +543,57 @@ struct TickK {
   if (a.tail.enabled) controller_tail<TB>(a.tail, a.part_out, nblk, &tl);
   }
 };
+// K4b / K5 for the UNSEEDED ticks and the debug linearisation: the correspondences corr[] of the search that just ran (API order) -> one partial row per
+// block, and the controller step in the last block (controller_tail).  phase 0: linearize - M = (C_B + R C_A R^T)^-1, e = mu_B - T mu_A, H += J^T M J, b += J^T M e,
+// cost += e^T M e; phase 1: compute_error at the trial transform xi with the cached correspondences.  The sums are formed by emit_point - seven values at a time, folded
+// across the wave at once - as in the tracked ticks: a thread never holds 28 f64 accumulators (this kernel ran at 150 VGPRs = three waves per SIMD with them, and its
+// final 28 wave-wide DPP sums were 500 of its 800 instructions per wave).  Fixed grid, fixed striding, fixed fold order => bitwise reproducible rows.
+struct AccumulateK {
+  static constexpr int TB = QN_BLOCK, OCC = 4;
+  struct Args { const float4* src_raw; uint32_t ns; const double* nrm_s; const TargetRec* tgt_rec; const int32_t* corr; const GicpState* st; double* partials; int cond; TailArgs tail; };
+  static __device__ __forceinline__ void run(const Args& a, const uint32_t bx, const uint32_t nbx) {
+    __shared__ double red[QN_BLOCK / 64][7 * 64];
+    __shared__ double wsum[QN_BLOCK / 64][QN_NPART];
+    __shared__ TailLds tl;
+    __shared__ double sG[9];
+    const int tid = threadIdx.x;
+    for (int i = tid; i < (int)(sizeof(GicpState) / 8); i += QN_BLOCK) ((unsigned long long*)&tl.sh)[i] = ((const unsigned long long*)a.st)[i];
+    __syncthreads();
+    const int phase = tl.sh.phase;
+    const bool skip = phase == 2 || (a.cond && !(tl.sh.reserved & a.cond));      // done, or a conditional launch behind look_decide whose flag is not set
+    if (skip) { if (a.tail.enabled) state_pass_through<QN_BLOCK>(a.tail, bx); return; }
+    pose_gram(tl.sh.x0, sG, tid);
+    __syncthreads();
+    const bool lin = phase == 0;
+    const double* sTx = lin ? tl.sh.x0 : tl.sh.xi;
+    const uint32_t ns = a.ns;
+    bool first = true;
+    for (uint32_t base = bx * QN_BLOCK; base < ns; base += nbx * QN_BLOCK, first = false) {      // (wave-uniform trip count: emit_point folds across the wave)
+      const uint32_t i = base + (uint32_t)tid;
+      const int j = i < ns ? a.corr[i] : -1;
+      const bool have = j >= 0;
+      float4 pa = make_float4(0.f, 0.f, 0.f, 1.f), pb = make_float4(0.f, 0.f, 0.f, 0.f);
+      double na[3] = {0.0, 0.0, 0.0}, nb[3] = {0.0, 0.0, 0.0};
+      if (have) {
+        const TargetRec* rec = a.tgt_rec + j;
+        const float4 ps = a.src_raw[i];
+        pa = make_float4(ps.x, ps.y, ps.z, 1.f); pb = rec->p;
+        na[0] = a.nrm_s[(size_t)i * 3]; na[1] = a.nrm_s[(size_t)i * 3 + 1]; na[2] = a.nrm_s[(size_t)i * 3 + 2];
+        nb[0] = rec->n[0]; nb[1] = rec->n[1]; nb[2] = rec->n[2];
+      }
+      wave_lds_fence();
+      emit_point(have, lin, first, tl.sh.x0, sTx, sG, pa, pb, na, nb, red[tid >> 6], wsum[tid >> 6]);
+    }
+    __syncthreads();
+    if (tid < QN_NPART) { double v = 0;
+#pragma unroll
+      for (int w = 0; w < QN_BLOCK / 64; w++) v += wsum[w][tid];
+      row_store(&a.partials[(size_t)bx * QN_NPART + tid], v, a.tail.enabled != 0); }
+    if (a.tail.enabled) controller_tail<QN_BLOCK>(a.tail, a.partials, nbx, &tl);
+  }
+};
+static __global__ void __launch_bounds__(QN_BLOCK, 4) k_accumulate(AccumulateK::Args a) { AccumulateK::run(a, blockIdx.x, gridDim.x); }
+
 template <int TB, int OCC, int MODE, bool PROBE>
 __global__ void __launch_bounds__(TB, OCC) k_tick(TickArgs a) { TickK<TB, OCC, MODE, PROBE>::run(a, blockIdx.x, gridDim.x); }
 
