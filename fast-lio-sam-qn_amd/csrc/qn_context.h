@@ -94,6 +94,7 @@ struct qn_ctx {
   hipStream_t stream2 = nullptr; hipEvent_t ev_pair = nullptr; bool pair_pipeline = true, pair_failed = false, tgt_on_stream2 = false, tgt_pending = false, no_pipe = false;
   uint32_t* scan_sums2 = nullptr; uint2* fb_list2 = nullptr; uint2* big_list2 = nullptr; uint32_t* fb_count2b = nullptr; int32_t* knn_idx2 = nullptr;   // 128 blocks = 768 atomics on six words: 10.6 us per cloud; 32: 5 us   // experiment: one selection round, every leftover to the one-query-per-wave pass
   uint32_t tick_ppt_min = 1;            // source points per lane of k_tick (knob: fewer, longer blocks)
+  uint32_t tick_rpb = 2;                // batch members: partial rows a k_tick block forms, one after the other (rows and results are those of 1; the launch has half the blocks)
   uint32_t tick_tb = 512;               // threads per block of k_tick (and of k_solve: both run the same row reduction)
   int tick_occ = 4;                     // k_tick variant: waves per SIMD the register budget allows (4 = 128 VGPRs: other streams' kernels keep half of the register file)
   // persistent align kernel (qn_persist.cuh): granule buffers, give-up status, epoch counter; `persist` = knob, `persist_batch_off` = this context works in a batch

@@ -524,7 +524,9 @@ static void enqueue_verify(qn_ctx* c, bool fused) {
 }
 static uint32_t acc_blocks(const qn_ctx* c) { return std::min<uint32_t>((c->cloud[0].n + QN_BLOCK - 1) / QN_BLOCK, QN_ACC_MAX_BLOCKS); }
 static uint32_t tick_ppt(const qn_ctx* c) { return std::max<uint32_t>(c->tick_ppt_min, (c->cloud[0].n + c->tick_tb * QN_ACC_MAX_BLOCKS - 1) / (c->tick_tb * QN_ACC_MAX_BLOCKS)); }
-static uint32_t tick_blocks(const qn_ctx* c) { const uint32_t per = c->tick_tb * tick_ppt(c); return (c->cloud[0].n + per - 1) / per; }
+static uint32_t tick_rows(const qn_ctx* c) { const uint32_t per = c->tick_tb * tick_ppt(c); return (c->cloud[0].n + per - 1) / per; }      // partial rows of a tick: one per tick_tb x ppt source points
+static uint32_t tick_rpb(const qn_ctx* c) { return c->persist_batch_off ? std::max(1u, c->tick_rpb) : 1u; }      // rows a block forms: batch members take fewer, longer blocks (the rows - every bit downstream - are the same)
+static uint32_t tick_blocks(const qn_ctx* c) { const uint32_t rpb = tick_rpb(c); return (tick_rows(c) + rpb - 1) / rpb; }
 // The controller step of a producer launch (controller_tail): generation g -> g + 1 inside the launch that wrote the rows.
 static TailArgs tail_args(qn_ctx* c, int enabled, int rows, const LookArgs* look = nullptr) {
   TailArgs t; memset(&t, 0, sizeof(t));
@@ -566,9 +568,9 @@ static TickArgs tick_args(qn_ctx* c, int mode = 0) {
   TickArgs a;
   a.src = S.grid; a.tgt = T.grid; a.part_out = part_cur(c);
   a.thr2 = c->params.max_corr_dist * c->params.max_corr_dist;
-  a.nn_idx = c->nn_idx; a.nn_ref = c->nn_ref; a.nrm_s = c->nrm_s_sorted; a.tgt_rec = c->tgt_rec; a.ppt = tick_ppt(c);
+  a.nn_idx = c->nn_idx; a.nn_ref = c->nn_ref; a.nrm_s = c->nrm_s_sorted; a.tgt_rec = c->tgt_rec; a.ppt = tick_ppt(c); a.rpb = tick_rpb(c); a.rows = tick_rows(c);
   a.far_mode = c->far_enabled ? c->far_mode : 0; a.tgt_raw = T.raw; a.cand = c->far_cand; a.cand_ref = c->far_cand_ref; a.cand_b = c->far_cand_b; a.far_req = c->far_req; a.far_stats = c->far_stats;
-  a.tail = tail_args(c, (mode == 0 && a.far_mode != 1) ? 1 : 0, (int)tick_blocks(c));
+  a.tail = tail_args(c, (mode == 0 && a.far_mode != 1) ? 1 : 0, (int)tick_rows(c));
   a.aligned = c->aligned; a.fit_psum = c->fit_psum; a.fit_pcnt = c->fit_pcnt;
   a.clk = c->clk_probe ? c->clk_probe + 8 * (c->clk_n++ % 256) : nullptr; a.clk_blk = c->clk_probe ? c->clk_probe + 8 * 256 : nullptr;
   return a;
@@ -581,7 +583,7 @@ static FarArgs far_args(qn_ctx* c) {         // k_far behind the tick that just 
   return f;
 }
 static FarReduceK::Args far_reduce_args(qn_ctx* c) {      // behind k_far: the side table -> one more row, then the controller step the tick left to it
-  return FarReduceK::Args{c->far_rows, part_cur(c), (int)tick_blocks(c), c->far_stats, tail_args(c, 1, (int)tick_blocks(c) + 1)};
+  return FarReduceK::Args{c->far_rows, part_cur(c), (int)tick_rows(c), c->far_stats, tail_args(c, 1, (int)tick_rows(c) + 1)};
 }
 static void enqueue_tick_fused(qn_ctx* c) {
   TickArgs a = tick_args(c);
@@ -622,7 +624,7 @@ static void enqueue_epilogue(qn_ctx* c, double max_range, bool tracked) {
       const dim3 gr(tick_blocks(c)), bl(c->tick_tb);
       if (c->tick_tb == 256) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_tick<256, 4, 1, false>), gr, bl, 0, c->stream, a);
       else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_tick<512, 4, 1, false>), gr, bl, 0, c->stream, a); }
-    hipLaunchKernelGGL(k_finalize_fit, dim3(1), dim3(64), 0, c->stream, st_cur(c), c->result_host, c->far_stats, c->fit_psum, c->fit_pcnt, (int)tick_blocks(c));
+    hipLaunchKernelGGL(k_finalize_fit, dim3(1), dim3(64), 0, c->stream, st_cur(c), c->result_host, c->far_stats, c->fit_psum, c->fit_pcnt, (int)tick_rows(c));
     return;
   }
   GicpState* st = st_cur(c);                                    // (already stepped by the controller tail of the chunk's last tick)
@@ -663,7 +665,7 @@ static int launch_persist(qn_ctx* c, uint32_t max_ticks, int cond = 0) {
   PersistArgs A;
   A.t = tick_args(c);                                                // (tail.st_in: the state the chain left, already stepped; tail.st_out: where the reducer leaves the final state)
   A.cond = cond; A.status_host = c->pg_status_host;
-  A.t.ppt = persist_ppt(c); A.t.clk = nullptr; A.t.clk_blk = nullptr;
+  A.t.ppt = persist_ppt(c); A.t.rpb = 1; A.t.rows = 0; A.t.clk = nullptr; A.t.clk_blk = nullptr;
   A.t.far_mode = c->far_enabled ? 2 : 0;
   const uint32_t per = QN_PERSIST_TB * A.t.ppt;
   A.nblk = (c->cloud[0].n + per - 1) / per;
@@ -1142,6 +1144,7 @@ extern "C" int qn_debug_set(qn_ctx* c, const char* key, double v) {
   }
   else if (k == "tick_tb") c->tick_tb = v >= 512 ? 512 : 256;
   else if (k == "tick_ppt_min") c->tick_ppt_min = v < 1 ? 1u : (uint32_t)v;
+  else if (k == "tick_rpb") c->tick_rpb = v < 1 ? 1u : (uint32_t)v;
   else if (k == "verify_track") {
     if (v != 0 && !c->v_counters) {
       const size_t n = c->max_points;

@@ -31,7 +31,9 @@ struct TickArgs {
   int32_t* nn_idx; float4* nn_ref;
   const double* nrm_s;                 // [n][3] source normals, cell-sorted order
   const TargetRec* tgt_rec;
-  uint32_t ppt;                        // source points per thread (1 up to 131072 points)
+  uint32_t ppt;                        // source points per thread AND ROW (1 up to 131072 points)
+  uint32_t rpb, rows;                  // k_tick: a block forms `rpb` consecutive rows one after the other (batch members: fewer, longer blocks - their prologue, barrier ladder and ticket once per
+                                       // rpb x 512 points - while the rows, hence every bit downstream, stay those of rpb = 1); rows = ceil(n / (block size x ppt))
   // far queries (neighbour several cells away: no overlap there, occlusion): candidate cache + refresh requests (below)
   int far_mode;                        // 0: resolve big balls in the kernel; 1: cache, misses go to k_far (request bits); 2: cache, misses resolved in the kernel
   const float4* tgt_raw;
@@ -476,7 +478,7 @@ struct TickK {
     TickArgs a = a_in;
 
   __shared__ WaveScratch sc[TB / 64];
-  __shared__ double wsum[TB / 64][QN_NPART];
+  __shared__ double wsum[2][TB / 64][QN_NPART];                      // (two buffers: the row a block has just finished is summed while its waves start the next one)
   __shared__ TailLds tl;                                            // the state this launch runs under; in the last block: the controller's workspace and the next state
   __shared__ double sG[9];                                          // R R^T of the pose (emit_point)
   const int tid = threadIdx.x;
@@ -490,7 +492,8 @@ struct TickK {
   }
   const uint32_t lblk = xcd_block(bx, nblk);               // XCD x works on one contiguous eighth of the cell-sorted source
   // ---- pose-independent loads of this thread's first point, in flight during the prologue
-  uint32_t t = (lblk * a.ppt) * TB + tid;
+  const uint32_t row0 = lblk * a.rpb;
+  uint32_t t = (row0 * a.ppt) * TB + tid;
   bool valid = t < a.src.n;
   float4 p = valid ? a.src.pts[t] : make_float4(0, 0, 0, 0);
   int32_t j0s = valid ? a.nn_idx[t] : -1;
@@ -516,24 +519,29 @@ struct TickK {
   for (int j = 0; j < 12; j++) Tf[j] = (float)tl.sh.x0[j];
   pose_gram(tl.sh.x0, sG, tid);
   __syncthreads();
-  for (uint32_t it = 0; it < a.ppt; it++) {
-    if (it > 0) {                                                  // (only clouds beyond 131072 points)
-      t = (lblk * a.ppt + it) * TB + tid; valid = t < a.src.n;
-      p = valid ? a.src.pts[t] : make_float4(0, 0, 0, 0);
-      j0s = valid ? a.nn_idx[t] : -1;
-      ref = valid ? a.nn_ref[t] : make_float4(0, 0, 0, 0);
-      if (valid && (uint32_t)j0s < a.tgt.n) { const TargetRec* r = a.tgt_rec + j0s; rec0.p = r->p; rec0.n[0] = r->n[0]; rec0.n[1] = r->n[1]; rec0.n[2] = r->n[2]; }
+  for (uint32_t rr = 0; rr < a.rpb; rr++) {
+    const uint32_t row = row0 + rr;
+    if (row >= a.rows) break;
+    double (*ws)[QN_NPART] = wsum[rr & 1u];
+    for (uint32_t it = 0; it < a.ppt; it++) {
+      if (rr > 0 || it > 0) {                                        // (more than one point per thread: batch members, clouds beyond 131072 points)
+        t = (row * a.ppt + it) * TB + tid; valid = t < a.src.n;
+        p = valid ? a.src.pts[t] : make_float4(0, 0, 0, 0);
+        j0s = valid ? a.nn_idx[t] : -1;
+        ref = valid ? a.nn_ref[t] : make_float4(0, 0, 0, 0);
+        if (valid && (uint32_t)j0s < a.tgt.n) { const TargetRec* r = a.tgt_rec + j0s; rec0.p = r->p; rec0.n[0] = r->n[0]; rec0.n[1] = r->n[1]; rec0.n[2] = r->n[2]; }
+      }
+      tick_point<MODE, PROBE, false, true>(a, Tf, tl.sh.x0, tl.sh.xi, sG, lin, it == 0, t, valid, p, j0s, ref, na, rec0, no_t2, &sc[tid >> 6].w, sc[tid >> 6].red, ws[tid >> 6], nullptr, nullptr, probe);
     }
-    tick_point<MODE, PROBE, false, true>(a, Tf, tl.sh.x0, tl.sh.xi, sG, lin, it == 0, t, valid, p, j0s, ref, na, rec0, no_t2, &sc[tid >> 6].w, sc[tid >> 6].red, wsum[tid >> 6], nullptr, nullptr, probe);
-  }
-  __syncthreads();
-  if (MODE == 1) {
-    if (tid == 0) { double sv = 0, cv = 0; for (int w = 0; w < TB / 64; w++) { sv += wsum[w][0]; cv += wsum[w][1]; } a.fit_psum[lblk] = sv; a.fit_pcnt[lblk] = (uint32_t)cv; }
-    return;
-  }
-  if (tid < QN_NPART) { double v = 0;
+    __syncthreads();
+    if (MODE == 1) {
+      if (tid == 0) { double sv = 0, cv = 0; for (int w = 0; w < TB / 64; w++) { sv += ws[w][0]; cv += ws[w][1]; } a.fit_psum[row] = sv; a.fit_pcnt[row] = (uint32_t)cv; }
+    } else if (tid < QN_NPART) { double v = 0;
 #pragma unroll
-    for (int w = 0; w < TB / 64; w++) v += wsum[w][tid]; row_store(&a.part_out[(size_t)lblk * QN_NPART + tid], v, a.tail.enabled != 0); }
+      for (int w = 0; w < TB / 64; w++) v += ws[w][tid];
+      row_store(&a.part_out[(size_t)row * QN_NPART + late((uint32_t)tid)], v, a.tail.enabled != 0); }      // (late: the store address is formed here, not carried - spilled - across the body)
+  }
+  if (MODE == 1) return;
   if (PROBE) {
     if (probe) a.clk[5] = wall_clock64();
     if (threadIdx.x == 0) atomicMax(&a.clk[6], wall_clock64());        // latest block end
