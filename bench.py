@@ -124,7 +124,7 @@ def batched_roofline_leg(engine, ctx, pairs, lanes, rounds=3):
     ab = algorithmic_bytes()
     single_k = {"knn_select": ("k_lanes<KnnHistK<false, 32>>", N_PTS * (16 + 16 * K_COV)),
                 "gn_tick_fused": ("k_lanes<TickK<512, 4, 0, false>>", ab["gn_iteration"]),
-                "nn_search": ("k_lanes<NnSearchK<0, false, 256>>", ab["gn_iteration"]),
+                "nn_search": ("k_lanes<NnLaneK<0>>", ab["gn_iteration"]),
                 "nn_fallback": ("k_lanes<NnSearchK<0, true, 256, true>>", ab["gn_iteration"]),
                 "accumulate": ("k_lanes<AccumulateK>", ab["gn_iteration"])}
     dom = max((k for k in fam_ms if k in single_k), key=fam_ms.get)
@@ -139,7 +139,9 @@ def batched_roofline_leg(engine, ctx, pairs, lanes, rounds=3):
     def traffic_of(k):
         e = (pmc_all or {}).get("batched", {}).get(k) if isinstance(pmc_all, dict) else None
         return e.get("hbm_bytes_per_registration_launch") if isinstance(e, dict) else None
-    kernels = {k: {"kernel": single_k[k][0], "avg_launch_ms_per_registration": round(fam_avg[k], 6), "avg_batched_launch_ms": round(fam_avg[k] * lanes, 5),
+    per_lane = {"knn_select": 2}                                                 # table entries a lane contributes to one launch: the k-NN selection carries the source AND the target cloud of every lane
+    kernels = {k: {"kernel": single_k[k][0], "avg_launch_ms_per_entry": round(fam_avg[k], 6), "entries_per_launch": per_lane.get(k, 1) * lanes,
+                   "entry": "one cloud" if per_lane.get(k, 1) == 2 else "one registration", "avg_batched_launch_ms": round(fam_avg[k] * lanes * per_lane.get(k, 1), 5),
                    "launches_per_registration": round(stats[k][1] / nreg, 2), "algorithmic_bytes_per_registration_launch": single_k[k][1],
                    "achieved_GBs": round(single_k[k][1] / (fam_avg[k] * 1e-3) / 1e9, 2), "frac": round(single_k[k][1] / (fam_avg[k] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
                    "traffic": traffic_of(k)} for k in single_k if k in fam_avg}
@@ -150,7 +152,7 @@ def batched_roofline_leg(engine, ctx, pairs, lanes, rounds=3):
             "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the same batched workload (tools/gpu_round.sh <tag> pmc -> profiles/pmc_latest.json); null = not collected for this state",
             "stale_from": (pmc_all or {}).get("_meta", {}).get("tag") if isinstance(pmc_all, dict) else None,
             "lanes": lanes, "registrations_profiled": nreg,
-            "avg_batched_launch_ms": round(fam_avg[dom] * lanes, 5), "avg_launch_ms_per_registration": round(fam_avg[dom], 6), "algorithmic_bytes_per_launch": per_launch_bytes * lanes,
+            "avg_batched_launch_ms": round(fam_avg[dom] * lanes * per_lane.get(dom, 1), 5), "avg_launch_ms_per_entry": round(fam_avg[dom], 6), "algorithmic_bytes_per_launch": per_launch_bytes * lanes * per_lane.get(dom, 1),
             "family_ms_per_registration": {k: round(v, 4) for k, v in fam_ms.items()}, "kernel_ms_per_registration_one_context": round(total_ms, 4),
             "kernels": kernels,
             "path": "qn_gicp_align_batch on one context alone on the GPU: hipEvents around every k_lanes launch on the context's stream; every feature of the measured path is on "
@@ -454,6 +456,7 @@ def main():
     ap.add_argument("--pairs", type=int, default=8, help="distinct synthetic pairs (scenes) per rank, cycled over the steps (>= 2 x in-flight)")
     ap.add_argument("--in-flight", type=int, default=3, help="contexts (= hipStreams) per GPU; each registers `--lanes` candidate pairs per kernel launch")
     ap.add_argument("--lanes", type=int, default=8, help="candidate pairs per kernel launch of a context (qn_gicp_align_batch: the pair as a grid dimension); 1 = the classic one-registration-per-stream chain")
+    ap.add_argument("--c2f-in-flight", type=int, default=4, help="contexts (streams) of the batched coarse-to-fine leg (batch64.coarse_to_fine)")
     ap.add_argument("--repeats", type=int, default=5, help="extra timed repeats of the --steps block for the spread of `value` (reported in config.value_repeats)")
     ap.add_argument("--shift", type=float, default=None, help="developer: scene-window shift of the synthetic pairs in metres (default: the generator's 5 m = ~96 %% overlap; 24 = 80 %%)")
     ap.add_argument("--batch-pairs", type=int, default=64, help="BASELINE configs[3]: candidate pairs of one query, sharded over the ranks")
@@ -626,6 +629,35 @@ def main():
         batch64 = {"pairs": nb, "distinct_pairs": nb, "wall_ms": round(1e3 * bwall, 3), "pairs_per_s": round(nb / bwall, 2), "ms_per_pair": round(1e3 * bwall / nb, 4),
                    "winner_pair": int(bwin[0]), "winner_score": bwin[2], "sharding": "pair i -> rank i mod %d; qn_multi_align_best per rank on its GPU (a process that owns several GPUs gathers its 96-byte records with RCCL inside the C-ABI), all_gather of the rank winners" % world,
                    "valid_pairs_this_rank": int(sum(r.valid for r in recs))}
+        # ---- two of the 64 records against the CPU oracle (rank 0, when the CPU leg is on): a plain scene pair and a re-posed variant from the second half of the batch
+        if rank == 0 and world == 1 and not args.no_cpu_baseline and recs:
+            from oracle import oracle as orc                  # checker only
+            chk = []
+            for li in sorted({min(1, len(recs) - 1), len(recs) - 3 if len(recs) > 3 else 0}):
+                s_np, t_np = bpairs[li][0].cpu().numpy(), bpairs[li][1].cpu().numpy()
+                o = orc.GicpOracle(k=K_COV, max_iter=GN_ITERS, max_corr_dist=52.5, optimizer="gn", force_iterations=GN_ITERS)
+                o.set_source(s_np); o.compute_covariances(0); o.set_target(t_np); o.compute_covariances(1)
+                ro = o.align(); r = recs[li]
+                dT = float(np.abs(np.array(r.T, dtype=np.float32).reshape(4, 4) - ro["Tf"]).max())
+                chk.append({"pair": int(my_ids[li]), "max_abs_T_f32_diff": dT, "iterations": [int(r.iterations), int(ro["iterations"])],
+                            "score_rel_diff": abs(r.fitness - ro["fitness"]) / max(ro["fitness"], 1e-300),
+                            "ok": bool(dT <= 1e-6 and r.iterations == ro["iterations"] and abs(r.fitness - ro["fitness"]) <= 1e-6 * ro["fitness"])})
+            batch64["parity_vs_oracle"] = {"records_checked": chk, "ok": bool(all(c["ok"] for c in chk)),
+                                           "note": "the 96-byte records carry getFinalTransformation() (f32): compared with the oracle's f32 matrix"}
+        # ---- what ONE rank does at N = 8 (BASELINE configs[3]: 64 pairs over 8 GPUs = 8 pairs per rank), measurable on one GPU: the wall of an 8-pair
+        # qn_multi_align_best call, median of 10.  projected_speedup_at_8 = wall(64 pairs on one GPU) / (wall(8 pairs) + gather) - a PROJECTION: no N > 1 run exists.
+        if world == 1:
+            share = max(1, nb // 8)
+            w8 = []
+            for rep in range(11):
+                sub = [descs[(rep * share + j) % len(descs)] for j in range(share)]
+                torch.cuda.synchronize(); t8 = time.perf_counter(); r8, _ = mg.align_best(sub); torch.cuda.synchronize(); w8.append(1e3 * (time.perf_counter() - t8))
+                assert all(r.status == 0 for r in r8)
+            w8 = w8[1:]; _, g_ms = mg.timing()
+            batch64["per_rank_share_at_8"] = {"pairs": share, "wall_ms": pct(w8), "gather_ms_last": round(g_ms, 4),
+                                              "projected_speedup_at_8": round(1e3 * bwall / (float(np.median(w8)) + g_ms), 2),
+                                              "note": "a rank's whole work at N = 8 is ONE short call; projected = wall(%d pairs, 1 GPU) / (median wall(%d pairs) + gather); the gather here is a 1-rank ncclAllGather - "
+                                                      "the 8-rank one moves 8 x %d x 96 B over xGMI (latency-bound, tens of microseconds).  No N > 1 measurement exists in this repository." % (nb, share, share)}
         # ---- the same 64 distinct pairs at the reference's operating point (k = 15, LM, <= 32 iterations, the real stopping rule):
         # here the accept test `hasConverged() && score < thr` (loop_closure.cpp:129) is live, so `valid`, best_found and the arg-min of
         # qn_multi_align_best are exercised in a measured run, and the winner is the C-ABI's, not this script's
@@ -674,6 +706,55 @@ def main():
         batch64["shared_query"] = {"pairs": nb, "wall_ms": round(1e3 * swall, 3), "pairs_per_s": round(nb / swall, 2),
                                    "note": "64 candidate targets against ONE query cloud per rank: source grid + covariances prepared once per context"}
         mg.close()
+        # ---- the reference's DEFAULT per-candidate path as a batch: coarseToFineAlignment (Quatro -> transformPcd -> Nano-GICP, loop_closure.cpp:138-159 with enable_quatro_) on
+        # 64 distinct 30k-point candidate pairs (the reference's keyframe size, BASELINE configs[0]) at its operating point, through qn_coarse_to_fine_align_batch
+        if world == 1 and not args.no_quatro:
+            try:
+                NQ = 30000
+                c2f_ctxs = [engine.Context(NQ + 1024, device=local) for _ in range(max(1, args.c2f_in_flight))]
+                for cx in c2f_ctxs:
+                    cx.debug_set("batch_lanes", max(1, args.lanes))
+                    gq = engine.NanoGICP(cx); gq.setCorrespondenceRandomness(15); gq.setMaximumIterations(32); gq.setMaxCorrespondenceDistance(52.5); gq.setTransformationEpsilon(0.01); gq.bind()
+                    engine.Quatro(cx)
+                scenes = [synth.make_pair(400 + j, NQ, mode="quatro") for j in range(8)]
+                qdev = [(torch.from_numpy(s_).cuda(), torch.from_numpy(t_).cuda()) for s_, t_, _ in scenes]
+                qd = []
+                for i in range(nb):
+                    s_, t_ = qdev[i % len(qdev)]; v = i // len(qdev)
+                    if v:
+                        a = 0.02 * v; ca, sa = float(np.cos(a)), float(np.sin(a))
+                        R = torch.tensor([[ca, -sa, 0.0], [sa, ca, 0.0], [0.0, 0.0, 1.0]], dtype=torch.float32, device=t_.device)
+                        t_ = (t_ @ R.T + torch.tensor([0.3 * v, -0.2 * v, 0.0], dtype=torch.float32, device=t_.device)).contiguous()
+                    qd.append((s_, t_))
+                torch.cuda.synchronize()
+                qdescs = [(s_.data_ptr(), NQ, t_.data_ptr(), NQ, 12, 1) for s_, t_ in qd]
+                engine.coarse_to_fine_align_batch(c2f_ctxs, qdescs[:2 * len(c2f_ctxs) * max(1, args.lanes)])           # untimed: lane contexts and their Quatro buffers are created on first use
+                walls = []
+                for _ in range(3):
+                    torch.cuda.synchronize(); tq = time.perf_counter(); qr = engine.coarse_to_fine_align_batch(c2f_ctxs, qdescs); torch.cuda.synchronize(); walls.append(time.perf_counter() - tq)
+                assert all(r["status"] == 0 for r in qr)
+                qwall = float(np.median(walls))
+                e = {"pairs": nb, "points": NQ, "in_flight": len(c2f_ctxs), "lanes": max(1, args.lanes), "wall_ms": round(1e3 * qwall, 3), "pairs_per_s": round(nb / qwall, 2),
+                     "wall_ms_runs": [round(1e3 * w, 3) for w in walls], "valid_pairs": int(sum(r["valid"] for r in qr)),
+                     "config": "Quatro (r_n 0.9, r_f 1.5, cap 200, thr 35 m, noise 0.3) + Nano-GICP k=15, LM, max 32 iterations, eps_t 0.01, score thr 1.5 (SURVEY App. C)"}
+                # one pair at a time on one context, same pairs: what the batch replaces
+                t1 = time.perf_counter()
+                for (s_, t_) in qd[:8]:
+                    engine.coarse_to_fine_alignment_device(c2f_ctxs[0], s_.data_ptr(), NQ, t_.data_ptr(), NQ, 12)
+                e["one_pair_at_a_time_pairs_per_s"] = round(8 / (time.perf_counter() - t1), 2)
+                if not args.no_cpu_baseline:
+                    from oracle import oracle as orc              # checker only: record 1 and a re-posed one against the oracle
+                    chk = []
+                    for li in (1, nb - 3):
+                        o = orc.coarse_to_fine_alignment(qd[li][0].cpu().numpy(), qd[li][1].cpu().numpy())
+                        dtq, drq = synth.pose_error(qr[li]["T"], o["T"]) if o["valid"] else (0.0, 0.0)
+                        chk.append({"pair": li, "valid": [bool(qr[li]["valid"]), bool(o["valid"])], "dt_m": dtq, "dr_rad": drq, "ok": bool(qr[li]["valid"] == o["valid"] and dtq <= 1e-4 and drq <= 1e-4)})
+                    e["parity_vs_oracle"] = {"records_checked": chk, "ok": bool(all(c["ok"] for c in chk))}
+                batch64["coarse_to_fine"] = e
+                for cx in c2f_ctxs:
+                    cx.close()
+            except Exception as ex:
+                batch64["coarse_to_fine"] = {"error": repr(ex)}
 
     out = None
     if rank == 0:
@@ -765,6 +846,9 @@ def main():
         os.write(json_fd, (json.dumps(out) + "\n").encode())
         if parity is not None and not parity["ok"]:
             raise SystemExit("bench.py: the benched workload does NOT match the oracle: %r" % (parity,))
+        for name, par in (("batch64", (batch64 or {}).get("parity_vs_oracle")), ("batch64.coarse_to_fine", ((batch64 or {}).get("coarse_to_fine") or {}).get("parity_vs_oracle"))):
+            if par is not None and not par["ok"]:
+                raise SystemExit("bench.py: %s records do NOT match the oracle: %r" % (name, par))
         qpar = ((quatro or {}).get("30k") or {}).get("parity_vs_oracle") if isinstance(quatro, dict) else None
         if qpar is not None and not qpar["ok"]:
             raise SystemExit("bench.py: the Quatro stage (configs[2]) does NOT match the oracle: %r" % (qpar,))

@@ -13,6 +13,7 @@
 #include <chrono>
 #include "qn_instances.h"      // heavy template kernels: declared here, compiled in qn_inst.hip (one TU per group)
 #include "qn_context.h"
+#include "qn_pool.h"
 
 using namespace qn;
 
@@ -202,6 +203,7 @@ extern "C" void qn_ctx_destroy(qn_ctx* c) {
   for (int w = 0; w < 2; w++) { hipFree(c->q_normals[w]); hipFree(c->q_spfh[w]); hipFree(c->q_fpfh_s[w]); hipFree(c->q_fpfh[w]); hipFree(c->q_key[w]); hipFree(c->q_pair[w]); hipFree(c->q_pair_hash[w]); }
   hipFree(c->q_hit); hipFree(c->q_list); hipFree(c->q_sel); hipFree(c->q_pairs); hipFree(c->q_counts); hipFree(c->q_T); hipFree(c->q_mean); hipFree(c->q_mean_psum);
   if (c->q_host) hipHostFree(c->q_host);
+  hipFree(c->c2f_src); hipFree(c->c2f_dst);
   hipFree(c->dbg_knn_idx); hipFree(c->dbg_knn_d2); hipFree(c->dbg_counters);
   hipFree(c->v_corr); hipFree(c->v_nn_idx); hipFree(c->v_sqd); hipFree(c->v_nn_ref); hipFree(c->v_counters);
   if (c->result_host) hipHostFree(c->result_host);
@@ -880,6 +882,20 @@ extern "C" int qn_gicp_get_trace(qn_ctx* c, qn_iter_trace* out, uint32_t cap, ui
   return QN_OK;
 }
 
+// the iteration trace of the registration lane `lane` carried in the latest run of qn_gicp_align_batch (lane l of a run = the l-th pair of that run;
+// with n_pairs <= batch_lanes: pair l).  Parity tests compare a batched lane's y0 / lambda trajectory with the oracle's, iteration by iteration.
+extern "C" int qn_gicp_get_lane_trace(qn_ctx* c, uint32_t lane, qn_iter_trace* out, uint32_t cap, uint32_t* n) {
+  if (!c || !out || !n) return QN_ERR_INVALID_ARG;
+  if (c->lanes.empty()) return lane == 0 ? qn_gicp_get_trace(c, out, cap, n) : QN_ERR_NOT_READY;
+  if (lane >= c->lanes.size()) return QN_ERR_INVALID_ARG;
+  qn_ctx* l = c->lanes[lane];
+  uint32_t m = std::min(cap, l->trace_len);
+  HIPCHK(c, hipSetDevice(c->device));
+  if (m) HIPCHK(c, hipMemcpy(out, l->trace, sizeof(qn_iter_trace) * m, hipMemcpyDeviceToHost));
+  *n = m;
+  return QN_OK;
+}
+
 // LoopClosure::icpAlignment (loop_closure.cpp:110-136).  where: 0 = both clouds on the host, 1 = both on the device,
 // 2 = source on the device as packed float4 (the coarse-aligned cloud of coarseToFineAlignment), target on the host,
 // 3 = like 2 with the target on the device too.
@@ -973,10 +989,7 @@ extern "C" int qn_icp_alignment_batch(qn_ctx* const* ctxs, uint32_t n_ctx, const
       last = status[i] == QN_OK ? &p : nullptr;
     }
   };
-  std::vector<std::thread> th;
-  for (uint32_t i = 1; i < n_ctx; i++) th.emplace_back(worker, ctxs[i], use_lanes[i] != 0);
-  worker(ctxs[0], use_lanes[0] != 0);
-  for (auto& t : th) t.join();
+  qn::WorkerPool::instance().run(n_ctx, [&](uint32_t i) { worker(ctxs[i], use_lanes[i] != 0); });      // parked threads, not one std::thread per context per call (qn_pool.h)
   for (uint32_t i = 0; i < n_ctx; i++) { ctxs[i]->pair_pipeline = saved[i] != 0; ctxs[i]->persist_batch_off = saved_p[i] != 0; }
   return QN_OK;
 }

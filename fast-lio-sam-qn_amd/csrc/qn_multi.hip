@@ -21,6 +21,7 @@
 #include <thread>
 #include <vector>
 #include "../../include/qn_engine.h"
+#include "qn_pool.h"
 
 static_assert(sizeof(qn_pair_record) == 96, "result records are 96 bytes (SURVEY 8e)");
 
@@ -42,6 +43,7 @@ struct qn_multi {
   decltype(&ncclGroupEnd) p_group_end = nullptr;
   decltype(&ncclGetErrorString) p_err = nullptr;
   std::vector<double> gpu_ms; double gather_ms = 0;   // timing of the latest qn_multi_align_best: per GPU (first pair start .. last pair end), the gather
+  bool quatro_on = false;                         // enable_quatro_: pairs are coarse-to-fine registrations (qn_multi_set_quatro_params)
   bool poisoned = false;                          // a collective failed: the communicator state is undefined, every later call is refused
   std::string last_error;
 };
@@ -129,6 +131,14 @@ extern "C" int qn_multi_set_params(qn_multi* m, const qn_gicp_params* p) {
   return QN_OK;
 }
 
+extern "C" int qn_multi_set_quatro_params(qn_multi* m, const qn_quatro_params* p) {      // loop_closure.cpp:18-27 on every context; NULL: back to Nano-GICP only
+  if (!m) return QN_ERR_INVALID_ARG;
+  if (!p) { m->quatro_on = false; return QN_OK; }
+  for (auto& v : m->ctx) for (qn_ctx* c : v) { const int rc = qn_quatro_set_params(c, p); if (rc != QN_OK) return rc; }
+  m->quatro_on = true;
+  return QN_OK;
+}
+
 extern "C" int qn_multi_debug_set(qn_multi* m, const char* key, double value) {      // a developer knob (qn_debug_set) on every context, e.g. "batch_lanes"
   if (!m || !key) return QN_ERR_INVALID_ARG;
   for (auto& v : m->ctx) for (qn_ctx* c : v) { const int rc = qn_debug_set(c, key, value); if (rc != QN_OK) return rc; }
@@ -169,7 +179,13 @@ extern "C" int qn_multi_align_best(qn_multi* m, const qn_pair_desc* pairs, uint3
     std::vector<qn_pair_desc> mp; std::vector<uint32_t> ids;
     for (uint32_t l = 0; l < per; l++) { const uint64_t i = (uint64_t)g + (uint64_t)l * N; if (i < n_pairs) { mp.push_back(pairs[i]); ids.push_back((uint32_t)i); } }
     std::vector<qn_gicp_result> res(mp.size()); std::vector<int> val(mp.size(), 0), st(mp.size(), QN_ERR_HIP);
-    if (!mp.empty()) gpu_rc[g] = qn_icp_alignment_batch(m->ctx[g].data(), (uint32_t)m->ctx[g].size(), mp.data(), (uint32_t)mp.size(), score_thr, res.data(), val.data(), st.data());
+    std::vector<double> Tt;
+    if (!mp.empty() && m->quatro_on) {                                          // coarseToFineAlignment per pair (loop_closure.cpp:188-192 with enable_quatro_)
+      Tt.resize(16 * mp.size());
+      gpu_rc[g] = qn_coarse_to_fine_align_batch(m->ctx[g].data(), (uint32_t)m->ctx[g].size(), mp.data(), (uint32_t)mp.size(), score_thr, res.data(), Tt.data(), nullptr, val.data(), st.data());
+      for (size_t l = 0; l < mp.size(); l++) for (int k = 0; k < 16; k++) res[l].T[k] = (float)Tt[16 * l + k];      // the record's T = pose_between (:156), cast to the record's f32
+    }
+    else if (!mp.empty()) gpu_rc[g] = qn_icp_alignment_batch(m->ctx[g].data(), (uint32_t)m->ctx[g].size(), mp.data(), (uint32_t)mp.size(), score_thr, res.data(), val.data(), st.data());
     for (size_t l = 0; l < mp.size(); l++) {
       qn_pair_record& r = mine[g][l];
       const int s_ = gpu_rc[g] == QN_OK ? st[l] : gpu_rc[g];
@@ -179,10 +195,7 @@ extern "C" int qn_multi_align_best(qn_multi* m, const qn_pair_desc* pairs, uint3
     }
     t_end[g] = std::chrono::duration_cast<std::chrono::nanoseconds>(clk::now() - t_start).count();
   };
-  std::vector<std::thread> th;
-  for (int g = 1; g < N; g++) th.emplace_back(gpu_worker, g);
-  gpu_worker(0);
-  for (auto& t : th) t.join();
+  qn::WorkerPool::instance().run((uint32_t)N, [&](uint32_t g) { gpu_worker((int)g); });      // one parked worker per GPU (qn_pool.h); each fans out over its contexts
   m->gpu_ms.assign(N, 0.0);
   for (int g = 0; g < N; g++) m->gpu_ms[g] = 1e-6 * (double)t_end[g];
   const clk::time_point t_gather = clk::now();

@@ -492,6 +492,34 @@ def gicp_align_batch(ctx, pairs, score_thr=1.5):
     return results, list(valid), list(status)
 
 
+def coarse_to_fine_align_batch(contexts, pairs, score_thr=1.5):
+    """qn_coarse_to_fine_align_batch: n independent coarseToFineAlignment calls (loop_closure.cpp:138-159) over the contexts' lanes.  pairs as icp_alignment_batch; every
+    context must carry its NanoGICP and Quatro parameters.  -> list of dict(valid, converged, score, iterations, T (= T_gicp * T_quatro), T_quatro, T_gicp (f32 record as f64), status)"""
+    n = len(pairs)
+    descs = (PairDesc * max(n, 1))(); keep = []
+    for i, (s, ns, d, nt, stride, dev) in enumerate(pairs):
+        if not dev:
+            s = np.ascontiguousarray(s, dtype=np.float32); d = np.ascontiguousarray(d, dtype=np.float32); keep += [s, d]
+            descs[i] = PairDesc(s.ctypes.data, ns, d.ctypes.data, nt, stride, 0)
+        else:
+            descs[i] = PairDesc(s, ns, d, nt, stride, 1)
+    results = (GicpResult * max(n, 1))(); valid = (C.c_int * max(n, 1))(); status = (C.c_int * max(n, 1))()
+    Tt = np.zeros((max(n, 1), 4, 4)); Tq = np.zeros((max(n, 1), 4, 4))
+    hs = (C.c_void_p * len(contexts))(*[c.h for c in contexts])
+    st = lib().qn_coarse_to_fine_align_batch(hs, C.c_uint32(len(contexts)), descs, C.c_uint32(n), C.c_double(score_thr), results, _p(Tt), _p(Tq), valid, status)
+    if st != QN_OK:
+        raise EngineError(st, lib().qn_status_str(st).decode())
+    return [dict(valid=bool(valid[i]), converged=bool(results[i].converged), score=results[i].fitness, iterations=results[i].iterations, T=Tt[i].copy(), T_quatro=Tq[i].copy(),
+                 T_gicp=np.array(results[i].T, dtype=np.float32).reshape(4, 4).astype(np.float64), status=int(status[i])) for i in range(n)]
+
+
+def lane_trace(ctx, lane):
+    """qn_gicp_get_lane_trace: the iteration trace (y0, lambda, rho, max_dR, max_dt, inner, accepted) of lane `lane` of the latest qn_gicp_align_batch run"""
+    buf = (IterTrace * 1024)(); n = C.c_uint32()
+    ctx.check(lib().qn_gicp_get_lane_trace(ctx.h, C.c_uint32(lane), buf, C.c_uint32(1024), C.byref(n)))
+    return np.array([[t.y0, t.lambda_, t.rho, t.max_dR, t.max_dt, t.inner, t.accepted] for t in buf[:n.value]]).reshape(-1, 7)
+
+
 class PairRecord(C.Structure):
     _fields_ = [("pair_id", C.c_int32), ("status", C.c_int32), ("valid", C.c_int32), ("converged", C.c_int32), ("iterations", C.c_int32),
                 ("reserved", C.c_int32), ("fitness", C.c_double), ("T", C.c_float * 16)]
@@ -529,6 +557,10 @@ class MultiGpu:
 
     def debug_set(self, key, value):
         self._check(self._l.qn_multi_debug_set(self.h, key.encode(), C.c_double(value)))
+
+    def set_quatro_params(self, qp):
+        """enable_quatro_ (loop_closure.h:54): a QuatroParams = every pair becomes a coarseToFineAlignment; None = Nano-GICP only"""
+        self._check(self._l.qn_multi_set_quatro_params(self.h, C.byref(qp) if qp is not None else None))
 
     def timing(self):
         """(per-GPU ms [n_gpus], gather ms) of the latest align_best"""

@@ -121,6 +121,8 @@ int  qn_gicp_align(qn_ctx*, const float guess[16], qn_gicp_result* out);  /* ali
 int  qn_gicp_fitness(qn_ctx*, double max_range, double* score);       /* getFitnessScore(), loop_closure.cpp:127 */
 int  qn_gicp_transformed_source(qn_ctx*, float* xyz_out, uint32_t stride_bytes);  /* the `aligned_` cloud align() fills, loop_closure.cpp:124 */
 int  qn_gicp_get_trace(qn_ctx*, qn_iter_trace* out, uint32_t cap, uint32_t* n);
+/* the same for lane `lane` of the latest qn_gicp_align_batch run on this context (lane l of a run carries the l-th pair of that run) */
+int  qn_gicp_get_lane_trace(qn_ctx*, uint32_t lane, qn_iter_trace* out, uint32_t cap, uint32_t* n);
 
 /* LoopClosure::icpAlignment in one call (loop_closure.cpp:110-136): set x2, cov x2, align, score,
  * accept test `converged && score < score_thr` (loop_closure.cpp:129).  *valid receives is_valid_. */
@@ -215,6 +217,18 @@ int  qn_coarse_to_fine_alignment(qn_ctx*, const float* src, uint32_t ns, const f
  * only the selected correspondences (<= ~6 KB) and the result record cross PCIe                                            */
 int  qn_coarse_to_fine_alignment_device(qn_ctx*, const float* d_src, uint32_t ns, const float* d_dst, uint32_t nt, uint32_t stride_bytes, double score_thr,
                                         qn_gicp_result* gicp_out, double T_total[16], double T_quatro[16], int* valid);
+/* The reference's DEFAULT per-candidate path for MANY candidates (enable_quatro_ = true, include/loop_closure.h:54 + config.yaml:31; dispatch loop_closure.cpp:188-192 ->
+ * coarseToFineAlignment :138-159): n_pairs independent coarse-to-fine registrations over n_ctx contexts (= streams, one pooled host worker each).  Each context takes runs of
+ * `batch_lanes` pairs: the Quatro device stages of a run are enqueued back to back (one lane's buffers per pair, ONE synchronisation per run), the host solver runs per pair,
+ * transformPcd stays on the device, and the run's accepted pairs go through the GICP lanes (qn_gicp_align_batch's machinery).  Parameters: each context's own
+ * (qn_gicp_set_params / qn_quatro_set_params).  results[i] = the fine stage's record, T_total[16 i ..] = T_gicp * T_quatro (row-major f64), T_quatro (optional) = the coarse
+ * estimate, valid[i] = Quatro converged && GICP converged && score < score_thr, status[i] = the pair's own status.  Records equal qn_coarse_to_fine_alignment[_device] of
+ * the same pair bit for bit.  Memory: every lane allocates its own Quatro buffers on first use (~0.7 KB per point of max_points per lane).                              */
+int  qn_coarse_to_fine_align_batch(qn_ctx* const* ctxs, uint32_t n_ctx, const qn_pair_desc* pairs, uint32_t n_pairs, double score_thr,
+                                   qn_gicp_result* results, double* T_total, double* T_quatro, int* valid, int* status);
+/* enable_quatro_ (include/loop_closure.h:54): non-NULL = every pair of qn_multi_align_best is a coarseToFineAlignment (qn_coarse_to_fine_align_batch per GPU) with these
+ * Quatro parameters, and the records carry T_gicp * T_quatro (cast to f32: the record layout is fixed); NULL = Nano-GICP only (icpAlignment), the default.             */
+int  qn_multi_set_quatro_params(qn_multi*, const qn_quatro_params* p);
 /* The two stages upstream Quatro exposes on its own:
  *  qn_fpfh            = FPFH descriptors of one cloud (pcl::FPFHEstimationOMP with the context's radii): n x 33 f32, caller order
  *  qn_match_optimized = teaser::Matcher::optimizedMatching(thr_dist, num_max_corres, tuple_scale) on two clouds + their

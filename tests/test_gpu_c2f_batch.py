@@ -1,0 +1,125 @@
+"""qn_coarse_to_fine_align_batch: the reference's DEFAULT per-candidate path - LoopClosure::coarseToFineAlignment, Quatro -> transformPcd -> Nano-GICP ->
+T_gicp * T_quatro (fast_lio_sam_qn/src/loop_closure.cpp:138-159; enable_quatro_ = true, include/loop_closure.h:54, dispatch :188-192) - for MANY candidate pairs:
+per context the Quatro device stages of a run of pairs are enqueued back to back on the lanes' buffers, the host solver runs per pair, the accepted pairs go
+through the GICP lanes.  Every record must equal the one-pair entry point's (qn_coarse_to_fine_alignment[_device]) BIT FOR BIT, and the oracle's
+(oracle.coarse_to_fine_alignment) within the north star's 1e-4 m / 1e-4 rad."""
+import ctypes as C
+import numpy as np
+import pytest
+from qn_amd import synth
+
+pytestmark = pytest.mark.gpu
+TOL_T, TOL_R = 1e-4, 1e-4
+
+
+def make_ctx(engine, cap, lanes):
+    ctx = engine.Context(cap)
+    ctx.debug_set("batch_lanes", lanes)
+    p = engine.GicpParams(); engine.lib().qn_gicp_default_params(C.byref(p))
+    p.k_correspondences = 15; p.max_iterations = 32; p.max_corr_dist = 52.5; p.transformation_epsilon = 0.01      # SURVEY App. C (loop_closure.cpp:9-16 + config.yaml)
+    ctx.check(engine.lib().qn_gicp_set_params(ctx.h, C.byref(p)))
+    engine.Quatro(ctx)                                                                                             # quatro<> ctor: the reference's 10 arguments (loop_closure.cpp:18-27)
+    return ctx
+
+
+def same_record(a, b):
+    return (a["valid"] == b["valid"] and a["converged"] == b["converged"] and a["score"] == b["score"] and a["iterations"] == b["iterations"]
+            and np.array_equal(a["T"], b["T"]) and np.array_equal(a["T_quatro"], b["T_quatro"]))
+
+
+@pytest.mark.parametrize("n_ctx,lanes,device", [(1, 8, False), (2, 3, True)])
+def test_c2f_batch_30k_equals_the_one_pair_path_and_the_oracle(oracle, n_ctx, lanes, device):
+    import torch
+    from qn_amd import engine
+    N = 30000
+    clouds = [synth.make_pair(520 + i, N, mode="quatro")[:2] for i in range(8)]
+    ctxs = [make_ctx(engine, N + 1024, lanes) for _ in range(n_ctx)]
+    keep = []
+    if device:
+        pairs = []
+        for s, t in clouds:
+            ds, dt_ = torch.from_numpy(s).cuda(), torch.from_numpy(t).cuda(); keep += [ds, dt_]
+            pairs.append((ds.data_ptr(), len(s), dt_.data_ptr(), len(t), 12, 1))
+        torch.cuda.synchronize()
+    else:
+        pairs = [(s, len(s), t, len(t), 12, 0) for s, t in clouds]
+    got = engine.coarse_to_fine_align_batch(ctxs, pairs)
+    again = engine.coarse_to_fine_align_batch(ctxs, pairs)
+    assert all(g["status"] == 0 for g in got)
+    assert sum(c.debug_get("batch_pairs") for c in ctxs) > 0, "the fine stage did not go through the lanes"
+    one = engine.Context(N + 1024)
+    for i, ((s, t), g) in enumerate(zip(clouds, got)):
+        assert same_record(g, again[i]), "pair %d: a rerun of the batch must reproduce itself bit for bit" % i
+        if device:
+            r = engine.coarse_to_fine_alignment_device(one, pairs[i][0], len(s), pairs[i][2], len(t), 12)
+        else:
+            r = engine.coarse_to_fine_alignment(one, s, t)
+        assert same_record(g, r), "pair %d differs from the one-pair path: %r vs %r" % (i, {k: g[k] for k in ("valid", "score", "iterations")}, {k: r[k] for k in ("valid", "score", "iterations")})
+        o = oracle.coarse_to_fine_alignment(s, t)
+        assert g["valid"] == o["valid"] and g["converged"] == o["converged"], (i, g["valid"], o["valid"])
+        if o["valid"]:
+            dt, dr = synth.pose_error(g["T"], o["T"])
+            assert dt <= TOL_T and dr <= TOL_R, (i, dt, dr)
+            assert abs(g["score"] - o["score"]) <= 1e-6 * o["score"], (i, g["score"], o["score"])
+    one.close()
+    for c in ctxs:
+        c.close()
+
+
+def test_c2f_batch_with_invalid_quatro_empty_and_ragged_pairs(oracle):
+    """a pair Quatro cannot register (no correspondences: is_converged = false -> invalid, no fine stage, loop_closure.cpp:145-148), an empty candidate, pairs of different
+    sizes, 7 pairs through 2 contexts x 3 lanes: nobody disturbs a batch mate"""
+    from qn_amd import engine
+    rng = np.random.default_rng(3)
+    clouds = [synth.make_pair(560 + i, 5000 + 700 * i, extent=42.0, mode="quatro")[:2] for i in range(5)]
+    sparse = (rng.uniform(-20, 20, size=(300, 3)).astype(np.float32), rng.uniform(-20, 20, size=(280, 3)).astype(np.float32))      # too sparse for any normal
+    items = [clouds[0], sparse, clouds[1], (np.zeros((0, 3), np.float32), clouds[2][1]), clouds[2], clouds[3], clouds[4]]
+    ctxs = [make_ctx(engine, 9000, 3) for _ in range(2)]
+    got = engine.coarse_to_fine_align_batch(ctxs, [(s, len(s), t, len(t), 12, 0) for s, t in items])
+    one = engine.Context(9000)
+    for i, ((s, t), g) in enumerate(zip(items, got)):
+        if len(s) == 0:
+            assert g["status"] == engine.QN_ERR_EMPTY_CLOUD and not g["valid"]
+            continue
+        assert g["status"] == 0
+        r = engine.coarse_to_fine_alignment(one, s, t)
+        assert same_record(g, r), i
+        o = oracle.coarse_to_fine_alignment(s, t)
+        assert g["valid"] == o["valid"], i
+        if o["valid"]:
+            dt, dr = synth.pose_error(g["T"], o["T"])
+            assert dt <= TOL_T and dr <= TOL_R, (i, dt, dr)
+    assert not got[1]["valid"] and np.array_equal(got[1]["T"], np.eye(4))
+    one.close()
+    for c in ctxs:
+        c.close()
+
+
+def test_qn_multi_routes_through_coarse_to_fine_when_quatro_is_enabled(oracle):
+    """qn_multi_set_quatro_params = enable_quatro_: every pair of qn_multi_align_best is a coarseToFineAlignment; records carry T_gicp * T_quatro (f32); NULL switches back"""
+    import torch
+    from qn_amd import engine
+    clouds = [synth.make_pair(580 + i, 6000, extent=42.0, mode="quatro")[:2] for i in range(5)]
+    mg = engine.MultiGpu(torch.cuda.device_count(), 8192, in_flight=2)
+    p = engine.GicpParams(); engine.lib().qn_gicp_default_params(C.byref(p))
+    p.k_correspondences = 15; p.max_iterations = 32; p.max_corr_dist = 52.5; p.transformation_epsilon = 0.01
+    mg.set_params(p); mg.debug_set("batch_lanes", 2)
+    mg.set_quatro_params(engine.quatro_default_params())
+    recs, best = mg.align_best([(s, len(s), t, len(t), 12, 0) for s, t in clouds])
+    nvalid = 0
+    for i, ((s, t), r) in enumerate(zip(clouds, recs)):
+        o = oracle.coarse_to_fine_alignment(s, t)
+        assert r.status == 0 and bool(r.valid) == o["valid"], (i, r.status, r.valid, o["valid"])
+        if o["valid"]:
+            nvalid += 1
+            T = np.array(r.T, dtype=np.float32).reshape(4, 4).astype(np.float64)
+            assert np.abs(T - o["T"]).max() <= 2e-5, (i, np.abs(T - o["T"]).max())          # the record's f32 cast of pose_between (translations of tens of metres: 1 ulp = 4e-6)
+            assert abs(r.fitness - o["score"]) <= 1e-6 * o["score"]
+    assert nvalid >= 3 and best is not None
+    mg.set_quatro_params(None)                                                               # back to icpAlignment: Quatro-scale offsets do not converge to a valid loop with GICP alone
+    recs2, _ = mg.align_best([(s, len(s), t, len(t), 12, 0) for s, t in clouds])
+    ctx = engine.Context(8192)
+    for (s, t), r in zip(clouds, recs2):
+        e = engine.icp_alignment(ctx, s, t)
+        assert r.fitness == e["score"] and r.iterations == e["iterations"]
+    ctx.close(); mg.close()
