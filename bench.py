@@ -30,6 +30,7 @@ import numpy as np
 import torch
 
 N_PTS, K_COV, GN_ITERS = 100000, 20, 20
+C2F_TRUE_LOOP_SCENES = (402, 403, 404, 409, 410, 412, 419, 420)      # synth.make_pair(id, 30000, mode="quatro") ids on which the coarse-to-fine ORACLE registers the pair (clique 11-33, 2 LM iterations)
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec (MI355X_MICROARCH.md); 6290 GB/s measured-achievable
 FP32_VALU_PEAK_TF = 157.3    # f32 vector peak with FMA (MI355X_MICROARCH.md); 78.6 without FMA contraction
 MFMA_F16_PEAK_TF = 2500.0    # dense f16 / bf16 matrix-core peak (MI355X_MICROARCH.md)
@@ -456,6 +457,7 @@ def main():
     ap.add_argument("--pairs", type=int, default=8, help="distinct synthetic pairs (scenes) per rank, cycled over the steps (>= 2 x in-flight)")
     ap.add_argument("--in-flight", type=int, default=3, help="contexts (= hipStreams) per GPU; each registers `--lanes` candidate pairs per kernel launch")
     ap.add_argument("--lanes", type=int, default=8, help="candidate pairs per kernel launch of a context (qn_gicp_align_batch: the pair as a grid dimension); 1 = the classic one-registration-per-stream chain")
+    ap.add_argument("--c2f-scenes", type=int, nargs="*", default=None, help="developer: synth pair ids (mode quatro, 30k) of the batched coarse-to-fine leg")
     ap.add_argument("--c2f-in-flight", type=int, default=4, help="contexts (streams) of the batched coarse-to-fine leg (batch64.coarse_to_fine)")
     ap.add_argument("--repeats", type=int, default=5, help="extra timed repeats of the --steps block for the spread of `value` (reported in config.value_repeats)")
     ap.add_argument("--shift", type=float, default=None, help="developer: scene-window shift of the synthetic pairs in metres (default: the generator's 5 m = ~96 %% overlap; 24 = 80 %%)")
@@ -716,15 +718,19 @@ def main():
                     cx.debug_set("batch_lanes", max(1, args.lanes))
                     gq = engine.NanoGICP(cx); gq.setCorrespondenceRandomness(15); gq.setMaximumIterations(32); gq.setMaxCorrespondenceDistance(52.5); gq.setTransformationEpsilon(0.01); gq.bind()
                     engine.Quatro(cx)
-                scenes = [synth.make_pair(400 + j, NQ, mode="quatro") for j in range(8)]
+                # TRUE LOOPS: scenes on which the coarse estimate is right (the oracle says so too) - a revisited place, what the radius gate of fetchClosestKeyframeIdx
+                # (loop_closure.cpp:34-56) hands over.  On this generator's near-symmetric street scenes Quatro's clique collapses (4 members) for about half of the
+                # yaw-U(-180, 180) pairs, oracle and engine alike; Nano-GICP then runs its 32 iterations on misaligned clouds (every query "far") and the pair is rejected by
+                # the score test: that mix is reported separately below (`mixed_scenes`), it measures the failure path, not the registration.
+                scenes = [synth.make_pair(j, NQ, mode="quatro") for j in (args.c2f_scenes or C2F_TRUE_LOOP_SCENES)]
                 qdev = [(torch.from_numpy(s_).cuda(), torch.from_numpy(t_).cuda()) for s_, t_, _ in scenes]
                 qd = []
                 for i in range(nb):
                     s_, t_ = qdev[i % len(qdev)]; v = i // len(qdev)
                     if v:
-                        a = 0.02 * v; ca, sa = float(np.cos(a)), float(np.sin(a))
+                        a = 0.004 * v; ca, sa = float(np.cos(a)), float(np.sin(a))
                         R = torch.tensor([[ca, -sa, 0.0], [sa, ca, 0.0], [0.0, 0.0, 1.0]], dtype=torch.float32, device=t_.device)
-                        t_ = (t_ @ R.T + torch.tensor([0.3 * v, -0.2 * v, 0.0], dtype=torch.float32, device=t_.device)).contiguous()
+                        t_ = (t_ @ R.T + torch.tensor([0.02 * v, -0.01 * v, 0.0], dtype=torch.float32, device=t_.device)).contiguous()
                     qd.append((s_, t_))
                 torch.cuda.synchronize()
                 qdescs = [(s_.data_ptr(), NQ, t_.data_ptr(), NQ, 12, 1) for s_, t_ in qd]
@@ -750,6 +756,15 @@ def main():
                         dtq, drq = synth.pose_error(qr[li]["T"], o["T"]) if o["valid"] else (0.0, 0.0)
                         chk.append({"pair": li, "valid": [bool(qr[li]["valid"]), bool(o["valid"])], "dt_m": dtq, "dr_rad": drq, "ok": bool(qr[li]["valid"] == o["valid"] and dtq <= 1e-4 and drq <= 1e-4)})
                     e["parity_vs_oracle"] = {"records_checked": chk, "ok": bool(all(c["ok"] for c in chk))}
+                # the failure mix: scenes 400..407 of the generator as they come (Quatro's estimate is wrong on five of them - see above)
+                mixed = [synth.make_pair(400 + j, NQ, mode="quatro") for j in range(8)]
+                mdev = [(torch.from_numpy(s_).cuda(), torch.from_numpy(t_).cuda()) for s_, t_, _ in mixed]; torch.cuda.synchronize()
+                mdescs = [(mdev[i % 8][0].data_ptr(), NQ, mdev[i % 8][1].data_ptr(), NQ, 12, 1) for i in range(nb)]
+                engine.coarse_to_fine_align_batch(c2f_ctxs, mdescs[:8])
+                torch.cuda.synchronize(); tq = time.perf_counter(); mr = engine.coarse_to_fine_align_batch(c2f_ctxs, mdescs); torch.cuda.synchronize(); mwall = time.perf_counter() - tq
+                e["mixed_scenes"] = {"pairs": nb, "wall_ms": round(1e3 * mwall, 3), "pairs_per_s": round(nb / mwall, 2), "valid_pairs": int(sum(r["valid"] for r in mr)),
+                                     "note": "generator scenes 400-407 cycled: on five of the eight Quatro's maximum clique has 4 members and the coarse pose is wrong (oracle: same); Nano-GICP then spends its 32 LM "
+                                             "iterations on misaligned clouds before the score test rejects the pair"}
                 batch64["coarse_to_fine"] = e
                 for cx in c2f_ctxs:
                     cx.close()

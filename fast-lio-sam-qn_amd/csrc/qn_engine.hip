@@ -954,6 +954,7 @@ extern "C" int qn_icp_alignment_batch(qn_ctx* const* ctxs, uint32_t n_ctx, const
   auto worker = [&](qn_ctx* c, bool lanes) {
     if (lanes) {
       (void)hipSetDevice(c->device);
+      (void)join_target(c);                                               // a target an earlier qn_gicp_set_target left in flight on the second stream still owns scratch set 2
       const uint32_t B = (uint32_t)c->lanes.size();
       // (pairs are dealt in runs of B; towards the end of the batch - and when the batch is smaller than the lanes of all contexts together - the runs shrink to an n-th of
       //  what is left, so that the contexts finish together instead of one of them registering the last full run alone)

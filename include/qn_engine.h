@@ -153,7 +153,10 @@ int  qn_icp_alignment_batch(qn_ctx* const* ctxs, uint32_t n_ctx, const qn_pair_d
  * pair's entry of a device-resident argument table - on the context's one stream.  Each pair is an independent icpAlignment (loop_closure.cpp:110-136) with the
  * context's parameters; pairs of ONE call that name the same source buffer (pointer, size, stride) share one preparation of it - grid and covariances - the way the
  * candidates of one loop-closure query share the query cloud (qn_debug_set(ctx, "batch_share_source", 0): every pair rebuilds its source like loop_closure.cpp:120-121).
- * Records are bit-identical to qn_icp_alignment_batch's one-pair-per-stream path.  qn_icp_alignment_batch itself uses this per context.          */
+ * Records are bit-identical to qn_icp_alignment_batch's one-pair-per-stream path.  qn_icp_alignment_batch itself uses this per context.
+ * MEMORY: a context that registers batches owns `batch_lanes` - 1 sub-contexts, each with a full max_points slab (~1.2 KB per point of max_points: 119 MB at 100k), created on the
+ * first batch call: batch_lanes x in_flight x slab in total (8 x 3 x 119 MB = 2.9 GB at the bench's setting; batch_lanes = 64 at 100k is 7.6 GB per context).  If the lanes cannot be
+ * allocated, the ones created so far are freed again and both entry points register the pairs one at a time on the context itself (same records).                        */
 int  qn_gicp_align_batch(qn_ctx*, const qn_pair_desc* pairs, uint32_t n_pairs, double score_thr, qn_gicp_result* results, int* valid, int* status);
 
 /* ---- candidate pairs sharded over the GPUs of one node (BASELINE "batch of 64 candidate keyframe pairs sharded

@@ -183,3 +183,16 @@ def test_batch_strided_clouds_capacity_and_context_reuse():
     assert st[1] == engine.QN_ERR_CAPACITY and val[1] == 0
     assert rec(res[0], val[0], st[0]) == ref[0] and rec(res[2], val[2], st[2]) == ref[2]
     ctx.close()
+
+
+def test_batch_argument_arena_overflow_is_flushed_not_failed():
+    """a forced Gauss-Newton run of 1500 iterations x 8 lanes needs ~6 MB of argument tables in one segment - more than the 4 MB arena: the plan is launched in pieces
+    (it used to fail the whole batch with QN_ERR_HIP although the classic path handles the same parameters); records = the classic path's"""
+    from qn_amd import engine
+    clouds = [synth.make_pair(890 + i, 2000 + 100 * i, extent=30.0)[:2] for i in range(8)]
+    p = params(engine, k=10, optimizer="gn", force=1500, max_iter=1500)
+    ref = classic(engine, 4096, p, host_pairs(clouds[:2]))
+    got, launches, npairs = batched(engine, 4096, p, host_pairs(clouds), lanes=8)
+    assert [g[0] for g in got] == [0] * 8 and npairs == 8
+    assert got[0] == ref[0] and got[1] == ref[1]
+    assert all(g[2] == 1500 for g in got)
