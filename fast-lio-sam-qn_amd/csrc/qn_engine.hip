@@ -900,7 +900,7 @@ extern "C" int qn_gicp_get_lane_trace(qn_ctx* c, uint32_t lane, qn_iter_trace* o
 // 2 = source on the device as packed float4 (the coarse-aligned cloud of coarseToFineAlignment), target on the host,
 // 3 = like 2 with the target on the device too.
 static int icp_alignment(qn_ctx* c, const float* src, uint32_t ns, const float* dst, uint32_t nt, uint32_t stride, double thr,
-                         qn_gicp_result* out, int* valid, int where, bool reuse_source = false) {
+                         qn_gicp_result* out, int* valid, int where, bool reuse_source = false, bool target_ready = false) {
   if (!c || !out || !valid) return QN_ERR_INVALID_ARG;
   *valid = 0;
   memset(out, 0, sizeof(*out)); out->fitness = DBL_MAX;
@@ -912,8 +912,11 @@ static int icp_alignment(qn_ctx* c, const float* src, uint32_t ns, const float* 
     if ((rc = set_cloud(c, QN_SOURCE, src, ns, where >= 2 ? 16 : stride, where != 0)) != QN_OK) return rc;   // :120
     if ((rc = qn_gicp_compute_covariances(c, QN_SOURCE)) != QN_OK) return rc;         // :121
   }
-  if ((rc = set_cloud(c, QN_TARGET, dst, nt, stride, where == 1 || where == 3)) != QN_OK) return rc;     // :122 (on the second stream: see TargetScope)
-  if ((rc = qn_gicp_compute_covariances(c, QN_TARGET)) != QN_OK) return rc;         // :123
+  // target_ready: coarseToFineAlignment prepared the target (grid + covariances, :122-123) while Quatro's matching ran - it depends on nothing Quatro computes (coarse_to_fine)
+  if (!(target_ready && c->cloud[1].has_grid && c->cloud[1].has_cov && c->cloud[1].n == nt)) {
+    if ((rc = set_cloud(c, QN_TARGET, dst, nt, stride, where == 1 || where == 3)) != QN_OK) return rc;     // :122 (on the second stream: see TargetScope)
+    if ((rc = qn_gicp_compute_covariances(c, QN_TARGET)) != QN_OK) return rc;         // :123
+  }
   if ((rc = qn_gicp_align(c, nullptr, out)) != QN_OK) return rc;                    // :124, :127
   *valid = (out->converged && out->fitness < thr) ? 1 : 0;                          // :129
   return QN_OK;
@@ -1098,6 +1101,10 @@ extern "C" int qn_debug_set(qn_ctx* c, const char* key, double v) {
   else if (k == "bbox_blocks") c->bbox_blocks = std::max(1, (int)v);
   else if (k == "device_look") c->device_look = v != 0;
   else if (k == "far_group") c->far_group = (int)v;
+  else if (k == "c2f_overlap") c->c2f_overlap = v != 0;
+  else if (k == "quatro_fused") c->quatro_fused = v != 0;
+  else if (k == "normals_fg") c->normals_fg = (int)v;
+  else if (k == "fpfh_fg") c->fpfh_fg = (int)v;
   else if (k == "list_small") c->list_small = std::max(0, (int)v);
   else if (k == "far_chunk") c->far_chunk = std::max(1, (int)v);
   else if (k == "far_ranked") c->far_ranked = v != 0;

@@ -53,7 +53,7 @@ __device__ __forceinline__ void for_each_in_ball_cells(const GridView& g, float 
 // walks ~150 candidates through a chain of dependent loads: latency-bound with half the chip empty.  Eight lanes per query give 8x the
 // waves and 8x the loads in flight per query.
 #define QN_FG 8
-template <class Body>
+template <int FG = QN_FG, class Body>
 __device__ __forceinline__ void for_each_in_ball_cells_group(const GridView& g, float qx, float qy, float qz, float r, int gl, Body&& body) {
   const int bx0 = cell_coord(qx - r, g.ox, g.inv_cell, g.nx), bx1 = cell_coord(qx + r, g.ox, g.inv_cell, g.nx);
   const int by0 = cell_coord(qy - r, g.oy, g.inv_cell, g.ny), by1 = cell_coord(qy + r, g.oy, g.inv_cell, g.ny);
@@ -62,11 +62,47 @@ __device__ __forceinline__ void for_each_in_ball_cells_group(const GridView& g, 
     const int xa = max(bx0, tx << 3), xb = min(bx1, (tx << 3) + 7);
     const uint32_t k0 = cell_key(g, xa, ry, rz);
     const uint32_t s = g.cell_start[k0], e = g.cell_start[k0 + (xb - xa) + 1];
-    for (uint32_t u = s + gl; u < e; u += QN_FG) body(u, g.pts[u]);
+    for (uint32_t u = s + gl; u < e; u += FG) body(u, g.pts[u]);
   }
 }
-__device__ __forceinline__ int group_sum_i(int v) { v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); return v; }
-__device__ __forceinline__ double group_sum_d(double v) { v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); return v; }      // fixed butterfly: deterministic
+// The same walk with the segment bounds fetched UP FRONT (round 5).  The loop above pays two dependent cell_start loads per segment before it can touch a point, segment
+// after segment: a 5 x 5 x 5-cell box is ~50 segments of which ~8 hold points (surfaces), so a group spent most of its life waiting for the bounds of empty rows - 70 us for
+// a kernel whose arithmetic is a few microseconds.  Here the FG lanes of the group fetch the bounds of ALL segments in parallel (lane gl takes segments gl, gl + FG, ...)
+// into a small LDS table of the group, then walk the segments in the SAME order with the SAME dealing of the points to the lanes: body() sees exactly the sequence it saw
+// before - bit-identical sums - minus ~40 dependent round trips (measured: k_fpfh 0.157 -> 0.139 ms, k_normals_group 0.069 -> 0.064 ms at 30k, both clouds; prefetching the
+// next candidate's point on top of it measured SLOWER - 0.170 / 0.078 - and was dropped).  `seg`: this group's table (QN_SEG_CAP entries; a box with more segments takes the loop above).
+// Every lane of the wave must call (the table hand-over is a wave-level LDS fence); on = false: nothing to walk.
+#define QN_SEG_CAP 80
+template <int FG, class Body>
+__device__ __forceinline__ void for_each_in_ball_cells_group_pre(const GridView& g, bool on, float qx, float qy, float qz, float r, int gl, uint2* __restrict__ seg, Body&& body) {
+  const int bx0 = cell_coord(qx - r, g.ox, g.inv_cell, g.nx), bx1 = cell_coord(qx + r, g.ox, g.inv_cell, g.nx);
+  const int by0 = cell_coord(qy - r, g.oy, g.inv_cell, g.ny), by1 = cell_coord(qy + r, g.oy, g.inv_cell, g.ny);
+  const int bz0 = cell_coord(qz - r, g.oz, g.inv_cell, g.nz), bz1 = cell_coord(qz + r, g.oz, g.inv_cell, g.nz);
+  const int tx0 = bx0 >> 3, ntx = (bx1 >> 3) - tx0 + 1, ny = by1 - by0 + 1, nz = bz1 - bz0 + 1;
+  const int nseg = on ? nz * ny * ntx : 0;
+  const bool fits = nseg <= QN_SEG_CAP;
+  if (fits) for (int si = gl; si < nseg; si += FG) {
+    const int it = si % ntx, rest = si / ntx, ry = by0 + rest % ny, rz = bz0 + rest / ny, tx = tx0 + it;
+    const int xa = max(bx0, tx << 3), xb = min(bx1, (tx << 3) + 7);
+    const uint32_t k0 = cell_key(g, xa, ry, rz);
+    seg[si] = make_uint2(g.cell_start[k0], g.cell_start[k0 + (xb - xa) + 1]);
+  }
+  wave_lds_fence();
+  if (fits) {
+    for (int si = 0; si < nseg; si++) { const uint2 se = seg[si]; for (uint32_t u = se.x + gl; u < se.y; u += FG) body(u, g.pts[u]); }
+  } else if (on) {
+    for (int rz = bz0; rz <= bz1; rz++) for (int ry = by0; ry <= by1; ry++) for (int tx = bx0 >> 3; tx <= (bx1 >> 3); tx++) {
+      const int xa = max(bx0, tx << 3), xb = min(bx1, (tx << 3) + 7);
+      const uint32_t k0 = cell_key(g, xa, ry, rz);
+      const uint32_t s = g.cell_start[k0], e = g.cell_start[k0 + (xb - xa) + 1];
+      for (uint32_t u = s + gl; u < e; u += FG) body(u, g.pts[u]);
+    }
+  }
+  wave_lds_fence();                                                          // (the table is reused by the group's next walk, if any)
+}
+// sums over the FG (8 or 16) consecutive lanes of a group: fixed butterfly, deterministic
+template <int FG = QN_FG> __device__ __forceinline__ int group_sum_i(int v) { v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); if (FG > 8) v += __shfl_xor(v, 8); return v; }
+template <int FG = QN_FG> __device__ __forceinline__ double group_sum_d(double v) { v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); if (FG > 8) v += __shfl_xor(v, 8); return v; }
 
 // K9: PCL NormalEstimation, radius search.  normals[t] = (nx, ny, nz, 1) or NaNs.
 static __global__ void __launch_bounds__(QN_BLOCK) k_normals(GridView g, float r, float r2, float4* __restrict__ normals) {
@@ -92,6 +128,42 @@ static __global__ void __launch_bounds__(QN_BLOCK) k_normals(GridView g, float r
   normals[t] = make_float4((float)nx, (float)ny, (float)nz, 1.f);
 }
 
+// The same with FG lanes per query (round 5): at 30k points the one-query-per-lane kernel is 470 waves for 1024 SIMDs, each lane walking ~60 candidates through dependent
+// loads - 54 us of pure latency, 0.8 % of the nominal roof.  Lane gl of a group takes the candidates gl, gl + FG, ... of every segment; the count is an integer, the nine
+// f64 sums of each lane meet in a fixed butterfly.  The sums are formed in a different association than the sequential kernel's (and the oracle's index order): normals
+// agree to the last bit of f64 rounding, i.e. a handful of f32 normals per cloud differ in their last bit - the tolerance the FPFH parity tests already carry against the oracle.
+template <int FG>
+static __global__ void __launch_bounds__(QN_BLOCK) k_normals_group(GridView g, float r, float r2, float4* __restrict__ normals) {
+  g = grid_resolve(g);
+  const uint32_t t0 = (blockIdx.x * QN_BLOCK + threadIdx.x) / FG; const int gl = threadIdx.x & (FG - 1);
+  const bool in_range = t0 < g.n;
+  const uint32_t t = in_range ? t0 : 0;
+  const float4 p = g.pts[t];
+  int cnt = 0; double s[3] = {0, 0, 0}, c[6] = {0, 0, 0, 0, 0, 0};
+  __shared__ uint2 seg_tab[QN_BLOCK / FG][QN_SEG_CAP];
+  for_each_in_ball_cells_group_pre<FG>(g, in_range, p.x, p.y, p.z, r, gl, seg_tab[threadIdx.x / FG], [&](uint32_t, float4 q) __attribute__((always_inline)) {
+    if (sqdist(p.x, p.y, p.z, q.x, q.y, q.z) < r2) {
+      const double dx = (double)q.x - (double)p.x, dy = (double)q.y - (double)p.y, dz = (double)q.z - (double)p.z;
+      cnt++; s[0] += dx; s[1] += dy; s[2] += dz;
+      c[0] += dx * dx; c[1] += dx * dy; c[2] += dx * dz; c[3] += dy * dy; c[4] += dy * dz; c[5] += dz * dz;
+    }
+  });
+  cnt = group_sum_i<FG>(cnt);
+#pragma unroll
+  for (int a = 0; a < 3; a++) s[a] = group_sum_d<FG>(s[a]);
+#pragma unroll
+  for (int a = 0; a < 6; a++) c[a] = group_sum_d<FG>(c[a]);
+  if (!in_range || gl != 0) return;
+  const float qnan = __int_as_float(0x7fc00000);
+  if (cnt < 3) { normals[t] = make_float4(qnan, qnan, qnan, 0.f); return; }
+  const double inv = 1.0 / cnt, mx = s[0] * inv, my = s[1] * inv, mz = s[2] * inv;
+  const double cov[6] = {c[0] * inv - mx * mx, c[1] * inv - mx * my, c[2] * inv - mx * mz, c[3] * inv - my * my, c[4] * inv - my * mz, c[5] * inv - mz * mz};
+  double w[3], V[3][3]; sym_eig3(cov, w, V);
+  double nx = V[0][2], ny = V[1][2], nz = V[2][2];
+  if (-(nx * (double)p.x + ny * (double)p.y + nz * (double)p.z) < 0) { nx = -nx; ny = -ny; nz = -nz; }
+  normals[t] = make_float4((float)nx, (float)ny, (float)nz, 1.f);
+}
+
 // pcl::computePairFeatures in f32 with the oracle's operation order
 __device__ __forceinline__ bool pair_features(const float4 p1, const float4 n1, const float4 p2, const float4 n2, float& f1, float& f2, float& f3) {
   float dx = p2.x - p1.x, dy = p2.y - p1.y, dz = p2.z - p1.z;
@@ -114,9 +186,10 @@ __device__ __forceinline__ bool pair_features(const float4 p1, const float4 n1, 
 
 // K10: SPFH - 3 x 11-bin histograms of (theta, alpha, phi) over the r_f neighbourhood; bin = count * 100 / (n_nbrs - 1).
 // QN_FG lanes per query: integer counts, so the split of the neighbours over the lanes changes nothing.
+template <int FG>
 static __global__ void __launch_bounds__(QN_BLOCK) k_spfh(GridView g, float r, float r2, const float4* __restrict__ normals, float* __restrict__ spfh) {
   g = grid_resolve(g);
-  const uint32_t t0 = (blockIdx.x * QN_BLOCK + threadIdx.x) / QN_FG; const int gl = threadIdx.x & (QN_FG - 1);
+  const uint32_t t0 = (blockIdx.x * QN_BLOCK + threadIdx.x) / FG; const int gl = threadIdx.x & (FG - 1);
   const bool in_range = t0 < g.n;
   const uint32_t t = in_range ? t0 : 0;
   const float4 p = g.pts[t], np = normals[t];
@@ -127,7 +200,8 @@ static __global__ void __launch_bounds__(QN_BLOCK) k_spfh(GridView g, float r, f
   for (int b = 0; b < 33; b++) cnt[b] = 0;
   int nn = 0;
   const float d_pi = 1.0f / (2.0f * 3.14159265358979323846f);
-  if (active) for_each_in_ball_cells_group(g, p.x, p.y, p.z, r, gl, [&](uint32_t u, float4 q) __attribute__((always_inline)) {
+  // (the up-front segment table measured slower here - 0.147 against 0.138 ms at 30k - and faster in k_normals_group / k_fpfh: this kernel keeps the plain walk)
+  if (active) for_each_in_ball_cells_group<FG>(g, p.x, p.y, p.z, r, gl, [&](uint32_t u, float4 q) __attribute__((always_inline)) {
     if (!(sqdist(p.x, p.y, p.z, q.x, q.y, q.z) < r2)) return;
     nn++;
     if (u == t) return;
@@ -141,23 +215,24 @@ static __global__ void __launch_bounds__(QN_BLOCK) k_spfh(GridView g, float r, f
 #pragma unroll
     for (int b = 0; b < 11; b++) { cnt[b] += (h1 == b); cnt[11 + b] += (h2 == b); cnt[22 + b] += (h3 == b); }
   });
-  nn = group_sum_i(nn);
+  nn = group_sum_i<FG>(nn);
 #pragma unroll
-  for (int b = 0; b < 33; b++) cnt[b] = group_sum_i(cnt[b]);
+  for (int b = 0; b < 33; b++) cnt[b] = group_sum_i<FG>(cnt[b]);
   if (!in_range) return;
   const float incr = 100.0f / (float)(nn - 1);
-  // the group writes the row together: lane gl takes the slots gl, gl + QN_FG, ...
+  // the group writes the row together: lane gl takes the slots gl, gl + FG, ...
 #pragma unroll
-  for (int b = 0; b < QN_FROW; b++) if ((b & (QN_FG - 1)) == gl) out[b] = (active && b < 33 && cnt[b < 33 ? b : 0] > 0) ? (float)cnt[b < 33 ? b : 0] * incr : 0.f;
+  for (int b = 0; b < QN_FROW; b++) if ((b & (FG - 1)) == gl) out[b] = (active && b < 33 && cnt[b < 33 ? b : 0] > 0) ? (float)cnt[b < 33 ? b : 0] * incr : 0.f;
 }
 
 // K11: FPFH(p) = sum_q SPFH(q) / d2(p, q) over the r_f neighbourhood (d2 > 0), each 11-bin group normalised to 100.
 // QN_FG lanes per query: each lane sums its share of the neighbours in f64, the eight partial sums meet in a fixed butterfly.  (The f64
 // sums of f32-sized terms are rounded to f32 at the end: the result does not depend on the order except when a sum sits within 1e-16 of a
 // rounding boundary - no difference against the sequential oracle on any cloud tried; the parity tests hold it to 1e-4 per bin.)
+template <int FG>
 static __global__ void __launch_bounds__(QN_BLOCK) k_fpfh(GridView g, float r, float r2, const float4* __restrict__ normals, const float* __restrict__ spfh, float* __restrict__ fpfh) {
   g = grid_resolve(g);
-  const uint32_t t0 = (blockIdx.x * QN_BLOCK + threadIdx.x) / QN_FG; const int gl = threadIdx.x & (QN_FG - 1);
+  const uint32_t t0 = (blockIdx.x * QN_BLOCK + threadIdx.x) / FG; const int gl = threadIdx.x & (FG - 1);
   const bool in_range = t0 < g.n;
   const uint32_t t = in_range ? t0 : 0;
   const float4 p = g.pts[t], np = normals[t];
@@ -166,8 +241,9 @@ static __global__ void __launch_bounds__(QN_BLOCK) k_fpfh(GridView g, float r, f
   double acc[33];
 #pragma unroll
   for (int b = 0; b < 33; b++) acc[b] = 0.0;
-  if (in_range && np.x == np.x) {
-    for_each_in_ball_cells_group(g, p.x, p.y, p.z, r, gl, [&](uint32_t u, float4 q) __attribute__((always_inline)) {
+  __shared__ uint2 seg_tab[QN_BLOCK / FG][QN_SEG_CAP];
+  {
+    for_each_in_ball_cells_group_pre<FG>(g, in_range && np.x == np.x, p.x, p.y, p.z, r, gl, seg_tab[threadIdx.x / FG], [&](uint32_t u, float4 q) __attribute__((always_inline)) {
       const float d2 = sqdist(p.x, p.y, p.z, q.x, q.y, q.z);
       if (!(d2 < r2) || d2 == 0.0f) return;
       const float w = 1.0f / d2;
@@ -183,14 +259,14 @@ static __global__ void __launch_bounds__(QN_BLOCK) k_fpfh(GridView g, float r, f
     });
   }
 #pragma unroll
-  for (int b = 0; b < 33; b++) acc[b] = group_sum_d(acc[b]);
+  for (int b = 0; b < 33; b++) acc[b] = group_sum_d<FG>(acc[b]);
   if (!in_range) return;
   double sum[3] = {0, 0, 0};
 #pragma unroll
   for (int b = 0; b < 33; b++) sum[b / 11] += acc[b];
   const bool dead = !(np.x == np.x) || sum[0] == 0.0;
 #pragma unroll
-  for (int b = 0; b < QN_FROW; b++) if ((b & (QN_FG - 1)) == gl)
+  for (int b = 0; b < QN_FROW; b++) if ((b & (FG - 1)) == gl)
     out[b] = b >= 33 ? 0.f : (dead ? qnan : (float)(acc[b < 33 ? b : 0] * (sum[(b < 33 ? b : 0) / 11] != 0.0 ? 100.0 / sum[(b < 33 ? b : 0) / 11] : 0.0)));
 }
 
@@ -348,6 +424,83 @@ static __global__ void k_mean_final(const double* __restrict__ psum, uint32_t n,
   if (threadIdx.x >= 3 || blockIdx.x != 0) return;
   double t = 0; for (int b = 0; b < QN_MEAN_BLOCKS; b++) t += psum[b * 3 + threadIdx.x];
   mean3[threadIdx.x] = (float)(t / (double)n);
+}
+
+// ---- fused bookkeeping launches of the matching stage (round 5).  A quatro::align at 30k points used to issue 26 launches of ~5 us each (memsets, fills, row
+// hashes, counters, means) between its real kernels: 130 us of a 0.95 ms align.  The independent ones are one grid-stride kernel each now.
+// k_match_init: everything the stage needs zeroed / filled / hashed before the forward search.
+struct MatchInitArgs {
+  uint32_t* counts; uint32_t n_counts;                     // q_counts: hit counter, query-list counter, mean tickets
+  uint32_t* hit; uint32_t ni;                              // one flag per point of the larger cloud
+  unsigned long long* key_j; uint32_t nj; unsigned long long* key_i;      // best keys of both searches, start at QN_INF_KEY
+  float* rows0; uint32_t n0; float* rows1; uint32_t n1;    // descriptor sets: 32-bit row hash into slot 34 (k_row_hash)
+  unsigned long long* mm_table; uint32_t mm_table_n; uint32_t* mm_L; uint32_t mm_L_n; uint32_t* mm_cnt; uint32_t mm_cnt_n;      // matrix-core search: de-duplication table (all ones), lower bounds, counters (null: VALU search)
+};
+__device__ __forceinline__ void row_hash_one(float* __restrict__ r) {
+  uint32_t h = 2166136261u;
+#pragma unroll
+  for (int d = 0; d < 33; d++) { h ^= __float_as_uint(r[d]); h *= 16777619u; h ^= h >> 15; }
+  r[34] = __uint_as_float(h);
+}
+static __global__ void __launch_bounds__(256) k_match_init(MatchInitArgs a) {
+  const uint32_t t0 = blockIdx.x * 256u + threadIdx.x, stride = gridDim.x * 256u;
+  for (uint32_t i = t0; i < a.n_counts; i += stride) a.counts[i] = 0u;
+  for (uint32_t i = t0; i < a.ni; i += stride) { a.hit[i] = 0u; a.key_i[i] = QN_INF_KEY; }
+  for (uint32_t i = t0; i < a.nj; i += stride) a.key_j[i] = QN_INF_KEY;
+  for (uint32_t i = t0; i < a.n0; i += stride) row_hash_one(a.rows0 + (size_t)i * QN_FROW);
+  for (uint32_t i = t0; i < a.n1; i += stride) row_hash_one(a.rows1 + (size_t)i * QN_FROW);
+  if (a.mm_table) {
+    for (uint32_t i = t0; i < a.mm_table_n; i += stride) a.mm_table[i] = ~0ull;
+    for (uint32_t i = t0; i < a.mm_L_n; i += stride) a.mm_L[i] = 0u;
+    for (uint32_t i = t0; i < a.mm_cnt_n; i += stride) a.mm_cnt[i] = 0u;
+  }
+}
+// between the two searches: the forward winners mark their candidates (k_mark_hits), the forward survivor count is handed over, and the matrix-core search's table and
+// lower bounds are reset for the reverse search (its counters are reset by k_compact_hits_reset, the next launch: the count is read here first)
+static __global__ void __launch_bounds__(256) k_mark_hits_reset(const unsigned long long* __restrict__ j_key, uint32_t nj, uint32_t* __restrict__ hit,
+                                                                const uint32_t* __restrict__ mm_cnt, uint32_t* __restrict__ survivors_out,
+                                                                unsigned long long* __restrict__ mm_table, uint32_t mm_table_n, uint32_t* __restrict__ mm_L, uint32_t mm_L_n) {
+  const uint32_t t0 = blockIdx.x * 256u + threadIdx.x, stride = gridDim.x * 256u;
+  if (t0 == 0 && mm_cnt) *survivors_out = mm_cnt[0];
+  for (uint32_t j = t0; j < nj; j += stride) { const unsigned long long k = j_key[j]; if (k != QN_INF_KEY) hit[(uint32_t)k] = 1u; }
+  if (mm_table) {
+    for (uint32_t i = t0; i < mm_table_n; i += stride) mm_table[i] = ~0ull;
+    for (uint32_t i = t0; i < mm_L_n; i += stride) mm_L[i] = 0u;
+  }
+}
+static __global__ void __launch_bounds__(256) k_compact_hits_reset(const uint32_t* __restrict__ hit, uint32_t ni, uint32_t* __restrict__ list, uint32_t* __restrict__ count,
+                                                                   uint32_t* __restrict__ mm_cnt, uint32_t mm_cnt_n) {
+  const uint32_t t0 = blockIdx.x * 256u + threadIdx.x, stride = gridDim.x * 256u;
+  for (uint32_t i = t0; i < ni; i += stride) if (hit[i]) list[atomicAdd(count, 1u)] = i;
+  if (mm_cnt) for (uint32_t i = t0; i < mm_cnt_n; i += stride) mm_cnt[i] = 0u;
+}
+// normalizePoints' means of BOTH clouds in one launch: 2 x QN_MEAN_BLOCKS blocks form the partial sums (k_mean_partial's), the last block of each cloud to draw its
+// ticket sums them in the fixed order of k_mean_final - same bits - and zeroes the ticket for the next align
+static __global__ void __launch_bounds__(QN_BLOCK) k_means2(const float4* __restrict__ p0, uint32_t n0, const float4* __restrict__ p1, uint32_t n1,
+                                                            double* __restrict__ psum /* [2][QN_MEAN_BLOCKS][3] */, uint32_t* __restrict__ tickets /* [2], zero */, float* __restrict__ mean /* [2][4] */) {
+  __shared__ double sh[QN_BLOCK / 64][3];
+  __shared__ uint32_t last_sh;
+  const int w = blockIdx.x >= QN_MEAN_BLOCKS ? 1 : 0; const uint32_t b = blockIdx.x - (uint32_t)w * QN_MEAN_BLOCKS;
+  const float4* __restrict__ pts = w ? p1 : p0; const uint32_t n = w ? n1 : n0;
+  double* __restrict__ ps = psum + (size_t)w * QN_MEAN_BLOCKS * 3;
+  double s[3] = {0, 0, 0};
+  for (uint32_t i = b * QN_BLOCK + threadIdx.x; i < n; i += QN_MEAN_BLOCKS * QN_BLOCK) { const float4 p = pts[i]; s[0] += (double)p.x; s[1] += (double)p.y; s[2] += (double)p.z; }
+#pragma unroll
+  for (int d = 0; d < 3; d++) s[d] = wave_sum_f64_dpp(s[d]);
+  if ((threadIdx.x & 63) == 0) { for (int d = 0; d < 3; d++) sh[threadIdx.x >> 6][d] = s[d]; }
+  __syncthreads();
+  if (threadIdx.x < 3) { double t = 0; for (int v = 0; v < QN_BLOCK / 64; v++) t += sh[v][threadIdx.x]; __hip_atomic_store(&ps[b * 3 + threadIdx.x], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+  __threadfence();
+  __syncthreads();
+  if (threadIdx.x == 0) last_sh = atomicAdd(&tickets[w], 1u) == QN_MEAN_BLOCKS - 1 ? 1u : 0u;
+  __syncthreads();
+  if (!last_sh) return;
+  __threadfence();
+  if (threadIdx.x < 3) {
+    double t = 0; for (int v = 0; v < QN_MEAN_BLOCKS; v++) t += __hip_atomic_load(&ps[v * 3 + threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    mean[4 * w + threadIdx.x] = (float)(t / (double)n);
+  }
+  if (threadIdx.x == 0) tickets[w] = 0u;
 }
 
 __device__ __forceinline__ float norm_dist(const float4 a, const float* __restrict__ ma, const float4 b, const float* __restrict__ mb) {
