@@ -150,7 +150,7 @@ def batched_roofline_leg(engine, ctx, pairs, lanes, rounds=3):
     total_ms = sum(fam_ms.values())
     return {"bound": "hbm", "kernel": dom_kernel, "family": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
             "traffic": traffic_of(dom),
-            "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the same batched workload (tools/gpu_round.sh <tag> pmc -> profiles/pmc_latest.json); null = not collected for this state",
+            "traffic_source": "NOT measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the same batched workload (tools/gpu_round4.sh <tag> pmc -> profiles/pmc_latest.json, build named in stale_from); null = not collected",
             "stale_from": (pmc_all or {}).get("_meta", {}).get("tag") if isinstance(pmc_all, dict) else None,
             "lanes": lanes, "registrations_profiled": nreg,
             "avg_batched_launch_ms": round(fam_avg[dom] * lanes * per_lane.get(dom, 1), 5), "avg_launch_ms_per_entry": round(fam_avg[dom], 6), "algorithmic_bytes_per_launch": per_launch_bytes * lanes * per_lane.get(dom, 1),
@@ -782,6 +782,35 @@ def main():
         if max(1, args.lanes) >= 2:
             roofline = batched_roofline_leg(engine, ctx, pairs, max(1, args.lanes))
             roofline["single_stream_chain"] = chain_roofline
+            # ---- the SAME kernel under the load `value` is measured at: hipEvents around every batched launch of EVERY in-flight context while all of them work (one more
+            # --steps block, untimed).  This is the figure a `rocprofv3 --kernel-trace --stats` of this command reports (profiles/r5_*_kernel_stats.csv) - a launch that shares
+            # the chip with the other contexts' kernels lasts 1.5-1.8 x longer than alone - and it is the one the top-level achieved / frac are quoted on; the context-alone
+            # figures stay beside it as `alone_on_gpu`.
+            try:
+                for cx in ctxs:
+                    cx.prof_reset(); cx.prof_enable(True)
+                n_l = max(args.steps, 2 * len(ctxs) * max(1, args.lanes))
+                _, _, st_l = batch(n_l)
+                torch.cuda.synchronize()
+                assert all(x == 0 for x in st_l), st_l
+                tot, cnt = {}, {}
+                for cx in ctxs:
+                    cx.synchronize(); cx.prof_enable(False)
+                    for k, v in cx.prof_stats().items():
+                        tot[k] = tot.get(k, 0.0) + v[0]; cnt[k] = cnt.get(k, 0) + v[1]
+                fam = roofline["family"]; per_lane = {"knn_select": 2}.get(fam, 1); NL = max(1, args.lanes)
+                if cnt.get(fam, 0) > 0:
+                    per_entry = tot[fam] / cnt[fam]                       # ms per table entry of a launch (a family's `launches` count the entries its launches carried)
+                    bytes_entry = roofline["algorithmic_bytes_per_launch"] / (NL * per_lane)
+                    ach = bytes_entry / (per_entry * 1e-3) / 1e9
+                    alone = {k: roofline[k] for k in ("achieved", "frac", "avg_batched_launch_ms", "avg_launch_ms_per_entry")}
+                    roofline["alone_on_gpu"] = dict(alone, note="one context alone on the GPU (the per-kernel table `kernels` below is measured this way)")
+                    roofline["achieved"] = round(ach, 2); roofline["frac"] = round(ach / HBM_PEAK_GBS, 5)
+                    roofline["avg_batched_launch_ms"] = round(per_entry * NL * per_lane, 5); roofline["avg_launch_ms_per_entry"] = round(per_entry, 6)
+                    roofline["measured"] = "under the load `value` runs at: %d contexts x %d lanes in flight, hipEvents on every context's stream" % (len(ctxs), NL)
+                    roofline["family_ms_per_registration_under_load"] = {k: round(tot[k] / n_l, 4) for k in tot if cnt.get(k, 0) > 0}
+            except Exception as ex:
+                roofline["under_load_error"] = repr(ex)
         else:
             roofline = chain_roofline
         roofline["whole_registration"] = whole_registration(ms_step)
@@ -791,7 +820,9 @@ def main():
                 vb = json.load(open(vb_path)); qc = float(vb["quad_cycles_per_registration"])
                 chip_us = qc * 4.0 / (1024 * float(vb.get("clock_ghz", 2.1)) * 1e3)
                 roofline["valu_issue"] = {"quad_cycles_per_registration": qc, "us_of_a_fully_issuing_chip": round(chip_us, 1), "frac_of_issue_slots": round(chip_us / (ms_step * 1e3), 4),
-                                          "source": vb.get("source"), "note": "1024 SIMDs x one wave64 VALU instruction per 4 cycles; frac = that time / the measured step time of this run"}
+                                          "source": vb.get("source"), "measured_in_this_run": False,
+                                          "note": "quad_cycles_per_registration is NOT measured in this run: it is read from profiles/valu_budget_latest.json (SQ_ACTIVE_INST_VALU passes of the build named in `source`; "
+                                                  "the kernels of the GICP chain are unchanged since) - only the division by this run's step time is live.  1024 SIMDs x one wave64 VALU instruction per 4 cycles"}
             except Exception as ex:
                 roofline["valu_issue"] = {"error": repr(ex)}
         # parity of the BATCHED path on the headline workload: the timed batch's own record of pair 0 against the oracle (the classic path's check is `parity`)
