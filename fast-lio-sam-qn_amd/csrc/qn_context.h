@@ -100,6 +100,7 @@ struct qn_ctx {
   uint32_t tick_ppt_min = 1;            // source points per lane of k_tick (knob: fewer, longer blocks)
   uint32_t tick_rpb = 2;                // batch members: partial rows a k_tick block forms, one after the other (rows and results are those of 1; the launch has half the blocks)
   uint32_t tick_tb = 512;               // threads per block of k_tick (and of k_solve: both run the same row reduction)
+  int tick_lds_pad = 0;                 // experiment: dynamic LDS bytes added to the batched k_tick launches (40000 = one block per CU: the latency-bound tick then leaves half of every CU's register file to the other contexts' kernels)
   int tick_occ = 4;                     // k_tick variant: waves per SIMD the register budget allows (4 = 128 VGPRs: other streams' kernels keep half of the register file)
   // persistent align kernel (qn_persist.cuh): granule buffers, give-up status, epoch counter; `persist` = knob, `persist_batch_off` = this context works in a batch
   unsigned long long* pg_rows = nullptr; unsigned long long* pg_bc = nullptr; unsigned long long* pg_fit = nullptr; uint32_t* pg_status = nullptr; uint32_t* pg_status_host = nullptr;

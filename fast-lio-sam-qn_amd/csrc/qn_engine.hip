@@ -1166,6 +1166,7 @@ extern "C" int qn_debug_set(qn_ctx* c, const char* key, double v) {
   else if (k == "tick_tb") c->tick_tb = v >= 512 ? 512 : 256;
   else if (k == "tick_ppt_min") c->tick_ppt_min = v < 1 ? 1u : (uint32_t)v;
   else if (k == "tick_rpb") c->tick_rpb = v < 1 ? 1u : (uint32_t)v;
+  else if (k == "tick_lds_pad") c->tick_lds_pad = v < 0 ? 0 : (int)v;
   else if (k == "verify_track") {
     if (v != 0 && !c->v_counters) {
       const size_t n = c->max_points;
