@@ -110,7 +110,7 @@ struct qn_ctx {
   // verify_track (debug): scratch of the fresh search every tracked pass is compared with
   bool verify_track = false; int32_t* v_corr = nullptr; int32_t* v_nn_idx = nullptr; float* v_sqd = nullptr; float4* v_nn_ref = nullptr; uint32_t* v_counters = nullptr;
   // profiling
-  bool prof_on = false;
+  bool prof_on = false, prof_open = false; int prof_depth = 0;      // prof_open / prof_depth: a span is open / scopes nested inside it (they join it)
   std::vector<ProfSpan> spans;
   qn_kernel_stat stats[QN_K_COUNT] = {};
   std::string last_error;

@@ -30,13 +30,18 @@ void qn_ctx::set_error(const char* what, hipError_t e, int line) {
 // ------------------------------------------------------------------ profiling (bench roofline leg)
 void qn_ctx::prof_begin(int family, int count) {
   if (!prof_on) return;
+  if (prof_open) { prof_depth++; return; }      // spans do not nest: an inner scope is part of the span that is open (its family is the outer one's)
   ProfSpan sp; sp.family = family; sp.count = count;
-  if (hipEventCreate(&sp.a) != hipSuccess || hipEventCreate(&sp.b) != hipSuccess) return;
+  if (hipEventCreate(&sp.a) != hipSuccess) return;
+  if (hipEventCreate(&sp.b) != hipSuccess) { hipEventDestroy(sp.a); return; }
   hipEventRecord(sp.a, stream);
   spans.push_back(sp);
+  prof_open = true; prof_depth = 0;
 }
 void qn_ctx::prof_end() {
-  if (!prof_on || spans.empty()) return;
+  if (!prof_on || spans.empty() || !prof_open) return;
+  if (prof_depth > 0) { prof_depth--; return; }
+  prof_open = false;
   hipEventRecord(spans.back().b, stream);
 }
 void qn_ctx::prof_collect() {
@@ -44,7 +49,7 @@ void qn_ctx::prof_collect() {
     float ms = 0; if (hipEventSynchronize(sp.b) == hipSuccess && hipEventElapsedTime(&ms, sp.a, sp.b) == hipSuccess) { stats[sp.family].total_ms += ms; stats[sp.family].launches += sp.count; }
     hipEventDestroy(sp.a); hipEventDestroy(sp.b);
   }
-  spans.clear();
+  spans.clear(); prof_open = false; prof_depth = 0;
 }
 struct ProfScope { qn_ctx* c; ProfScope(qn_ctx* c_, int fam) : c(c_) { c->prof_begin(fam); } ~ProfScope() { c->prof_end(); } };
 

@@ -116,3 +116,22 @@ def test_quatro_no_correspondences_is_invalid_not_a_crash(eng):
     assert not valid and np.array_equal(T, np.eye(4))
     T, valid = engine.Quatro(ctx).align(np.zeros((0, 3), np.float32), b)
     assert not valid
+
+
+def test_profiled_quatro_align_leaves_no_error_behind(eng, pair):
+    """bench.py's Quatro leg: an align under qn_prof_enable (hipEvents around every kernel family), its statistics, then more aligns on the same context.  Profiling scopes
+    that nested (the fused bookkeeping launches of round 5 around launch_feat_nn_mm's own scope) left an end event unrecorded; hipEventElapsedTime on it poisoned
+    hipGetLastError and the NEXT grid build failed with 'invalid resource handle'."""
+    engine, ctx = eng
+    src, tgt, _ = pair
+    q = engine.Quatro(ctx)
+    T0, v0 = q.align(src, tgt)
+    ctx.prof_reset(); ctx.prof_enable(True)
+    T1, v1 = q.align(src, tgt)
+    ctx.synchronize(); ctx.prof_enable(False)
+    st = ctx.prof_stats()
+    for fam in ("fpfh_normals", "fpfh_spfh", "fpfh_fpfh", "feat_match", "match_tail"):
+        assert st[fam][1] > 0 and st[fam][0] > 0.0, (fam, st[fam])
+    T2, v2 = q.align(src, tgt)
+    r = engine.icp_alignment(ctx, src[:3000], tgt[:3000])
+    assert v0 == v1 == v2 and np.array_equal(T0, T1) and np.array_equal(T0, T2) and r["iterations"] >= 0
