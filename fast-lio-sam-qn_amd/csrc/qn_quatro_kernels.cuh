@@ -69,8 +69,10 @@ __device__ __forceinline__ void for_each_in_ball_cells_group(const GridView& g, 
 // after segment: a 5 x 5 x 5-cell box is ~50 segments of which ~8 hold points (surfaces), so a group spent most of its life waiting for the bounds of empty rows - 70 us for
 // a kernel whose arithmetic is a few microseconds.  Here the FG lanes of the group fetch the bounds of ALL segments in parallel (lane gl takes segments gl, gl + FG, ...)
 // into a small LDS table of the group, then walk the segments in the SAME order with the SAME dealing of the points to the lanes: body() sees exactly the sequence it saw
-// before - bit-identical sums - minus ~40 dependent round trips (measured: k_fpfh 0.157 -> 0.139 ms, k_normals_group 0.069 -> 0.064 ms at 30k, both clouds; prefetching the
-// next candidate's point on top of it measured SLOWER - 0.170 / 0.078 - and was dropped).  `seg`: this group's table (QN_SEG_CAP entries; a box with more segments takes the loop above).
+// before - bit-identical sums - minus ~40 dependent round trips and ~120 vector instructions of per-segment bookkeeping in every lane (tools/isa_loops.py: the segment loop of
+// k_spfh is 121 VALU instructions around a 200-instruction point loop).  Measured, both clouds of a pair: at 100k points k_spfh 0.366 -> 0.339 ms, k_fpfh 0.476 -> 0.435,
+// k_normals_group 0.125 -> 0.117; at 30k k_fpfh 0.157 -> 0.145, k_normals_group 0.069 -> 0.064, k_spfh unchanged (0.14: one round of waves, as long as its densest
+// neighbourhoods).  Prefetching the next candidate's point on top of it measured SLOWER (0.170 / 0.078) and was dropped.  `seg`: this group's table (QN_SEG_CAP entries; a box with more segments takes the loop above).
 // Every lane of the wave must call (the table hand-over is a wave-level LDS fence); on = false: nothing to walk.
 #define QN_SEG_CAP 80
 template <int FG, class Body>
@@ -81,11 +83,17 @@ __device__ __forceinline__ void for_each_in_ball_cells_group_pre(const GridView&
   const int tx0 = bx0 >> 3, ntx = (bx1 >> 3) - tx0 + 1, ny = by1 - by0 + 1, nz = bz1 - bz0 + 1;
   const int nseg = on ? nz * ny * ntx : 0;
   const bool fits = nseg <= QN_SEG_CAP;
-  if (fits) for (int si = gl; si < nseg; si += FG) {
-    const int it = si % ntx, rest = si / ntx, ry = by0 + rest % ny, rz = bz0 + rest / ny, tx = tx0 + it;
-    const int xa = max(bx0, tx << 3), xb = min(bx1, (tx << 3) + 7);
-    const uint32_t k0 = cell_key(g, xa, ry, rz);
-    seg[si] = make_uint2(g.cell_start[k0], g.cell_start[k0 + (xb - xa) + 1]);
+  // lane gl takes the (y, z) rows gl, gl + FG, ... of the box (each row = ntx segments, 1 or 2).  No integer division: a 32-bit division is ~40 instructions on this
+  // machine and four of them per segment cost what the table saves; row -> (y, z) through a float reciprocal, exact for these sizes ((r + 0.5) / ny is never an integer).
+  const float inv_ny = 1.0f / (float)max(ny, 1);
+  if (fits) for (int r = gl; r < ny * nz; r += FG) {
+    const int rzi = (int)(((float)r + 0.5f) * inv_ny), ryi = r - rzi * ny;
+    for (int it = 0; it < ntx; it++) {
+      const int tx = tx0 + it;
+      const int xa = max(bx0, tx << 3), xb = min(bx1, (tx << 3) + 7);
+      const uint32_t k0 = cell_key(g, xa, by0 + ryi, bz0 + rzi);
+      seg[r * ntx + it] = make_uint2(g.cell_start[k0], g.cell_start[k0 + (xb - xa) + 1]);
+    }
   }
   wave_lds_fence();
   if (fits) {
@@ -200,8 +208,8 @@ static __global__ void __launch_bounds__(QN_BLOCK) k_spfh(GridView g, float r, f
   for (int b = 0; b < 33; b++) cnt[b] = 0;
   int nn = 0;
   const float d_pi = 1.0f / (2.0f * 3.14159265358979323846f);
-  // (the up-front segment table measured slower here - 0.147 against 0.138 ms at 30k - and faster in k_normals_group / k_fpfh: this kernel keeps the plain walk)
-  if (active) for_each_in_ball_cells_group<FG>(g, p.x, p.y, p.z, r, gl, [&](uint32_t u, float4 q) __attribute__((always_inline)) {
+  __shared__ uint2 seg_tab[QN_BLOCK / FG][QN_SEG_CAP];
+  for_each_in_ball_cells_group_pre<FG>(g, active, p.x, p.y, p.z, r, gl, seg_tab[threadIdx.x / FG], [&](uint32_t u, float4 q) __attribute__((always_inline)) {
     if (!(sqdist(p.x, p.y, p.z, q.x, q.y, q.z) < r2)) return;
     nn++;
     if (u == t) return;
