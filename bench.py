@@ -756,6 +756,22 @@ def main():
                         dtq, drq = synth.pose_error(qr[li]["T"], o["T"]) if o["valid"] else (0.0, 0.0)
                         chk.append({"pair": li, "valid": [bool(qr[li]["valid"]), bool(o["valid"])], "dt_m": dtq, "dr_rad": drq, "ok": bool(qr[li]["valid"] == o["valid"] and dtq <= 1e-4 and drq <= 1e-4)})
                     e["parity_vs_oracle"] = {"records_checked": chk, "ok": bool(all(c["ok"] for c in chk))}
+                # the candidates of ONE query: 64 re-posed targets against scene 0's source cloud - per run of lanes the source's grid / normals / SPFH / FPFH are made once (batch_share_source)
+                s0_, t0q = qdev[0]
+                sq = []
+                for v in range(nb):
+                    a = 0.004 * (v + 1); ca, sa = float(np.cos(a)), float(np.sin(a))
+                    R = torch.tensor([[ca, -sa, 0.0], [sa, ca, 0.0], [0.0, 0.0, 1.0]], dtype=torch.float32, device=t0q.device)
+                    sq.append((t0q @ R.T + torch.tensor([0.02 * v, -0.01 * v, 0.0], dtype=torch.float32, device=t0q.device)).contiguous())
+                torch.cuda.synchronize()
+                sqd = [(s0_.data_ptr(), NQ, t_.data_ptr(), NQ, 12, 1) for t_ in sq]
+                engine.coarse_to_fine_align_batch(c2f_ctxs, sqd[:len(c2f_ctxs) * max(1, args.lanes)])
+                sw = []
+                for _ in range(3):
+                    torch.cuda.synchronize(); tq = time.perf_counter(); sr = engine.coarse_to_fine_align_batch(c2f_ctxs, sqd); torch.cuda.synchronize(); sw.append(time.perf_counter() - tq)
+                assert all(r["status"] == 0 for r in sr)
+                e["shared_query"] = {"pairs": nb, "wall_ms": round(1e3 * float(np.median(sw)), 3), "pairs_per_s": round(nb / float(np.median(sw)), 2), "valid_pairs": int(sum(r["valid"] for r in sr)),
+                                     "note": "64 candidate targets against ONE query cloud: the source's Quatro features are prepared once per run of lanes and borrowed by the other lanes"}
                 # the failure mix: scenes 400..407 of the generator as they come (Quatro's estimate is wrong on five of them - see above)
                 mixed = [synth.make_pair(400 + j, NQ, mode="quatro") for j in range(8)]
                 mdev = [(torch.from_numpy(s_).cuda(), torch.from_numpy(t_).cuda()) for s_, t_, _ in mixed]; torch.cuda.synchronize()

@@ -226,7 +226,9 @@ int  qn_coarse_to_fine_alignment_device(qn_ctx*, const float* d_src, uint32_t ns
  * transformPcd stays on the device, and the run's accepted pairs go through the GICP lanes (qn_gicp_align_batch's machinery).  Parameters: each context's own
  * (qn_gicp_set_params / qn_quatro_set_params).  results[i] = the fine stage's record, T_total[16 i ..] = T_gicp * T_quatro (row-major f64), T_quatro (optional) = the coarse
  * estimate, valid[i] = Quatro converged && GICP converged && score < score_thr, status[i] = the pair's own status.  Records equal qn_coarse_to_fine_alignment[_device] of
- * the same pair bit for bit.  Memory: every lane allocates its own Quatro buffers on first use (~0.7 KB per point of max_points per lane).                              */
+ * the same pair bit for bit.  Pairs of one run that name the same source buffer (the candidates of ONE loop-closure query) share the source's Quatro preparation - grid, normals,
+ * SPFH, FPFH are made once per run of lanes and borrowed read-only by the other lanes (qn_debug_set(ctx, "batch_share_source", 0): every pair prepares its own, same records).
+ * Memory: every lane allocates its own Quatro buffers on first use (~0.7 KB per point of max_points per lane).                                                          */
 int  qn_coarse_to_fine_align_batch(qn_ctx* const* ctxs, uint32_t n_ctx, const qn_pair_desc* pairs, uint32_t n_pairs, double score_thr,
                                    qn_gicp_result* results, double* T_total, double* T_quatro, int* valid, int* status);
 /* enable_quatro_ (include/loop_closure.h:54): non-NULL = every pair of qn_multi_align_best is a coarseToFineAlignment (qn_coarse_to_fine_align_batch per GPU) with these

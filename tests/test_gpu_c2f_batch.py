@@ -123,3 +123,38 @@ def test_qn_multi_routes_through_coarse_to_fine_when_quatro_is_enabled(oracle):
         e = engine.icp_alignment(ctx, s, t)
         assert r.fitness == e["score"] and r.iterations == e["iterations"]
     ctx.close(); mg.close()
+
+
+def test_c2f_batch_candidates_of_one_query_share_the_source_features(oracle):
+    """the candidates of ONE loop-closure query name the same source buffer: per run of lanes the source's grid, normals, SPFH and FPFH are prepared once and borrowed by the
+    other lanes (batch_share_source, as in qn_gicp_align_batch).  Records must equal the one-pair entry point's bit for bit - with the sharing on and off - and the oracle's;
+    a different source in between must be prepared on its own."""
+    from qn_amd import engine
+    src, tgt0, _ = synth.make_pair(402, 12000, mode="quatro")
+    other = synth.make_pair(403, 11000, mode="quatro")[:2]
+    src = np.ascontiguousarray(src, dtype=np.float32)
+    tg = []
+    for v in range(7):
+        a = 0.004 * v; c, s = np.cos(a), np.sin(a)
+        R = np.array([[c, -s, 0], [s, c, 0], [0, 0, 1]])
+        tg.append(np.ascontiguousarray((tgt0.astype(np.float64) @ R.T + np.array([0.02 * v, -0.01 * v, 0.0])).astype(np.float32)))
+    items = [(src, tg[0]), (src, tg[1]), (src, tg[2]), other, (src, tg[3]), (src, tg[4]), (src, tg[5]), (src, tg[6])]
+    pairs = [(s_, len(s_), t_, len(t_), 12, 0) for s_, t_ in items]
+    one = engine.Context(13024)
+    ref = [engine.coarse_to_fine_alignment(one, s_, t_) for s_, t_ in items]
+    for share in (1, 0):
+        ctxs = [make_ctx(engine, 13024, 4) for _ in range(2)]
+        for c in ctxs:
+            c.debug_set("batch_share_source", share)
+        got = engine.coarse_to_fine_align_batch(ctxs, pairs)
+        for i, (g, r) in enumerate(zip(got, ref)):
+            assert g["status"] == 0 and same_record(g, r), "pair %d (share %d) differs from the one-pair path" % (i, share)
+        for c in ctxs:
+            c.close()
+    for (s_, t_), r in list(zip(items, ref))[:4]:
+        o = oracle.coarse_to_fine_alignment(s_, t_)
+        assert r["valid"] == o["valid"]
+        if o["valid"]:
+            dt, dr = synth.pose_error(r["T"], o["T"])
+            assert dt <= TOL_T and dr <= TOL_R, (dt, dr)
+    one.close()
