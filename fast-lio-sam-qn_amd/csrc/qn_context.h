@@ -70,6 +70,8 @@ struct qn_ctx {
   uint32_t q_mm_mask = 0;
   uint2* q_mm_pairs = nullptr; uint32_t* q_mm_cnt = nullptr; uint32_t q_mm_cap = 0, q_mm_ncnt = 0; bool feat_mfma = true, feat_mm_retry = false; int feat_sample = 4 /* = QN_MM_SAMPLE */; bool feat_verify = false; int feat_min_blocks = 1536; double q_wall_ms[3] = {0, 0, 0}; unsigned long long* q_mm_vkeys = nullptr; uint32_t* q_mm_vcnt = nullptr; uint32_t feat_fallbacks = 0, feat_survivors = 0;
   bool c2f_overlap = false;            // (measured neutral, 1.386 vs 1.393 ms per 30k pair: icpAlignment already prepares the target on the second stream beside the source's k-NN - off, the proven order)              // coarseToFineAlignment: the fine stage's TARGET preparation (grid, k-NN, covariances) is enqueued behind Quatro's matching instead of after its host solve
+  bool c2f_lanes_fpfh = false;         // batched coarse-to-fine: grid builds and K9-K11 of every lane's clouds in nine k_lanes launches per run instead of eighteen launches per pair.  Built, bit-identical,
+                                       // measured (64 true-loop 30k pairs): 4 x 8 1400 vs 1405, 8 x 4 1462 vs 1466, 3 x 8 1358 vs 1398 pairs/s - the FPFH kernels are VALU-issue-bound, a shared launch buys them nothing: off
   bool quatro_fused = true;            // the matching stage's bookkeeping (memsets, fills, row hashes, hit marking, means) in four fused launches instead of nineteen
   int normals_fg = 0, fpfh_fg = 0;     // lanes per query of k_normals (1 / 8 / 16) and of k_spfh + k_fpfh (8 / 16); 0 = by cloud size (quatro_fpfh)
   float4* c2f_src = nullptr; float4* c2f_dst = nullptr;   // batched coarse-to-fine (qn_coarse_to_fine_align_batch): this lane's coarse-aligned source (transformPcd, loop_closure.cpp:152) and its target, float4 in caller order, until the GICP lanes have packed them

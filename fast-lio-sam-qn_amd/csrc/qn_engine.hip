@@ -1108,6 +1108,7 @@ extern "C" int qn_debug_set(qn_ctx* c, const char* key, double v) {
   else if (k == "far_group") c->far_group = (int)v;
   else if (k == "c2f_overlap") c->c2f_overlap = v != 0;
   else if (k == "quatro_fused") c->quatro_fused = v != 0;
+  else if (k == "c2f_lanes_fpfh") c->c2f_lanes_fpfh = v != 0;
   else if (k == "normals_fg") c->normals_fg = (int)v;
   else if (k == "fpfh_fg") c->fpfh_fg = (int)v;
   else if (k == "list_small") c->list_small = std::max(0, (int)v);

@@ -141,9 +141,9 @@ static __global__ void __launch_bounds__(QN_BLOCK) k_normals(GridView g, float r
 // f64 sums of each lane meet in a fixed butterfly.  The sums are formed in a different association than the sequential kernel's (and the oracle's index order): normals
 // agree to the last bit of f64 rounding, i.e. a handful of f32 normals per cloud differ in their last bit - the tolerance the FPFH parity tests already carry against the oracle.
 template <int FG>
-static __global__ void __launch_bounds__(QN_BLOCK) k_normals_group(GridView g, float r, float r2, float4* __restrict__ normals) {
+__device__ __forceinline__ void normals_group_body(GridView g, const float r, const float r2, float4* __restrict__ normals, const uint32_t bx) {
   g = grid_resolve(g);
-  const uint32_t t0 = (blockIdx.x * QN_BLOCK + threadIdx.x) / FG; const int gl = threadIdx.x & (FG - 1);
+  const uint32_t t0 = (bx * QN_BLOCK + threadIdx.x) / FG; const int gl = threadIdx.x & (FG - 1);
   const bool in_range = t0 < g.n;
   const uint32_t t = in_range ? t0 : 0;
   const float4 p = g.pts[t];
@@ -171,6 +171,14 @@ static __global__ void __launch_bounds__(QN_BLOCK) k_normals_group(GridView g, f
   if (-(nx * (double)p.x + ny * (double)p.y + nz * (double)p.z) < 0) { nx = -nx; ny = -ny; nz = -nz; }
   normals[t] = make_float4((float)nx, (float)ny, (float)nz, 1.f);
 }
+template <int FG>
+static __global__ void __launch_bounds__(QN_BLOCK) k_normals_group(GridView g, float r, float r2, float4* __restrict__ normals) { normals_group_body<FG>(g, r, r2, normals, blockIdx.x); }
+// the same as a functor for k_lanes<F> (the batched coarse-to-fine path carries the clouds of a whole run of candidate pairs in ONE launch)
+template <int FG> struct NormalsK {
+  static constexpr int TB = QN_BLOCK, OCC = 1;
+  struct Args { GridView g; float r, r2; float4* normals; };
+  static __device__ __forceinline__ void run(const Args& a, const uint32_t bx, const uint32_t) { normals_group_body<FG>(a.g, a.r, a.r2, a.normals, bx); }
+};
 
 // pcl::computePairFeatures in f32 with the oracle's operation order
 __device__ __forceinline__ bool pair_features(const float4 p1, const float4 n1, const float4 p2, const float4 n2, float& f1, float& f2, float& f3) {
@@ -195,9 +203,9 @@ __device__ __forceinline__ bool pair_features(const float4 p1, const float4 n1, 
 // K10: SPFH - 3 x 11-bin histograms of (theta, alpha, phi) over the r_f neighbourhood; bin = count * 100 / (n_nbrs - 1).
 // QN_FG lanes per query: integer counts, so the split of the neighbours over the lanes changes nothing.
 template <int FG>
-static __global__ void __launch_bounds__(QN_BLOCK) k_spfh(GridView g, float r, float r2, const float4* __restrict__ normals, float* __restrict__ spfh) {
+__device__ __forceinline__ void spfh_body(GridView g, const float r, const float r2, const float4* __restrict__ normals, float* __restrict__ spfh, const uint32_t bx) {
   g = grid_resolve(g);
-  const uint32_t t0 = (blockIdx.x * QN_BLOCK + threadIdx.x) / FG; const int gl = threadIdx.x & (FG - 1);
+  const uint32_t t0 = (bx * QN_BLOCK + threadIdx.x) / FG; const int gl = threadIdx.x & (FG - 1);
   const bool in_range = t0 < g.n;
   const uint32_t t = in_range ? t0 : 0;
   const float4 p = g.pts[t], np = normals[t];
@@ -232,15 +240,22 @@ static __global__ void __launch_bounds__(QN_BLOCK) k_spfh(GridView g, float r, f
 #pragma unroll
   for (int b = 0; b < QN_FROW; b++) if ((b & (FG - 1)) == gl) out[b] = (active && b < 33 && cnt[b < 33 ? b : 0] > 0) ? (float)cnt[b < 33 ? b : 0] * incr : 0.f;
 }
+template <int FG>
+static __global__ void __launch_bounds__(QN_BLOCK) k_spfh(GridView g, float r, float r2, const float4* __restrict__ normals, float* __restrict__ spfh) { spfh_body<FG>(g, r, r2, normals, spfh, blockIdx.x); }
+template <int FG> struct SpfhK {
+  static constexpr int TB = QN_BLOCK, OCC = 1;
+  struct Args { GridView g; float r, r2; const float4* normals; float* spfh; };
+  static __device__ __forceinline__ void run(const Args& a, const uint32_t bx, const uint32_t) { spfh_body<FG>(a.g, a.r, a.r2, a.normals, a.spfh, bx); }
+};
 
 // K11: FPFH(p) = sum_q SPFH(q) / d2(p, q) over the r_f neighbourhood (d2 > 0), each 11-bin group normalised to 100.
 // QN_FG lanes per query: each lane sums its share of the neighbours in f64, the eight partial sums meet in a fixed butterfly.  (The f64
 // sums of f32-sized terms are rounded to f32 at the end: the result does not depend on the order except when a sum sits within 1e-16 of a
 // rounding boundary - no difference against the sequential oracle on any cloud tried; the parity tests hold it to 1e-4 per bin.)
 template <int FG>
-static __global__ void __launch_bounds__(QN_BLOCK) k_fpfh(GridView g, float r, float r2, const float4* __restrict__ normals, const float* __restrict__ spfh, float* __restrict__ fpfh) {
+__device__ __forceinline__ void fpfh_body(GridView g, const float r, const float r2, const float4* __restrict__ normals, const float* __restrict__ spfh, float* __restrict__ fpfh, const uint32_t bx) {
   g = grid_resolve(g);
-  const uint32_t t0 = (blockIdx.x * QN_BLOCK + threadIdx.x) / FG; const int gl = threadIdx.x & (FG - 1);
+  const uint32_t t0 = (bx * QN_BLOCK + threadIdx.x) / FG; const int gl = threadIdx.x & (FG - 1);
   const bool in_range = t0 < g.n;
   const uint32_t t = in_range ? t0 : 0;
   const float4 p = g.pts[t], np = normals[t];
@@ -277,7 +292,24 @@ static __global__ void __launch_bounds__(QN_BLOCK) k_fpfh(GridView g, float r, f
   for (int b = 0; b < QN_FROW; b++) if ((b & (FG - 1)) == gl)
     out[b] = b >= 33 ? 0.f : (dead ? qnan : (float)(acc[b < 33 ? b : 0] * (sum[(b < 33 ? b : 0) / 11] != 0.0 ? 100.0 / sum[(b < 33 ? b : 0) / 11] : 0.0)));
 }
+template <int FG>
+static __global__ void __launch_bounds__(QN_BLOCK) k_fpfh(GridView g, float r, float r2, const float4* __restrict__ normals, const float* __restrict__ spfh, float* __restrict__ fpfh) { fpfh_body<FG>(g, r, r2, normals, spfh, fpfh, blockIdx.x); }
+template <int FG> struct FpfhK {
+  static constexpr int TB = QN_BLOCK, OCC = 1;
+  struct Args { GridView g; float r, r2; const float4* normals; const float* spfh; float* fpfh; };
+  static __device__ __forceinline__ void run(const Args& a, const uint32_t bx, const uint32_t) { fpfh_body<FG>(a.g, a.r, a.r2, a.normals, a.spfh, a.fpfh, bx); }
+};
 
+struct RowsToOriginalK {      // k_rows_to_original (below) for k_lanes<F>
+  static constexpr int TB = QN_BLOCK, OCC = 1;
+  struct Args { const float4* pts; uint32_t n; const float* in; float* out; int w_in, w_out; };
+  static __device__ __forceinline__ void run(const Args& a, const uint32_t bx, const uint32_t) {
+    const uint32_t t = bx * QN_BLOCK + threadIdx.x;
+    if (t >= a.n) return;
+    const uint32_t i = __float_as_uint(a.pts[t].w);
+    for (int b = 0; b < a.w_out; b++) a.out[(size_t)i * a.w_out + b] = b < a.w_in ? a.in[(size_t)t * a.w_in + b] : 0.f;
+  }
+};
 // sorted-position rows -> original-index rows (rows of `w` floats)
 static __global__ void k_rows_to_original(const float4* __restrict__ pts, uint32_t n, const float* __restrict__ in, float* __restrict__ out, int w_in, int w_out) {
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;

@@ -142,13 +142,13 @@ def test_c2f_batch_candidates_of_one_query_share_the_source_features(oracle):
     pairs = [(s_, len(s_), t_, len(t_), 12, 0) for s_, t_ in items]
     one = engine.Context(13024)
     ref = [engine.coarse_to_fine_alignment(one, s_, t_) for s_, t_ in items]
-    for share in (1, 0):
+    for share, lanes_fpfh in ((1, 0), (0, 0), (1, 1), (0, 1)):      # lanes_fpfh: grid builds + K9-K11 of all lanes in nine k_lanes launches per run (knob c2f_lanes_fpfh; measured neutral, off by default)
         ctxs = [make_ctx(engine, 13024, 4) for _ in range(2)]
         for c in ctxs:
-            c.debug_set("batch_share_source", share)
+            c.debug_set("batch_share_source", share); c.debug_set("c2f_lanes_fpfh", lanes_fpfh)
         got = engine.coarse_to_fine_align_batch(ctxs, pairs)
         for i, (g, r) in enumerate(zip(got, ref)):
-            assert g["status"] == 0 and same_record(g, r), "pair %d (share %d) differs from the one-pair path" % (i, share)
+            assert g["status"] == 0 and same_record(g, r), "pair %d (share %d, lanes_fpfh %d) differs from the one-pair path" % (i, share, lanes_fpfh)
         for c in ctxs:
             c.close()
     for (s_, t_), r in list(zip(items, ref))[:4]:
