@@ -158,3 +158,36 @@ def test_c2f_batch_candidates_of_one_query_share_the_source_features(oracle):
             dt, dr = synth.pose_error(r["T"], o["T"])
             assert dt <= TOL_T and dr <= TOL_R, (dt, dr)
     one.close()
+
+
+def test_concurrent_callers_share_the_worker_pool():
+    """two host threads, each with contexts of its own, call the batch entry points at the same time (ctypes releases the GIL): the parked workers of csrc/qn_pool.h are
+    shared by both calls (and grow with them); every record equals the same call made alone"""
+    import threading
+    from qn_amd import engine
+    cq = [synth.make_pair(590 + i, 5000, extent=42.0, mode="quatro")[:2] for i in range(6)]
+    cg = [synth.make_pair(596 + i, 6000, extent=40.0)[:2] for i in range(7)]
+    pq = [(s, len(s), t, len(t), 12, 0) for s, t in cq]; pg = [(s, len(s), t, len(t), 12, 0) for s, t in cg]
+
+    def run_c2f(out):
+        ctxs = [make_ctx(engine, 8192, 2) for _ in range(2)]
+        out.append(engine.coarse_to_fine_align_batch(ctxs, pq))
+        for c in ctxs:
+            c.close()
+
+    def run_gicp(out):
+        ctxs = [make_ctx(engine, 8192, 3) for _ in range(2)]
+        res, val, st = engine.icp_alignment_batch(ctxs, pg, score_thr=1.5)
+        out.append([(s_, v_, r_.iterations, r_.fitness, np.array(r_.T64).tobytes()) for r_, v_, s_ in zip(res, val, st)])
+        for c in ctxs:
+            c.close()
+
+    alone_q, alone_g = [], []
+    run_c2f(alone_q); run_gicp(alone_g)
+    for _ in range(3):
+        oq, og = [], []
+        th = [threading.Thread(target=run_c2f, args=(oq,)), threading.Thread(target=run_gicp, args=(og,))]
+        [t.start() for t in th]; [t.join() for t in th]
+        assert len(oq) == 1 and len(og) == 1
+        assert all(same_record(a, b) and a["status"] == b["status"] for a, b in zip(oq[0], alone_q[0]))
+        assert og[0] == alone_g[0]
