@@ -646,20 +646,26 @@ def main():
                             "ok": bool(dT <= 1e-6 and r.iterations == ro["iterations"] and abs(r.fitness - ro["fitness"]) <= 1e-6 * ro["fitness"])})
             batch64["parity_vs_oracle"] = {"records_checked": chk, "ok": bool(all(c["ok"] for c in chk)),
                                            "note": "the 96-byte records carry getFinalTransformation() (f32): compared with the oracle's f32 matrix"}
-        # ---- what ONE rank does at N = 8 (BASELINE configs[3]: 64 pairs over 8 GPUs = 8 pairs per rank), measurable on one GPU: the wall of an 8-pair
-        # qn_multi_align_best call, median of 10.  projected_speedup_at_8 = wall(64 pairs on one GPU) / (wall(8 pairs) + gather) - a PROJECTION: no N > 1 run exists.
-        if world == 1:
+        # ---- what ONE rank does at N = 8 (BASELINE configs[3]: 64 pairs over 8 GPUs = 8 pairs per rank), measurable on one GPU: the walls of 8-pair qn_multi_align_best
+        # calls over the SAME 64 pairs, eight blocks of 8 consecutive pairs (block v = the 8 scenes at re-pose variant v: the blocks differ in difficulty), median of 3 each.
+        # projected_speedup_at_8 = wall(64 pairs on one GPU) / (mean block wall + gather): what 8 ranks holding one block each would need - a PROJECTION, no N > 1 run exists.
+        if world == 1 and nb >= 16:
             share = max(1, nb // 8)
-            w8 = []
-            for rep in range(11):
-                sub = [descs[(rep * share + j) % len(descs)] for j in range(share)]
-                torch.cuda.synchronize(); t8 = time.perf_counter(); r8, _ = mg.align_best(sub); torch.cuda.synchronize(); w8.append(1e3 * (time.perf_counter() - t8))
-                assert all(r.status == 0 for r in r8)
-            w8 = w8[1:]; _, g_ms = mg.timing()
-            batch64["per_rank_share_at_8"] = {"pairs": share, "wall_ms": pct(w8), "gather_ms_last": round(g_ms, 4),
-                                              "projected_speedup_at_8": round(1e3 * bwall / (float(np.median(w8)) + g_ms), 2),
-                                              "note": "a rank's whole work at N = 8 is ONE short call; projected = wall(%d pairs, 1 GPU) / (median wall(%d pairs) + gather); the gather here is a 1-rank ncclAllGather - "
-                                                      "the 8-rank one moves 8 x %d x 96 B over xGMI (latency-bound, tens of microseconds).  No N > 1 measurement exists in this repository." % (nb, share, share)}
+            blocks = []
+            mg.align_best(descs[:share])
+            for blk in range(nb // share):
+                sub = descs[blk * share:(blk + 1) * share]; w8 = []
+                for _ in range(3):
+                    torch.cuda.synchronize(); t8 = time.perf_counter(); r8, _ = mg.align_best(sub); torch.cuda.synchronize(); w8.append(1e3 * (time.perf_counter() - t8))
+                    assert all(r.status == 0 for r in r8)
+                blocks.append(float(np.median(w8)))
+            _, g_ms = mg.timing()
+            batch64["per_rank_share_at_8"] = {"pairs": share, "block_wall_ms": [round(x, 3) for x in blocks], "mean_block_wall_ms": round(float(np.mean(blocks)), 3), "gather_ms_last": round(g_ms, 4),
+                                              "projected_speedup_at_8": round(1e3 * bwall / (float(np.mean(blocks)) + g_ms), 2),
+                                              "projected_speedup_easiest_block": round(1e3 * bwall / (min(blocks) + g_ms), 2),
+                                              "note": "a rank's whole work at N = 8 is ONE short call: 8 pairs are latency, not throughput (2 contexts x 4 lanes serve them; the chain of ~42 launches is what lasts) - the eight "
+                                                      "blocks together cost 1.5-1.6 x the 64-pair call.  projected = wall(%d pairs, 1 GPU) / (mean block wall + gather); the gather here is a 1-rank ncclAllGather - the 8-rank one "
+                                                      "moves 8 x %d x 96 B over xGMI (latency-bound, tens of microseconds).  No N > 1 measurement exists in this repository." % (nb, share)}
         # ---- the same 64 distinct pairs at the reference's operating point (k = 15, LM, <= 32 iterations, the real stopping rule):
         # here the accept test `hasConverged() && score < thr` (loop_closure.cpp:129) is live, so `valid`, best_found and the arg-min of
         # qn_multi_align_best are exercised in a measured run, and the winner is the C-ABI's, not this script's
@@ -803,20 +809,26 @@ def main():
             # the chip with the other contexts' kernels lasts 1.5-1.8 x longer than alone - and it is the one the top-level achieved / frac are quoted on; the context-alone
             # figures stay beside it as `alone_on_gpu`.
             try:
-                for cx in ctxs:
-                    cx.prof_reset(); cx.prof_enable(True)
-                n_l = max(args.steps, 2 * len(ctxs) * max(1, args.lanes))
-                _, _, st_l = batch(n_l)
-                torch.cuda.synchronize()
-                assert all(x == 0 for x in st_l), st_l
-                tot, cnt = {}, {}
-                for cx in ctxs:
-                    cx.synchronize(); cx.prof_enable(False)
-                    for k, v in cx.prof_stats().items():
-                        tot[k] = tot.get(k, 0.0) + v[0]; cnt[k] = cnt.get(k, 0) + v[1]
+                n_l = max(min(args.steps, 96), 2 * len(ctxs) * max(1, args.lanes))
                 fam = roofline["family"]; per_lane = {"knn_select": 2}.get(fam, 1); NL = max(1, args.lanes)
-                if cnt.get(fam, 0) > 0:
-                    per_entry = tot[fam] / cnt[fam]                       # ms per table entry of a launch (a family's `launches` count the entries its launches carried)
+                trials = []
+                for _ in range(3):                                        # three blocks, the median block is reported (a block that catches a clock transition reads 40 % long)
+                    for cx in ctxs:
+                        cx.prof_reset(); cx.prof_enable(True)
+                    _, _, st_l = batch(n_l)
+                    torch.cuda.synchronize()
+                    assert all(x == 0 for x in st_l), st_l
+                    tot, cnt = {}, {}
+                    for cx in ctxs:
+                        cx.synchronize(); cx.prof_enable(False)
+                        for k, v in cx.prof_stats().items():
+                            tot[k] = tot.get(k, 0.0) + v[0]; cnt[k] = cnt.get(k, 0) + v[1]
+                    if cnt.get(fam, 0) > 0:
+                        trials.append((tot[fam] / cnt[fam], tot, cnt))
+                trials.sort(key=lambda x: x[0])
+                if trials:
+                    per_entry, tot, cnt = trials[len(trials) // 2]        # ms per table entry of a launch (a family's `launches` count the entries its launches carried)
+                    roofline["under_load_trials_ms_per_entry"] = [round(x[0], 6) for x in trials]
                     bytes_entry = roofline["algorithmic_bytes_per_launch"] / (NL * per_lane)
                     ach = bytes_entry / (per_entry * 1e-3) / 1e9
                     alone = {k: roofline[k] for k in ("achieved", "frac", "avg_batched_launch_ms", "avg_launch_ms_per_entry")}

@@ -72,6 +72,7 @@ struct qn_ctx {
   bool c2f_overlap = false;            // (measured neutral, 1.386 vs 1.393 ms per 30k pair: icpAlignment already prepares the target on the second stream beside the source's k-NN - off, the proven order)              // coarseToFineAlignment: the fine stage's TARGET preparation (grid, k-NN, covariances) is enqueued behind Quatro's matching instead of after its host solve
   bool c2f_lanes_fpfh = false;         // batched coarse-to-fine: grid builds and K9-K11 of every lane's clouds in nine k_lanes launches per run instead of eighteen launches per pair.  Built, bit-identical,
                                        // measured (64 true-loop 30k pairs): 4 x 8 1400 vs 1405, 8 x 4 1462 vs 1466, 3 x 8 1358 vs 1398 pairs/s - the FPFH kernels are VALU-issue-bound, a shared launch buys them nothing: off
+  bool tgt_early = true;               // icpAlignment in one call: the target's grid build is enqueued before the source's k-NN launches (second stream busy ~50 us earlier)
   bool quatro_fused = true;            // the matching stage's bookkeeping (memsets, fills, row hashes, hit marking, means) in four fused launches instead of nineteen
   int normals_fg = 0, fpfh_fg = 0;     // lanes per query of k_normals (1 / 8 / 16) and of k_spfh + k_fpfh (8 / 16); 0 = by cloud size (quatro_fpfh)
   float4* c2f_src = nullptr; float4* c2f_dst = nullptr;   // batched coarse-to-fine (qn_coarse_to_fine_align_batch): this lane's coarse-aligned source (transformPcd, loop_closure.cpp:152) and its target, float4 in caller order, until the GICP lanes have packed them
@@ -102,6 +103,7 @@ struct qn_ctx {
   uint32_t tick_ppt_min = 1;            // source points per lane of k_tick (knob: fewer, longer blocks)
   uint32_t tick_rpb = 2;                // batch members: partial rows a k_tick block forms, one after the other (rows and results are those of 1; the launch has half the blocks)
   uint32_t tick_tb = 512;               // threads per block of k_tick (and of k_solve: both run the same row reduction)
+  int batch_min_share = 4;              // the last round of a multi-context batch call is dealt in equal shares, but not smaller than this many pairs per context (qn_icp_alignment_batch)
   int tick_lds_pad = 0;                 // experiment: dynamic LDS bytes added to the batched k_tick launches (40000 = one block per CU: the latency-bound tick then leaves half of every CU's register file to the other contexts' kernels)
   int tick_occ = 4;                     // k_tick variant: waves per SIMD the register budget allows (4 = 128 VGPRs: other streams' kernels keep half of the register file)
   // persistent align kernel (qn_persist.cuh): granule buffers, give-up status, epoch counter; `persist` = knob, `persist_batch_off` = this context works in a batch

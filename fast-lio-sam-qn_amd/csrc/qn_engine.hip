@@ -913,13 +913,19 @@ static int icp_alignment(qn_ctx* c, const float* src, uint32_t ns, const float* 
   int rc;
   // reuse_source: the context still holds this source cloud's grid and covariances (the candidates of ONE loop-closure query share their
   // source; loop_closure.cpp:116-123 rebuilds it for every call because the reference only ever tries one candidate)
-  if (!(reuse_source && c->cloud[0].has_grid && c->cloud[0].has_cov && c->cloud[0].n == ns)) {
+  const bool need_source = !(reuse_source && c->cloud[0].has_grid && c->cloud[0].has_cov && c->cloud[0].n == ns);
+  // target_ready: coarseToFineAlignment prepared the target (grid + covariances, :122-123) while Quatro's matching ran - it depends on nothing Quatro computes (coarse_to_fine)
+  const bool need_target = !(target_ready && c->cloud[1].has_grid && c->cloud[1].has_cov && c->cloud[1].n == nt);
+  // tgt_early: the target's upload + grid build (second stream, own scratch) is ENQUEUED right behind the source's, before the source's k-NN launches: the host needs
+  // ~50 us to submit those, and the second stream used to sit empty that long (lone registration: the target chain started 77 us into the call).  Same kernels, same data.
+  const bool early = c->tgt_early && need_source && need_target;
+  if (need_source) {
     if ((rc = set_cloud(c, QN_SOURCE, src, ns, where >= 2 ? 16 : stride, where != 0)) != QN_OK) return rc;   // :120
+    if (early && (rc = set_cloud(c, QN_TARGET, dst, nt, stride, where == 1 || where == 3)) != QN_OK) return rc;     // :122, early
     if ((rc = qn_gicp_compute_covariances(c, QN_SOURCE)) != QN_OK) return rc;         // :121
   }
-  // target_ready: coarseToFineAlignment prepared the target (grid + covariances, :122-123) while Quatro's matching ran - it depends on nothing Quatro computes (coarse_to_fine)
-  if (!(target_ready && c->cloud[1].has_grid && c->cloud[1].has_cov && c->cloud[1].n == nt)) {
-    if ((rc = set_cloud(c, QN_TARGET, dst, nt, stride, where == 1 || where == 3)) != QN_OK) return rc;     // :122 (on the second stream: see TargetScope)
+  if (need_target) {
+    if (!early && (rc = set_cloud(c, QN_TARGET, dst, nt, stride, where == 1 || where == 3)) != QN_OK) return rc;     // :122 (on the second stream: see TargetScope)
     if ((rc = qn_gicp_compute_covariances(c, QN_TARGET)) != QN_OK) return rc;         // :123
   }
   if ((rc = qn_gicp_align(c, nullptr, out)) != QN_OK) return rc;                    // :124, :127
@@ -941,6 +947,10 @@ extern "C" int qn_icp_alignment_device(qn_ctx* c, const float* src, uint32_t ns,
 
 // batch over several contexts (streams): one host worker thread per context, dynamic pair assignment.  A context whose batch_lanes is >= 2 (the default) takes
 // `batch_lanes` pairs at a time and registers them in lockstep, the pair as a grid dimension of every launch (qn_batch.inc); otherwise one pair at a time.
+// The last round of a batch call is dealt in equal shares so that the contexts finish together - but not in shares smaller than this: a run of two or three lanes is
+// latency, not throughput, and three contexts grinding through their k-NN phases at once slow each other down.  Measured on one MI355X, 8 pairs of 100k points (one rank's
+// whole work at 8 GPUs, tools/gpu_share8_probe.py): 3 contexts x (3 + 3 + 2) 3.52 ms, 4 x 2 3.08, 1 x 8 2.78, 2 x 4 2.46 ms.
+// (qn_ctx::batch_min_share of the FIRST context of the call, default 4; knob batch_min_share)
 namespace { bool batch_supported(const qn_ctx* c); int batch_ensure_lanes(qn_ctx* c);
             int batch_register(qn_ctx* owner, const qn_pair_desc* pairs, const uint32_t* idx, uint32_t m, double thr, qn_gicp_result* results, int* valid, int* status,
                                std::vector<const float*>& last_src, std::vector<uint64_t>& last_key); }
@@ -976,7 +986,7 @@ extern "C" int qn_icp_alignment_batch(qn_ctx* const* ctxs, uint32_t n_ctx, const
           if (rem > n_ctx * B) m = B;
           else {                                                        // the last round: what is left, in n_ctx equal shares (fixed by the first context that gets here)
             uint32_t q = final_share.load();
-            if (q == 0) { uint32_t want = std::min<uint32_t>(B, std::max<uint32_t>(1u, (rem + n_ctx - 1) / n_ctx)); if (final_share.compare_exchange_strong(q, want)) q = want; }
+            if (q == 0) { uint32_t want = std::min<uint32_t>(B, std::max<uint32_t>((uint32_t)std::max(1, ctxs[0]->batch_min_share), (rem + n_ctx - 1) / n_ctx)); if (final_share.compare_exchange_strong(q, want)) q = want; }
             m = std::min(q, rem);
           }
           if (next.compare_exchange_weak(base, base + m)) break;
@@ -1108,6 +1118,7 @@ extern "C" int qn_debug_set(qn_ctx* c, const char* key, double v) {
   else if (k == "far_group") c->far_group = (int)v;
   else if (k == "c2f_overlap") c->c2f_overlap = v != 0;
   else if (k == "quatro_fused") c->quatro_fused = v != 0;
+  else if (k == "tgt_early") c->tgt_early = v != 0;
   else if (k == "c2f_lanes_fpfh") c->c2f_lanes_fpfh = v != 0;
   else if (k == "normals_fg") c->normals_fg = (int)v;
   else if (k == "fpfh_fg") c->fpfh_fg = (int)v;
@@ -1173,6 +1184,7 @@ extern "C" int qn_debug_set(qn_ctx* c, const char* key, double v) {
   else if (k == "tick_ppt_min") c->tick_ppt_min = v < 1 ? 1u : (uint32_t)v;
   else if (k == "tick_rpb") c->tick_rpb = v < 1 ? 1u : (uint32_t)v;
   else if (k == "tick_lds_pad") c->tick_lds_pad = v < 0 ? 0 : (int)v;
+  else if (k == "batch_min_share") c->batch_min_share = v < 1 ? 1 : (int)v;
   else if (k == "verify_track") {
     if (v != 0 && !c->v_counters) {
       const size_t n = c->max_points;
