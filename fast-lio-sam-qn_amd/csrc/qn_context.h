@@ -104,6 +104,8 @@ struct qn_ctx {
   uint32_t tick_rpb = 2;                // batch members: partial rows a k_tick block forms, one after the other (rows and results are those of 1; the launch has half the blocks)
   uint32_t tick_tb = 512;               // threads per block of k_tick (and of k_solve: both run the same row reduction)
   int batch_min_share = 4;              // the last round of a multi-context batch call is dealt in equal shares, but not smaller than this many pairs per context (qn_icp_alignment_batch)
+  int knn_lds_pad = 0;                  // experiment: dynamic LDS bytes added to the batched k-NN selection launches (one-wave blocks, 8.5 KB each: 4300 -> 12 instead of 16 per CU, i.e. the issue-bound
+                                        // selection leaves a wave slot per SIMD to the other contexts' latency-bound kernels, which otherwise queue behind it - profiles/r5_final_share8_timeline.txt)
   int tick_lds_pad = 0;                 // experiment: dynamic LDS bytes added to the batched k_tick launches (40000 = one block per CU: the latency-bound tick then leaves half of every CU's register file to the other contexts' kernels)
   int tick_occ = 4;                     // k_tick variant: waves per SIMD the register budget allows (4 = 128 VGPRs: other streams' kernels keep half of the register file)
   // persistent align kernel (qn_persist.cuh): granule buffers, give-up status, epoch counter; `persist` = knob, `persist_batch_off` = this context works in a batch

@@ -1184,6 +1184,7 @@ extern "C" int qn_debug_set(qn_ctx* c, const char* key, double v) {
   else if (k == "tick_ppt_min") c->tick_ppt_min = v < 1 ? 1u : (uint32_t)v;
   else if (k == "tick_rpb") c->tick_rpb = v < 1 ? 1u : (uint32_t)v;
   else if (k == "tick_lds_pad") c->tick_lds_pad = v < 0 ? 0 : (int)v;
+  else if (k == "knn_lds_pad") c->knn_lds_pad = v < 0 ? 0 : (int)v;
   else if (k == "batch_min_share") c->batch_min_share = v < 1 ? 1 : (int)v;
   else if (k == "verify_track") {
     if (v != 0 && !c->v_counters) {
