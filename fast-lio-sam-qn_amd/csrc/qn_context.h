@@ -35,7 +35,8 @@ struct qn_ctx {
   qn::BBoxAcc* bbox_acc = nullptr; qn::BBoxAcc* bbox_acc2 = nullptr;     // bounding-box accumulators (k_pack_bbox_dims), one per stream
   unsigned long long* scan_status = nullptr; unsigned long long* scan_status2 = nullptr; uint32_t build_epoch = 0;   // look-back scan: tile status words, tagged with the build's epoch
   int far_group = -1;                   // far-list grouping (wave_search_far16): -1 = by regime (enqueue_nn), 0 = off, n = ceil(list length / n) entries per wave for every list
-  int far_chunk = 4;                    // tracked ticks of a forced run that keep the far-query refresh kernel behind them before the host looks again
+  int far_chunk = 2;                    // tracked ticks of a forced run that keep the far-query refresh kernel behind them before the host looks again (round 5: 4 -> 2: the refresh regime is over after
+                                        // two ticks on the 80 %-overlap pairs - 2332 -> 2400 registrations/s on 3 x 8, lone registration 1.279 -> 1.252 ms; aligned pairs unchanged; 1 and 3 measured between)
   bool batch_look = false;              // batch members take the device-side look as well (third unseeded iteration conditional): measured neutral for throughput (2239-2253 vs 2246-2247), off
   bool far_ranked = true;               // k_far deals its requests by global rank (off: the word-per-block distribution that clouds beyond 262144 points use)
   unsigned long long* list_probe = nullptr;   // developer probe (knob list_probe)
