@@ -1,6 +1,6 @@
 """Developer sweep (GPU box), ONE process, pairs generated once: throughput of the headline workload (BASELINE configs[1]) for (contexts x lanes) under several
 knob sets, then the lone-registration latency (one registration at a time on one stream, and align() alone) under several knob sets.
-usage: python tools/gpu_knob_sweep.py '<json: {"cfgs": ["3x8", ...], "knobs": [{}, {"tick_rpb": 3}, ...], "lone_knobs": [{}, {"nn_lane": 1}], "steps": 200, "shift": null}>'"""
+usage: python tools/gpu_knob_sweep.py '<json: {"cfgs": ["3x8", ...], "knobs": [{}, {"tick_rpb": 3}, ...], "lone_knobs": [{}, {"nn_lane": 1}], "steps": 200, "shift": null, "params": "rop" (optional: LM at the reference's operating point instead of 20 forced GN)}>'"""
 import os, sys, time, json
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "fast-lio-sam-qn_amd"))
@@ -19,7 +19,11 @@ torch.cuda.synchronize()
 
 
 def bind(cx):
-    g = engine.NanoGICP(cx); g.setCorrespondenceRandomness(20); g.setMaximumIterations(20); g.setMaxCorrespondenceDistance(52.5); g.setOptimizer("gn"); g.setForceIterations(20); g.bind()
+    g = engine.NanoGICP(cx)
+    if spec.get("params") == "rop":      # the reference's operating point: k = 15, LM, <= 32 iterations, the real stopping rule
+        g.setCorrespondenceRandomness(15); g.setMaximumIterations(32); g.setMaxCorrespondenceDistance(52.5); g.setTransformationEpsilon(0.01); g.bind()
+    else:
+        g.setCorrespondenceRandomness(20); g.setMaximumIterations(20); g.setMaxCorrespondenceDistance(52.5); g.setOptimizer("gn"); g.setForceIterations(20); g.bind()
     return g
 
 
