@@ -88,6 +88,10 @@ struct qn_ctx {
   int track_from_tick = 3;              // NN passes before this tick search unseeded (ball around the query) instead of tracking the previous neighbour
   int fused_from_tick = 3;
   int unseeded_until = 3; bool count_far_now = false; int last_extra_unseeded = 0;   // per align: ticks below this index search unseeded; far-query statistics of this pass; the adaptive decision (debug read-back)
+  int unseeded_cap = 10;                // batch members: a lane whose latest pose step still moves the source by more than 0.4 target cells at the end of its unseeded ticks runs ONE MORE outer
+                                        // iteration unseeded and the host looks again, up to this many unseeded outer iterations per align (<= track_from_tick: the fixed schedule).  A tracked tick behind a
+                                        // step of metres re-searches every neighbourhood cooperatively inside the tick (100-1800 us per 4-lane launch, and the launch ends with its slowest lane); the
+                                        // dedicated unseeded search does not care (round 6: an 8-pair call of the hardest re-pose variant 5.64 -> 3.2 ms)
   int single_from_tick = 2;             // the same hand-over for a registration that is alone on the GPU (not a batch member): one tick earlier - the tracked tick is the slower
                                         // kernel for the large early steps, but it saves four launches and the persistent kernel starts sooner (align 0.506 -> 0.477 ms; batches: 2268 -> 2031 /s)
   bool fused_final = true;              // closing pass (last controller step + fitness sweep + output cloud) in one launch

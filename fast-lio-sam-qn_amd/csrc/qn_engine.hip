@@ -694,6 +694,24 @@ static int launch_persist(qn_ctx* c, uint32_t max_ticks, int cond = 0) {
   return QN_OK;
 }
 
+// Batch members: does the lane's unseeded phase go on for one more outer iteration?  The pose step the controller just took (step_dt / step_dr of the result block the chunk's
+// k_finalize / closing pass wrote; the same quantity as look_decide's) would move the source points by more than 0.4 target cells: the NEXT step is then still large enough that a
+// tracked tick - which re-finds every neighbour inside the ball of its previous one - degenerates into cooperative big-ball searches for most of the cloud inside the tick (an
+// initial misalignment of a few degrees more than the bench's default turns one 25 us tick launch into 200-1800 us, and a launch ends with its slowest lane), while the dedicated
+// unseeded search costs the same whatever the step was.  Searches are exact in both regimes; the rule only decides which kernels run, and it reads nothing but the controller's own
+// step and the grids' numbers - the classic batch-member path (gicp_align) and the lanes (batch_register) take the same decision, so their records stay bit-identical.
+static bool unseeded_goes_on(const qn_ctx* c, int tick_no, int per_outer, int ticks_left) {
+  if (!c->persist_batch_off || !c->far_enabled || !c->fused_ticks) return false;
+  if (tick_no != c->unseeded_until || tick_no + per_outer > c->unseeded_cap * per_outer || ticks_left < per_outer) return false;
+  const qn::ResultBlock* rb = c->result_host;
+  if (rb->phase == 2) return false;
+  const GridDims& sg = *c->cloud[0].dims_host;                       // (valid: the stream has been synchronised since the grids were built)
+  double reach2 = 0; const double lo[3] = {sg.ox, sg.oy, sg.oz}, ext[3] = {sg.nx * (double)sg.cell, sg.ny * (double)sg.cell, sg.nz * (double)sg.cell};
+  for (int d = 0; d < 3; d++) { const double m = std::max(std::fabs(lo[d]), std::fabs(lo[d] + ext[d])); reach2 += m * m; }
+  const double moved = rb->step_dt + rb->step_dr * std::sqrt(reach2), ok = 0.4 * (double)c->cloud[1].dims_host->cell;
+  return moved > ok;                                                 // (NaN compares false: the fixed schedule)
+}
+
 static int ready(qn_ctx* c) {
   if (!c) return QN_ERR_INVALID_ARG;
   for (int w = 0; w < 2; w++) { if (c->cloud[w].n == 0) return QN_ERR_EMPTY_CLOUD; if (!c->cloud[w].has_grid || !c->cloud[w].has_cov) return QN_ERR_NOT_READY; }
@@ -815,6 +833,10 @@ static int gicp_align(qn_ctx* c, const float guess[16], qn_gicp_result* out, boo
     if (!exact_ticks) chunk = first_chunk ? c->ticks_per_chunk : std::max(2 * per_outer, c->ticks_per_chunk / 2);   // convergence is usually near after the first chunks: ticks past it are wasted launches
     else chunk = c->far_mode == 1 ? std::min(ticks_left, c->far_chunk) : ticks_left;      // the refresh regime is needed for the first few tracked ticks only: an empty k_far + k_far_reduce behind every later tick cost 14 us each (80 %-overlap pairs: 1384 -> 1429 registrations/s with 4 instead of 8)
     if (budget <= 0) { c->last_error = "align: device state machine did not terminate"; return QN_ERR_HIP; }
+    if (first_chunk && !adaptive && unseeded_goes_on(c, tick_no, per_outer, ticks_left)) {      // a batch member whose pose still moves by more than a fraction of a cell: one more unseeded outer iteration, then look again
+      c->unseeded_until = tick_no + per_outer; chunk = per_outer;
+      continue;                                                      // (first_chunk stays set: the far-query statistics are those of the LAST unseeded linearisation)
+    }
     if (look && !declined) {
       // how far the NEXT step will move the source points at most: the step just taken (translation + rotation x the cloud's reach from the origin), shrunk
       // by 10 (what the optimiser does per iteration at this stage, measured on the synthetic pairs: 12x - 50x)
@@ -1126,6 +1148,7 @@ extern "C" int qn_debug_set(qn_ctx* c, const char* key, double v) {
   else if (k == "far_chunk") c->far_chunk = std::max(1, (int)v);
   else if (k == "far_ranked") c->far_ranked = v != 0;
   else if (k == "batch_look") c->batch_look = v != 0;
+  else if (k == "unseeded_cap") c->unseeded_cap = (int)v;
   else if (k == "pair_pipeline") c->pair_pipeline = v != 0;
   else if (k == "persist") c->persist = v != 0;
   else if (k == "persist_timeout") c->persist_timeout = v < 1 ? 1ull : (unsigned long long)v;      // 100 MHz ticks a spin of the persistent kernel may last (tests force a give-up with a tiny value)

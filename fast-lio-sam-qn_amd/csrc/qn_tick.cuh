@@ -629,6 +629,9 @@ struct FinalizeFitK {
   out->phase = st->phase; out->trace_len = st->trace_len;
   out->far_requests = far_stats ? far_stats[1] : 0u; out->far_misses = far_stats ? far_stats[0] : 0u; out->far_queries = far_stats ? far_stats[3] : 0u;
   if (far_stats) { far_stats[0] = 0u; far_stats[1] = 0u; far_stats[3] = 0u; }
+  double mr = 0, mt = 0;                                             // the latest pose step, as k_finalize reports it (host: does the unseeded phase go on - unseeded_goes_on)
+  for (int u = 0; u < 3; u++) { for (int b = 0; b < 3; b++) mr = fmax(mr, fabs(st->delta[4 * u + b] - (u == b ? 1.0 : 0.0))); mt = fmax(mt, fabs(st->delta[4 * u + 3])); }
+  out->step_dt = mt; out->step_dr = mr;
   }
 };
 static __global__ void __launch_bounds__(64) k_finalize_fit(const GicpState* __restrict__ st, ResultBlock* out, uint32_t* __restrict__ far_stats,
