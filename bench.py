@@ -50,6 +50,15 @@ def algorithmic_bytes(n=N_PTS, k=K_COV, it=GN_ITERS):
     }
 
 
+def profile_stale(stored_sha):
+    """True when a stored profile (profiles/pmc_latest.json, profiles/valu_budget_latest.json) was NOT collected on the kernel sources of this tree (or carries no tag)"""
+    try:
+        from qn_amd.build import csrc_sha1
+        return not (stored_sha and stored_sha == csrc_sha1())
+    except Exception:
+        return True
+
+
 def pct(xs):
     xs = np.sort(np.asarray(xs, dtype=np.float64))
     return {"median": round(float(np.median(xs)), 4), "p10": round(float(np.percentile(xs, 10)), 4), "p90": round(float(np.percentile(xs, 90)), 4), "n": int(len(xs))}
@@ -152,6 +161,7 @@ def batched_roofline_leg(engine, ctx, pairs, lanes, rounds=3):
             "traffic": traffic_of(dom),
             "traffic_source": "NOT measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the same batched workload (tools/gpu_round4.sh <tag> pmc -> profiles/pmc_latest.json, build named in stale_from); null = not collected",
             "stale_from": (pmc_all or {}).get("_meta", {}).get("tag") if isinstance(pmc_all, dict) else None,
+            "traffic_stale": profile_stale((pmc_all or {}).get("_meta", {}).get("csrc_sha1") if isinstance(pmc_all, dict) else None),      # the stored PMC passes were collected on other kernel sources than this tree's
             "lanes": lanes, "registrations_profiled": nreg,
             "avg_batched_launch_ms": round(fam_avg[dom] * lanes * per_lane.get(dom, 1), 5), "avg_launch_ms_per_entry": round(fam_avg[dom], 6), "algorithmic_bytes_per_launch": per_launch_bytes * lanes * per_lane.get(dom, 1),
             "family_ms_per_registration": {k: round(v, 4) for k, v in fam_ms.items()}, "kernel_ms_per_registration_one_context": round(total_ms, 4),
@@ -159,6 +169,29 @@ def batched_roofline_leg(engine, ctx, pairs, lanes, rounds=3):
             "path": "qn_gicp_align_batch on one context alone on the GPU: hipEvents around every k_lanes launch on the context's stream; every feature of the measured path is on "
                     "(the batched path has no second stream and no persistent kernel to switch off)",
             "note": "working set of a batch (lanes x ~30 MB) is MALL/L2 resident: nominal HBM yardstick (SURVEY 8d); the engine is VALU-issue / latency bound - see valu_issue"}
+
+
+def shim_latency(synth, reps=12):
+    """ms per icpAlignment / coarseToFineAlignment call of the compiled shim programs (their own process, their own contexts), 30k and 100k points"""
+    import tempfile
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import test_shim
+    if not (os.path.exists(test_shim.BIN) and os.path.exists(test_shim.BIN2)):
+        test_shim.build_shim_program()
+    out = {"note": "wall time inside the C++ process around the reference's call sequence, median of %d calls after one warm-up call; host buffers of pcl::PointXYZI (32 B / point)" % reps}
+    with tempfile.TemporaryDirectory() as td:
+        for npts in (30000, N_PTS):
+            e = {}
+            s_, t_, _ = synth.make_pair(700 + npts // 1000, npts)
+            a, b = os.path.join(td, "s.bin"), os.path.join(td, "t.bin"); s_.tofile(a); t_.tofile(b)
+            o = subprocess.check_output([test_shim.BIN, a, b, "s", str(reps)], stderr=subprocess.DEVNULL).decode().split("BENCH")
+            e["icpAlignment_ms"] = float(o[1].split()[1]); e["icpAlignment_min_ms"] = float(o[1].split()[2]); e["icpAlignment_valid"] = bool(int(o[0].split()[0]))
+            qs, qt, _ = synth.make_pair(C2F_TRUE_LOOP_SCENES[0], npts, mode="quatro")
+            qs.tofile(a); qt.tofile(b)
+            o = subprocess.check_output([test_shim.BIN2, a, b, str(max(3, reps // 2))], stderr=subprocess.DEVNULL).decode().split("BENCH")
+            e["coarseToFine_ms"] = float(o[1].split()[1]); e["coarseToFine_min_ms"] = float(o[1].split()[2]); e["coarseToFine_valid"] = bool(int(o[0].split()[0]))
+            out["%dk" % (npts // 1000)] = e
+    return out
 
 
 def spawn_ranks(args):
@@ -405,8 +438,13 @@ def single_process(args, engine, synth, json_fd):
             out.append((s.data_ptr(), N_PTS, t.data_ptr(), N_PTS, 12, 1))
         return out
 
-    if args.warmup > 0:
-        mg.align_best(descs(args.warmup))
+    # fail fast, BEFORE anything is timed: the communicator must have the N ranks that were asked for (ncclCommCount, RCCL's own answer), and the gather of an
+    # untimed call must have delivered the same record table to every GPU - a multi-GPU figure is never quoted on a communicator that is not what it claims to be
+    rccl_ranks = mg.rccl_ranks()
+    if rccl_ranks != n:
+        raise SystemExit("bench.py --gpus %d --single-process: RCCL reports %d ranks in the communicator (%s)" % (n, rccl_ranks, engine.lib().qn_multi_last_error(mg.h).decode()))
+    mg.align_best(descs(max(args.warmup, 1)))
+    mg.verify_gather()
     for g in range(n):
         torch.cuda.synchronize(g)
     t0 = time.perf_counter()
@@ -438,7 +476,8 @@ def single_process(args, engine, synth, json_fd):
            "config": {"workload": "Nano-GICP icpAlignment, synthetic 100k x 100k street-scene pairs, k=20 covariances, 20 forced GN iterations (BASELINE configs[1])",
                       "mode": "single process: qn_multi_init(%d) -> ncclCommInitAll(%d), qn_multi_align_best with %d pairs (pair i -> GPU i mod N), one grouped ncclAllGather of the 96-byte records" % (n, n, n * args.steps),
                       "points": N_PTS, "k": K_COV, "gn_iterations": GN_ITERS, "in_flight": max(1, args.in_flight), "distinct_pairs_per_gpu": len(host_pairs),
-                      "rccl_ranks": mg.gpu_count(), "per_gpu_pairs_per_s": [round(args.steps / (1e-3 * m), 2) if m > 0 else None for m in per_gpu_ms],
+                      "rccl_ranks": rccl_ranks, "rccl_ranks_note": "ncclCommCount of every GPU's communicator, asserted == --gpus before timing; the gather of the untimed call was verified on every GPU (qn_multi_verify_gather)",
+                      "per_gpu_pairs_per_s": [round(args.steps / (1e-3 * m), 2) if m > 0 else None for m in per_gpu_ms],
                       "per_gpu_ms": [round(m, 3) for m in per_gpu_ms], "gather_ms": round(gather_ms, 4),
                       "winner_pair": int(winner.pair_id), "winner_score": winner.fitness, "ms_per_align": pct(lat)["median"]},
            "roofline": roofline, "cpu_baseline": None}
@@ -848,7 +887,7 @@ def main():
                 vb = json.load(open(vb_path)); qc = float(vb["quad_cycles_per_registration"])
                 chip_us = qc * 4.0 / (1024 * float(vb.get("clock_ghz", 2.1)) * 1e3)
                 roofline["valu_issue"] = {"quad_cycles_per_registration": qc, "us_of_a_fully_issuing_chip": round(chip_us, 1), "frac_of_issue_slots": round(chip_us / (ms_step * 1e3), 4),
-                                          "source": vb.get("source"), "measured_in_this_run": False,
+                                          "source": vb.get("source"), "measured_in_this_run": False, "stale": profile_stale(vb.get("csrc_sha1")),
                                           "note": "quad_cycles_per_registration is NOT measured in this run: it is read from profiles/valu_budget_latest.json (SQ_ACTIVE_INST_VALU passes of the build named in `source`; "
                                                   "the kernels of the GICP chain are unchanged since) - only the division by this run's step time is live.  1024 SIMDs x one wave64 VALU instruction per 4 cycles"}
             except Exception as ex:
@@ -878,8 +917,27 @@ def main():
                                        "family_ms_per_registration": L.get("overlap80_family_ms"),
                                        "note": "SURVEY 8d generator: target scene window shifted so that the clouds overlap 80 % (20 % of the source has no counterpart)"}
                 extras["reference_operating_point"] = L.get("rop")
+                # ---- SURVEY 8d's generator text, literally: "80 % spatial overlap (target scene window shifted 10 m)" - on the 120 m scene a 10 m shift is 92 % overlap (the
+                # 24 m of `overlap80` are the 80 %); same workload and in-flight setting as `value`, 8 distinct pairs
+                p10 = []
+                for j in range(8):
+                    s10, t10, _ = synth.make_pair(9100 + j, N_PTS, shift=10.0)
+                    p10.append((torch.from_numpy(s10).cuda(), torch.from_numpy(t10).cuda(), None))
+                torch.cuda.synchronize()
+                batch(8, p10); torch.cuda.synchronize()
+                t8 = time.perf_counter(); _, _, st10 = batch(n80, p10); torch.cuda.synchronize(); w10 = time.perf_counter() - t8
+                assert all(x == 0 for x in st10), st10
+                extras["shift10"] = {"registrations_per_s": round(n80 / w10, 2), "ms_per_step": round(1e3 * w10 / n80, 4), "steps": n80, "distinct_pairs": len(p10), "in_flight": len(ctxs),
+                                     "note": "target scene window shifted 10 m (SURVEY 8d's literal generator parameter; 92 % overlap on the 120 m scene)"}
             except Exception as ex:                                      # an extra must never cost the headline line
                 extras["extras_error"] = repr(ex)
+            # ---- the drop-in path's own latency: the compiled C++ programs that run the reference's call sequences against the header-only shims (tests/shim_icp_alignment.cpp =
+            # loop_closure.cpp:113-135, tests/shim_coarse_to_fine.cpp = :138-159): pcl::PointXYZI clouds (32-byte stride) from the host, deep copies, aligned_ downloaded, a second
+            # context for Quatro, CPU transformPcd, the target uploaded twice - what an UNMODIFIED LoopClosure would see per call (reference operating point: k = 15, LM, eps 0.01)
+            try:
+                extras["shim"] = shim_latency(synth)
+            except Exception as ex:
+                extras["shim"] = {"error": repr(ex)}
 
         quatro = L.get("quatro")
 
@@ -907,6 +965,7 @@ def main():
                "config": {"workload": "Nano-GICP icpAlignment, synthetic 100k x 100k street-scene pairs, k=20 covariances, 20 forced GN iterations (BASELINE configs[1])",
                           "points": N_PTS, "k": K_COV, "gn_iterations": GN_ITERS, "sharding": "pair i -> rank i mod N, all_gather of best record",
                           "in_flight": len(ctxs), "lanes": max(1, args.lanes), "distinct_pairs_per_rank": len(pairs),
+                          "rccl_ranks": (dist.get_world_size() if dist is not None else 1), "collective_backend": (backend if dist is not None else None),
                           "launch_structure": "%d contexts (streams) x %d candidate pairs per kernel launch (qn_gicp_align_batch: k_lanes<F>, blockIdx.y = pair); launches per registration %.2f" % (len(ctxs), max(1, args.lanes), ctx.debug_get("batch_launches") / max(1.0, ctx.debug_get("batch_pairs"))),
                           "value_repeats": {"values": [round(v, 1) for v in rep_vals], "median": round(float(np.median(rep_vals)), 1) if rep_vals else None,
                                             "min": round(min(rep_vals), 1) if rep_vals else None, "max": round(max(rep_vals), 1) if rep_vals else None,
@@ -916,6 +975,11 @@ def main():
                           "ms_per_align": align_ms, "ms_per_align_stats": align, "winner_pair": int(winner[0]), "winner_score": winner[2],
                           "max_abs_T_diff_vs_oracle": dtp, "parity_vs_oracle": parity, "batch64": batch64, "quatro": quatro, **extras},
                "value_overlap80": (extras.get("overlap80") or {}).get("registrations_per_s"),
+               "value_shift10": (extras.get("shift10") or {}).get("registrations_per_s"),
+               "value_repeats": {"median": round(float(np.median(rep_vals)), 1) if rep_vals else None, "min": round(min(rep_vals), 1) if rep_vals else None,
+                                 "max": round(max(rep_vals), 1) if rep_vals else None, "n": len(rep_vals)},
+               "shim_ms_per_icpAlignment": {k: v.get("icpAlignment_ms") for k, v in (extras.get("shim") or {}).items() if isinstance(v, dict)} or None,
+               "shim_ms_per_coarseToFine": {k: v.get("coarseToFine_ms") for k, v in (extras.get("shim") or {}).items() if isinstance(v, dict)} or None,
                "roofline": roofline, "cpu_baseline": cpu}
         os.write(json_fd, (json.dumps(out) + "\n").encode())
         if parity is not None and not parity["ok"]:

@@ -29,6 +29,8 @@ struct qn_ctx {
   // pair-as-grid-dimension batches (qn_gicp_align_batch, qn_batch.inc): lane 0 is this context, lanes 1 .. are sub-contexts with buffers of their own;
   // every kernel of the chain is launched ONCE for all lanes (k_lanes<F>) with its per-lane arguments in a device-resident table (args_d, staged in args_h)
   std::vector<qn_ctx*> lanes; int batch_lanes = 8; char* args_h = nullptr; char* args_d = nullptr; size_t args_cap = 0; uint64_t batch_launches = 0, batch_pairs = 0; bool is_lane = false, batch_trace = false, batch_share_source = true;      // batch_share_source: pairs of one batch call that name the same source buffer share its grid and covariances (the candidates of ONE query); off = every pair rebuilds its source like loop_closure.cpp:120-121
+  bool lanes_failed = false; int fail_lane_create = 0;      // lanes_failed: creating this context's lanes failed once (out of memory, typically): the batch entry points take the one-pair path until batch_lanes is set again - no
+                                                             // retry (GBs of hipMalloc / hipFree) per call; fail_lane_create: test knob - the creation of lane index >= this fails (0 = off)
   void* slab = nullptr;                 // ONE device allocation behind every per-context buffer of the GICP path (qn_ctx_create)
   qn_gicp_params params{};
   CloudBuf cloud[2];
@@ -43,6 +45,10 @@ struct qn_ctx {
   bool device_look = true;              // the hand-over decision of a lone forced-GN registration on the device (look_decide) instead of a host round trip
   bool clear_far_now = false;           // the next unseeded search resets the far-candidate references (first search of an align)
   char* staging2 = nullptr;             // the second stream's landing zone (TargetScope)
+  // page-locked HOST landing zones (one per device landing zone; allocated on the first pageable host cloud): a pageable caller buffer is packed into it by the CPU (xyz, 12 B per
+  // point) and crosses PCIe from there.  hipMemcpyAsync straight from pageable memory PINS the caller's pages for copies above ~1 MB; a caller that hands over a freshly allocated
+  // cloud every call - LoopClosure::icpAlignment does, loop_closure.cpp:116-119 - paid 14-27 ms for that on every other call at 100k points (round 6, tests/shim_icp_alignment bench)
+  struct PinZone { char* h = nullptr; hipEvent_t ev = nullptr; bool busy = false; } pin_up, pin_up2;
   char* staging = nullptr;              // [max_points * 32] H2D landing zone for strided host clouds
   uint32_t* scan_sums = nullptr;
 

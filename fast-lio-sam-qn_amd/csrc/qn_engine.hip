@@ -216,6 +216,7 @@ extern "C" void qn_ctx_destroy(qn_ctx* c) {
   if (c->scalar_host) hipHostFree(c->scalar_host);
   hipFree(c->pg_clk); if (c->list_probe) hipFree(c->list_probe); if (c->pg_status_host) hipHostFree(c->pg_status_host);
   if (c->ev_pair) hipEventDestroy(c->ev_pair);
+  for (qn_ctx::PinZone* z : {&c->pin_up, &c->pin_up2}) { if (z->ev) hipEventDestroy(z->ev); if (z->h) hipHostFree(z->h); }
   if (c->stream2) { hipStreamSynchronize(c->stream2); hipStreamDestroy(c->stream2); }
   if (c->stream && c->owns_stream) hipStreamDestroy(c->stream);
   delete c;
@@ -278,6 +279,7 @@ static void swap_scratch(qn_ctx* c) {
   std::swap(c->stream, c->stream2); std::swap(c->scan_sums, c->scan_sums2); std::swap(c->fb_list, c->fb_list2); std::swap(c->big_list, c->big_list2);
   std::swap(c->fb_count2, c->fb_count2b); std::swap(c->knn_idx, c->knn_idx2);
   std::swap(c->bbox_acc, c->bbox_acc2); std::swap(c->scan_status, c->scan_status2);
+  std::swap(c->pin_up, c->pin_up2);
   std::swap(c->staging, c->staging2);       // (setInputSource no longer waits for its pack kernel: the target's upload must not land in the source's landing zone)
 }
 struct TargetScope {                    // RAII: the body of set_cloud / compute_cov runs with the second stream's scratch; the event marks its end
@@ -341,6 +343,30 @@ static int clouds_valid(qn_ctx* c) {
   return QN_OK;
 }
 
+// A HOST cloud into the context's device landing zone (c->staging; the caller has the right scratch set swapped in).  Page-locked caller memory is read by the DMA engine
+// directly (asynchronously: the buffer must stay unchanged until the next synchronisation, include/qn_engine.h); pageable memory is packed by the CPU into the context's own
+// page-locked zone first - consumed when this returns - and never handed to hipMemcpyAsync itself (see qn_ctx::PinZone).  -> *dsrc / stride: what the pack kernel reads.
+static int upload_host_cloud(qn_ctx* c, const float* xyz, uint32_t n, uint32_t& stride, hipStream_t s, const char** dsrc) {
+  hipPointerAttribute_t at;
+  const bool pinned = hipPointerGetAttributes(&at, xyz) == hipSuccess && at.type == hipMemoryTypeHost;
+  if (!pinned) (void)hipGetLastError();                             // (an unregistered pointer is an "invalid value" to the query: not an error of ours)
+  if (pinned) {
+    if (stride <= 32) { HIPCHK(c, hipMemcpyAsync(c->staging, xyz, (size_t)(n - 1) * stride + 12, hipMemcpyHostToDevice, s)); }      // one contiguous H2D; PointXYZI's intensity half is dropped by the pack kernel
+    else { HIPCHK(c, hipMemcpy2DAsync(c->staging, 16, xyz, stride, 16, n, hipMemcpyHostToDevice, s)); stride = 16; }                  // fat point types: only the leading 16 B of each point cross PCIe
+    *dsrc = (const char*)c->staging;
+    return QN_OK;
+  }
+  qn_ctx::PinZone& z = c->pin_up;
+  if (!z.h) { HIPCHK(c, hipHostMalloc((void**)&z.h, (size_t)c->max_points * 16, hipHostMallocDefault)); HIPCHK(c, hipEventCreateWithFlags(&z.ev, hipEventDisableTiming)); }
+  if (z.busy) { HIPCHK(c, hipEventSynchronize(z.ev)); z.busy = false; }      // the zone's previous cloud has left it (it has, long ago, in every sequence but back-to-back setters)
+  float* o = (float*)z.h; const char* in = (const char*)xyz;
+  for (uint32_t i = 0; i < n; i++, in += stride, o += 3) { const float* p = (const float*)in; o[0] = p[0]; o[1] = p[1]; o[2] = p[2]; }
+  HIPCHK(c, hipMemcpyAsync(c->staging, z.h, (size_t)n * 12, hipMemcpyHostToDevice, s));
+  HIPCHK(c, hipEventRecord(z.ev, s)); z.busy = true;
+  stride = 12; *dsrc = (const char*)c->staging;
+  return QN_OK;
+}
+
 static int set_cloud(qn_ctx* c, int which, const float* xyz, uint32_t n, uint32_t stride, bool on_device) {
   if (!c || (which != 0 && which != 1)) return QN_ERR_INVALID_ARG;
   CloudBuf& b = c->cloud[which];
@@ -354,15 +380,7 @@ static int set_cloud(qn_ctx* c, int which, const float* xyz, uint32_t n, uint32_
   TargetScope scope(c, which == QN_TARGET && c->tgt_on_stream2);
   hipStream_t s = c->stream;
   const char* dsrc = (const char*)xyz;
-  if (!on_device) {
-    if (stride <= 32) {   // one contiguous H2D of the caller's buffer; PointXYZI's intensity half is dropped by k_pack_points
-      HIPCHK(c, hipMemcpyAsync(c->staging, xyz, (size_t)(n - 1) * stride + 12, hipMemcpyHostToDevice, s));
-    } else {              // fat point types: only the leading 16 B of each point cross PCIe
-      HIPCHK(c, hipMemcpy2DAsync(c->staging, 16, xyz, stride, 16, n, hipMemcpyHostToDevice, s));
-      stride = 16;
-    }
-    dsrc = (const char*)c->staging;
-  }
+  if (!on_device) { const int rc = upload_host_cloud(c, xyz, n, stride, s, &dsrc); if (rc != QN_OK) return rc; }
   b.n = n;
   return build_grid(c, b, dsrc, stride);
 }
@@ -895,8 +913,15 @@ extern "C" int qn_gicp_transformed_source(qn_ctx* c, float* xyz_out, uint32_t st
   if (!c->aligned_valid) return QN_ERR_NOT_READY;
   HIPCHK(c, hipSetDevice(c->device));
   const size_t w = stride >= 16 ? 16 : 12;
-  HIPCHK(c, hipMemcpy2DAsync(xyz_out, stride, c->aligned, 16, w, c->cloud[0].n, hipMemcpyDeviceToHost, c->stream));
+  // through the context's page-locked zone (one contiguous D2H + a CPU scatter): a strided 2-D copy into pageable memory is 100k row transfers and pins the caller's pages
+  qn_ctx::PinZone& z = c->pin_up;
+  if (!z.h) { HIPCHK(c, hipHostMalloc((void**)&z.h, (size_t)c->max_points * 16, hipHostMallocDefault)); HIPCHK(c, hipEventCreateWithFlags(&z.ev, hipEventDisableTiming)); }
+  if (z.busy) { HIPCHK(c, hipEventSynchronize(z.ev)); z.busy = false; }
+  const uint32_t n = c->cloud[0].n;
+  HIPCHK(c, hipMemcpyAsync(z.h, c->aligned, (size_t)n * 16, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
+  const char* in = z.h; char* o = (char*)xyz_out;
+  for (uint32_t i = 0; i < n; i++, in += 16, o += stride) memcpy(o, in, w);
   return QN_OK;
 }
 
@@ -1011,6 +1036,7 @@ extern "C" int qn_icp_alignment_batch(qn_ctx* const* ctxs, uint32_t n_ctx, const
             if (q == 0) { uint32_t want = std::min<uint32_t>(B, std::max<uint32_t>((uint32_t)std::max(1, ctxs[0]->batch_min_share), (rem + n_ctx - 1) / n_ctx)); if (final_share.compare_exchange_strong(q, want)) q = want; }
             m = std::min(q, rem);
           }
+          m = std::min(m, B);                                           // (the share was fixed by whichever context got there first, with ITS lane count: never more than this context's - ADVICE r5)
           if (next.compare_exchange_weak(base, base + m)) break;
         }
         if (base >= n_pairs) break;
@@ -1161,8 +1187,9 @@ extern "C" int qn_debug_set(qn_ctx* c, const char* key, double v) {
   else if (k == "batch_lanes") {                                 // candidate pairs per kernel launch of the batch entry points (qn_batch.inc); < 2: one pair at a time on this context's stream
     const int b = std::max(1, std::min((int)v, 64));
     if (b < (int)c->lanes.size()) { if (hipStreamSynchronize(c->stream) != hipSuccess) return QN_ERR_HIP; while ((int)c->lanes.size() > std::max(b, 1)) { qn_ctx* l = c->lanes.back(); c->lanes.pop_back(); if (l != c) qn_ctx_destroy(l); } }
-    c->batch_lanes = b;
+    c->batch_lanes = b; c->lanes_failed = false;
   }
+  else if (k == "fail_lane_create") c->fail_lane_create = (int)v;   // test knob: creating lane index >= v fails (the out-of-memory fallback of the batch entry points)
   else if (k == "batch_share_source") c->batch_share_source = v != 0;      // batch entry points: pairs that name the same source buffer share its preparation (default on: the candidates of one query)
   else if (k == "batch_trace") c->batch_trace = v != 0;           // developer: host timeline of every batched segment on stderr
   else if (k == "batch_member") c->persist_batch_off = v != 0;      // this context registers beside others (qn_multi with in_flight > 1): no persistent launches
@@ -1254,6 +1281,7 @@ extern "C" int qn_debug_get(qn_ctx* c, const char* key, double* value) {
   if (k == "persist_resident_blocks") { *value = c->persist_resident_blocks; return QN_OK; }
   if (k == "batch_launches") { *value = (double)c->batch_launches; return QN_OK; }      // kernel launches / pairs of the batched path so far (launches per registration = the ratio)
   if (k == "batch_pairs") { *value = (double)c->batch_pairs; return QN_OK; }
+  if (k == "lanes_failed") { *value = c->lanes_failed ? 1.0 : 0.0; return QN_OK; }
   if (k == "batch_lanes") { *value = (double)c->batch_lanes; return QN_OK; }      // aligns of this context that ran the persistent kernel
   if (k == "feat_fallbacks") { *value = c->feat_fallbacks; return QN_OK; }      // matrix-core feature searches repeated with the VALU kernel (survivor overflow)
   if (k == "feat_survivors") { *value = c->feat_survivors; return QN_OK; }      // survivors of the latest forward search (exactly re-evaluated pairs)

@@ -42,6 +42,8 @@ struct qn_multi {
   decltype(&ncclGroupStart) p_group_start = nullptr;
   decltype(&ncclGroupEnd) p_group_end = nullptr;
   decltype(&ncclGetErrorString) p_err = nullptr;
+  decltype(&ncclCommCount) p_count = nullptr;
+  uint32_t last_per = 0;                          // records per GPU of the latest gather (qn_multi_verify_gather)
   std::vector<double> gpu_ms; double gather_ms = 0;   // timing of the latest qn_multi_align_best: per GPU (first pair start .. last pair end), the gather
   bool quatro_on = false;                         // enable_quatro_: pairs are coarse-to-fine registrations (qn_multi_set_quatro_params)
   bool poisoned = false;                          // a collective failed: the communicator state is undefined, every later call is refused
@@ -103,7 +105,7 @@ extern "C" int qn_multi_init(int n_gpus, const int* device_ids, uint32_t max_poi
   if (!m->rccl) return fail(QN_ERR_HIP, std::string("qn_multi_init: cannot load RCCL: ") + dlerror());
 #define QN_SYM(field, name) m->field = (decltype(m->field))dlsym(m->rccl, name); if (!m->field) return fail(QN_ERR_HIP, std::string("qn_multi_init: RCCL lacks ") + name)
   QN_SYM(p_init_all, "ncclCommInitAll"); QN_SYM(p_destroy, "ncclCommDestroy"); QN_SYM(p_all_gather, "ncclAllGather");
-  QN_SYM(p_group_start, "ncclGroupStart"); QN_SYM(p_group_end, "ncclGroupEnd"); QN_SYM(p_err, "ncclGetErrorString");
+  QN_SYM(p_group_start, "ncclGroupStart"); QN_SYM(p_group_end, "ncclGroupEnd"); QN_SYM(p_err, "ncclGetErrorString"); QN_SYM(p_count, "ncclCommCount");
 #undef QN_SYM
   m->ctx.resize(n_gpus); m->stream.assign(n_gpus, nullptr); m->d_send.assign(n_gpus, nullptr); m->d_recv.assign(n_gpus, nullptr);
   for (int g = 0; g < n_gpus; g++) {
@@ -145,6 +147,27 @@ extern "C" int qn_multi_debug_set(qn_multi* m, const char* key, double value) { 
   return QN_OK;
 }
 extern "C" int qn_multi_gpu_count(const qn_multi* m) { return m ? m->n_gpus : 0; }
+extern "C" int qn_multi_rccl_ranks(qn_multi* m) {      // what RCCL says, not what the caller asked for
+  if (!m || m->comm.empty() || !m->p_count) return -1;
+  int least = 1 << 30;
+  for (int g = 0; g < m->n_gpus; g++) {
+    int cnt = -1;
+    if (!m->comm[g] || m->p_count(m->comm[g], &cnt) != ncclSuccess) { m->last_error = "qn_multi_rccl_ranks: ncclCommCount failed"; return -1; }
+    least = cnt < least ? cnt : least;
+  }
+  return least;
+}
+extern "C" int qn_multi_verify_gather(qn_multi* m) {
+  if (!m) return QN_ERR_INVALID_ARG;
+  if (m->poisoned || m->last_per == 0 || !m->h_all) return QN_ERR_NOT_READY;
+  const size_t bytes = sizeof(qn_pair_record) * m->last_per * (size_t)m->n_gpus;
+  std::vector<char> got(bytes);
+  for (int g = 1; g < m->n_gpus; g++) {
+    if (hipSetDevice(m->dev[g]) != hipSuccess || hipMemcpy(got.data(), m->d_recv[g], bytes, hipMemcpyDeviceToHost) != hipSuccess) { m->last_error = "qn_multi_verify_gather: download failed"; return QN_ERR_HIP; }
+    if (memcmp(got.data(), m->h_all, bytes) != 0) { char buf[120]; snprintf(buf, sizeof(buf), "qn_multi_verify_gather: GPU %d holds a different record table than GPU 0", g); m->last_error = buf; return QN_ERR_HIP; }
+  }
+  return QN_OK;
+}
 extern "C" int qn_multi_get_timing(const qn_multi* m, double* per_gpu_ms, double* gather_ms) {
   if (!m || !per_gpu_ms || !gather_ms) return QN_ERR_INVALID_ARG;
   if ((int)m->gpu_ms.size() != m->n_gpus) return QN_ERR_NOT_READY;
@@ -218,6 +241,7 @@ extern "C" int qn_multi_align_best(qn_multi* m, const qn_pair_desc* pairs, uint3
   if (hipSetDevice(m->dev[0]) != hipSuccess || hipMemcpyAsync(m->h_all, m->d_recv[0], sizeof(qn_pair_record) * per * N, hipMemcpyDeviceToHost, m->stream[0]) != hipSuccess) return bail("download of the gathered table failed", false);
   for (int g = 0; g < N; g++) { if (hipSetDevice(m->dev[g]) != hipSuccess || hipStreamSynchronize(m->stream[g]) != hipSuccess) return bail("stream synchronisation after the gather failed", true); }
   m->gather_ms = 1e-6 * (double)std::chrono::duration_cast<std::chrono::nanoseconds>(clk::now() - t_gather).count();
+  m->last_per = per;
   // ---- the winner, from the GATHERED table (what rank 0 sees after the collective)
   int status = QN_OK;
   for (uint32_t e = 0; e < per * (uint32_t)N; e++) {

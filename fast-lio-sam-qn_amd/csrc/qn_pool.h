@@ -9,7 +9,9 @@
 // The pool is deliberately leaked (threads detached): a static destructor joining threads that sit in HIP calls at process exit is a known way to hang.
 #pragma once
 #include <condition_variable>
+#include <cstdint>
 #include <deque>
+#include <exception>
 #include <functional>
 #include <mutex>
 #include <thread>
@@ -20,7 +22,10 @@ class WorkerPool {
  public:
   static WorkerPool& instance() { static WorkerPool* p = new WorkerPool(); return *p; }
 
-  // fn(i) for i in [0, n): i = 0 on the calling thread, the rest on pool threads; returns after every fn returned
+  // fn(i) for i in [0, n): i = 0 on the calling thread, the rest on pool threads; returns after every fn returned.  Whatever goes wrong - a thread cannot be created,
+  // an fn throws (bad_alloc in a worker's std::vector, ...) - the queued tasks are all executed or withdrawn BEFORE run() returns (they point at this frame's latch and fn),
+  // and the first exception is rethrown on the caller.  The pool never holds more than kMaxThreads threads: tasks beyond that run on the caller, in order.
+  static constexpr uint32_t kMaxThreads = 256;
   void run(uint32_t n, const std::function<void(uint32_t)>& fn) {
     if (n <= 1) { if (n == 1) fn(0); return; }
     Latch latch; latch.left = n - 1;
@@ -28,18 +33,39 @@ class WorkerPool {
       std::unique_lock<std::mutex> lk(mu_);
       for (uint32_t i = 1; i < n; i++) queue_.push_back(Task{&fn, i, &latch});
       in_flight_ += n - 1;
-      while (threads_ < in_flight_) { threads_++; std::thread(&WorkerPool::loop, this).detach(); }
+      while (threads_ < in_flight_ && threads_ < kMaxThreads) {
+        try { std::thread(&WorkerPool::loop, this).detach(); threads_++; }
+        catch (...) { break; }                                          // no more threads to be had: the caller works the rest off below
+      }
     }
     cv_.notify_all();
-    fn(0);
-    std::unique_lock<std::mutex> lk(latch.mu);
-    latch.cv.wait(lk, [&] { return latch.left == 0; });
+    std::exception_ptr err;
+    try { fn(0); } catch (...) { err = std::current_exception(); }
+    // tasks of THIS call that no pool thread has taken yet (too few threads, or every thread busy with a task that is itself waiting): run them here
+    for (;;) {
+      Task t; bool have = false;
+      {
+        std::unique_lock<std::mutex> lk(mu_);
+        if (threads_ >= in_flight_) break;                              // every queued task has a thread coming for it
+        for (auto it = queue_.begin(); it != queue_.end(); ++it) if (it->latch == &latch) { t = *it; queue_.erase(it); have = true; break; }
+        if (have) in_flight_--;
+      }
+      if (!have) break;
+      try { (*t.fn)(t.i); } catch (...) { if (!err) err = std::current_exception(); }
+      { std::unique_lock<std::mutex> lk(latch.mu); --latch.left; }
+    }
+    {
+      std::unique_lock<std::mutex> lk(latch.mu);
+      latch.cv.wait(lk, [&] { return latch.left == 0; });
+      if (!err && latch.err) err = latch.err;
+    }
+    if (err) std::rethrow_exception(err);
   }
 
   uint32_t threads() { std::unique_lock<std::mutex> lk(mu_); return threads_; }
 
  private:
-  struct Latch { std::mutex mu; std::condition_variable cv; uint32_t left = 0; };
+  struct Latch { std::mutex mu; std::condition_variable cv; uint32_t left = 0; std::exception_ptr err; };
   struct Task { const std::function<void(uint32_t)>* fn; uint32_t i; Latch* latch; };
 
   void loop() {
@@ -50,9 +76,10 @@ class WorkerPool {
         cv_.wait(lk, [&] { return !queue_.empty(); });
         t = queue_.front(); queue_.pop_front();
       }
-      (*t.fn)(t.i);
+      std::exception_ptr err;
+      try { (*t.fn)(t.i); } catch (...) { err = std::current_exception(); }      // (an exception must not take the process down from a detached thread: it goes back to the caller of run())
       { std::unique_lock<std::mutex> lk(mu_); in_flight_--; }
-      { std::unique_lock<std::mutex> lk(t.latch->mu); if (--t.latch->left == 0) t.latch->cv.notify_all(); }      // (notify under the lock: the latch lives on the waiter's stack)
+      { std::unique_lock<std::mutex> lk(t.latch->mu); if (err && !t.latch->err) t.latch->err = err; if (--t.latch->left == 0) t.latch->cv.notify_all(); }      // (notify under the lock: the latch lives on the waiter's stack)
     }
   }
 

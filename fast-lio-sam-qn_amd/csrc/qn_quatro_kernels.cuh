@@ -82,7 +82,8 @@ __device__ __forceinline__ void for_each_in_ball_cells_group_pre(const GridView&
   const int bz0 = cell_coord(qz - r, g.oz, g.inv_cell, g.nz), bz1 = cell_coord(qz + r, g.oz, g.inv_cell, g.nz);
   const int tx0 = bx0 >> 3, ntx = (bx1 >> 3) - tx0 + 1, ny = by1 - by0 + 1, nz = bz1 - bz0 + 1;
   const int nseg = on ? nz * ny * ntx : 0;
-  const bool fits = nseg <= QN_SEG_CAP;
+  const bool fits = on && nseg <= QN_SEG_CAP;      // (an inactive lane walks nothing and must not FILL anything either: its box is whatever its placeholder query gives - ADVICE r5: with fits true for nseg = 0 the
+                                                   //  fill loop below ran over that box and could write past the group's QN_SEG_CAP entries)
   // lane gl takes the (y, z) rows gl, gl + FG, ... of the box (each row = ntx segments, 1 or 2).  No integer division: a 32-bit division is ~40 instructions on this
   // machine and four of them per segment cost what the table saves; row -> (y, z) through a float reciprocal, exact for these sizes ((r + 0.5) / ny is never an integer).
   const float inv_ny = 1.0f / (float)max(ny, 1);

@@ -25,6 +25,16 @@ def _deps():
     return [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".cuh", ".h", ".inc"))] + [os.path.join(ROOT, "include", "qn_engine.h")]
 
 
+def csrc_sha1():
+    """sha1 over the kernel / host sources of the library (names + contents, sorted): what a stored profile is tagged with, so that bench.py can tell whether
+    profiles/pmc_latest.json and profiles/valu_budget_latest.json were collected on THIS source state (`stale` in the bench line)."""
+    import hashlib
+    h = hashlib.sha1()
+    for f in sorted(sources() + _deps()):
+        h.update(os.path.basename(f).encode()); h.update(open(f, "rb").read())
+    return h.hexdigest()
+
+
 def needs_build():
     if not os.path.exists(LIB):
         return True

@@ -435,7 +435,8 @@ def coarse_to_fine_alignment(ctx, src, dst, *, quatro=None, k=15, max_iter=32, m
     if st == QN_ERR_EMPTY_CLOUD:
         return dict(valid=False, converged=False, score=1.7976931348623157e308, T=np.eye(4), T_quatro=np.eye(4))
     ctx.check(st)
-    return dict(valid=bool(valid.value), converged=bool(res.converged), score=res.fitness, T=T, T_quatro=Tq, iterations=res.iterations)
+    return dict(valid=bool(valid.value), converged=bool(res.converged), score=res.fitness, T=T, T_quatro=Tq, iterations=res.iterations,
+                T_gicp=np.array(res.T, dtype=np.float32).reshape(4, 4).astype(np.float64))
 
 
 def coarse_to_fine_alignment_device(ctx, src_ptr, ns, dst_ptr, nt, stride, *, quatro=None, k=15, max_iter=32, max_corr_dist=52.5, trans_eps=0.01, score_thr=1.5):
@@ -446,7 +447,8 @@ def coarse_to_fine_alignment_device(ctx, src_ptr, ns, dst_ptr, nt, stride, *, qu
         _reference_gicp(ctx, k, max_iter, max_corr_dist, trans_eps)
         ctx.check(ctx._l.qn_coarse_to_fine_alignment_device(ctx.h, C.c_void_p(src_ptr), C.c_uint32(ns), C.c_void_p(dst_ptr), C.c_uint32(nt), C.c_uint32(stride),
                                                            C.c_double(score_thr), C.byref(res), _p(T), _p(Tq), C.byref(valid)))
-    return dict(valid=bool(valid.value), converged=bool(res.converged), score=res.fitness, T=T, T_quatro=Tq, iterations=res.iterations)
+    return dict(valid=bool(valid.value), converged=bool(res.converged), score=res.fitness, T=T, T_quatro=Tq, iterations=res.iterations,
+                T_gicp=np.array(res.T, dtype=np.float32).reshape(4, 4).astype(np.float64))
 
 
 # ---------------------------------------------------------------------------------------- batch
@@ -570,6 +572,14 @@ class MultiGpu:
 
     def gpu_count(self):
         return int(self._l.qn_multi_gpu_count(self.h))
+
+    def rccl_ranks(self):
+        """ranks of the communicator as RCCL reports them (ncclCommCount), -1 on failure"""
+        return int(self._l.qn_multi_rccl_ranks(self.h))
+
+    def verify_gather(self):
+        """after align_best: every GPU's receive buffer holds the table GPU 0 received"""
+        self._check(self._l.qn_multi_verify_gather(self.h))
 
     def align_best(self, pairs, score_thr=1.5):
         """pairs as for icp_alignment_batch.  -> (records[n], best or None)"""

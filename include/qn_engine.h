@@ -180,6 +180,11 @@ int  qn_multi_init(int n_gpus, const int* device_ids /* NULL: 0 .. n_gpus-1 */, 
 void qn_multi_destroy(qn_multi*);
 const char* qn_multi_last_error(const qn_multi*);    /* NULL argument: why the last qn_multi_init on this thread failed */
 int  qn_multi_gpu_count(const qn_multi*);
+/* ranks of the RCCL communicator as RCCL itself reports them (ncclCommCount on every GPU's communicator; the smallest answer, -1 if a query fails): a caller that
+ * asked for N GPUs checks this equals N before it trusts a multi-GPU figure.  qn_multi_verify_gather: after a qn_multi_align_best, QN_OK iff EVERY GPU's receive buffer
+ * holds the same gathered record table as GPU 0's (the all-gather delivered every rank's records to every rank, not just to the one the host reads)                     */
+int  qn_multi_rccl_ranks(qn_multi*);
+int  qn_multi_verify_gather(qn_multi*);
 int  qn_multi_set_params(qn_multi*, const qn_gicp_params*);            /* loop_closure.cpp:9-16, on every context */
 int  qn_multi_debug_set(qn_multi*, const char* key, double value);     /* qn_debug_set on every context (e.g. "batch_lanes": pairs per kernel launch of each context) */
 /* host wall clock of the latest qn_multi_align_best: per GPU from the call's start to its last pair's end [n_gpus], and the gather step */

@@ -3,6 +3,7 @@
 #include <atomic>
 #include <cstdint>
 #include <cstdio>
+#include <stdexcept>
 #include <thread>
 #include <vector>
 #include "qn_pool.h"
@@ -38,6 +39,15 @@ int main() {
   // 4. n = 0 and n = 1 never touch the pool
   int ran = 0; p.run(0, [&](uint32_t) { ran++; }); p.run(1, [&](uint32_t i) { ran += 1 + (int)i; });
   if (ran != 1) { printf("FAIL: degenerate fan-outs\n"); return 1; }
+  // 5. a task that throws (pool thread or caller): every other task still runs, run() returns only after all of them, the exception reaches the caller, the pool lives on
+  for (uint32_t bad : {0u, 2u}) {
+    std::atomic<int> done{0}; bool caught = false;
+    try { p.run(4, [&](uint32_t i) { std::this_thread::sleep_for(std::chrono::milliseconds(1)); if (i == bad) throw std::runtime_error("boom"); done++; }); }
+    catch (const std::runtime_error&) { caught = true; }
+    if (!caught || done != 3) { printf("FAIL: exception path (bad %u): caught %d done %d\n", bad, (int)caught, (int)done); return 1; }
+  }
+  std::atomic<int> c5{0}; p.run(5, [&](uint32_t) { c5++; });
+  if (c5 != 5) { printf("FAIL: pool unusable after an exception\n"); return 1; }
   printf("ok: %u parked threads\n", p.threads());
   return 0;
 }

@@ -1,7 +1,11 @@
 // LoopClosure's constructor and coarseToFineAlignment (fast_lio_sam_qn/src/loop_closure.cpp:3-30, 138-159)
 // written against the two drop-in shims, in the reference's own shape.
-// usage: shim_coarse_to_fine src.bin dst.bin -> prints valid converged score T(16)
+// usage: shim_coarse_to_fine src.bin dst.bin [reps] -> prints valid converged score T(16) (reps > 0: coarseToFineAlignment is repeated and a second line
+// "BENCH reps median_ms min_ms" reports its wall time - what an unmodified LoopClosure would see: second context for Quatro, CPU transformPcd, target uploaded twice)
 #include <algorithm>
+#include <chrono>
+#include <cstdlib>
+#include <vector>
 #include <cstdio>
 #include <limits>
 #include <memory>
@@ -78,7 +82,8 @@ struct LoopClosureLike {
 int main(int argc, char** argv) {
   if (argc < 3) return 2;
   LoopClosureLike lc;
-  const RegistrationOutput r = lc.coarseToFineAlignment(load(argv[1]), load(argv[2]));
+  const pcl::PointCloud<PointType> src_in = load(argv[1]), dst_in = load(argv[2]);
+  const RegistrationOutput r = lc.coarseToFineAlignment(src_in, dst_in);
   std::printf("%d %d %.17g", (int)r.is_valid_, (int)r.is_converged_, r.score_);
   for (int a = 0; a < 4; a++) for (int b = 0; b < 4; b++) std::printf(" %.17g", r.pose_between_eig_(a, b));
   // the matcher on its own, with upstream's optimizedMatching(thr_dist, num_max_corres, tuple_scale) signature
@@ -96,5 +101,15 @@ int main(int argc, char** argv) {
     qn_ctx_destroy(mctx);
   }
   std::printf("\n");
+  const int reps = argc > 3 ? std::atoi(argv[3]) : 0;
+  if (reps > 0) {
+    std::vector<double> ms;
+    for (int i = 0; i < reps; i++) {
+      const auto t0 = std::chrono::steady_clock::now(); (void)lc.coarseToFineAlignment(src_in, dst_in);
+      ms.push_back(std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+    }
+    std::sort(ms.begin(), ms.end());
+    std::printf("BENCH %d %.4f %.4f\n", reps, ms[ms.size() / 2], ms[0]);
+  }
   return 0;
 }

@@ -1,6 +1,10 @@
 // LoopClosure::icpAlignment (fast_lio_sam_qn/src/loop_closure.cpp:110-136) written against the drop-in
 // shim exactly as the reference writes it against nano_gicp - proves the shim's surface is sufficient.
-// usage: shim_icp_alignment src.bin dst.bin [t]  (raw float32 xyz triplets; t = set the target first) -> prints valid converged score T(16)
+// usage: shim_icp_alignment src.bin dst.bin [t|s [reps]]  (raw float32 xyz triplets; t = set the target first; reps > 0: the icpAlignment sequence is repeated and a second
+// line "BENCH reps median_ms min_ms" reports its wall time - the latency an unmodified LoopClosure would see: 32-byte PointXYZI stride, deep copies, aligned_ filled) -> prints valid converged score T(16)
+#include <algorithm>
+#include <chrono>
+#include <cstdlib>
 #include <cstdio>
 #include <vector>
 #include <limits>
@@ -38,11 +42,18 @@ int main(int argc, char** argv) {
   // icpAlignment, loop_closure.cpp:113-135
   RegistrationOutput reg_output;
   pcl::PointCloud<PointType> aligned_;
+  const bool target_first = argc > 3 && argv[3][0] == 't';
+  const bool trace = std::getenv("QN_SHIM_TRACE") != nullptr;      // developer: wall time of the sections of every call on stderr
+  auto icpAlignment = [&]() {
+  const auto c0 = std::chrono::steady_clock::now();
+  reg_output = RegistrationOutput();
+  aligned_.clear();
   pcl::PointCloud<PointType>::Ptr src_cloud(new pcl::PointCloud<PointType>());
   pcl::PointCloud<PointType>::Ptr dst_cloud(new pcl::PointCloud<PointType>());
   *src_cloud = src;
   *dst_cloud = dst;
-  if (argc > 3 && argv[3][0] == 't') {   // the usual PCL order (target first); with a larger source this regrows the shim's context AFTER the target was set
+  const auto s0 = std::chrono::steady_clock::now();
+  if (target_first) {   // the usual PCL order (target first); with a larger source this regrows the shim's context AFTER the target was set
     nano_gicp_.setInputTarget(dst_cloud);
     nano_gicp_.calculateTargetCovariances();
     nano_gicp_.setInputSource(src_cloud);
@@ -53,16 +64,31 @@ int main(int argc, char** argv) {
   nano_gicp_.setInputTarget(dst_cloud);
   nano_gicp_.calculateTargetCovariances();
   }
+  const auto s1 = std::chrono::steady_clock::now();
   nano_gicp_.align(aligned_);
+  if (trace) std::fprintf(stderr, "shim trace: copies %.3f ms, set + covariances %.3f ms, align + aligned_ %.3f ms\n", std::chrono::duration<double, std::milli>(s0 - c0).count(),
+                          std::chrono::duration<double, std::milli>(s1 - s0).count(), std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - s1).count());
   reg_output.score_ = nano_gicp_.getFitnessScore();
   if (nano_gicp_.hasConverged() && reg_output.score_ < 1.5) {
     reg_output.is_valid_ = true;
     reg_output.is_converged_ = true;
     reg_output.pose_between_eig_ = nano_gicp_.getFinalTransformation().cast<double>();
   }
+  };
+  icpAlignment();
   std::printf("%d %d %.17g", (int)reg_output.is_valid_, (int)nano_gicp_.hasConverged(), reg_output.score_);
   const Eigen::Matrix4f T = nano_gicp_.getFinalTransformation();
   for (int r = 0; r < 4; r++) for (int c = 0; c < 4; c++) std::printf(" %.9g", T(r, c));
   std::printf(" %zu %.9g %.9g\n", aligned_.size(), aligned_.size() ? aligned_[0].x : 0.f, aligned_.size() ? aligned_[0].intensity : 0.f);
+  const int reps = argc > 4 ? std::atoi(argv[4]) : 0;
+  if (reps > 0) {
+    std::vector<double> ms;
+    for (int i = 0; i < reps; i++) {
+      const auto t0 = std::chrono::steady_clock::now(); icpAlignment();
+      ms.push_back(std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+    }
+    std::sort(ms.begin(), ms.end());
+    std::printf("BENCH %d %.4f %.4f\n", reps, ms[ms.size() / 2], ms[0]);
+  }
   return 0;
 }

@@ -196,3 +196,29 @@ def test_batch_argument_arena_overflow_is_flushed_not_failed():
     assert [g[0] for g in got] == [0] * 8 and npairs == 8
     assert got[0] == ref[0] and got[1] == ref[1]
     assert all(g[2] == 1500 for g in got)
+
+
+def test_lane_creation_failure_falls_back_to_the_one_pair_path_once():
+    """when the lanes cannot be created (out of memory: batch_lanes x a full max_points slab; forced here by the fail_lane_create knob) the batch entry
+    points register the pairs one at a time with the SAME records, the failed allocation's sticky HIP error does not surface as the first pair's status, and later calls do not
+    try to create the lanes again."""
+    from qn_amd import engine
+    clouds = [synth.make_pair(760 + i, 5000 + 700 * i, extent=36.0)[:2] for i in range(4)]
+    p = params(engine)
+    ref = classic(engine, 12000, p, host_pairs(clouds))
+    ctx = engine.Context(12000)
+    ctx.debug_set("batch_lanes", 4); ctx.debug_set("fail_lane_create", 2)
+    set_params(engine, ctx, p)
+    for call in range(2):
+        res, val, st = engine.gicp_align_batch(ctx, host_pairs(clouds), score_thr=1.5)
+        got = [rec(r, v, s) for r, v, s in zip(res, val, st)]
+        assert [g[0] for g in got] == [0] * 4, "call %d: statuses %s" % (call, [g[0] for g in got])
+        for i, (g, r) in enumerate(zip(got, ref)):
+            assert g == r, "call %d pair %d differs from the one-pair path" % (call, i)
+        assert ctx.debug_get("lanes_failed") == 1.0 and ctx.debug_get("batch_pairs") == 0.0
+    # setting batch_lanes again (with the fault gone) re-arms the lanes
+    ctx.debug_set("fail_lane_create", 0); ctx.debug_set("batch_lanes", 4)
+    res, val, st = engine.gicp_align_batch(ctx, host_pairs(clouds), score_thr=1.5)
+    assert ctx.debug_get("lanes_failed") == 0.0 and ctx.debug_get("batch_pairs") == 4.0
+    assert [rec(r, v, s) for r, v, s in zip(res, val, st)] == ref
+    ctx.close()

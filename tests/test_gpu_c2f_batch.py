@@ -24,7 +24,8 @@ def make_ctx(engine, cap, lanes):
 
 def same_record(a, b):
     return (a["valid"] == b["valid"] and a["converged"] == b["converged"] and a["score"] == b["score"] and a["iterations"] == b["iterations"]
-            and np.array_equal(a["T"], b["T"]) and np.array_equal(a["T_quatro"], b["T_quatro"]))
+            and np.array_equal(a["T"], b["T"]) and np.array_equal(a["T_quatro"], b["T_quatro"])
+            and ("T_gicp" not in a or "T_gicp" not in b or np.array_equal(a["T_gicp"], b["T_gicp"])))      # the Nano-GICP record's own T too: the identity for a pair Quatro could not register, on both paths
 
 
 @pytest.mark.parametrize("n_ctx,lanes,device", [(1, 8, False), (2, 3, True)])

@@ -3,6 +3,8 @@ usage: python tools/pmc_summary_batch.py gpurun_out/<tag> <lanes>     (reads pmc
 Units and corrections follow /opt/skills/guides/MI355X_MICROARCH.md (HBM section): separate passes (TCC slot limit), KB, FETCH_SIZE x2 on gfx950.
 A batched launch carries `entries` registrations (or clouds): the per-registration-launch figure is the launch's traffic / entries."""
 import csv, json, os, sys
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "fast-lio-sam-qn_amd"))
+from qn_amd.build import csrc_sha1
 from collections import defaultdict
 FAMILY = [("KnnHistK<false, 32>", "knn_select", 2), ("TickK<512, 4, 0,", "gn_tick_fused", 1), ("TickK<512, 4, 1,", "closing_pass", 1), ("NnLaneK<0>", "nn_search", 1),
           ("NnSearchK<0, true,", "nn_fallback", 1), ("AccumulateK", "accumulate", 1), ("CovFromIdxK", "cov_from_idx", 2), ("PackBBoxK", "grid_pack", 2), ("ScatterK", "grid_scatter", 2)]
@@ -22,4 +24,4 @@ for pat, fam, per_lane in FAMILY:
     out[fam] = {"kernel": k.split("(")[0], "launches_sampled": nf[k], "entries_per_launch": entries, "FETCH_SIZE_KB_per_launch": round(f, 1), "WRITE_SIZE_KB_per_launch": round(w, 1),
                 "hbm_bytes_per_launch": int((2.0 * f + w) * 1024), "hbm_bytes_per_registration_launch": int((2.0 * f + w) * 1024 / entries),
                 "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, KB; FETCH_SIZE x2 (gfx950 under-count, MI355X_MICROARCH.md HBM section); WRITE_SIZE uncalibrated; working set is MALL resident"}
-print(json.dumps({"batched": out, "_meta": {"tag": os.path.basename(os.path.normpath(d)), "lanes": lanes}}, indent=1))
+print(json.dumps({"batched": out, "_meta": {"tag": os.path.basename(os.path.normpath(d)), "lanes": lanes, "csrc_sha1": csrc_sha1()}}, indent=1))

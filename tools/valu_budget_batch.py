@@ -2,6 +2,8 @@
 that run.  A quad-cycle of VALU-active is one wave64 VALU instruction on one SIMD; the chip offers 1024 SIMDs x clock / 4 of them per second.
 usage: python tools/valu_budget_batch.py <dir with sq_pass*.csv> <registrations in the run> <tag> [clock_GHz=2.1]  -> table on stdout, <dir>/valu_budget.json"""
 import csv, glob, json, os, sys
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "fast-lio-sam-qn_amd"))
+from qn_amd.build import csrc_sha1
 from collections import defaultdict
 d, nreg, tag = sys.argv[1], float(sys.argv[2]), sys.argv[3]; clock = float(sys.argv[4]) if len(sys.argv) > 4 else 2.1
 tot = defaultdict(lambda: defaultdict(float)); cnt = defaultdict(lambda: defaultdict(int))
@@ -20,5 +22,5 @@ for va, k, n, v in sorted(rows, reverse=True)[:14]:
         100 * v.get("SQ_ACTIVE_INST_VALU", 0) / max(v.get("SQ_WAVE_CYCLES", 0), 1), 100 * v.get("SQ_WAIT_INST_ANY", 0) / max(v.get("SQ_WAVE_CYCLES", 0), 1)))
 us = total / 1024 / (clock * 1e9 / 4) * 1e6
 print("one registration: %.1f M VALU quad-cycles = %.0f us of a chip whose 1024 SIMDs issue VALU every cycle (%.1f GHz); run: %d registrations, batched path (1 context x 8 lanes)" % (total / 1e6, us, clock, nreg))
-json.dump({"quad_cycles_per_registration": round(total, 0), "clock_ghz": clock, "us_of_a_fully_issuing_chip": round(us, 1), "source": "profiles/%s_valu_budget.txt (tools/gpu_sq_batch.sh: rocprofv3 --pmc SQ_ACTIVE_INST_VALU over the batched path, 1 context x 8 lanes)" % tag,
+json.dump({"csrc_sha1": csrc_sha1(), "quad_cycles_per_registration": round(total, 0), "clock_ghz": clock, "us_of_a_fully_issuing_chip": round(us, 1), "source": "profiles/%s_valu_budget.txt (tools/gpu_sq_batch.sh: rocprofv3 --pmc SQ_ACTIVE_INST_VALU over the batched path, 1 context x 8 lanes)" % tag,
            "per_kernel_quad_cycles_per_registration": {k: round(va, 0) for va, k, n, v in sorted(rows, reverse=True)[:14]}}, open(os.path.join(d, "valu_budget.json"), "w"), indent=1)
