@@ -67,7 +67,7 @@ struct qn_ctx {
   qn::ResultBlock* result_host = nullptr; double* scalar_host = nullptr;
   int32_t* dbg_knn_idx = nullptr; float* dbg_knn_d2 = nullptr;
   // Quatro (allocated on first use)
-  qn_quatro_params qparams{}; bool qparams_set = false, q_ready = false;
+  qn_quatro_params qparams{}; bool qparams_set = false, q_ready = false; double q_last_scale = 1.0;      // q_last_scale: the scale of the latest host solve (1 unless estimate_scale)
   float4* q_normals[2] = {nullptr, nullptr}; float* q_spfh[2] = {nullptr, nullptr}; float* q_fpfh_s[2] = {nullptr, nullptr}; float* q_fpfh[2] = {nullptr, nullptr};
   unsigned long long* q_key[2] = {nullptr, nullptr};
   float* q_pair[2] = {nullptr, nullptr}; uint32_t* q_pair_hash[2] = {nullptr, nullptr};   // descriptors in candidate-pair layout + row hashes (k_feat_nn)

@@ -404,6 +404,12 @@ class Quatro:
         self.ctx.check(self._l.qn_quatro_align_device(self.ctx.h, C.c_void_p(src_ptr), C.c_uint32(ns), C.c_void_p(dst_ptr), C.c_uint32(nt), C.c_uint32(stride), _p(T), C.byref(valid)))
         return T, bool(valid.value)
 
+    def scale(self):
+        """TEASER++'s scale estimate of the latest align (1 unless estimate_scale)"""
+        v = C.c_double()
+        self.ctx.check(self._l.qn_quatro_get_scale(self.ctx.h, C.byref(v)))
+        return v.value
+
     def features(self, which):
         n = self._n[which]
         nrm = np.zeros((n, 3), np.float32); sp = np.zeros((n, 33), np.float32); fp = np.zeros((n, 33), np.float32)
@@ -417,10 +423,11 @@ def quatro_solve(src, dst, corres, params=None):
     a, _, stride = _cloud_arg(src); b, _, _ = _cloud_arg(dst)
     corres = np.ascontiguousarray(corres, dtype=np.int32)
     T = np.zeros((4, 4)); valid = C.c_int(); clique = np.zeros(max(len(corres), 1), np.int32); nq = C.c_uint32()
-    st = lib().qn_quatro_solve(_p(a), _p(b), C.c_uint32(stride), _p(corres), C.c_uint32(len(corres)), C.byref(p), _p(T), C.byref(valid), _p(clique), C.byref(nq))
+    scale = C.c_double(1.0)
+    st = lib().qn_quatro_solve_scaled(_p(a), _p(b), C.c_uint32(stride), _p(corres), C.c_uint32(len(corres)), C.byref(p), _p(T), C.byref(valid), _p(clique), C.byref(nq), C.byref(scale))
     if st != QN_OK:
         raise EngineError(st, lib().qn_status_str(st).decode())
-    return dict(T=T, valid=bool(valid.value), clique=clique[:nq.value].copy())
+    return dict(T=T, valid=bool(valid.value), clique=clique[:nq.value].copy(), scale=scale.value)
 
 
 def coarse_to_fine_alignment(ctx, src, dst, *, quatro=None, k=15, max_iter=32, max_corr_dist=52.5, trans_eps=0.01, score_thr=1.5):

@@ -205,7 +205,9 @@ typedef struct {
   double  rot_gnc_factor;          /* :21 */
   double  rot_cost_diff_thr;       /* :22 */
   int32_t rot_max_iter;            /* :23 */
-  int32_t estimate_scale;          /* :24 (must be 0: the reference never enables it) */
+  int32_t estimate_scale;          /* :24 estimat_scale_ (include/loop_closure.h:44; config.yaml ships false): 1 = TEASER++'s TLS scale solver over the TIM norm ratios runs in front of the
+                                      consistency graph; rotation on dst TIMs / scale with the bound x 2 / scale, translation on dst - scale R src.  T stays [R | t] (upstream's quatro::align
+                                      returns rotation and translation only); the scale itself: qn_quatro_get_scale */
   int32_t use_optimized_matching;  /* :25  1: Matcher::optimizedMatching (gate + cap), 0: Matcher::advancedMatching */
   double  distance_threshold;      /* :26 */
   int32_t max_num_corres;          /* :27 */
@@ -256,6 +258,10 @@ int  qn_quatro_align_debug(qn_ctx*, const float* src, uint32_t ns, const float* 
                            int32_t* clique, uint32_t* n_clique, int32_t* rot_iterations);
 int  qn_quatro_solve(const float* src, const float* dst, uint32_t stride_bytes, const int32_t* corres_pairs, uint32_t n_corres,
                      const qn_quatro_params* p, double T[16], int* valid, int32_t* clique, uint32_t* n_clique);
+/* the scale TEASER++'s solver estimated (1 unless estimate_scale): of the context's latest qn_quatro_align[_device/_debug] / coarse-to-fine call, and of the host solver alone */
+int  qn_quatro_get_scale(qn_ctx*, double* scale);
+int  qn_quatro_solve_scaled(const float* src, const float* dst, uint32_t stride_bytes, const int32_t* corres_pairs, uint32_t n_corres,
+                            const qn_quatro_params* p, double T[16], int* valid, int32_t* clique, uint32_t* n_clique, double* scale);
 
 /* ---- feeder of the path, kept on the device -------------------------------
  * Keyframe clouds (PosePcd::pcd_, sensor frame, include/pose_pcd.hpp:7-19) are uploaded once and stay resident;

@@ -190,6 +190,14 @@ def quatro_solve(src, dst, corres, p=None):
     return dict(T=T, valid=bool(oi[0]), clique=clique[:oi[1]].copy(), rot_iterations=int(oi[2]))
 
 
+def quatro_solve_scaled(src, dst, corres, p):
+    """solve with estimate_scale: also returns TEASER++'s scale estimate"""
+    src = _f32(src); dst = _f32(dst); corres = np.ascontiguousarray(corres, dtype=np.int32)
+    T = np.zeros((4, 4)); oi = np.zeros(3, np.int32); clique = np.zeros(max(len(corres), 1), np.int32); od = np.zeros(1)
+    lib().orc_quatro_solve_scaled(_p(src), _p(dst), _p(corres), C.c_int(len(corres)), _p(p.dp), _p(p.ip), _p(T), _p(oi), _p(clique), _p(od))
+    return dict(T=T, valid=bool(oi[0]), clique=clique[:oi[1]].copy(), rot_iterations=int(oi[2]), scale=float(od[0]))
+
+
 def quatro_align(src, dst, p=None):
     p = p or QuatroParams(); src = _f32(src); dst = _f32(dst)
     T = np.zeros((4, 4)); oi = np.zeros(4, np.int32); corres = np.zeros((4096, 2), np.int32)

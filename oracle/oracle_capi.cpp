@@ -96,6 +96,13 @@ void orc_quatro_align(const float* src, int ns, const float* dst, int nt, const 
   std::memcpy(T, r.T, sizeof(r.T)); out_i[0] = r.valid; out_i[1] = (int)r.clique.size(); out_i[2] = r.rot_iterations; out_i[3] = (int)r.corres.size();
   for (size_t i = 0; i < r.corres.size() && (int)i < corres_cap; i++) { corres[2 * i] = r.corres[i].first; corres[2 * i + 1] = r.corres[i].second; }
 }
+// the solver with its scale estimate (estimate_scale): out_d[0] = scale
+void orc_quatro_solve_scaled(const float* src, const float* dst, const int* corres, int ncorr, const double* dp, const int* ip, double* T, int* out_i, int* clique, double* out_d) {
+  std::vector<std::pair<int, int>> c(ncorr); for (int i = 0; i < ncorr; i++) c[i] = {corres[2 * i], corres[2 * i + 1]};
+  QuatroResult r; solve(src, dst, c, qp_from(dp, ip), &r);
+  std::memcpy(T, r.T, sizeof(r.T)); out_i[0] = r.valid; out_i[1] = (int)r.clique.size(); out_i[2] = r.rot_iterations; out_d[0] = r.scale;
+  for (size_t i = 0; i < r.clique.size(); i++) clique[i] = r.clique[i];
+}
 int orc_max_clique(const unsigned char* adj, int n, int* out) { std::vector<uint8_t> a(adj, adj + (size_t)n * n); auto c = max_clique_lex(a, n); for (size_t i = 0; i < c.size(); i++) out[i] = c[i]; return (int)c.size(); }
 float orc_atan2f(float y, float x) { return qn_atan2f(y, x); }
 

@@ -26,7 +26,7 @@ from scipy.spatial import cKDTree
 class Params:
     def __init__(self, fpfh_normal_radius=0.9, fpfh_radius=1.5, noise_bound=0.3, rot_gnc_factor=1.4, rot_cost_diff_thr=1e-4,
                  rot_max_iter=50, use_optimized_matching=True, distance_threshold=35.0, max_num_corres=200, rng_seed=1,
-                 tuple_scale=0.95):
+                 tuple_scale=0.95, estimate_scale=False):
         self.__dict__.update(locals()); del self.__dict__["self"]
 
 
@@ -263,23 +263,56 @@ def _tls_1d(X, alpha):
     return best[1]
 
 
+def _tls_ranges(X, R):
+    """TEASER++ scalar TLS with one range per measurement (the scale stage), as prefix sums over the sorted interval ends: for every sweep position the consensus set's
+    weighted mean (weights 1 / range^2) and cost = sum_in (x - xh)^2 + sum_out range; the first minimum in sweep order wins.  -> (estimate, inlier mask)"""
+    X = np.asarray(X, np.float64); R = np.asarray(R, np.float64); N = len(X)
+    val = np.concatenate([X - R, X + R]); kind = np.concatenate([np.zeros(N, np.int64), np.ones(N, np.int64)]); idx = np.concatenate([np.arange(N), np.arange(N)])
+    order = np.lexsort((np.where(kind == 0, -idx, idx), kind, val))      # by value; at equal values the C++ sort's "tag descending": starts (tag i + 1) before ends (tag -i - 1), starts by
+    # descending index, ends by ascending index
+    sgn = np.where(kind[order] == 0, 1.0, -1.0); ii = idx[order]
+    w = 1.0 / (R[ii] ** 2)
+    card = np.cumsum(sgn); sw = np.cumsum(sgn * w); sxw = np.cumsum(sgn * w * X[ii]); sx = np.cumsum(sgn * X[ii]); sxx = np.cumsum(sgn * X[ii] ** 2)
+    out_pen = R.sum() - np.cumsum(sgn * R[ii])
+    with np.errstate(divide="ignore", invalid="ignore"):
+        xh = sxw / sw
+        cost = (card * xh * xh + sxx - 2 * sx * xh) + out_pen
+    cost = np.where(np.isnan(cost), np.inf, cost)
+    k = int(np.argmin(cost))                                   # first minimum
+    est = float(xh[k])
+    return est, np.abs(X - est) <= R
+
+
 def solve(src, dst, corres, p):
-    out = dict(T=np.eye(4), valid=False, clique=[], rot_iterations=0)
+    out = dict(T=np.eye(4), valid=False, clique=[], rot_iterations=0, scale=1.0)
     M = len(corres)
     if M == 0:
         return out
     S = src[corres[:, 0]].astype(np.float64); D = dst[corres[:, 1]].astype(np.float64)
     beta = 2.0 * p.noise_bound
     da = np.linalg.norm(S[None, :, :] - S[:, None, :], axis=2); db = np.linalg.norm(D[None, :, :] - D[:, None, :], axis=2)
-    adj = (np.abs(db - da) <= beta).astype(np.uint8); np.fill_diagonal(adj, 0)
+    scale = 1.0
+    if getattr(p, "estimate_scale", False):                    # TLSScaleSolver over all TIMs; its inliers are the edges
+        iu, ju = np.triu_indices(M, 1)
+        ok = da[iu, ju] > 0
+        iu, ju = iu[ok], ju[ok]
+        if len(iu) == 0:
+            return out
+        scale, inl = _tls_ranges(db[iu, ju] / da[iu, ju], beta / da[iu, ju])
+        if not scale > 0:
+            return out
+        adj = np.zeros((M, M), np.uint8); adj[iu[inl], ju[inl]] = 1; adj[ju[inl], iu[inl]] = 1
+        out["scale"] = scale
+    else:
+        adj = (np.abs(db - da) <= beta).astype(np.uint8); np.fill_diagonal(adj, 0)
     C = max_clique_lex(adj)
     out["clique"] = C
     m = len(C)
     if m <= 1:
         return out
     nxt = C[1:] + C[:1]
-    A = S[nxt] - S[C]; B = D[nxt] - D[C]                      # chain TIMs
-    nb2 = (2.0 * p.noise_bound) ** 2                          # TEASER++ rescales the rotation solver's bound by 2 / scale
+    A = S[nxt] - S[C]; B = (D[nxt] - D[C]) / scale            # chain TIMs (dst TIMs with the scale removed)
+    nb2 = (2.0 * p.noise_bound / scale) ** 2                  # TEASER++ rescales the rotation solver's bound by 2 / scale
     if nb2 < 1e-16:
         nb2 = 1e-2
     w = np.ones(m); mu = 1.0; prev = np.inf; R2 = np.eye(2)
@@ -304,7 +337,7 @@ def solve(src, dst, corres, p):
         if diff < p.rot_cost_diff_thr:
             break
     R = np.eye(3); R[:2, :2] = R2
-    X = D[C] - S[C] @ R.T
+    X = D[C] - scale * (S[C] @ R.T)
     t = np.array([_tls_1d(list(X[:, k]), p.noise_bound) for k in range(3)])
     T = np.eye(4); T[:3, :3] = R; T[:3, 3] = t
     out["T"] = T; out["valid"] = True

@@ -300,17 +300,60 @@ static double tls_estimate(const std::vector<double>& X, double alpha) {
   return best_x;
 }
 
+// ScalarTLSEstimator::estimate with one range per measurement (TLSScaleSolver::solveForScale: s_ij = |b_ij| / |a_ij|, range beta / |a_ij|): the sweep of tls_estimate with
+// weights 1 / range^2 in the estimate, unweighted squared residuals + the ranges of the measurements outside the consensus set in the cost (TEASER++ registration.cc as recalled:
+// un-vendored, parity unpinned).  inliers: |X - estimate| <= range.
+static double tls_estimate_ranges(const std::vector<double>& X, const std::vector<double>& ranges, std::vector<char>& inliers) {
+  const int N = (int)X.size();
+  struct H { double v; int tag; };
+  std::vector<H> h; h.reserve(2 * (size_t)N);
+  double ranges_inverse_sum = 0;
+  for (int i = 0; i < N; i++) { h.push_back({X[i] - ranges[i], i + 1}); h.push_back({X[i] + ranges[i], -i - 1}); ranges_inverse_sum += ranges[i]; }
+  std::sort(h.begin(), h.end(), [](const H& a, const H& b) { return a.v < b.v || (a.v == b.v && a.tag > b.tag); });
+  double dot_X_weights = 0, dot_weights_consensus = 0, sum_xi = 0, sum_xi_square = 0;
+  int card = 0; double best_cost = DBL_MAX, best_x = 1.0; bool have = false;
+  for (size_t i = 0; i < h.size(); i++) {
+    const int idx = std::abs(h[i].tag) - 1, eps = h[i].tag > 0 ? 1 : -1;
+    const double w = 1.0 / (ranges[idx] * ranges[idx]);
+    card += eps; dot_weights_consensus += eps * w; dot_X_weights += eps * w * X[idx]; ranges_inverse_sum -= eps * ranges[idx];
+    sum_xi += eps * X[idx]; sum_xi_square += eps * X[idx] * X[idx];
+    const double x_hat = dot_X_weights / dot_weights_consensus;
+    const double residual = card * x_hat * x_hat + sum_xi_square - 2 * sum_xi * x_hat;
+    const double cost = residual + ranges_inverse_sum;
+    if (cost == cost && (!have || cost < best_cost)) { best_cost = cost; best_x = x_hat; have = true; }
+  }
+  inliers.assign(N, 0);
+  for (int i = 0; i < N; i++) inliers[i] = std::fabs(X[i] - best_x) <= ranges[i];
+  return best_x;
+}
+
 void solve(const float* src, const float* dst, const std::vector<std::pair<int, int>>& corres, const QuatroParams& p, QuatroResult* out) {
   for (int i = 0; i < 16; i++) out->T[i] = (i % 5 == 0) ? 1.0 : 0.0;
-  out->valid = 0; out->clique.clear(); out->rot_iterations = 0;
+  out->valid = 0; out->clique.clear(); out->rot_iterations = 0; out->scale = 1.0;
   const int M = (int)corres.size();
   if (M == 0) return;
   std::vector<std::array<double, 3>> S(M), D(M);
   for (int k = 0; k < M; k++) for (int d = 0; d < 3; d++) { S[k][d] = (double)src[3 * corres[k].first + d]; D[k][d] = (double)dst[3 * corres[k].second + d]; }
   auto norm3 = [](const double a[3]) { return std::sqrt(a[0] * a[0] + a[1] * a[1] + a[2] * a[2]); };
-  // TIMs + scale-consistency graph (scale fixed to 1: estimate_scale = false, loop_closure.cpp:24)
+  // TIMs + scale-consistency graph (scale fixed to 1 when estimate_scale = false - the shipped config, loop_closure.cpp:24 / config.yaml:37)
   const double beta = 2.0 * p.noise_bound * std::sqrt(1.0);
   std::vector<uint8_t> adj((size_t)M * M, 0);
+  double scale = 1.0;
+  if (p.estimate_scale) {      // TLSScaleSolver::solveForScale on all TIMs; its inliers are the graph's edges (a TIM of two coincident source points has no scale: no edge)
+    std::vector<double> X, ranges; std::vector<std::pair<int, int>> ij;
+    for (int i = 0; i < M; i++) for (int j = i + 1; j < M; j++) {
+      double a[3], b[3]; for (int d = 0; d < 3; d++) { a[d] = S[j][d] - S[i][d]; b[d] = D[j][d] - D[i][d]; }
+      const double na = norm3(a), nb = norm3(b);
+      if (!(na > 0.0) || !(nb == nb)) continue;
+      X.push_back(nb / na); ranges.push_back(beta / na); ij.push_back({i, j});
+    }
+    if (X.empty()) return;
+    std::vector<char> inl;
+    scale = tls_estimate_ranges(X, ranges, inl);
+    if (!(scale > 0.0)) return;
+    for (size_t k = 0; k < ij.size(); k++) if (inl[k]) adj[(size_t)ij[k].first * M + ij[k].second] = adj[(size_t)ij[k].second * M + ij[k].first] = 1;
+    out->scale = scale;
+  } else
   for (int i = 0; i < M; i++) for (int j = i + 1; j < M; j++) {
     double a[3], b[3]; for (int d = 0; d < 3; d++) { a[d] = S[j][d] - S[i][d]; b[d] = D[j][d] - D[i][d]; }
     if (std::fabs(norm3(b) - norm3(a)) <= beta) adj[(size_t)i * M + j] = adj[(size_t)j * M + i] = 1;
@@ -325,7 +368,12 @@ void solve(const float* src, const float* dst, const std::vector<std::pair<int, 
   // Quatro rotation: GNC-TLS restricted to yaw
   // TEASER++ RobustRegistrationSolver::solve(): "params.noise_bound *= (2 / solution_.scale)" on the rotation solver's params
   // before solveForRotation (TIMs are differences of two bounded measurements), which then uses pow(params_.noise_bound, 2).
-  double nb2 = (2.0 * p.noise_bound) * (2.0 * p.noise_bound); if (nb2 < 1e-16) nb2 = 1e-2;
+  double nb2 = (2.0 * p.noise_bound) * (2.0 * p.noise_bound);
+  if (p.estimate_scale) {      // pruned_dst_tims_ *= (1 / solution_.scale); params.noise_bound *= (2 / solution_.scale)
+    for (int i = 0; i < m; i++) for (int d = 0; d < 3; d++) B[i][d] *= 1.0 / scale;
+    const double nbr = p.noise_bound * (2.0 / scale); nb2 = nbr * nbr;
+  }
+  if (nb2 < 1e-16) nb2 = 1e-2;
   std::vector<double> wgt(m, 1.0), res(m);
   double mu = 1.0, prev_cost = std::numeric_limits<double>::infinity(), c = 1.0, s = 0.0;
   for (int it = 0; it < p.rot_max_iter; it++) {
@@ -356,7 +404,7 @@ void solve(const float* src, const float* dst, const std::vector<std::pair<int, 
     for (int i = 0; i < m; i++) {
       const double* sp = S[C[i]].data();
       const double r[3] = {c * sp[0] - s * sp[1], s * sp[0] + c * sp[1], sp[2]};
-      X[i] = D[C[i]][d] - r[d];
+      X[i] = D[C[i]][d] - (p.estimate_scale ? scale * r[d] : r[d]);      // solveForTranslation(scale * R * src, dst)
     }
     t[d] = tls_estimate(X, p.noise_bound);
   }

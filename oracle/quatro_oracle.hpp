@@ -42,6 +42,7 @@ struct QuatroResult {
   std::vector<std::pair<int, int>> corres;      // after the tuple test, sorted unique (src idx, dst idx)
   std::vector<int> clique;                      // indices into corres
   int rot_iterations;
+  double scale = 1.0;                           // TEASER++ TLSScaleSolver's estimate (1 unless estimate_scale)
 };
 
 float qn_atan2f(float y, float x);

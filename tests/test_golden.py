@@ -194,13 +194,28 @@ def test_gpu_reproduces_quatro_golden(name):
 
 
 @pytest.mark.gpu
-def test_gpu_quatro_params_are_not_silently_ignored():
-    """estimate_scale has no implementation: refused (QN_ERR_INVALID_ARG), never accepted and ignored; use_optimized_matching = 0
-    selects advancedMatching (covered above)."""
-    from qn_amd import engine
-    ctx = engine.Context(1024)
+def test_gpu_quatro_params_are_not_silently_ignored(oracle):
+    """estimate_scale (estimat_scale_, include/loop_closure.h:44, passed at loop_closure.cpp:24) runs TEASER++'s TLS scale solver: on a target that IS the source scaled by
+    1.03 and moved (FPFH at fixed radii is not scale invariant: a few per cent is what the descriptors still match across), quatro<>::align recovers scale, yaw and
+    translation - same correspondence set, same scale, same pose as the oracle; use_optimized_matching = 0 selects advancedMatching (covered above); nonsense parameters are refused."""
+    from qn_amd import engine, synth
+    src, _, _ = synth.make_pair(340, 6000, extent=42.0, mode="quatro")
+    th = 0.6; R = np.array([[np.cos(th), -np.sin(th), 0], [np.sin(th), np.cos(th), 0], [0, 0, 1]])
+    rng = np.random.default_rng(5)
+    tgt = (1.03 * (src.astype(np.float64) @ R.T) + np.array([4.0, -3.0, 0.2]) + rng.normal(0, 0.01, src.shape)).astype(np.float32)
+    ctx = engine.Context(8192)
+    kw = dict(estimate_scale=True)
+    q = engine.Quatro(ctx, **kw)
+    r = q.align(src, tgt, debug=True)
+    o = oracle.quatro_align(src, tgt, oracle.QuatroParams(**kw))
+    assert r["valid"] == o["valid"] and np.array_equal(r["corres"], o["corres"])
+    os_ = oracle.quatro_solve_scaled(src, tgt, o["corres"], oracle.QuatroParams(**kw))
+    assert abs(q.scale() - os_["scale"]) <= 1e-12 and np.abs(r["T"] - o["T"]).max() <= 1e-9
+    assert r["valid"] and abs(q.scale() - 1.03) < 0.01, (r["valid"], q.scale())
+    dt, dr = synth.pose_error(r["T"], np.block([[R, np.array([[4.0], [-3.0], [0.2]])], [np.zeros((1, 3)), np.ones((1, 1))]]))
+    assert dt < 0.5 and dr < 0.02
     with pytest.raises(engine.EngineError) as ei:
-        engine.Quatro(ctx, estimate_scale=True)
+        engine.Quatro(ctx, noise_bound=-1.0)
     assert ei.value.status == engine.QN_ERR_INVALID_ARG
     engine.Quatro(ctx, use_optimized_matching=False)
     ctx.close()

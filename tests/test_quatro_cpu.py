@@ -75,6 +75,50 @@ def test_product_host_solver_matches_oracle(oracle, seed):
     assert np.abs(a["T"] - b["T"]).max() < 1e-9
 
 
+@pytest.mark.parametrize("seed,true_scale,noise", [(0, 1.37, 0.05), (1, 0.8, 0.02), (2, 1.0, 0.05), (3, 2.5, 0.1), (4, 1.1, 0.0)])
+def test_scale_estimation_three_implementations(oracle, seed, true_scale, noise):
+    """estimate_scale = true (estimat_scale_, loop_closure.h:44 / loop_closure.cpp:24): TEASER++'s TLS scale solver over the TIM norm ratios in front of the consistency graph.
+    The PRODUCT's host solver (qn_quatro_solve_scaled), the C++ oracle and the independent numpy restatement (oracle/py_quatro.py) on the same correspondences with a third of
+    outliers: same clique, same scale (1e-12), same pose (1e-9), and the known scale / yaw / translation recovered."""
+    from qn_amd import engine
+    from oracle import py_quatro as pq
+    rng = np.random.default_rng(900 + seed)
+    M = 110
+    src = rng.uniform(-20, 20, size=(M, 3)).astype(np.float32); src[:, 2] = rng.uniform(0, 4, M)
+    T = yaw_T(rng.uniform(-3, 3), [rng.uniform(-6, 6), rng.uniform(-6, 6), 0.3])
+    dst = (true_scale * (src.astype(np.float64) @ T[:3, :3].T) + T[:3, 3] + rng.normal(0, noise, (M, 3))).astype(np.float32)
+    bad = rng.choice(M, M // 3, replace=False); dst[bad] = rng.uniform(-30, 30, size=(len(bad), 3))
+    corres = np.c_[np.arange(M), np.arange(M)].astype(np.int32)
+    ep = engine.quatro_default_params(); ep.estimate_scale = 1
+    a = engine.quatro_solve(src, dst, corres, ep)
+    b = oracle.quatro_solve_scaled(src, dst, corres, oracle.QuatroParams(estimate_scale=True))
+    c = pq.solve(src, dst, corres, pq.Params(estimate_scale=True))
+    assert a["valid"] and b["valid"] and c["valid"]
+    assert a["clique"].tolist() == b["clique"].tolist() == list(c["clique"])
+    assert abs(a["scale"] - b["scale"]) <= 1e-12 and abs(b["scale"] - c["scale"]) <= 1e-12
+    assert np.abs(a["T"] - b["T"]).max() < 1e-9 and np.abs(b["T"] - c["T"]).max() < 1e-9
+    good = sorted(set(range(M)) - set(bad.tolist()))
+    assert len(set(good) & set(a["clique"].tolist())) >= 0.8 * len(good)
+    assert abs(a["scale"] - true_scale) < 0.02 * true_scale + 3 * noise / 10
+    dt, dr = synth.pose_error(a["T"], T)
+    assert dt < 0.1 + 3 * noise and dr < 0.01 + noise / 5
+    # and with the flag off the product still takes the fixed-scale path (the reference's shipped configuration): identical to before
+    a1 = engine.quatro_solve(src, dst, corres); b1 = oracle.quatro_solve(src, dst, corres)
+    assert a1["scale"] == 1.0 and a1["valid"] == b1["valid"] and a1["clique"].tolist() == b1["clique"].tolist()
+
+
+def test_scalar_tls_with_ranges_known_answers():
+    """the scale stage's estimator (numpy restatement): an exact consensus is returned exactly, outliers with tight ranges lose to a majority with loose ones, ties in the
+    sweep resolve like the C++ sort"""
+    from oracle import py_quatro as pq
+    est, inl = pq._tls_ranges([2.0, 2.0, 2.0, 5.0], [0.1, 0.1, 0.1, 0.1])
+    assert est == 2.0 and inl.tolist() == [True, True, True, False]
+    est, inl = pq._tls_ranges([1.0, 1.02, 0.98, 3.0, 3.01], [0.05, 0.05, 0.05, 0.001, 0.001])
+    assert abs(est - 1.0) < 0.02 and inl.tolist() == [True, True, True, False, False]
+    est, inl = pq._tls_ranges([1.5], [0.2])
+    assert est == 1.5 and inl.tolist() == [True]
+
+
 def test_oracle_coarse_to_fine_recovers_large_yaw(oracle):
     src, tgt, T = synth.make_pair(300, 6000, extent=40.0, mode="quatro")
     r = oracle.coarse_to_fine_alignment(src, tgt)
