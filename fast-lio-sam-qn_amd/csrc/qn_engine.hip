@@ -718,8 +718,8 @@ static int launch_persist(qn_ctx* c, uint32_t max_ticks, int cond = 0) {
 // initial misalignment of a few degrees more than the bench's default turns one 25 us tick launch into 200-1800 us, and a launch ends with its slowest lane), while the dedicated
 // unseeded search costs the same whatever the step was.  Searches are exact in both regimes; the rule only decides which kernels run, and it reads nothing but the controller's own
 // step and the grids' numbers - the classic batch-member path (gicp_align) and the lanes (batch_register) take the same decision, so their records stay bit-identical.
-static bool unseeded_goes_on(const qn_ctx* c, int tick_no, int per_outer, int ticks_left) {
-  if (!c->persist_batch_off || !c->far_enabled || !c->fused_ticks) return false;
+static bool unseeded_goes_on(const qn_ctx* c, int tick_no, int per_outer, int ticks_left, bool lone = false) {      // lone: a registration on the adaptive lone path whose persistent launch declined on the second look (look_again)
+  if ((!c->persist_batch_off && !lone) || !c->far_enabled || !c->fused_ticks) return false;
   if (tick_no != c->unseeded_until || tick_no + per_outer > c->unseeded_cap * per_outer || ticks_left < per_outer) return false;
   const qn::ResultBlock* rb = c->result_host;
   if (rb->phase == 2) return false;
@@ -787,8 +787,9 @@ static int gicp_align(qn_ctx* c, const float guess[16], qn_gicp_result* out, boo
   c->result_host->phase = 0;
   c->unseeded_until = adaptive ? chunk : fixed_unseeded;           // ticks below this index search unseeded (enqueue_tick)
   bool seeded = false; int tick_no = 0;   // the first linearisation runs the full grid search; every later NN pass tracks from it
+  bool extending = false;                 // the unseeded phase goes on beyond the look, one outer iteration per host look (unseeded_goes_on)
   for (;;) {
-    const bool look = adaptive && first_chunk && ticks_left > chunk;      // the adaptive look: the state behind the chunk's last tick (its controller tail has stepped it)
+    const bool look = adaptive && first_chunk && !extending && ticks_left > chunk;      // the adaptive look: the state behind the chunk's last tick (its controller tail has stepped it)
     // A registration that is alone on the GPU takes the look ON THE DEVICE (look_decide, at the end of that controller tail): the conditional third unseeded iteration and
     // the persistent launch are enqueued behind it and read its flags - no host round trip between the unseeded ticks and the tracked regime (it cost 15-30 us of a
     // 0.6 ms align).  If the flags say "not the persistent kernel" (many far neighbours: the k_far regime), that launch returns at once and the chain goes on from the host below.
@@ -809,7 +810,8 @@ static int gicp_align(qn_ctx* c, const float guess[16], qn_gicp_result* out, boo
     if (dev_look) {
       c->unseeded_until = tick_no + 1;
       enqueue_nn(c, 0, c->sqd, false, tick_no / per_outer, QN_LOOK_EXTRA);
-      enqueue_accumulate(c, QN_LOOK_EXTRA, true);                   // (flag not set: the launch hands the state on unchanged)
+      LookArgs la2 = la; la2.enabled = 2; la2.allow_extra = 0;      // the second look, at the tail of the extra iteration: the persistent launch goes ahead only if THAT step is small too (look_again)
+      enqueue_accumulate(c, QN_LOOK_EXTRA, true, c->unseeded_cap > fixed_unseeded / per_outer ? &la2 : nullptr);      // (flag not set: the launch hands the state on unchanged)
       if (with_persist && (rc = launch_persist(c, (uint32_t)(budget - chunk) + 2u, QN_LOOK_GO)) != QN_OK) return rc;
       HIPCHK(c, hipGetLastError());
       HIPCHK(c, hipStreamSynchronize(s));
@@ -851,9 +853,11 @@ static int gicp_align(qn_ctx* c, const float guess[16], qn_gicp_result* out, boo
     if (!exact_ticks) chunk = first_chunk ? c->ticks_per_chunk : std::max(2 * per_outer, c->ticks_per_chunk / 2);   // convergence is usually near after the first chunks: ticks past it are wasted launches
     else chunk = c->far_mode == 1 ? std::min(ticks_left, c->far_chunk) : ticks_left;      // the refresh regime is needed for the first few tracked ticks only: an empty k_far + k_far_reduce behind every later tick cost 14 us each (80 %-overlap pairs: 1384 -> 1429 registrations/s with 4 instead of 8)
     if (budget <= 0) { c->last_error = "align: device state machine did not terminate"; return QN_ERR_HIP; }
-    if (first_chunk && !adaptive && unseeded_goes_on(c, tick_no, per_outer, ticks_left)) {      // a batch member whose pose still moves by more than a fraction of a cell: one more unseeded outer iteration, then look again
-      c->unseeded_until = tick_no + per_outer; chunk = per_outer;
-      continue;                                                      // (first_chunk stays set: the far-query statistics are those of the LAST unseeded linearisation)
+    if (first_chunk && (!adaptive || declined || extending) && unseeded_goes_on(c, tick_no, per_outer, ticks_left, adaptive)) {
+      // a batch member - or a lone registration whose persistent launch declined on its second look - whose pose still moves by more than a fraction of a cell: one more
+      // unseeded outer iteration, then look again (first_chunk stays set: the far-query statistics are those of the LAST unseeded linearisation)
+      c->unseeded_until = tick_no + per_outer; chunk = per_outer; extending = true;
+      continue;
     }
     if (look && !declined) {
       // how far the NEXT step will move the source points at most: the step just taken (translation + rotation x the cloud's reach from the origin), shrunk
@@ -867,11 +871,15 @@ static int gicp_align(qn_ctx* c, const float guess[16], qn_gicp_result* out, boo
       int extra = moved <= ok ? 0 : 1;
       extra = std::min(extra * per_outer, std::max(0, std::min(ticks_left - 1, per_outer)));
       if (!(moved == moved)) extra = 0;
+      c->last_extra_unseeded = extra;
+      if (extra > 0 && c->unseeded_cap > fixed_unseeded / per_outer) {      // the extra iteration as a chunk of its own with a look behind it: the same decisions as the device route (look_again), one iteration per look
+        c->unseeded_until = tick_no + extra; chunk = extra; extending = true;
+        continue;
+      }
       c->unseeded_until = tick_no + extra;
       for (int t = 0; t < extra; t++) { enqueue_tick(c, seeded, tick_no); tick_no++; }
       budget -= extra; ticks_left -= extra;
       if (exact_ticks) chunk = c->far_mode == 1 ? std::min(ticks_left, c->far_chunk) : ticks_left;
-      c->last_extra_unseeded = extra;
     }
     if (tick_no > 0 && persist_usable(c, alone)) {          // everything that is left - ticks, closing pass, result - in ONE persistent launch (first chunk end, or once the far-query refreshes have died down)
       if ((rc = launch_persist(c, (uint32_t)budget + 2u)) != QN_OK) return rc;
