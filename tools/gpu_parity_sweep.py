@@ -1,6 +1,8 @@
 """Stress tool (GPU box): randomized GPU-vs-oracle parity over many seeded pairs, sizes, k, optimizers and stopping rules.
 Prints one line per mismatch and a summary; exit code 1 on any mismatch.
-usage: python tools/gpu_parity_sweep.py [n_cases [seed]] [--lanes B]
+usage: python tools/gpu_parity_sweep.py [n_cases [seed]] [--lanes B] [--hard]
+  --hard: half of the pairs get their target re-posed by a further 0.03-0.09 rad of yaw and up to 0.5 m (the bench's "re-pose variants"): their pose still moves by metres at the
+          third to sixth iteration, so the unseeded phase is extended per lane / per look (unseeded_goes_on, look_again) - lanes of ONE launch then run in different regimes
   seed != 0: other pairs and, for a third of the cases, 80 % overlap
   --lanes B: the cases go through qn_gicp_align_batch B at a time (the pair as a grid dimension: NnLaneK, TickK with two rows per block, the grouped list pass) -
              the path bench.py's headline runs; the parameters (k, optimizer, max_iter, eps) are drawn per batch (a batch shares its context's parameters),
@@ -12,10 +14,10 @@ import numpy as np
 from qn_amd import engine, synth
 from oracle import oracle as orc          # checker only
 ap = argparse.ArgumentParser()
-ap.add_argument("ncases", nargs="?", type=int, default=40); ap.add_argument("seed", nargs="?", type=int, default=0); ap.add_argument("--lanes", type=int, default=0)
+ap.add_argument("ncases", nargs="?", type=int, default=40); ap.add_argument("seed", nargs="?", type=int, default=0); ap.add_argument("--lanes", type=int, default=0); ap.add_argument("--hard", action="store_true")
 args = ap.parse_args()
 ncases, seed, lanes = args.ncases, args.seed, args.lanes
-rng = np.random.default_rng(2024 + seed + (7919 * lanes if lanes else 0))
+rng = np.random.default_rng(2024 + seed + (7919 * lanes if lanes else 0) + (104729 if args.hard else 0))
 ctx = engine.Context(70000)
 if lanes:
     ctx.debug_set("batch_lanes", lanes)
@@ -37,6 +39,10 @@ def draw_pair(case):
         src, tgt, T = synth.make_pair(pid, n, extent=ext, shift=shift)
     except RuntimeError:
         src, tgt, T = synth.make_pair(pid, n)
+    if args.hard and rng.random() < 0.5:                                    # a target that is a few degrees further off: large pose steps for several iterations
+        a = float(rng.uniform(0.03, 0.09)) * (1 if rng.random() < 0.5 else -1); ca, sa = np.cos(a), np.sin(a)
+        R = np.array([[ca, -sa, 0.0], [sa, ca, 0.0], [0.0, 0.0, 1.0]])
+        tgt = (tgt.astype(np.float64) @ R.T + np.array([rng.uniform(-0.5, 0.5), rng.uniform(-0.5, 0.5), 0.0])).astype(np.float32)
     if rng.random() < 0.25: tgt = tgt[: int(0.7 * n)]                      # ragged sizes
     if rng.random() < 0.35:                                                 # isolated points scattered in the bounding volume (far-query k-NN / 1-NN paths)
         frac = float(rng.choice([0.005, 0.02, 0.1]))
@@ -91,5 +97,5 @@ while case < ncases:
         if bool(val[i]) != bool(ro["converged"] and ro["fitness"] < 1.5):
             bad += 1; print("MISMATCH case %d pair %d: valid %d vs oracle" % (case + i, pid, val[i]))
     case += m
-print("%d cases%s, %d mismatches, worst |dT| %.2e m %.2e rad, %.1f s" % (ncases, " through %d lanes" % lanes if lanes else "", bad, worst_t, worst_r, time.time() - t0))
+print("%d cases%s%s, %d mismatches, worst |dT| %.2e m %.2e rad, %.1f s" % (ncases, " through %d lanes" % lanes if lanes else "", " (hard: half re-posed)" if args.hard else "", bad, worst_t, worst_r, time.time() - t0))
 sys.exit(1 if bad else 0)
