@@ -605,6 +605,9 @@ def main():
         batch(max(args.warmup, 4 * len(ctxs) * max(1, args.lanes)))
         while time.perf_counter() - tw < 0.25:
             batch(2 * len(ctxs) * max(1, args.lanes))
+        # ... and ONE untimed run of exactly the block that is timed next (the pairs dealt to the contexts the same way): the first block behind a warm-up of another shape read 1-3 %
+        # below its own repeats in every round's record (r5: 4064 against repeats of 4078-4209; r6: 3969 against 4084-4133) - the timed block and its repeats now start from the same state
+        batch(args.steps)
     if dist is not None:          # untimed: bring up the communicator's channels (RCCL connects lazily on the first collective)
         gather_best([0.0] * 19)
         dist.all_reduce(torch.zeros(1, dtype=torch.float64, device=cdev), op=dist.ReduceOp.MAX)
