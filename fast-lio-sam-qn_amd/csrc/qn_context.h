@@ -102,6 +102,7 @@ struct qn_ctx {
                                         // kernel for the large early steps, but it saves four launches and the persistent kernel starts sooner (align 0.506 -> 0.477 ms; batches: 2268 -> 2031 /s)
   bool fused_final = true;              // closing pass (last controller step + fitness sweep + output cloud) in one launch
   int knn_rounds = 2;                   // rounds of the first k-NN pass before a query goes to the list pass
+  int knn_mm = 1;                       // k-NN selection: squared distances of the two passes on the matrix cores (v_mfma_f32_16x16x4_f32 screen + exact re-evaluation of the listed candidates); 0 = VALU scoring (k <= 24 only)
   int knn_trips = 3;                    // batched launches: groups of 16 queries a wave of the k-NN selection pass serves (grid = n / 64 / knn_trips blocks)
   int knn_hist = 1;                     // 1: k-NN by histogram selection (wave_knn_hist), 0: sorted-list sink (wave_search + BestK)
   int big_blocks0 = 4096, fb_blocks0 = 512;   // grid of the list pass behind the first (unseeded) ticks: one-far-query-per-wave blocks, wave-stride leftover blocks

@@ -480,10 +480,11 @@ __device__ __forceinline__ void stream_chunks(const GridView& g, WaveLds* lds, c
 }
 // REUSE: the caller streams the SAME clusters a second time (the two passes of the histogram selection): when all segments fit one table (nseg_all <= 64) the
 // table of the first walk is still in LDS - `reuse_total` is what that walk returned - and the cell_start gather, the divisions and the scan are skipped.
-template <int S, bool REUSE = false, class Fn>
-__device__ __forceinline__ uint32_t stream_clusters(const GridView& g, WaveLds* lds, int ncl, uint32_t nseg_all, Fn&& fn, const uint32_t reuse_total = 0) {
+// (stream_tables: the segment tables of all cluster boxes, 64 segments at a time; `chunks(total)` consumes the `total` candidates of the table that sits in LDS)
+template <bool REUSE = false, class Chunks>
+__device__ __forceinline__ uint32_t stream_tables(const GridView& g, WaveLds* lds, int ncl, uint32_t nseg_all, Chunks&& chunks, const uint32_t reuse_total = 0) {
   const int lane = threadIdx.x & 63;
-  if (REUSE && nseg_all <= 64u) { stream_chunks<S>(g, lds, reuse_total, fn); return reuse_total; }
+  if (REUSE && nseg_all <= 64u) { chunks(reuse_total); return reuse_total; }
   uint32_t ncand = 0;
   for (uint32_t sb = 0; sb < nseg_all; sb += 64) {
     const uint32_t sidx = sb + lane;
@@ -518,10 +519,14 @@ __device__ __forceinline__ uint32_t stream_clusters(const GridView& g, WaveLds* 
     wave_lds_fence();
     lds->seg_excl[lane] = incl - len; lds->seg_start[lane] = s; lds->seg_cid[lane] = scid;
     wave_lds_fence();
-    stream_chunks<S>(g, lds, total, fn);
+    chunks(total);
     ncand += total;
   }
   return ncand;
+}
+template <int S, bool REUSE = false, class Fn>
+__device__ __forceinline__ uint32_t stream_clusters(const GridView& g, WaveLds* lds, int ncl, uint32_t nseg_all, Fn&& fn, const uint32_t reuse_total = 0) {
+  return stream_tables<REUSE>(g, lds, ncl, nseg_all, [&](const uint32_t total) __attribute__((always_inline)) { stream_chunks<S>(g, lds, total, fn); }, reuse_total);
 }
 
 // wave_search: the ONE cooperative search routine (1-NN and k-NN, first search and seeded re-search).

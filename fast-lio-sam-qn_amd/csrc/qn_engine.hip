@@ -427,7 +427,8 @@ static void launch_knn_cov(qn_ctx* c, CloudBuf& b, int k, int32_t* kidx, float* 
     const KnnLaunch L = prep_knn(c, b, k, kidx, kd2);
     constexpr int HCAP = KMAX <= 24 ? 32 : 48;      // pass-2 list capacity: 32 keeps the selection kernel at 4 waves/SIMD
     { ProfScope sel(c, QN_K_KNN_SELECT);
-      hipLaunchKernelGGL(HIP_KERNEL_NAME(k_knn_hist<false, HCAP>), dim3(L.sel_nb), dim3(QN_KNN_BLOCK), 0, s, L.sel.g, L.sel.k, L.sel.r0, L.sel.max_rounds, L.sel.knn_idx, L.sel.knn_d2, L.sel.fb_list, L.sel.fb_count, L.sel.gen_list, L.sel.gen_count); }
+      if (HCAP == 32 && !c->knn_mm) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_knn_hist<false, 32, false>), dim3(L.sel_nb), dim3(QN_KNN_BLOCK), 0, s, L.sel.g, L.sel.k, L.sel.r0, L.sel.max_rounds, L.sel.knn_idx, L.sel.knn_d2, L.sel.fb_list, L.sel.fb_count, L.sel.gen_list, L.sel.gen_count);
+      else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_knn_hist<false, HCAP>), dim3(L.sel_nb), dim3(QN_KNN_BLOCK), 0, s, L.sel.g, L.sel.k, L.sel.r0, L.sel.max_rounds, L.sel.knn_idx, L.sel.knn_d2, L.sel.fb_list, L.sel.fb_count, L.sel.gen_list, L.sel.gen_count); }
     ProfScope ps(c, QN_K_KNN_COV);
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_knn_hist<true, HCAP>), dim3(L.lst_nb), dim3(QN_KNN_BLOCK), 0, s, L.lst.g, L.lst.k, L.lst.r0, L.lst.max_rounds, L.lst.knn_idx, L.lst.knn_d2, L.lst.fb_list, L.lst.fb_count, L.lst.gen_list, L.lst.gen_count);
     hipLaunchKernelGGL(k_knn_single, dim3(L.single_nb), dim3(QN_BLOCK), 0, s, L.single.g, L.single.k, L.single.knn_idx, L.single.knn_d2, L.single.list, L.single.count, L.single.gen_list, L.single.gen_count);
@@ -1210,6 +1211,7 @@ extern "C" int qn_debug_set(qn_ctx* c, const char* key, double v) {
   else if (k == "fused_from_tick") c->fused_from_tick = v < 1 ? 1 : (int)v;
   else if (k == "knn_rounds") c->knn_rounds = v < 1 ? 1 : (int)v;
   else if (k == "knn_trips") c->knn_trips = v < 1 ? 1 : (int)v;
+  else if (k == "knn_mm") c->knn_mm = v != 0;
   else if (k == "fused_ticks") c->fused_ticks = v != 0;
   else if (k == "big_ratio") c->big_ratio = (float)v;
   else if (k == "margin_nn_cap") c->margin_nn_cap = (int)v;

@@ -429,7 +429,8 @@ static __global__ void k_cov_from_normals(const double* __restrict__ nrm, uint32
 #define QN_KNN_BLOCK 64
 #endif
 struct KnnHistArgs { GridView g; int k; float r0; int max_rounds; int32_t* knn_idx; float* knn_d2; uint2* fb_list; uint32_t* fb_count; uint2* gen_list; uint32_t* gen_count; };
-template <bool LIST, int HCAP>
+__device__ __forceinline__ float late_s(float v) { asm volatile("" : "+s"(v)); return v; }      // (a scalar made opaque here: products with it are formed where they are used, not kept in a vector register across a search)
+template <bool LIST, int HCAP, bool MM = true>      // MM: distances of the two selection passes on the matrix cores (qn_knn_hist.cuh); false = the VALU scoring (knob knn_mm 0, A/B and verification)
 struct KnnHistK {
   static constexpr int TB = QN_KNN_BLOCK, OCC = HCAP <= 32 ? 4 : 3;
   using Args = KnnHistArgs;
@@ -440,6 +441,7 @@ struct KnnHistK {
     int32_t* __restrict__ knn_idx = a.knn_idx; float* __restrict__ knn_d2 = a.knn_d2;
     uint2* __restrict__ fb_list = a.fb_list; uint32_t* __restrict__ fb_count = a.fb_count; uint2* __restrict__ gen_list = a.gen_list; uint32_t* __restrict__ gen_count = a.gen_count;
     float r0 = a.r0; if (r0 < 0.f) r0 = -r0 * g.cell;              // (a negative radius is in cells: the host does not know the cell edge)
+    r0 = uni(r0);                                                   // (a scalar: as a vector register it was carried - spilled - across every group's search)
     WaveLdsH<HCAP>* my = &lds[threadIdx.x >> 6];
     const uint32_t nq = LIST ? uni(*fb_count) : g.n;
     if (LIST && g.dbg && bx == 0 && threadIdx.x == 0) atomicAdd(&g.dbg[4], nq);
@@ -453,21 +455,21 @@ struct KnnHistK {
       const uint32_t i = __float_as_uint(q.w);
       int status = 2;
       {
-        const int st = wave_knn_hist<HCAP>(g, q.x, q.y, q.z, active && !general, r, k, max_rounds < 0 ? -max_rounds : max_rounds, my, knn_idx + (size_t)i * k, knn_d2 ? knn_d2 + (size_t)i * k : nullptr);
+        const int st = wave_knn_hist<HCAP, MM>(g, q.x, q.y, q.z, active && !general, r, k, max_rounds < 0 ? -max_rounds : max_rounds, my, knn_idx, knn_d2, i);
         if (!general) status = st;
       }
       if (!active || (threadIdx.x & 63) >= 16 || status == 0) continue;
       if (LIST) { const uint32_t fs = atomicAdd(gen_count, 1u); gen_list[fs] = make_uint2(t, __float_as_uint(r)); }
-      else if (status == 2 || r > 2.5f * r0 || max_rounds < 0 /* every leftover: launch_knn_cov */) { const uint32_t fs = atomicAdd(gen_count, 1u); gen_list[fs] = make_uint2(t, __float_as_uint(r)); }   // far or overflowing: one query per wave (k_knn_single)
+      else if (status == 2 || r > 2.5f * late_s(r0) || max_rounds < 0 /* every leftover: launch_knn_cov */) { const uint32_t fs = atomicAdd(gen_count, 1u); gen_list[fs] = make_uint2(t, __float_as_uint(r)); }   // far or overflowing: one query per wave (k_knn_single)
       else { const uint32_t fs = atomicAdd(fb_count, 1u); fb_list[fs] = make_uint2(t, __float_as_uint(r)); }
     }
   }
 };
-template <bool LIST, int HCAP>
+template <bool LIST, int HCAP, bool MM = true>
 __global__ void __launch_bounds__(QN_KNN_BLOCK, HCAP <= 32 ? 4 : 3) k_knn_hist(GridView g, int k, float r0, int max_rounds, int32_t* __restrict__ knn_idx, float* __restrict__ knn_d2,
                                                        uint2* __restrict__ fb_list, uint32_t* __restrict__ fb_count, uint2* __restrict__ gen_list, uint32_t* __restrict__ gen_count) {
   const KnnHistArgs a{g, k, r0, max_rounds, knn_idx, knn_d2, fb_list, fb_count, gen_list, gen_count};
-  KnnHistK<LIST, HCAP>::run(a, blockIdx.x, gridDim.x);
+  KnnHistK<LIST, HCAP, MM>::run(a, blockIdx.x, gridDim.x);
 }
 
 // The far / overflowing k-NN queries, one per wave (wave_knn_single); what it cannot finish goes to the sorted-list kernel.

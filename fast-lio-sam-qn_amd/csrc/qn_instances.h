@@ -35,6 +35,7 @@ namespace qn {
 QN_G1 __global__ void k_knn_hist<false, 32> QN_KNN_HIST_ARGS;
 QN_G1 __global__ void k_knn_hist<true, 32> QN_KNN_HIST_ARGS;
 QN_G1 __global__ void k_knn_hist<false, 48> QN_KNN_HIST_ARGS;
+QN_G1 __global__ void k_knn_hist<false, 32, false> QN_KNN_HIST_ARGS;      // VALU scoring (knob knn_mm 0)
 QN_G1 __global__ void k_knn_hist<true, 48> QN_KNN_HIST_ARGS;
 QN_G1 __global__ void k_nn_search<0, false, QN_NN_BLOCK> QN_NN_SEARCH_ARGS;
 QN_G1 __global__ void k_nn_search<0, true, QN_BLOCK> QN_NN_SEARCH_ARGS;
@@ -57,6 +58,7 @@ QN_G1 __global__ void k_tick<512, 4, 0, true>(TickArgs);
 QN_G11 __global__ void k_lanes<KnnHistK<false, 32>>(const LaneEntry<KnnHistArgs>*);
 QN_G11 __global__ void k_lanes<KnnHistK<true, 32>>(const LaneEntry<KnnHistArgs>*);
 QN_G11 __global__ void k_lanes<KnnHistK<false, 48>>(const LaneEntry<KnnHistArgs>*);
+QN_G11 __global__ void k_lanes<KnnHistK<false, 32, false>>(const LaneEntry<KnnHistArgs>*);      // VALU scoring (knob knn_mm 0)
 QN_G11 __global__ void k_lanes<KnnHistK<true, 48>>(const LaneEntry<KnnHistArgs>*);
 QN_G11 __global__ void k_lanes<NnSearchK<0, false, QN_NN_BLOCK>>(const LaneEntry<NnSearchArgs>*);
 QN_G11 __global__ void k_lanes<NnSearchK<0, true, QN_BLOCK>>(const LaneEntry<NnSearchArgs>*);

@@ -31,14 +31,53 @@ struct WaveLdsH {
   } u;
   uint32_t cnt[16];
   uint32_t kth[16];
+  uint32_t tile_sc[64 * 4];                       // MM: position in pts[] (26 bits) | cluster id << 26 of the staged candidates of the round's first QN_MM_NCH chunks
 };
+
+// ---- the distance matrix of a chunk on the matrix cores (MM)
+// 16 queries x 64 staged candidates = four v_mfma_f32_16x16x4_f32: A = candidates (x', y', z', |c'|^2), B = queries (-2 x', -2 y', -2 z', 1), C = |q'|^2, primes = relative
+// to an origin O near the wave's queries: D = |q'|^2 - 2 q'.c' + |c'|^2, an fmaf chain in f32 (MI355X_MICROARCH.md: bitwise an fmaf chain).  Lane l gets its OWN query's
+// (l & 15) distances to candidates 4 (l >> 4) + 0..3 of the group: 256 squared distances per issue slot instead of 6 VALU instructions per candidate and lane, and
+// one ds_read_b32 per lane and group instead of four ds_read_b128.  The values are APPROXIMATE (cancellation: absolute error <= 50 * 2^-24 * R^2 against the oracle's
+// f32 `sqdist` of the original coordinates, R = the largest |q'|, |c'| of the round - the derivation is in DESIGN.md section 4f); they only SCREEN:
+//   pass 1  bins them; tau_a = upper edge of the first bin whose cumulative count reaches k  =>  at least k candidates have exact d2 < tau_a + E   (E = 2^-16 R^2);
+//   pass 2  lists every candidate with approximate d2 < tau_a + 2 E  =>  the list holds EVERY candidate with exact d2 < tau_a + E, at least k of them;
+//   exact   the listed candidates are re-evaluated with the defining arithmetic (sqdist on the original coordinates), keyed and ranked as before: the k smallest keys of
+//           the list are the k smallest keys of the scanned box, in the oracle's order, bit for bit.
+typedef float qn_f4v __attribute__((ext_vector_type(4)));
+#define QN_MM_FAR 1.0e15f                          // an empty slot of the last chunk: a finite point far beyond every bin and every threshold
+#define QN_MM_NCH 4                                // chunks of a round whose A operands stay in REGISTERS between the two passes (256 candidates: three rounds in four)
+// stages the 64 candidates [cb, cb + 64) of the segment table in LDS: lds->tile[c] = (p - O, |p - O|^2), sc_out[c] = position in pts[] | cluster id << 26; returns
+// how many of them are real (all 64 lanes call, convergent)
+__device__ __forceinline__ uint32_t stage_chunk_mm(const GridView& g, WaveLds* lds, uint32_t* __restrict__ sc_out, const uint32_t cb, const uint32_t total,
+                                                   const float Ox, const float Oy, const float Oz, float& c2max) {
+  const int lane = threadIdx.x & 63;
+  const uint32_t slot = cb + lane;
+  int j = 0;
+#pragma unroll
+  for (int step = 32; step > 0; step >>= 1) { const int t = j + step; if (t < 64 && lds->seg_excl[t] <= slot) j = t; }
+  float4 rel = make_float4(QN_MM_FAR, 0.f, 0.f, QN_MM_FAR * QN_MM_FAR); uint32_t sc = 63u << 26;      // (an empty slot belongs to no cluster: ids are < 16)
+  if (slot < total) {
+    const uint32_t sidx = lds->seg_start[j] + (slot - lds->seg_excl[j]);
+    sc = sidx | (lds->seg_cid[j] << 26);
+    const float4 p = g.pts[sidx];
+    rel.x = p.x - Ox; rel.y = p.y - Oy; rel.z = p.z - Oz; rel.w = (rel.x * rel.x + rel.y * rel.y) + rel.z * rel.z;
+    c2max = fmaxf(c2max, rel.w);
+  }
+  wave_lds_fence();
+  lds->tile[lane] = rel; sc_out[lane] = sc;
+  wave_lds_fence();
+  return min(64u, total - cb);
+}
 
 // All 64 lanes call; lane l serves query (l & 15) as sub-slot (l >> 4); the 4 lanes of a query pass identical q, r,
 // out pointers.  Returns the query's status in all of its lanes: 0 = done (k indices written, ascending),
 // 1 = not certified within max_rounds (continue from the returned r), 2 = needs the general path.
-template <int HCAP>
+template <int HCAP, bool MM = true>
 __device__ __forceinline__ int wave_knn_hist(const GridView& g, float qx, float qy, float qz, bool active, float& r, int k, int max_rounds,
-                                             WaveLdsH<HCAP>* L, int32_t* __restrict__ idx_out, float* __restrict__ d2_out) {
+                                             WaveLdsH<HCAP>* L, int32_t* __restrict__ idx_base, float* __restrict__ d2_base, const uint32_t row) {
+  // (outputs: row `row` of the [n][k] tables idx_base / d2_base - the addresses are formed where the row is written: as two per-lane 64-bit pointers they were carried
+  //  across the whole search and spilled)
   const int lane = threadIdx.x & 63, qs = lane & 15, sub = lane >> 4;
   WaveLds* lds = &L->s;
   const int cx = cell_coord(qx, g.ox, g.inv_cell, g.nx);
@@ -60,11 +99,82 @@ __device__ __forceinline__ int wave_knn_hist(const GridView& g, float qx, float 
     // (ONE cluster - 94 % of the rounds: neighbours in the sorted order - needs no cluster test: every real candidate is everybody's, and the empty slots of the last
     //  chunk sit at infinity, beyond every bin)
     const bool one_cluster = ncl == 1;
+    const int base1 = mine ? base : -(1 << 28);
+    uint32_t ncand;
+    // MM: origin of the relative coordinates = the first open query; B operand and C of this lane's query
+    float Ox = 0.f, Oy = 0.f, Oz = 0.f, bsel = 0.f, q2 = 0.f, c2max = 0.f;
+    if constexpr (MM) {
+      const int l0 = __ffsll((long long)todo) - 1;
+      Ox = uni(__shfl(qx, l0)); Oy = uni(__shfl(qy, l0)); Oz = uni(__shfl(qz, l0));
+      const float rx = qx - Ox, ry = qy - Oy, rz = qz - Oz;
+      q2 = (rx * rx + ry * ry) + rz * rz;
+      bsel = sub == 0 ? -2.f * rx : (sub == 1 ? -2.f * ry : (sub == 2 ? -2.f * rz : 1.f));
+    }
+    // the four groups of a chunk: d[e] = approximate squared distance from this lane's query to candidate 16 gi + 4 sub + e; av = the chunk's A operands
+    const float* tilef = (const float*)&lds->tile[0];
+    const qn_f4v cin = {q2, q2, q2, q2};
+    auto mm_groups = [&](const float (&av)[4], const uint32_t cnt, auto&& per_group) __attribute__((always_inline)) {
+#pragma unroll
+      for (int gi = 0; gi < 4; gi++) {
+        if ((uint32_t)(16 * gi) < cnt) {                                          // (wave-uniform)
+          const qn_f4v d = __builtin_amdgcn_mfma_f32_16x16x4f32(av[gi], bsel, cin, 0, 0, 0);
+          per_group(gi, d);
+        }
+      }
+    };
+    auto load_av = [&](float (&av)[4]) __attribute__((always_inline)) {
+#pragma unroll
+      for (int gi = 0; gi < 4; gi++) av[gi] = tilef[(16 * gi + qs) * 4 + sub];
+    };
+    // (one segment table, one cluster - three rounds in four: the A operands of its first QN_MM_NCH chunks are kept for pass 2, which then needs no staging at all)
+    const bool cached = nseg_all <= 64u && one_cluster;
+    float avc[QN_MM_NCH][4];
+    if constexpr (MM) {
+      auto p1_group = [&](const uint32_t* __restrict__ scb, const int gi, const qn_f4v d) __attribute__((always_inline)) {
+        if (one_cluster) {
+#pragma unroll
+          for (int e = 0; e < 4; e++) {                                           // (arithmetic shift: a rounding-negative distance - the query itself - lands in bin 0)
+            const int bin = min(max((__float_as_int(d[e]) >> 20) - base1, 0), QN_HB - 1);
+            atomicAdd(&L->u.hist[qs][bin], 1u);
+          }
+        } else {
+          const uint4 cc = *(const uint4*)&scb[16 * gi + 4 * sub];
+          const uint32_t ccv[4] = {cc.x >> 26, cc.y >> 26, cc.z >> 26, cc.w >> 26};
+#pragma unroll
+          for (int e = 0; e < 4; e++) {
+            const int bin = max((__float_as_int(d[e]) >> 20) - base, 0);
+            const bool ok = mine && ccv[e] == cid && bin < QN_HB - 1;
+            atomicAdd(&L->u.hist[qs][ok ? bin : QN_HB + sub], 1u);
+          }
+        }
+      };
+      ncand = stream_tables<false>(g, lds, ncl, nseg_all, [&](const uint32_t total) __attribute__((always_inline)) {
+        uint32_t cb0 = 0u;
+        if (cached) {
+#pragma unroll
+          for (int c = 0; c < QN_MM_NCH; c++) {
+            if ((uint32_t)(64 * c) < total) {
+              const uint32_t cnt = stage_chunk_mm(g, lds, L->tile_sc + 64 * c, 64u * c, total, Ox, Oy, Oz, c2max);
+              load_av(avc[c]);
+              mm_groups(avc[c], cnt, [&](const int, const qn_f4v d) __attribute__((always_inline)) {
+#pragma unroll
+                for (int e = 0; e < 4; e++) atomicAdd(&L->u.hist[qs][min(max((__float_as_int(d[e]) >> 20) - base1, 0), QN_HB - 1)], 1u);
+              });
+            }
+          }
+          cb0 = 64u * QN_MM_NCH;
+        }
+        for (uint32_t cb = cb0; cb < total; cb += 64) {
+          const uint32_t cnt = stage_chunk_mm(g, lds, lds->tile_cid, cb, total, Ox, Oy, Oz, c2max);
+          float av[4]; load_av(av);
+          mm_groups(av, cnt, [&](const int gi, const qn_f4v d) __attribute__((always_inline)) { p1_group(lds->tile_cid, gi, d); });
+        }
+      });
+    } else {
     auto bin_of = [&](const float4& cp) __attribute__((always_inline)) { return max((int)(__float_as_uint(sqdist(qx, qy, qz, cp.x, cp.y, cp.z)) >> 20) - base, 0); };
     // (one cluster: the bin index clamped into [0, QN_HB - 1] IS the column - column QN_HB - 1 collects what lies beyond (2 r)^2 and is left out of the sums below;
     //  lanes without an open query get a base that sends everything there)
-    const int base1 = mine ? base : -(1 << 28);
-    const uint32_t ncand = one_cluster
+    ncand = one_cluster
       ? stream_clusters<4>(g, lds, ncl, nseg_all, [&](const float4& cp, bool, uint32_t) __attribute__((always_inline)) {
           const int bin = min(max((int)(__float_as_uint(sqdist(qx, qy, qz, cp.x, cp.y, cp.z)) >> 20) - base1, 0), QN_HB - 1);
           atomicAdd(&L->u.hist[qs][bin], 1u);
@@ -74,6 +184,7 @@ __device__ __forceinline__ int wave_knn_hist(const GridView& g, float qx, float 
           const bool ok = mine && in_tile && ccid == cid && bin < QN_HB - 1;
           atomicAdd(&L->u.hist[qs][ok ? bin : QN_HB + sub], 1u);                      // branch-free: rejected candidates land in the sub-slot's reject column
         });
+    }
     wave_lds_fence();
     // ---- tau: sub-slot s sums bins [16 s, 16 s + 16), then looks for the crossing in its own range
     uint32_t hv[16], mysum = 0;
@@ -97,6 +208,84 @@ __device__ __forceinline__ int wave_knn_hist(const GridView& g, float qx, float 
     wave_lds_fence();
     // ---- pass 2: collect the candidates below tau
     const bool collect = mine && enough;
+    if constexpr (MM) {
+      // threshold on the approximate distances: tau_a + 2 E, E = 2^-16 R^2 (R^2 = the largest |q'|^2, |c'|^2 of this round), rounded up
+      const float R2 = wave_max_f(fmaxf(c2max, mine ? q2 : 0.f));
+      const float thr = collect ? (__uint_as_float(tau_bits) + 2.f * (R2 * 1.52587890625e-5f)) * 1.000001f : -__int_as_float(0x7f800000);
+      float dummy = 0.f;
+      const uint32_t cidm = cid;
+      if (cached) {
+        // the cached chunks straight from registers: one hit bit per result (sign of d - thr), first result on top; m_lo = chunks 0, 1, m_hi = chunks 2, 3
+        uint32_t mw[QN_MM_NCH / 2] = {0u, 0u};
+#pragma unroll
+        for (int c = 0; c < QN_MM_NCH; c++) {
+          uint32_t& m = mw[c >> 1];
+          if ((uint32_t)(64 * c) < ncand) {
+            const uint32_t cnt = min(64u, ncand - 64u * c);
+#pragma unroll
+            for (int gi = 0; gi < 4; gi++) {
+              if ((uint32_t)(16 * gi) < cnt) {
+                const qn_f4v d = __builtin_amdgcn_mfma_f32_16x16x4f32(avc[c][gi], bsel, cin, 0, 0, 0);
+#pragma unroll
+                for (int e = 0; e < 4; e++) m = __builtin_amdgcn_alignbit(m, __float_as_uint(d[e] - thr), 31);
+              } else m <<= 4;
+            }
+          } else m <<= 16;
+        }
+        // list positions without atomics: the four lanes of a query exchange their hit counts
+        const uint32_t cntl = (uint32_t)(__popc(mw[0]) + __popc(mw[1]));
+        const uint32_t h0 = __shfl(cntl, qs), h1 = __shfl(cntl, qs + 16), h2 = __shfl(cntl, qs + 32), h3 = __shfl(cntl, qs + 48);
+        uint32_t pos = (sub > 0 ? h0 : 0u) + (sub > 1 ? h1 : 0u) + (sub > 2 ? h2 : 0u);
+        if (sub == 0) L->cnt[qs] = h0 + h1 + h2 + h3;                             // (chunks beyond the cached ones append behind, with the counter)
+        while (__any((mw[0] | mw[1]) != 0u)) {
+          const bool lo = mw[0] != 0u;
+          uint32_t w = lo ? mw[0] : mw[1];
+          if (w != 0u) {
+            const uint32_t I = (uint32_t)__clz((int)w);                           // hit of chunk (I >> 4) of the pair, group (I >> 2) & 3, result I & 3
+            const uint32_t at = (lo ? 0u : 128u) + ((I >> 4) << 6) + (((I >> 2) & 3u) << 4) + 4u * (uint32_t)sub + (I & 3u);
+            if (pos < HCAP) L->u.list[qs][pos] = (unsigned long long)(L->tile_sc[at] & 0x03ffffffu);
+            pos++;
+            w &= ~(0x80000000u >> I);
+            if (lo) mw[0] = w; else mw[1] = w;
+          }
+        }
+        wave_lds_fence();
+      }
+      if (!cached || ncand > 64u * QN_MM_NCH) {
+      stream_tables<true>(g, lds, ncl, nseg_all, [&](const uint32_t total) __attribute__((always_inline)) {
+        for (uint32_t cb = cached ? 64u * QN_MM_NCH : 0u; cb < total; cb += 64) {
+          const uint32_t cnt = stage_chunk_mm(g, lds, lds->tile_cid, cb, total, Ox, Oy, Oz, dummy);
+          float av[4]; load_av(av);
+          mm_groups(av, cnt, [&](const int gi, const qn_f4v d) __attribute__((always_inline)) {
+            bool hit[4];
+#pragma unroll
+            for (int e = 0; e < 4; e++) hit[e] = d[e] < thr;
+            const uint4 cc = *(const uint4*)&lds->tile_cid[16 * gi + 4 * sub];
+            if (!one_cluster) { hit[0] = hit[0] && (cc.x >> 26) == cidm; hit[1] = hit[1] && (cc.y >> 26) == cidm; hit[2] = hit[2] && (cc.z >> 26) == cidm; hit[3] = hit[3] && (cc.w >> 26) == cidm; }
+            const uint32_t scv[4] = {cc.x, cc.y, cc.z, cc.w};
+            if (hit[0] || hit[1] || hit[2] || hit[3]) {
+#pragma unroll
+              for (int e = 0; e < 4; e++) if (hit[e]) {
+                const uint32_t pos = atomicAdd(&L->cnt[qs], 1u);
+                if (pos < HCAP) L->u.list[qs][pos] = (unsigned long long)(scv[e] & 0x03ffffffu);      // (position in pts[]: the exact stage fetches the point from there)
+              }
+            }
+          });
+        }
+      }, ncand);
+      }
+      wave_lds_fence();
+      // ---- exact stage: the listed candidates with the defining arithmetic
+      const uint32_t Pn = min(L->cnt[qs], (uint32_t)HCAP);
+#pragma unroll
+      for (int j = 0; j < HCAP / 4; j++) {
+        const uint32_t slot = (uint32_t)(sub + 4 * j);
+        if (collect && slot < Pn) {
+          const float4 p = g.pts[(uint32_t)L->u.list[qs][slot]];
+          L->u.list[qs][slot] = pack_key(sqdist(qx, qy, qz, p.x, p.y, p.z), __float_as_uint(p.w));
+        }
+      }
+    } else {
     auto collect_one = [&](const float4& cp) __attribute__((always_inline)) {
       const float d2 = sqdist(qx, qy, qz, cp.x, cp.y, cp.z);
       if (collect && __float_as_uint(d2) < tau_bits) {
@@ -107,6 +296,7 @@ __device__ __forceinline__ int wave_knn_hist(const GridView& g, float qx, float 
     // (the segment table of pass 1 is still in LDS when it fits one: `ncand`)
     if (one_cluster) stream_clusters<4, true>(g, lds, ncl, nseg_all, [&](const float4& cp, bool, uint32_t) __attribute__((always_inline)) { collect_one(cp); }, ncand);
     else stream_clusters<4, true>(g, lds, ncl, nseg_all, [&](const float4& cp, bool in_tile, uint32_t ccid) __attribute__((always_inline)) { if (in_tile && ccid == cid) collect_one(cp); }, ncand);
+    }
     wave_lds_fence();
     const uint32_t P = L->cnt[qs];
     const bool ok = collect && P <= HCAP;                                        // (P >= k by construction)
@@ -155,7 +345,8 @@ __device__ __forceinline__ int wave_knn_hist(const GridView& g, float qx, float 
         else {
           const uint32_t tot = s0 + s1 + s2 + s3;
           if (4u * tot < (uint32_t)k) {                                           // an isolated point (a quarter of k within 2 r): do not drag the wave through a
-            r = tot > 0 ? 2.f * r * sqrtf((float)k / (float)tot) * 1.1f : 4.f * r + g.cell;   // big-box round - hand it over with an extrapolated radius (count ~ r^2);
+            int kk = k; asm volatile("" : "+s"(kk));                          // (opaque: as a loop invariant (float)k was kept - spilled - across the whole search for this rare branch)
+            r = tot > 0 ? 2.f * r * sqrtf((float)kk / (float)tot) * 1.1f : 4.f * r + g.cell;   // big-box round - hand it over with an extrapolated radius (count ~ r^2);
           } else { r = 2.f * r + g.cell; retry = true; }                          // the caller sends radii beyond 2.5 r0 to the one-query-per-wave pass
         }
       } else if (!ok) status = 2;                                                   // list overflow
@@ -163,6 +354,8 @@ __device__ __forceinline__ int wave_knn_hist(const GridView& g, float qx, float 
         d -= g.eps;
         if (whole || (d > 0.f && kth_d2 < d * d)) {
           status = 0;
+          uint32_t row_l = row; asm volatile("" : "+v"(row_l));
+          int32_t* __restrict__ idx_out = idx_base + (size_t)row_l * k; float* __restrict__ d2_out = d2_base ? d2_base + (size_t)row_l * k : nullptr;
 #pragma unroll
           for (int j = 0; j < HCAP / 4; j++) if (own[j] != QN_INF_KEY && rank[j] < k) {
             idx_out[rank[j]] = (int32_t)key_idx(own[j]);
