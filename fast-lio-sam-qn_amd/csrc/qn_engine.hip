@@ -180,6 +180,10 @@ static int ctx_create(int device, uint32_t max_points, hipStream_t shared_stream
   CA(hipMemsetAsync(c->fb_count2, 0, 4 * sizeof(uint32_t), c->stream)); CA(hipMemsetAsync(c->fb_count2b, 0, 4 * sizeof(uint32_t), c->stream));      // the k-NN list counters: every covariance stage hands them back at zero (k_cov_from_idx)
   CA(hipMemsetAsync(c->scan_status, 0, sizeof(unsigned long long) * 2 * (c->max_cells / (QN_BLOCK * QN_SCAN_ITEMS) + 2), c->stream));
   for (int w = 0; w < 2; w++) CA(hipMemsetAsync(c->cloud[w].counts, 0, sizeof(uint32_t) * ((size_t)c->max_cells + 1), c->stream));      // the cell counters are handed back at zero by every build (k_scatter)
+  // the k-NN index tables start as `no neighbour` (-1): a cloud with non-finite coordinates is an empty grid on the device - the selection kernels write nothing - and the
+  // covariance kernel behind them gathers through the table as it is; a fresh allocation may hold anything (round 6: a GPU memory fault on the developer entry point qn_gicp_knn)
+  CA(hipMemsetAsync(c->knn_idx, 0xff, sizeof(int32_t) * (size_t)max_points * 32, c->stream));
+  if (c->knn_idx2) CA(hipMemsetAsync(c->knn_idx2, 0xff, sizeof(int32_t) * (size_t)max_points * 32, c->stream));
   CA(hipStreamSynchronize(c->stream));
 #undef CA
   { // the persistent align kernel needs all of its blocks resident at once (up to QN_PERSIST_MAX_BLOCKS + 1 blocks of 512 threads): on a smaller or compute-partitioned
@@ -1102,6 +1106,9 @@ extern "C" int qn_gicp_knn(qn_ctx* c, int which, int k, int32_t* idx_out, float*
   hipFree(c->dbg_knn_idx); hipFree(c->dbg_knn_d2); c->dbg_knn_idx = nullptr; c->dbg_knn_d2 = nullptr;
   HIPCHK(c, hipMalloc(&c->dbg_knn_idx, sizeof(int32_t) * (size_t)b.n * k));
   HIPCHK(c, hipMalloc(&c->dbg_knn_d2, sizeof(float) * (size_t)b.n * k));
+  // (a cloud with non-finite coordinates is an EMPTY grid on the device: the selection kernels write nothing, and the covariance kernel behind them must not gather through
+  //  whatever a fresh allocation holds - -1 reads as `no neighbour`; the call itself returns the cloud's error after its synchronisation)
+  HIPCHK(c, hipMemsetAsync(c->dbg_knn_idx, 0xff, sizeof(int32_t) * (size_t)b.n * k, c->stream));
   const int ksave = c->params.k_correspondences; const bool had = b.has_cov;
   c->params.k_correspondences = k;
   int rc = compute_cov(c, which, c->dbg_knn_idx, c->dbg_knn_d2);

@@ -320,7 +320,8 @@ __device__ __forceinline__ int wave_knn_hist(const GridView& g, float qx, float 
       }
     };
     if (HCAP > 32 && maxP > 32) rank_pass(std::integral_constant<int, HCAP / 4>());
-    else if (maxP > 24) rank_pass(std::integral_constant<int, 8>());
+    else if (maxP > 28) rank_pass(std::integral_constant<int, 8>());
+    else if (maxP > 24) rank_pass(std::integral_constant<int, 7>());      // (k = 20: the longest list of a wave's 16 queries is 25...28 entries every other time)
     else rank_pass(std::integral_constant<int, 6>());
 #pragma unroll
     for (int j = 0; j < HCAP / 4; j++) if (own[j] != QN_INF_KEY && rank[j] == k - 1) L->kth[qs] = (uint32_t)(own[j] >> 32);

@@ -51,10 +51,26 @@ def test_near_ties(eng, oracle):
     engine, ctx = eng
     rng = np.random.default_rng(11)
     gx, gy = np.meshgrid(np.arange(70, dtype=np.float32) * 0.25, np.arange(70, dtype=np.float32) * 0.25)
-    lat = np.stack([gx.ravel() + 31.0, gy.ravel() - 17.0, np.full(4900, 2.0, np.float32)], 1).astype(np.float32)
+    lat = np.stack([gx.ravel() + 31.0, gy.ravel() - 17.125, np.full(4900, 2.0, np.float32)], 1).astype(np.float32)      # (no coordinate is 0: its bit pattern minus 2 would be a NaN)
     bits = lat.view(np.int32) + rng.integers(-2, 3, lat.shape).astype(np.int32)
     cloud = bits.view(np.float32).copy()
+    assert np.isfinite(cloud).all()
     _check(engine, ctx, oracle, cloud, (16, 20))
+
+
+def test_knn_of_a_non_finite_cloud_is_refused_without_a_fault(eng):
+    """qn_gicp_knn on a cloud with a NaN: the grid is empty on the device, the call reports the cloud's error - and the covariance kernel behind the selection must not
+    gather through an uninitialised index table (a GPU memory fault in a long-lived process, round 6)."""
+    engine, ctx = eng
+    src, _, _ = synth.make_pair(49, 5000, extent=40.0)
+    src = src.copy(); src[77, 1] = np.nan
+    g = engine.NanoGICP(ctx); g.setInputSource(src)
+    with pytest.raises(engine.EngineError):
+        g.knn(0, 20)
+    good, _, _ = synth.make_pair(49, 5000, extent=40.0)
+    g.setInputSource(good)
+    idx, d2 = g.knn(0, 20)
+    assert (idx[:, 0] == np.arange(len(good))).all()
 
 
 def test_matches_valu_scoring_at_full_size(eng):
