@@ -6,7 +6,7 @@ import csv, json, os, sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "fast-lio-sam-qn_amd"))
 from qn_amd.build import csrc_sha1
 from collections import defaultdict
-FAMILY = [("KnnHistK<false, 32>", "knn_select", 2), ("TickK<512, 4, 0,", "gn_tick_fused", 1), ("TickK<512, 4, 1,", "closing_pass", 1), ("NnLaneK<0>", "nn_search", 1),
+FAMILY = [("KnnHistK<false, 32", "knn_select", 2), ("TickK<512, 4, 0,", "gn_tick_fused", 1), ("TickK<512, 4, 1,", "closing_pass", 1), ("NnLaneK<0>", "nn_search", 1),
           ("NnSearchK<0, true,", "nn_fallback", 1), ("AccumulateK", "accumulate", 1), ("CovFromIdxK", "cov_from_idx", 2), ("PackBBoxK", "grid_pack", 2), ("ScatterK", "grid_scatter", 2)]
 def per_kernel(path):
     tot, cnt = defaultdict(float), defaultdict(int)
