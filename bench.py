@@ -668,7 +668,12 @@ def main():
         if dist is not None:
             tmax = torch.tensor([bwall], dtype=torch.float64, device=cdev); dist.all_reduce(tmax, op=dist.ReduceOp.MAX); bwall = float(tmax.item())
         assert all(r.status == 0 for r in recs), [r.status for r in recs]
-        batch64 = {"pairs": nb, "distinct_pairs": nb, "wall_ms": round(1e3 * bwall, 3), "pairs_per_s": round(nb / bwall, 2), "ms_per_pair": round(1e3 * bwall / nb, 4),
+        bwalls = [bwall]
+        if world == 1:      # a one-shot 17 ms wall is at the mercy of one hiccup (a 64-pair call of the same build read 11.4 and 16.1 ms on two boxes): two more calls, the median is quoted
+            for _ in range(2):
+                barrier(); tb = time.perf_counter(); mg.align_best(descs); barrier(); bwalls.append(time.perf_counter() - tb)
+            bwall = float(np.median(bwalls))
+        batch64 = {"pairs": nb, "distinct_pairs": nb, "wall_ms": round(1e3 * bwall, 3), "wall_ms_runs": [round(1e3 * w, 3) for w in bwalls], "pairs_per_s": round(nb / bwall, 2), "ms_per_pair": round(1e3 * bwall / nb, 4),
                    "winner_pair": int(bwin[0]), "winner_score": bwin[2], "sharding": "pair i -> rank i mod %d; qn_multi_align_best per rank on its GPU (a process that owns several GPUs gathers its 96-byte records with RCCL inside the C-ABI), all_gather of the rank winners" % world,
                    "valid_pairs_this_rank": int(sum(r.valid for r in recs))}
         # ---- two of the 64 records against the CPU oracle (rank 0, when the CPU leg is on): a plain scene pair and a re-posed variant from the second half of the batch
@@ -743,15 +748,18 @@ def main():
         sdescs = [(s0.data_ptr(), N_PTS, t.data_ptr(), N_PTS, 12, 1) for t in stg]
         mg.debug_set("batch_share_source", 1)       # here the shared source IS the workload
         mg.align_best(sdescs[:min(len(sdescs), 4)])
-        barrier()
-        tb = time.perf_counter()
-        srecs, _ = mg.align_best(sdescs)
-        barrier()
-        swall = time.perf_counter() - tb
+        swalls = []
+        for _ in range(3 if world == 1 else 1):      # (median of three single-process calls, as above)
+            barrier()
+            tb = time.perf_counter()
+            srecs, _ = mg.align_best(sdescs)
+            barrier()
+            swalls.append(time.perf_counter() - tb)
+        swall = float(np.median(swalls))
         if dist is not None:
             tmax = torch.tensor([swall], dtype=torch.float64, device=cdev); dist.all_reduce(tmax, op=dist.ReduceOp.MAX); swall = float(tmax.item())
         assert all(r.status == 0 for r in srecs), [r.status for r in srecs]
-        batch64["shared_query"] = {"pairs": nb, "wall_ms": round(1e3 * swall, 3), "pairs_per_s": round(nb / swall, 2),
+        batch64["shared_query"] = {"pairs": nb, "wall_ms": round(1e3 * swall, 3), "wall_ms_runs": [round(1e3 * w, 3) for w in swalls], "pairs_per_s": round(nb / swall, 2),
                                    "note": "64 candidate targets against ONE query cloud per rank: source grid + covariances prepared once per context"}
         mg.close()
         # ---- the reference's DEFAULT per-candidate path as a batch: coarseToFineAlignment (Quatro -> transformPcd -> Nano-GICP, loop_closure.cpp:138-159 with enable_quatro_) on
