@@ -73,6 +73,18 @@ def test_knn_of_a_non_finite_cloud_is_refused_without_a_fault(eng):
     assert (idx[:, 0] == np.arange(len(good))).all()
 
 
+@pytest.mark.parametrize("cell", [1.5, 3.0, 0.25])
+def test_coarse_and_fine_cells(oracle, cell):
+    """Cell edges far from the default (knob `cell`): 1.5 m / 3 m cells put ~900 / ~3000 candidates into a round - chunks beyond the four whose operands stay in registers, several
+    segment tables per round -, 0.25 m cells make every query retry with larger radii (several clusters per wave)."""
+    from qn_amd import engine
+    ctx = engine.Context(40000)
+    ctx.debug_set("cell", cell)
+    src, _, _ = synth.make_pair(52, 30000, extent=80.0)
+    _check(engine, ctx, oracle, src, (20,))
+    ctx.close()
+
+
 def test_matches_valu_scoring_at_full_size(eng):
     """100k-point street scene: the matrix-core path and the VALU path (knn_mm 0) write the same tables."""
     engine, ctx = eng
