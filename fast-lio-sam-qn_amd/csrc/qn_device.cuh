@@ -152,13 +152,47 @@ __device__ __forceinline__ double wave_sum_f64_dpp(double v) {
   v += __shfl_xor(v, 16); v += __shfl_xor(v, 32);
   return v;
 }
+// Inclusive prefix sum over the 64 lanes (all lanes must call, convergent) on DPP: row_shr 1, 2, 4, 8 inside the rows of 16, then row_bcast:15 into rows 1 and 3 and
+// row_bcast:31 into rows 2 and 3 - six VALU instructions, no LDS; a lane without a source adds the `old` operand, 0.  (Rounds 1-5: six __shfl_up steps = six ds_bpermute round
+// trips and ~30 instructions, two to four times per search round of every kernel.)
+#define QN_DPP_ADD(v, ctrl, rmask) v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(v), ctrl, rmask, 0xF, false)
+#if defined(QN_INST_GROUP) && QN_INST_GROUP == 10
+// (the persistent align kernel keeps the shuffle form: with the DPP form its register allocation reserved a private segment - no instruction uses it, but a kernel with a
+//  private segment pays extra at dispatch, tests/test_no_scratch.py; its cooperative searches are the rare path of a tick)
 __device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v, int lane) {
 #pragma unroll
   for (int o = 1; o < 64; o <<= 1) { uint32_t t = __shfl_up(v, o); if (lane >= o) v += t; }
   return v;
 }
+#else
+__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v, int) {
+  QN_DPP_ADD(v, 0x111, 0xF); QN_DPP_ADD(v, 0x112, 0xF); QN_DPP_ADD(v, 0x114, 0xF); QN_DPP_ADD(v, 0x118, 0xF);
+  QN_DPP_ADD(v, 0x142, 0xA); QN_DPP_ADD(v, 0x143, 0xC);
+  return v;
+}
+#endif
+// the same shape with max (u32, identity 0)
+#define QN_DPP_MAX(v, ctrl, rmask) v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(v), ctrl, rmask, 0xF, false))
+__device__ __forceinline__ uint32_t wave_incl_max_u32(uint32_t v) {
+  QN_DPP_MAX(v, 0x111, 0xF); QN_DPP_MAX(v, 0x112, 0xF); QN_DPP_MAX(v, 0x114, 0xF); QN_DPP_MAX(v, 0x118, 0xF);
+  QN_DPP_MAX(v, 0x142, 0xA); QN_DPP_MAX(v, 0x143, 0xC);
+  return v;
+}
+// Slot -> segment for one 64-candidate chunk of a segment table, without a search: every non-empty segment [ex, nx) that reaches into [cb, cb + 64) writes (its lane + 1) at its
+// first slot inside the chunk; a running maximum over the chunk's slots (six DPP steps) is the segment each slot belongs to.  (Rounds 1-5: a six-step
+// binary search over the prefix table per lane and chunk - six DEPENDENT LDS round trips in front of every candidate fetch of every search kernel.)  ex / nx: the
+// first slot of this lane's OWN segment and of the next; marks: 64 words of wave-private LDS the caller does not need across the call.  All 64 lanes call.  (chunk_segment, below)
 // DS operations of one wave execute in issue order; this only stops the compiler from reordering.
 __device__ __forceinline__ void wave_lds_fence() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); }
+__device__ __forceinline__ int chunk_segment(uint32_t* __restrict__ marks, const uint32_t cb, const uint32_t ex, const uint32_t nx) {
+  const int lane = threadIdx.x & 63;
+  wave_lds_fence();
+  marks[lane] = 0u;
+  wave_lds_fence();
+  if (nx > ex && ex < cb + 64u && nx > cb) marks[ex > cb ? ex - cb : 0u] = (uint32_t)lane + 1u;      // (a segment that began in an earlier chunk marks slot 0: every chunk stands alone)
+  wave_lds_fence();
+  return (int)wave_incl_max_u32(marks[lane]) - 1;
+}
 
 // Wave-aggregated list append: one atomic per wave, the wave's entries land contiguously and in lane order (so the
 // list keeps the spatial coherence of the cell-sorted query order).  Must be called by the wave convergently.
@@ -329,6 +363,15 @@ __device__ __forceinline__ float tile_box_d2(const GridView& g, int tx, int ty, 
   return ((dx * dx + dy * dy) + dz * dz) * 0.999998f;
 }
 
+// Exact n / d and n % d for 0 <= n < 2^22, 1 <= d < 2^22 from one v_rcp_f32 and a +-1 correction (the generic u32 division
+// is ~25 VALU instructions, and the segment tables need four of them per lane and pass).
+__device__ __forceinline__ void divmod_small(int n, int d, int& q, int& r) {
+  q = (int)((float)n * __builtin_amdgcn_rcpf((float)d));
+  r = n - q * d;
+  if (r < 0) { q--; r += d; }
+  if (r >= d) { q++; r -= d; }
+}
+
 // ------------------------------------------------------------------ dense candidate stream over a cell box
 // Calls body(p, valid, cnt) once per 64-candidate chunk with one candidate per lane (`valid` = lane
 // holds a real one, `cnt` = candidates in this chunk, wave-uniform).  All 64 lanes must call.
@@ -348,13 +391,15 @@ __device__ __forceinline__ uint32_t stream_box(const GridView& g, int x0, int x1
     const int sidx = sb + lane;
     uint32_t s = 0, len = 0;
     if (sidx < nseg) {
-      const int t = sidx % ntr, r = sidx / ntr;
+      int t, r; divmod_small(sidx, ntr, r, t);                         // (t = sidx % ntr, r = sidx / ntr: the generic integer division is ~30 instructions, four of them per table)
       if (tile_mode) {
-        const int tzz = (z0 >> 2) + r / ntyr, tyy = ty0 + r % ntyr, txx = tx0 + t;
+        int qz_, ry_; divmod_small(r, ntyr, qz_, ry_);
+        const int tzz = (z0 >> 2) + qz_, tyy = ty0 + ry_, txx = tx0 + t;
         const uint32_t tile = ((uint32_t)tzz * g.nty + tyy) * g.ntx + txx;
         if (!(ball_r2 >= 0.f && tile_box_d2(g, txx, tyy, tzz, bqx, bqy, bqz) > ball_r2)) { s = g.cell_start[tile << 7]; len = g.cell_start[(tile + 1) << 7] - s; }
       } else {
-        const int ry = y0 + r % nyr, rz = z0 + r / nyr, tx = tx0 + t;
+        int qz_, ry_; divmod_small(r, nyr, qz_, ry_);
+        const int ry = y0 + ry_, rz = z0 + qz_, tx = tx0 + t;
         const int xa = max(x0, tx << 3), xb = min(x1, (tx << 3) + 7);
         const uint32_t k0 = cell_key(g, xa, ry, rz);
         s = g.cell_start[k0]; len = g.cell_start[k0 + (xb - xa) + 1] - s;
@@ -369,9 +414,7 @@ __device__ __forceinline__ uint32_t stream_box(const GridView& g, int x0, int x1
     for (uint32_t cb = 0; cb < total; cb += 64) {
       const uint32_t slot = cb + lane;
       const bool valid = slot < total;
-      int j = 0;
-#pragma unroll
-      for (int step = 32; step > 0; step >>= 1) { const int t = j + step; if (t < 64 && lds->seg_excl[t] <= slot) j = t; }
+      const int j = chunk_segment(lds->tile_cid, cb, incl - len, incl);
       float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
       if (valid) p = g.pts[lds->seg_start[j] + (slot - lds->seg_excl[j])];
       body(p, valid, min(64u, total - cb));
@@ -438,15 +481,6 @@ __device__ __forceinline__ void build_clusters(const GridView& g, WaveLds* lds, 
   wave_lds_fence();
 }
 
-// Exact n / d and n % d for 0 <= n < 2^22, 1 <= d < 2^22 from one v_rcp_f32 and a +-1 correction (the generic u32 division
-// is ~25 VALU instructions, and the segment tables need four of them per lane and pass).
-__device__ __forceinline__ void divmod_small(int n, int d, int& q, int& r) {
-  q = (int)((float)n * __builtin_amdgcn_rcpf((float)d));
-  r = n - q * d;
-  if (r < 0) { q--; r += d; }
-  if (r >= d) { q++; r -= d; }
-}
-
 // Step (4): the points of all cluster boxes as one dense candidate stream.  fn(cp, in_tile, ccid) is called once per
 // step by all 64 lanes; the S sub-slots see S consecutive candidates (cp = point, .w = original index bits; in_tile =
 // the slot holds a real candidate; ccid = the cluster whose box the candidate came from).  Returns the stream length.
@@ -455,11 +489,10 @@ template <int S, class Fn>
 __device__ __forceinline__ void stream_chunks(const GridView& g, WaveLds* lds, const uint32_t total, Fn&& fn) {
   const int lane = threadIdx.x & 63;
   const float INF = __int_as_float(0x7f800000);
+  const uint32_t ex = lds->seg_excl[lane], nxs = lane < 63 ? lds->seg_excl[(lane + 1) & 63] : total;      // (this lane's own segment of the table: first slot, first slot of the next)
   for (uint32_t cb = 0; cb < total; cb += 64) {
     const uint32_t slot = cb + lane;
-    int j = 0;
-#pragma unroll
-    for (int step = 32; step > 0; step >>= 1) { const int t = j + step; if (t < 64 && lds->seg_excl[t] <= slot) j = t; }
+    const int j = chunk_segment(lds->tile_cid, cb, ex, nxs);
     const uint32_t cnt = min(64u, total - cb);
     wave_lds_fence();
     // empty slots belong to no cluster and sit infinitely far away: the `ccid == cid` test of the scorers rejects them, and so does every distance test
@@ -674,15 +707,17 @@ __device__ __forceinline__ void wave_search_single(const GridView& g, float qx, 
       const int sidx = sb + lane;
       uint32_t s = 0, len = 0;
       if (sidx < nseg) {
-        const int t = sidx % ntr, rr = sidx / ntr;
+        int t, rr; divmod_small(sidx, ntr, rr, t);
         if (tile_mode) {                                               // only the tiles that reach into the ball of radius r and were not scanned by an earlier round
-          const int tzz = (z0 >> 2) + rr / ntyr, tyy = ty0 + rr % ntyr, txx = tx0 + t;
+          int qz_, ry_; divmod_small(rr, ntyr, qz_, ry_);
+          const int tzz = (z0 >> 2) + qz_, tyy = ty0 + ry_, txx = tx0 + t;
           const uint32_t tile = ((uint32_t)tzz * g.nty + tyy) * g.ntx + txx;
           const float tb2 = tile_box_d2(g, txx, tyy, tzz, qx, qy, qz);
           const bool seen = tb2 <= done2 && txx >= ptx0 && txx <= ptx1 && tyy >= pty0 && tyy <= pty1 && tzz >= ptz0 && tzz <= ptz1;
           if (!(tb2 > in2) && !seen) { s = g.cell_start[tile << 7]; len = g.cell_start[(tile + 1) << 7] - s; }
         } else {
-          const int ry = y0 + rr % nyr, rz = z0 + rr / nyr, tx = tx0 + t;
+          int qz_, ry_; divmod_small(rr, nyr, qz_, ry_);
+          const int ry = y0 + ry_, rz = z0 + qz_, tx = tx0 + t;
           const int xa = max(x0, tx << 3), xb = min(x1, (tx << 3) + 7);
           const uint32_t k0 = cell_key(g, xa, ry, rz);
           s = g.cell_start[k0]; len = g.cell_start[k0 + (xb - xa) + 1] - s;
@@ -698,9 +733,7 @@ __device__ __forceinline__ void wave_search_single(const GridView& g, float qx, 
       wave_lds_fence();
       for (uint32_t cb = 0; cb < total; cb += 64) {
         const uint32_t slot = cb + lane;
-        int j = 0;
-#pragma unroll
-        for (int step = 32; step > 0; step >>= 1) { const int t = j + step; if (t < 64 && lds->seg_excl[t] <= slot) j = t; }
+        const int j = chunk_segment(lds->tile_cid, cb, incl - len, incl);
         if (slot < total) {
           const float4 p = g.pts[lds->seg_start[j] + (slot - lds->seg_excl[j])];
           const float d2 = sqdist(qx, qy, qz, p.x, p.y, p.z);
@@ -807,8 +840,9 @@ __device__ __forceinline__ void wave_search_far16(const GridView& g, float qx_in
       const int sidx = sb + lane;
       uint32_t s = 0, len = 0;
       if (sidx < nseg) {
-        const int t = sidx % ntr, rr = sidx / ntr;
-        const int tzz = tz0 + rr / ntyr, tyy = ty0 + rr % ntyr, txx = tx0 + t;
+        int t, rr; divmod_small(sidx, ntr, rr, t);
+        int qz_, ry_; divmod_small(rr, ntyr, qz_, ry_);
+        const int tzz = tz0 + qz_, tyy = ty0 + ry_, txx = tx0 + t;
         const uint32_t tile = ((uint32_t)tzz * g.nty + tyy) * g.ntx + txx;
         const float tb2 = tile_box_d2(g, txx, tyy, tzz, cqx, cqy, cqz);
         const bool seen = tb2 <= done2 && txx >= ptx0 && txx <= ptx1 && tyy >= pty0 && tyy <= pty1 && tzz >= ptz0 && tzz <= ptz1;
@@ -824,9 +858,7 @@ __device__ __forceinline__ void wave_search_far16(const GridView& g, float qx_in
       wave_lds_fence();
       for (uint32_t cb = 0; cb < total; cb += 64) {
         const uint32_t slot = cb + lane;
-        int j = 0;
-#pragma unroll
-        for (int step = 32; step > 0; step >>= 1) { const int t = j + step; if (t < 64 && lds->seg_excl[t] <= slot) j = t; }
+        const int j = chunk_segment(lds->tile_cid, cb, incl - len, incl);
         const uint32_t cnt = min(64u, total - cb);
         wave_lds_fence();
         if (slot < total) lds->tile[lane] = g.pts[lds->seg_start[j] + (slot - lds->seg_excl[j])];

@@ -49,13 +49,11 @@ typedef float qn_f4v __attribute__((ext_vector_type(4)));
 #define QN_MM_NCH 4                                // chunks of a round whose A operands stay in REGISTERS between the two passes (256 candidates: three rounds in four)
 // stages the 64 candidates [cb, cb + 64) of the segment table in LDS: lds->tile[c] = (p - O, |p - O|^2), sc_out[c] = position in pts[] | cluster id << 26; returns
 // how many of them are real (all 64 lanes call, convergent)
+// (j: the segment of this lane's slot - chunk_segment, or the marker scan of the cached chunks)
 __device__ __forceinline__ uint32_t stage_chunk_mm(const GridView& g, WaveLds* lds, uint32_t* __restrict__ sc_out, const uint32_t cb, const uint32_t total,
-                                                   const float Ox, const float Oy, const float Oz, float& c2max) {
+                                                   const float Ox, const float Oy, const float Oz, float& c2max, const int j) {
   const int lane = threadIdx.x & 63;
   const uint32_t slot = cb + lane;
-  int j = 0;
-#pragma unroll
-  for (int step = 32; step > 0; step >>= 1) { const int t = j + step; if (t < 64 && lds->seg_excl[t] <= slot) j = t; }
   float4 rel = make_float4(QN_MM_FAR, 0.f, 0.f, QN_MM_FAR * QN_MM_FAR); uint32_t sc = 63u << 26;      // (an empty slot belongs to no cluster: ids are < 16)
   if (slot < total) {
     const uint32_t sidx = lds->seg_start[j] + (slot - lds->seg_excl[j]);
@@ -151,10 +149,20 @@ __device__ __forceinline__ int wave_knn_hist(const GridView& g, float qx, float 
       ncand = stream_tables<false>(g, lds, ncl, nseg_all, [&](const uint32_t total) __attribute__((always_inline)) {
         uint32_t cb0 = 0u;
         if (cached) {
+          // slot -> segment for the cached chunks without a binary search per chunk: every non-empty segment marks its first slot with (index + 1) in tile_sc (the slots
+          // are overwritten chunk by chunk as they are staged), a running maximum over the slots - six DPP steps per chunk and a carry - is the segment of each slot
+          ((uint4*)L->tile_sc)[lane] = make_uint4(0u, 0u, 0u, 0u);
+          wave_lds_fence();
+          { const uint32_t ex = lds->seg_excl[lane], nx = lane < 63 ? lds->seg_excl[(lane + 1) & 63] : total;
+            if (nx > ex && ex < 64u * QN_MM_NCH) L->tile_sc[ex] = (uint32_t)lane + 1u; }
+          wave_lds_fence();
+          uint32_t carry = 0u;
 #pragma unroll
           for (int c = 0; c < QN_MM_NCH; c++) {
             if ((uint32_t)(64 * c) < total) {
-              const uint32_t cnt = stage_chunk_mm(g, lds, L->tile_sc + 64 * c, 64u * c, total, Ox, Oy, Oz, c2max);
+              const uint32_t mk = max(wave_incl_max_u32(L->tile_sc[64 * c + lane]), carry);
+              carry = rflu(__shfl(mk, 63));
+              const uint32_t cnt = stage_chunk_mm(g, lds, L->tile_sc + 64 * c, 64u * c, total, Ox, Oy, Oz, c2max, (int)mk - 1);
               load_av(avc[c]);
               mm_groups(avc[c], cnt, [&](const int, const qn_f4v d) __attribute__((always_inline)) {
 #pragma unroll
@@ -164,8 +172,10 @@ __device__ __forceinline__ int wave_knn_hist(const GridView& g, float qx, float 
           }
           cb0 = 64u * QN_MM_NCH;
         }
+        const uint32_t exs = lds->seg_excl[lane], nxs = lane < 63 ? lds->seg_excl[(lane + 1) & 63] : total;
         for (uint32_t cb = cb0; cb < total; cb += 64) {
-          const uint32_t cnt = stage_chunk_mm(g, lds, lds->tile_cid, cb, total, Ox, Oy, Oz, c2max);
+          const int jg = chunk_segment(lds->tile_cid, cb, exs, nxs);
+          const uint32_t cnt = stage_chunk_mm(g, lds, lds->tile_cid, cb, total, Ox, Oy, Oz, c2max, jg);
           float av[4]; load_av(av);
           mm_groups(av, cnt, [&](const int gi, const qn_f4v d) __attribute__((always_inline)) { p1_group(lds->tile_cid, gi, d); });
         }
@@ -253,8 +263,10 @@ __device__ __forceinline__ int wave_knn_hist(const GridView& g, float qx, float 
       }
       if (!cached || ncand > 64u * QN_MM_NCH) {
       stream_tables<true>(g, lds, ncl, nseg_all, [&](const uint32_t total) __attribute__((always_inline)) {
+        const uint32_t exs = lds->seg_excl[lane], nxs = lane < 63 ? lds->seg_excl[(lane + 1) & 63] : total;
         for (uint32_t cb = cached ? 64u * QN_MM_NCH : 0u; cb < total; cb += 64) {
-          const uint32_t cnt = stage_chunk_mm(g, lds, lds->tile_cid, cb, total, Ox, Oy, Oz, dummy);
+          const int jg = chunk_segment(lds->tile_cid, cb, exs, nxs);
+          const uint32_t cnt = stage_chunk_mm(g, lds, lds->tile_cid, cb, total, Ox, Oy, Oz, dummy, jg);
           float av[4]; load_av(av);
           mm_groups(av, cnt, [&](const int gi, const qn_f4v d) __attribute__((always_inline)) {
             bool hit[4];
@@ -277,8 +289,10 @@ __device__ __forceinline__ int wave_knn_hist(const GridView& g, float qx, float 
       wave_lds_fence();
       // ---- exact stage: the listed candidates with the defining arithmetic
       const uint32_t Pn = min(L->cnt[qs], (uint32_t)HCAP);
+      const int pmax = wave_max_i(collect ? (int)Pn : 0);
 #pragma unroll
       for (int j = 0; j < HCAP / 4; j++) {
+        if (4 * j >= pmax) break;                                                  // (wave-uniform: the longest list of the wave's queries)
         const uint32_t slot = (uint32_t)(sub + 4 * j);
         if (collect && slot < Pn) {
           const float4 p = g.pts[(uint32_t)L->u.list[qs][slot]];

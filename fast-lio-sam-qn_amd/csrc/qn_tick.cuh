@@ -282,8 +282,9 @@ __device__ __forceinline__ void tick_point(const TickArgs& a, const float (&Tf)[
         for (int sg = 0; sg < QN_TRACK_SEG; sg++) {
           s[sg] = 0; e[sg] = 0;
           if (sg < nseg) {
-            const int tt = sg % ntr, rr = sg / ntr;
-            const int ry = by0 + rr % nyr, rz = bz0 + rr / nyr, tx = tx0 + tt;
+            int tt, rr; divmod_small(sg, ntr, rr, tt);
+            int qz_, ry_; divmod_small(rr, nyr, qz_, ry_);
+            const int ry = by0 + ry_, rz = bz0 + qz_, tx = tx0 + tt;
             const int xa = max(bx0, tx << 3), xb = min(bx1, (tx << 3) + 7);
             const uint32_t k0 = cell_key(tg, xa, ry, rz);
             s[sg] = tg.cell_start[k0]; e[sg] = tg.cell_start[k0 + (xb - xa) + 1];
