@@ -115,6 +115,11 @@ __device__ __forceinline__ float sqdist(float qx, float qy, float qz, float px, 
 __device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ __forceinline__ uint32_t rflu(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 
+// Wave-wide reductions whose result every lane needs (all 64 lanes must call, convergent).  DPP ladder - row_shr 1, 2, 4, 8, row_bcast:15 into rows 1 / 3, row_bcast:31 into rows
+// 2 / 3: lane 63 then holds the reduction of the wave - and one v_readlane; a lane without a source combines with the identity.  (Rounds 1-5: six __shfl_xor steps = six
+// ds_bpermute round trips each - twelve for a 64-bit key - in front of every certification of the one-query-per-wave searches.)  The persistent align kernel keeps the shuffle
+// forms (see wave_incl_scan_u32).
+#if defined(QN_INST_GROUP) && QN_INST_GROUP == 10
 __device__ __forceinline__ int wave_min_i(int v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) { int t = __shfl_xor(v, o); v = t < v ? t : v; }
@@ -130,6 +135,56 @@ __device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v)
   for (int o = 32; o > 0; o >>= 1) { unsigned long long t = __shfl_xor(v, o); v = t < v ? t : v; }
   return v;
 }
+__device__ __forceinline__ float wave_min_f(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o));
+  return v;
+}
+__device__ __forceinline__ float wave_max_f(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+  return v;
+}
+#else
+#define QN_DPP_LADDER(STEP) STEP(0x111, 0xF) STEP(0x112, 0xF) STEP(0x114, 0xF) STEP(0x118, 0xF) STEP(0x142, 0xA) STEP(0x143, 0xC)
+__device__ __forceinline__ int wave_min_i(int v) {
+#define QN_S(ctrl, rm) { const int t = __builtin_amdgcn_update_dpp(0x7fffffff, v, ctrl, rm, 0xF, false); v = t < v ? t : v; }
+  QN_DPP_LADDER(QN_S)
+#undef QN_S
+  return __builtin_amdgcn_readlane(v, 63);
+}
+__device__ __forceinline__ int wave_max_i(int v) {
+#define QN_S(ctrl, rm) { const int t = __builtin_amdgcn_update_dpp((int)0x80000000, v, ctrl, rm, 0xF, false); v = t > v ? t : v; }
+  QN_DPP_LADDER(QN_S)
+#undef QN_S
+  return __builtin_amdgcn_readlane(v, 63);
+}
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
+#define QN_S(ctrl, rm) { const uint32_t t = (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)v, ctrl, rm, 0xF, false); v = t < v ? t : v; }
+  QN_DPP_LADDER(QN_S)
+#undef QN_S
+  return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+// (a 64-bit key = high word first: the minimum of the high words, then the minimum of the low words among the lanes that hold it)
+__device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v) {
+  const uint32_t hi = (uint32_t)(v >> 32), lo = (uint32_t)v;
+  const uint32_t mh = wave_min_u32(hi);
+  const uint32_t ml = wave_min_u32(hi == mh ? lo : 0xffffffffu);
+  return ((unsigned long long)mh << 32) | ml;
+}
+__device__ __forceinline__ float wave_min_f(float v) {
+#define QN_S(ctrl, rm) v = fminf(v, __int_as_float(__builtin_amdgcn_update_dpp(0x7f800000, __float_as_int(v), ctrl, rm, 0xF, false)));
+  QN_DPP_LADDER(QN_S)
+#undef QN_S
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+__device__ __forceinline__ float wave_max_f(float v) {
+#define QN_S(ctrl, rm) v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp((int)0xff800000, __float_as_int(v), ctrl, rm, 0xF, false)));
+  QN_DPP_LADDER(QN_S)
+#undef QN_S
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+#endif
 __device__ __forceinline__ double wave_sum_f64(double v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
@@ -749,8 +804,7 @@ __device__ __forceinline__ void wave_search_single(const GridView& g, float qx, 
     const unsigned long long b = wave_min_u64(best);
     float c = (best == b) ? second : key_d2(best);
     if (best == QN_INF_KEY) c = INF;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) c = fminf(c, __shfl_xor(c, o));
+    c = wave_min_f(c);
     float d = INF;
     if (x0 > 0) d = fminf(d, cap_face_dist(cap, qx - (g.ox + x0 * g.cell), 0));
     if (x1 < g.nx - 1) d = fminf(d, cap_face_dist(cap, (g.ox + (x1 + 1) * g.cell) - qx, 0));
@@ -784,16 +838,6 @@ __device__ __forceinline__ void wave_search_single(const GridView& g, float qx, 
 // wave_search_single.  Query i is certified when its best distance is below R - |q_i - c| (everything unscanned inside the grid is farther than R from c), or
 // when nothing is left unscanned.  Exact for any spread of the members; efficient when the spread is small against the radii (the caller groups by that).
 // Outputs per member (identical in its 4 lanes): best key, runner-up d2, lower bound on everything unscanned.  All 64 lanes must call.
-__device__ __forceinline__ float wave_min_f(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o));
-  return v;
-}
-__device__ __forceinline__ float wave_max_f(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
-  return v;
-}
 __device__ __forceinline__ void wave_search_far16(const GridView& g, float qx_in, float qy_in, float qz_in, bool member_in, float r_in,
                                                   unsigned long long& best_out, float& second_out, float& d_unseen_out, WaveLds* lds) {
   const int lane = threadIdx.x & 63;
