@@ -114,6 +114,10 @@ __device__ __forceinline__ float sqdist(float qx, float qy, float qz, float px, 
 
 __device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ __forceinline__ uint32_t rflu(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+// the value a given lane holds, for a WAVE-UNIFORM lane number: one v_readlane_b32 (a __shfl with a computed lane is a ds_bpermute round trip)
+__device__ __forceinline__ int rdlane(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
+__device__ __forceinline__ uint32_t rdlane(uint32_t v, int l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, l); }
+__device__ __forceinline__ float rdlane(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
 
 // Wave-wide reductions whose result every lane needs (all 64 lanes must call, convergent).  DPP ladder - row_shr 1, 2, 4, 8, row_bcast:15 into rows 1 / 3, row_bcast:31 into rows
 // 2 / 3: lane 63 then holds the reduction of the wave - and one v_readlane; a lane without a source combines with the identity.  (Rounds 1-5: six __shfl_xor steps = six
@@ -204,8 +208,21 @@ __device__ __forceinline__ double dpp_add_f64(double v, const int ctrl_sel) {
 }
 __device__ __forceinline__ double wave_sum_f64_dpp(double v) {
   v = dpp_add_f64(v, 0); v = dpp_add_f64(v, 1); v = dpp_add_f64(v, 2); v = dpp_add_f64(v, 3);   // 16-lane row sums in every lane
+#if defined(QN_INST_GROUP) && QN_INST_GROUP == 10
   v += __shfl_xor(v, 16); v += __shfl_xor(v, 32);
   return v;
+#else
+  // the four row sums R0..R3 meet as (R3 + R2) + (R1 + R0) in lane 63 - bit for bit the value the two cross-row shuffle steps left in every lane (addition commutes exactly) -
+  // on row_bcast:15 / row_bcast:31 and two v_readlane instead of four ds_bpermute round trips (28 sums per block of the unseeded accumulation: 112 of them)
+  const int lane = threadIdx.x & 63;
+  union { double d; int i[2]; } a, b;
+  a.d = v; b.i[0] = __builtin_amdgcn_update_dpp(0, a.i[0], 0x142, 0xA, 0xF, false); b.i[1] = __builtin_amdgcn_update_dpp(0, a.i[1], 0x142, 0xA, 0xF, false);
+  v = (lane & 16) ? v + b.d : v;
+  a.d = v; b.i[0] = __builtin_amdgcn_update_dpp(0, a.i[0], 0x143, 0xC, 0xF, false); b.i[1] = __builtin_amdgcn_update_dpp(0, a.i[1], 0x143, 0xC, 0xF, false);
+  v = (lane & 32) ? v + b.d : v;
+  a.d = v; a.i[0] = __builtin_amdgcn_readlane(a.i[0], 63); a.i[1] = __builtin_amdgcn_readlane(a.i[1], 63);
+  return a.d;
+#endif
 }
 // Inclusive prefix sum over the 64 lanes (all lanes must call, convergent) on DPP: row_shr 1, 2, 4, 8 inside the rows of 16, then row_bcast:15 into rows 1 and 3 and
 // row_bcast:31 into rows 2 and 3 - six VALU instructions, no LDS; a lane without a source adds the `old` operand, 0.  (Rounds 1-5: six __shfl_up steps = six ds_bpermute round
@@ -257,7 +274,7 @@ __device__ __forceinline__ void wave_append(uint2* __restrict__ list, uint32_t* 
   const int lane = threadIdx.x & 63, leader = __ffsll((long long)mask) - 1;
   uint32_t base = 0;
   if (lane == leader) base = atomicAdd(count, (uint32_t)__popcll(mask));
-  base = rflu(__shfl(base, leader));
+  base = rdlane(base, leader);
   if (want) list[base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = rec;
 }
 
@@ -461,7 +478,7 @@ __device__ __forceinline__ uint32_t stream_box(const GridView& g, int x0, int x1
       }
     }
     const uint32_t incl = wave_incl_scan_u32(len, lane);
-    const uint32_t total = rflu(__shfl(incl, 63));
+    const uint32_t total = rdlane(incl, 63);
     if (total == 0) continue;
     wave_lds_fence();
     lds->seg_excl[lane] = incl - len; lds->seg_start[lane] = s;
@@ -496,7 +513,7 @@ __device__ __forceinline__ void build_clusters(const GridView& g, WaveLds* lds, 
   cid = 0xffffffffu; ncl = 0;
   for (unsigned long long rem = todo; rem != 0; ncl++) {
     const int leader = __ffsll((long long)rem) - 1;
-    const int ax = rfl(__shfl(cx, leader)), ay = rfl(__shfl(cy, leader)), az = rfl(__shfl(cz, leader));
+    const int ax = rdlane(cx, leader), ay = rdlane(cy, leader), az = rdlane(cz, leader);
     const bool in = ((rem >> lane) & 1ull) && abs(cx - ax) <= QN_CL_DX && abs(cy - ay) <= QN_CL_DY && abs(cz - az) <= QN_CL_DZ;
     if (in) cid = ncl;
     rem &= ~__ballot(in);
@@ -530,7 +547,7 @@ __device__ __forceinline__ void build_clusters(const GridView& g, WaveLds* lds, 
     lds->cl_tile_mode[lane] = tm;
   }
   const uint32_t seg_incl = wave_incl_scan_u32(my_nseg, lane);
-  nseg_all = rflu(__shfl(seg_incl, 63));
+  nseg_all = rdlane(seg_incl, 63);
   lds->cl_seg0[lane] = seg_incl - my_nseg;
   if (lane == 0) lds->cl_seg0[64] = nseg_all;
   wave_lds_fence();
@@ -602,7 +619,7 @@ __device__ __forceinline__ uint32_t stream_tables(const GridView& g, WaveLds* ld
       scid = (uint32_t)c;
     }
     const uint32_t incl = wave_incl_scan_u32(len, lane);
-    const uint32_t total = rflu(__shfl(incl, 63));
+    const uint32_t total = rdlane(incl, 63);
     if (total == 0) continue;
     wave_lds_fence();
     lds->seg_excl[lane] = incl - len; lds->seg_start[lane] = s; lds->seg_cid[lane] = scid;
@@ -779,7 +796,7 @@ __device__ __forceinline__ void wave_search_single(const GridView& g, float qx, 
         }
       }
       const uint32_t incl = wave_incl_scan_u32(len, lane);
-      const uint32_t total = rflu(__shfl(incl, 63));
+      const uint32_t total = rdlane(incl, 63);
       if (total == 0) continue;
       if (g.dbg && lane == 0) atomicAdd(&g.dbg[11], total);          // developer counter: candidates scanned
       if (stats) st_out.cand += total;
@@ -894,7 +911,7 @@ __device__ __forceinline__ void wave_search_far16(const GridView& g, float qx_in
         else if (!seen) { s = g.cell_start[tile << 7]; len = g.cell_start[(tile + 1) << 7] - s; }
       }
       const uint32_t incl = wave_incl_scan_u32(len, lane);
-      const uint32_t total = rflu(__shfl(incl, 63));
+      const uint32_t total = rdlane(incl, 63);
       if (total == 0) continue;
       if (g.dbg && lane == 0) atomicAdd(&g.dbg[11], total);
       wave_lds_fence();

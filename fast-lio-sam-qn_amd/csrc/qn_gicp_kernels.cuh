@@ -591,8 +591,8 @@ struct NnSearchK {
         unsigned long long todo = __ballot(active);
         while (todo) {
           const int al = __ffsll((long long)todo) - 1;                 // anchor: the first open query (its sub-slot 0 lane)
-          const float ax = __shfl(qx, al), ay = __shfl(qy, al), az = __shfl(qz, al), ar = __shfl(r, al);
-          const bool afin = __shfl((int)finite_q, al) != 0;
+          const float ax = rdlane(qx, al), ay = rdlane(qy, al), az = rdlane(qz, al), ar = rdlane(r, al);
+          const bool afin = rdlane((int)finite_q, al) != 0;
           const bool open_q = (todo >> lane) & 1ull;
           // members: within half the anchor's radius of it (their balls then share most of their volume); a non-finite entry is served alone
           const bool member = open_q && (qs == (al & 15) || (afin && finite_q && sqdist(qx, qy, qz, ax, ay, az) <= 0.25f * ar * ar));

@@ -103,7 +103,7 @@ __device__ __forceinline__ int wave_knn_hist(const GridView& g, float qx, float 
     float Ox = 0.f, Oy = 0.f, Oz = 0.f, bsel = 0.f, q2 = 0.f, c2max = 0.f;
     if constexpr (MM) {
       const int l0 = __ffsll((long long)todo) - 1;
-      Ox = uni(__shfl(qx, l0)); Oy = uni(__shfl(qy, l0)); Oz = uni(__shfl(qz, l0));
+      Ox = rdlane(qx, l0); Oy = rdlane(qy, l0); Oz = rdlane(qz, l0);
       const float rx = qx - Ox, ry = qy - Oy, rz = qz - Oz;
       q2 = (rx * rx + ry * ry) + rz * rz;
       bsel = sub == 0 ? -2.f * rx : (sub == 1 ? -2.f * ry : (sub == 2 ? -2.f * rz : 1.f));
@@ -161,7 +161,7 @@ __device__ __forceinline__ int wave_knn_hist(const GridView& g, float qx, float 
           for (int c = 0; c < QN_MM_NCH; c++) {
             if ((uint32_t)(64 * c) < total) {
               const uint32_t mk = max(wave_incl_max_u32(L->tile_sc[64 * c + lane]), carry);
-              carry = rflu(__shfl(mk, 63));
+              carry = rdlane(mk, 63);
               const uint32_t cnt = stage_chunk_mm(g, lds, L->tile_sc + 64 * c, 64u * c, total, Ox, Oy, Oz, c2max, (int)mk - 1);
               load_av(avc[c]);
               mm_groups(avc[c], cnt, [&](const int, const qn_f4v d) __attribute__((always_inline)) {
@@ -433,15 +433,15 @@ __device__ __forceinline__ int wave_knn_single(const GridView& g, float qx, floa
     wave_lds_fence();
     const uint32_t hv = lane < QN_HB - 1 ? L->hist[lane] : 0u;
     const uint32_t cum = wave_incl_scan_u32(hv, lane);
-    const uint32_t total = rflu(__shfl(cum, 63));
+    const uint32_t total = rdlane(cum, 63);
     const bool enough = total >= (uint32_t)k;
     const unsigned long long reach = __ballot(cum >= (uint32_t)k);
     const int cross = reach ? __ffsll((long long)reach) - 1 : QN_HB - 2;
     uint32_t tau_bits = (uint32_t)(base + cross + 1) << 20;
     // A far query's crossing bin can hold hundreds of points (the bins are 9 % wide in d2): refine it with 64 linear sub-bins
     // (bits 14..19 of the f32 pattern) so that the list of pass 2 stays short.
-    if (enough && rflu(__shfl(cum, cross)) > (uint32_t)QN_HCAP1 && cross > 0) {
-      const uint32_t below = rflu(__shfl(cum, cross - 1)), need = (uint32_t)k - below;       // below < k: all of them are among the k nearest
+    if (enough && rdlane(cum, cross) > (uint32_t)QN_HCAP1 && cross > 0) {
+      const uint32_t below = rdlane(cum, cross - 1), need = (uint32_t)k - below;       // below < k: all of them are among the k nearest
       const uint32_t hi20 = (uint32_t)(base + cross);
       wave_lds_fence();
       L->hist[lane] = 0;
