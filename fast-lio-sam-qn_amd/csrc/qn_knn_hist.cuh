@@ -112,12 +112,15 @@ __device__ __forceinline__ int wave_knn_hist(const GridView& g, float qx, float 
     const float* tilef = (const float*)&lds->tile[0];
     const qn_f4v cin = {q2, q2, q2, q2};
     auto mm_groups = [&](const float (&av)[4], const uint32_t cnt, auto&& per_group) __attribute__((always_inline)) {
+      // (software-pipelined by one group: the next group's instruction is issued before this group's results are used - 40 cycles of matrix-core latency behind ~17
+      //  instructions of work; the groups of a chunk's empty tail are computed too - far points - and not used)
+      qn_f4v d = __builtin_amdgcn_mfma_f32_16x16x4f32(av[0], bsel, cin, 0, 0, 0);
 #pragma unroll
       for (int gi = 0; gi < 4; gi++) {
-        if ((uint32_t)(16 * gi) < cnt) {                                          // (wave-uniform)
-          const qn_f4v d = __builtin_amdgcn_mfma_f32_16x16x4f32(av[gi], bsel, cin, 0, 0, 0);
-          per_group(gi, d);
-        }
+        qn_f4v dn = d;
+        if (gi < 3) dn = __builtin_amdgcn_mfma_f32_16x16x4f32(av[gi + 1], bsel, cin, 0, 0, 0);
+        if ((uint32_t)(16 * gi) < cnt) per_group(gi, d);                           // (wave-uniform)
+        d = dn;
       }
     };
     auto load_av = [&](float (&av)[4]) __attribute__((always_inline)) {
@@ -232,13 +235,14 @@ __device__ __forceinline__ int wave_knn_hist(const GridView& g, float qx, float 
           uint32_t& m = mw[c >> 1];
           if ((uint32_t)(64 * c) < ncand) {
             const uint32_t cnt = min(64u, ncand - 64u * c);
+            qn_f4v d = __builtin_amdgcn_mfma_f32_16x16x4f32(avc[c][0], bsel, cin, 0, 0, 0);
 #pragma unroll
-            for (int gi = 0; gi < 4; gi++) {
-              if ((uint32_t)(16 * gi) < cnt) {
-                const qn_f4v d = __builtin_amdgcn_mfma_f32_16x16x4f32(avc[c][gi], bsel, cin, 0, 0, 0);
+            for (int gi = 0; gi < 4; gi++) {                                       // (pipelined by one group, as in pass 1; an empty tail group is far points: no hit bits)
+              qn_f4v dn = d;
+              if (gi < 3) dn = __builtin_amdgcn_mfma_f32_16x16x4f32(avc[c][gi + 1], bsel, cin, 0, 0, 0);
 #pragma unroll
-                for (int e = 0; e < 4; e++) m = __builtin_amdgcn_alignbit(m, __float_as_uint(d[e] - thr), 31);
-              } else m <<= 4;
+              for (int e = 0; e < 4; e++) m = __builtin_amdgcn_alignbit(m, __float_as_uint(d[e] - thr), 31);
+              d = dn;
             }
           } else m <<= 16;
         }
