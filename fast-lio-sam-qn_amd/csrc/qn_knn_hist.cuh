@@ -31,7 +31,7 @@ struct WaveLdsH {
   } u;
   uint32_t cnt[16];
   uint32_t kth[16];
-  uint32_t tile_sc[64 * 4];                       // MM: position in pts[] (26 bits) | cluster id << 26 of the staged candidates of the round's first QN_MM_NCH chunks
+  alignas(16) uint32_t tile_sc[64 * 4];                       // MM: position in pts[] (26 bits) | cluster id << 26 of the staged candidates of the round's first QN_MM_NCH chunks
 };
 
 // ---- the distance matrix of a chunk on the matrix cores (MM)
