@@ -47,6 +47,7 @@ struct WaveLdsH {
 typedef float qn_f4v __attribute__((ext_vector_type(4)));
 #define QN_MM_FAR 1.0e15f                          // an empty slot of the last chunk: a finite point far beyond every bin and every threshold
 #define QN_MM_NCH 4                                // chunks of a round whose A operands stay in REGISTERS between the two passes (256 candidates: three rounds in four)
+static_assert(QN_MM_NCH == 4, "tile_sc holds 64 x QN_MM_NCH words and is cleared with one 16-byte store per lane; the hit masks are two 32-bit words");
 // stages the 64 candidates [cb, cb + 64) of the segment table in LDS: lds->tile[c] = (p - O, |p - O|^2), sc_out[c] = position in pts[] | cluster id << 26; returns
 // how many of them are real (all 64 lanes call, convergent)
 // (j: the segment of this lane's slot - chunk_segment, or the marker scan of the cached chunks)

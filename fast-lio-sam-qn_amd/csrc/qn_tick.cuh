@@ -191,29 +191,31 @@ __device__ __forceinline__ uint32_t wave_ball_collect(const GridView& g, float q
     z0 = (z0 >> 2) << 2; z1 = min(((z1 >> 2) << 2) + 3, g.nz - 1);
   }
   const int lane = threadIdx.x & 63;
-  wave_lds_fence();
-  if (lane == 0) *wcnt = 0;
-  wave_lds_fence();
   const float R2 = R * R;
   unsigned long long b = QN_INF_KEY; float s2 = __int_as_float(0x7f800000);
+  uint32_t found = 0;                                                  // (wave-uniform: list positions from a ballot's prefix count - up to 64 returning atomics on ONE LDS word per chunk before)
+  wave_lds_fence();
   const uint32_t streamed = stream_box(g, x0, x1, y0, y1, z0, z1, tile_mode, ws, [&](const float4& p, bool valid, uint32_t) __attribute__((always_inline)) {
     const float d2 = sqdist(qx, qy, qz, p.x, p.y, p.z);
-    if (valid && d2 <= R2) {
+    const bool in = valid && d2 <= R2;
+    const unsigned long long mk = __ballot(in);
+    if (in) {
       const unsigned long long k = pack_key(d2, __float_as_uint(p.w));
-      const uint32_t pos = atomicAdd(wcnt, 1u);
+      const uint32_t pos = found + __builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0u));
       if (pos < QN_HCAP1) wlist[pos] = k;
       if (k < b) { if (b != QN_INF_KEY) s2 = key_d2(b); b = k; } else if (d2 < s2) s2 = d2;
     }
+    found += (uint32_t)__popcll(mk);
   }, qx, qy, qz, tile_mode ? R2 * 1.000002f : -1.f);                    // (tiles outside the ball are not streamed: only points with d2 <= R2 are used)
+  if (lane == 0) *wcnt = found;
   wave_lds_fence();
   if (g.dbg && lane == 0) { atomicAdd(&g.dbg[14], 1u); atomicAdd(&g.dbg[15], streamed); atomicAdd(&g.dbg[9], (uint32_t)(tile_mode ? ((x1 >> 3) - (x0 >> 3) + 1) * ((y1 >> 2) - (y0 >> 2) + 1) * ((z1 >> 2) - (z0 >> 2) + 1) : ((x1 >> 3) - (x0 >> 3) + 1) * (y1 - y0 + 1) * (z1 - z0 + 1))); }      // developer counters: calls, candidates, segments
   const unsigned long long wb = wave_min_u64(b);
   float c = (b == wb) ? s2 : key_d2(b);
   if (b == QN_INF_KEY) c = __int_as_float(0x7f800000);
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) c = fminf(c, __shfl_xor(c, o));
+  c = wave_min_f(c);
   best = wb; second = c;
-  return *wcnt;
+  return found;
 }
 
 // Tracking state of one query beyond (j0, q_ref, bound): the RUNNER-UP.  Used by the persistent kernel only (TOP2), where it lives in registers.
