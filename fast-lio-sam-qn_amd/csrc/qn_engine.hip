@@ -13,6 +13,7 @@
 #include <chrono>
 #include "qn_instances.h"      // heavy template kernels: declared here, compiled in qn_inst.hip (one TU per group)
 #include "qn_context.h"
+#include "qn_selftest.cuh"
 #include "qn_pool.h"
 
 using namespace qn;
@@ -1263,6 +1264,26 @@ extern "C" int qn_debug_set(qn_ctx* c, const char* key, double v) {
     c->verify_track = v != 0;
   }
   else return QN_ERR_INVALID_ARG;
+  return QN_OK;
+}
+// developer / test entry point: the wave-level primitives of the search loops against plain restatements (qn_selftest.cuh); *mismatches = 0 when they agree
+extern "C" int qn_debug_selftest(qn_ctx* c, uint32_t n_waves, uint32_t seed, uint32_t* mismatches) {
+  if (!c || !mismatches || n_waves == 0 || n_waves > 65536) return QN_ERR_INVALID_ARG;
+  HIPCHK(c, hipSetDevice(c->device));
+  std::vector<uint32_t> h((size_t)n_waves * 128);
+  uint64_t x = 0x9e3779b97f4a7c15ull ^ seed;
+  for (auto& v : h) { x ^= x << 13; x ^= x >> 7; x ^= x << 17; v = (uint32_t)(x >> 16); }
+  uint32_t* d = nullptr;
+  HIPCHK(c, hipMalloc(&d, (h.size() + 1) * sizeof(uint32_t)));
+  int rc = QN_OK; uint32_t bad = 0xffffffffu;
+  if (hipMemcpyAsync(d, h.data(), h.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream) != hipSuccess || hipMemsetAsync(d + h.size(), 0, sizeof(uint32_t), c->stream) != hipSuccess) rc = QN_ERR_HIP;
+  if (rc == QN_OK) {
+    hipLaunchKernelGGL(k_selftest_wave, dim3(n_waves), dim3(64), 0, c->stream, d, d + (size_t)n_waves * 64, d + h.size());
+    if (hipMemcpyAsync(&bad, d + h.size(), sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) rc = QN_ERR_HIP;
+  }
+  (void)hipFree(d);
+  if (rc != QN_OK) { c->last_error = "selftest: HIP call failed"; return rc; }
+  *mismatches = bad;
   return QN_OK;
 }
 extern "C" int qn_debug_get_counters(qn_ctx* c, uint32_t out[16]) {

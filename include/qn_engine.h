@@ -295,6 +295,7 @@ int  qn_prof_get(qn_ctx*, int kernel_family, qn_kernel_stat* out);
 /* developer knobs (cell size, margins, debug counters); not part of the reference surface */
 int  qn_debug_set(qn_ctx*, const char* key, double value);
 int  qn_debug_get_counters(qn_ctx*, uint32_t out[16]);
+int  qn_debug_selftest(qn_ctx*, uint32_t n_waves, uint32_t seed, uint32_t* mismatches);      /* developer / tests: the device's wave-level search primitives against plain restatements (csrc/qn_selftest.cuh) */
 int  qn_debug_get(qn_ctx*, const char* key, double* value);   /* "verify_mismatches" / "verify_passes" / "verify_first" after qn_debug_set("verify_track", 1); "feat_survivors" / "feat_fallbacks" (matrix-core feature matching) */
 int  qn_debug_get_grid(qn_ctx*, int which, double out[8]);
 int  qn_debug_get_partials(qn_ctx*, double* out, uint32_t* rows_per_buffer, double* state);   /* developer: both partial-row buffers and both state buffers after an align */
